@@ -1,0 +1,199 @@
+"""``MilvusClient`` call surface of the reference, served by the HBM-resident StyleBank.
+
+Mirrors exactly the calls the reference makes (paths under /root/reference):
+  MilvusClient(db_path)                                     milvus/search_embeddings.py:31
+  .has_collection(collection_name=)                         src/search_milvus.py:177
+  .get_collection_info(name) / .describe_collection(name)   src/search_milvus.py:183
+  .search(collection_name=, data=[vec], anns_field="vector", metric_type="COSINE" | param={...},
+          limit=, filter=None, output_fields=[...])          milvus/search_embeddings.py:15-22,
+                                                            src/search_milvus.py:140-147,
+                                                            milvus/search_json.py:246-252
+  .create_collection(collection_name, dimension) / .insert(collection_name, data=[{...}]) /
+  .drop_collection(collection_name)                          milvus/RAG.py:49-57,541-544
+Result shape: ``list[Q]`` of ``list[k]`` of ``{'id': pk, 'distance': cosine_similarity,
+'entity': {field: value}}`` sorted by similarity descending (``distance`` IS the similarity for
+COSINE: output_emb/search_results.json holds 0.81..0.95, larger = closer).
+
+The file behind ``db_path`` is read with astts.milvus_lite (SQLite + protobuf wire format); the
+vectors go to HBM once per collection and stay there.  Errors raise ``MilvusException`` -- the
+reference wraps every call in try/except and degrades to ``[]`` itself
+(milvus/search_embeddings.py:24-27), so the shim does not swallow anything.
+
+Extra keys beyond pymilvus: each hit also carries ``'row'`` (row index in the bank == style id,
+because the reference's pk restarts per speaker and is not unique: milvus/RAG.py:507).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ..milvus_lite import MilvusLiteFile
+
+
+class MilvusException(Exception):
+    def __init__(self, code: int = 1, message: str = ""):
+        super().__init__(f"<MilvusException: (code={code}, message={message})>")
+        self.code = code
+        self.message = message
+
+
+class _Collection:
+    def __init__(self, name: str, dim: int, metric: str = "COSINE", pk_field: str = "id",
+                 vector_field: str = "vector", index_params: Optional[Dict[str, str]] = None):
+        self.name = name
+        self.dim = int(dim)
+        self.metric = metric.upper()
+        self.pk_field = pk_field
+        self.vector_field = vector_field
+        self.index_params = dict(index_params or {})
+        self.vectors: List[np.ndarray] = []
+        self.pks: List[int] = []
+        self.metas: List[Dict[str, Any]] = []
+        self._bank = None  # astts.knn.StyleBank, built lazily, dropped on insert
+
+    def matrix(self) -> np.ndarray:
+        if not self.vectors:
+            return np.zeros((0, self.dim), np.float32)
+        return np.stack(self.vectors).astype(np.float32, copy=False)
+
+    def bank(self):
+        if self._bank is None:
+            from ..knn import StyleBank  # needs the GPU + libastts.so; raises otherwise
+
+            m = self.matrix()
+            m16 = m.astype(np.float16)
+            # upload as fp16 when that is lossless (half the HBM traffic of every scan)
+            self._bank = StyleBank(m16 if np.array_equal(m16.astype(np.float32), m) else m, metric=self.metric)
+        return self._bank
+
+
+class MilvusClient:
+    def __init__(self, uri: str = "./milvus_demo.db", **_kwargs):
+        self.uri = uri
+        self._colls: Dict[str, _Collection] = {}
+        if os.path.exists(uri):
+            f = MilvusLiteFile(uri)
+            try:
+                for name in f.collections():
+                    info = f.info(name)
+                    c = _Collection(name, info.dim, info.metric_type, info.pk_field,
+                                    info.vector_field.name if info.vector_field else "vector",
+                                    info.index_params)
+                    v, pks, metas = f.load(name)
+                    c.vectors = [v[i] for i in range(v.shape[0])]
+                    c.pks = [int(x) for x in pks]
+                    c.metas = metas
+                    self._colls[name] = c
+            finally:
+                f.close()
+
+    # ------------------------------------------------------------------ collection management
+    def has_collection(self, collection_name: str, **_kw) -> bool:
+        return collection_name in self._colls
+
+    def list_collections(self, **_kw) -> List[str]:
+        return list(self._colls)
+
+    def _get(self, name: str) -> _Collection:
+        if name not in self._colls:
+            raise MilvusException(100, f"collection not found[collection={name}]")
+        return self._colls[name]
+
+    def describe_collection(self, collection_name: str, **_kw) -> Dict[str, Any]:
+        c = self._get(collection_name)
+        return {
+            "collection_name": c.name,
+            "auto_id": False,
+            "num_shards": 0,
+            "description": "",
+            "fields": [
+                {"field_id": 100, "name": c.pk_field, "description": "", "type": 5, "params": {}, "is_primary": True},
+                {"field_id": 101, "name": c.vector_field, "description": "", "type": 101, "params": {"dim": c.dim}},
+            ],
+            "enable_dynamic_field": True,
+            "num_entities": len(c.pks),
+            "metric_type": c.metric,
+        }
+
+    get_collection_info = describe_collection  # src/search_milvus.py:183 uses this older name
+
+    def create_collection(self, collection_name: str, dimension: Optional[int] = None,
+                          primary_field_name: str = "id", vector_field_name: str = "vector",
+                          metric_type: str = "COSINE", schema=None, index_params=None, **_kw) -> None:
+        if schema is not None and dimension is None:
+            dimension = getattr(schema, "dim", None) or (schema.get("dim") if isinstance(schema, dict) else None)
+        if not dimension:
+            raise MilvusException(1, "create_collection needs a dimension")
+        if collection_name in self._colls:
+            return
+        self._colls[collection_name] = _Collection(collection_name, int(dimension), metric_type,
+                                                   primary_field_name, vector_field_name)
+
+    def drop_collection(self, collection_name: str, **_kw) -> None:
+        self._colls.pop(collection_name, None)
+
+    def insert(self, collection_name: str, data, **_kw) -> Dict[str, Any]:
+        c = self._get(collection_name)
+        rows = [data] if isinstance(data, dict) else list(data)
+        ids = []
+        for r in rows:
+            vec = np.asarray(r[c.vector_field], dtype=np.float32)
+            if vec.shape != (c.dim,):
+                raise MilvusException(1100, f"the dim ({vec.size}) of field data({c.vector_field}) is not "
+                                            f"equal to schema dim ({c.dim})")
+            c.vectors.append(vec)
+            pk = int(r.get(c.pk_field, len(c.pks)))
+            c.pks.append(pk)
+            ids.append(pk)
+            c.metas.append({k: v for k, v in r.items() if k not in (c.vector_field, c.pk_field)})
+        c._bank = None
+        return {"insert_count": len(rows), "ids": ids}
+
+    # ------------------------------------------------------------------ search (the hot path)
+    def search(self, collection_name: str, data, filter: Optional[str] = "", limit: int = 10,
+               output_fields: Optional[Sequence[str]] = None, search_params: Optional[dict] = None,
+               anns_field: Optional[str] = None, metric_type: Optional[str] = None,
+               param: Optional[dict] = None, **_kw) -> List[List[Dict[str, Any]]]:
+        c = self._get(collection_name)
+        if filter:
+            raise MilvusException(1, "filter expressions are not implemented by astts (the reference only passes None)")
+        if anns_field is not None and anns_field != c.vector_field:
+            raise MilvusException(1, f"anns_field {anns_field!r} does not exist (vector field is {c.vector_field!r})")
+        mt = metric_type or (search_params or {}).get("metric_type") or (param or {}).get("metric_type")
+        if mt is not None and mt.upper() != c.metric:
+            raise MilvusException(1100, f"metric type not match: invalid parameter[expected={c.metric}][actual={mt}]")
+        q = np.asarray(data, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != c.dim:
+            raise MilvusException(1100, f"vector dimension mismatch, expected vector size(byte) {c.dim * 4}, "
+                                        f"actual {q.shape[-1] * 4}")
+        if len(c.pks) == 0:
+            return [[] for _ in range(q.shape[0])]
+        if limit < 1:
+            raise MilvusException(1, f"limit {limit} is invalid")
+        k = min(int(limit), len(c.pks))
+        idx, score = c.bank().search(q, k)
+        out: List[List[Dict[str, Any]]] = []
+        for qi in range(q.shape[0]):
+            hits = []
+            for j in range(k):
+                row = int(idx[qi, j])
+                if row < 0:
+                    continue
+                meta = c.metas[row]
+                if output_fields:
+                    ent = {f: meta[f] for f in output_fields if f in meta}
+                else:
+                    ent = {}
+                hits.append({"id": c.pks[row], "distance": float(score[qi, j]), "entity": ent, "row": row})
+            out.append(hits)
+        return out
+
+    def close(self) -> None:
+        for c in self._colls.values():
+            if c._bank is not None:
+                c._bank.close()
+                c._bank = None

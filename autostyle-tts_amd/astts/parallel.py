@@ -1,0 +1,65 @@
+"""Data-parallel sharding of utterance / query batches across the GPUs of one node.
+
+The reference processes utterances one by one with no cross-item state
+(/root/reference/tts_with_rag.py:172-197, /root/reference/milvus/search_json.py:382-411), so the
+path shards by item: rank r takes items [r*ceil(Q/W), (r+1)*ceil(Q/W)); the style bank and the model
+weights are replicated.  The ONLY collective on the data path is one all-gather of the retrieved
+style ids (int64 [ceil(Q/W), k] per rank, a few KB: latency-bound on xGMI) -- no waveform or mel
+crosses GPUs.  One process per GPU; backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """-> (begin, end, per_rank) with per_rank = ceil(n/world); trailing ranks may be short/empty."""
+    per = (n_items + world - 1) // world if n_items > 0 else 0
+    b = min(rank * per, n_items)
+    e = min(b + per, n_items)
+    return b, e, per
+
+
+def gather_style_ids(local_ids: torch.Tensor, dist, pad_rows: Optional[int] = None, pad_value: int = -1) -> torch.Tensor:
+    """All-gather ``local_ids`` ([q_local, k] int64) from every rank -> [W * pad_rows, k].
+    Every rank must contribute ``pad_rows`` rows (short shards are padded with ``pad_value``)."""
+    world = dist.get_world_size()
+    rows = pad_rows if pad_rows is not None else local_ids.shape[0]
+    if local_ids.shape[0] != rows:
+        pad = torch.full((rows - local_ids.shape[0], local_ids.shape[1]), pad_value,
+                         dtype=local_ids.dtype, device=local_ids.device)
+        local_ids = torch.cat([local_ids, pad], dim=0)
+    out = torch.empty((world * rows, local_ids.shape[1]), dtype=local_ids.dtype, device=local_ids.device)
+    dist.all_gather_into_tensor(out, local_ids.contiguous())
+    return out
+
+
+def sharded_search(search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
+                   queries: torch.Tensor, k: int, dist=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Query-sharded retrieval.  ``queries`` is the FULL [Q, D] batch (same on every rank);
+    ``search_fn(q_local, k) -> (idx [q,k] int64, score [q,k] fp32)`` is this rank's bank search
+    (StyleBank.search_device on GPUs).  Returns the full (idx [Q,k], score [Q,k]) on every rank.
+    The ids travel as int64; scores ride along bit-cast inside the same all-gather."""
+    nq = queries.shape[0]
+    if dist is None or dist.get_world_size() == 1:
+        return search_fn(queries, k)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b, e, per = shard_bounds(nq, world, rank)
+    if e > b:
+        idx, sc = search_fn(queries[b:e], k)
+    else:
+        idx = torch.empty((0, k), dtype=torch.int64, device=queries.device)
+        sc = torch.empty((0, k), dtype=torch.float32, device=queries.device)
+    packed = torch.cat([idx, sc.contiguous().view(torch.int32).to(torch.int64)], dim=1)  # [q, 2k]
+    allp = gather_style_ids(packed, dist, pad_rows=per)
+    # drop per-rank padding: rank r contributed rows [r*per, r*per + len_r)
+    keep = []
+    for r in range(world):
+        rb, re, _ = shard_bounds(nq, world, r)
+        keep.append(allp[r * per: r * per + (re - rb)])
+    allp = torch.cat(keep, dim=0)
+    out_idx = allp[:, :k].contiguous()
+    out_sc = allp[:, k:].to(torch.int32).view(torch.float32)
+    return out_idx, out_sc

@@ -1,0 +1,100 @@
+/* astts.h -- C ABI of libastts.so, the MI355X (gfx950) implementation of the AutoStyle-TTS
+ * inference hot path.  Plain C: pointers, sizes, integer status codes.  No torch types, no
+ * exceptions across the boundary.
+ *
+ * Conventions
+ *   - every function returns ASTTS_OK (0) or a negative ASTTS_ERR_* code; the message for the
+ *     calling thread's last failure is astts_last_error_string().
+ *   - pointers are DEVICE pointers owned by the caller unless the name ends in _host.
+ *   - every launch takes the HIP stream to enqueue on (astts_stream_t == hipStream_t); no
+ *     function in a launch path allocates, frees or synchronises (graph-capturable).
+ *   - handles are opaque and thread-compatible: one stream per handle at a time.
+ *
+ * What each group replaces in the reference (paths under /root/reference):
+ *   astts_knn_*      MilvusClient.search on the COSINE collection
+ *                    milvus/search_embeddings.py:15-22, src/search_milvus.py:140-147,
+ *                    milvus/search_json.py:232-259 (+ _ab_bio / _ab_text variants),
+ *                    milvus/RAG.py:368-395, milvus/search.py:159-186
+ *   astts_op_*       the tensor operators executed inside cosyvoice.inference_tts_with_st /
+ *                    inference_zero_shot / inference_vc (tts_with_rag.py:195,133,141;
+ *                    tts_with_style_and_timbre.py:93,47,57): acoustic-transformer, flow-matching
+ *                    decoder and HiFT vocoder arithmetic (third-party CosyVoice, not vendored).
+ */
+#ifndef ASTTS_H_
+#define ASTTS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASTTS_ABI_VERSION 1
+
+#define ASTTS_OK 0
+#define ASTTS_ERR_INVALID (-1)     /* bad argument (null pointer, size, dtype, k, ...)            */
+#define ASTTS_ERR_HIP (-2)         /* HIP runtime failure; message carries hipGetErrorString      */
+#define ASTTS_ERR_UNSUPPORTED (-3) /* valid in the reference API, not implemented by this build   */
+#define ASTTS_ERR_WORKSPACE (-4)   /* workspace too small / misaligned                            */
+#define ASTTS_ERR_RANGE (-5)       /* data not representable (e.g. bank value overflows fp16)     */
+
+typedef void* astts_stream_t; /* hipStream_t */
+
+int astts_abi_version(void);
+const char* astts_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",
+ * metric_type="COSINE", limit=k) -- milvus/search_embeddings.py:15-22.
+ *
+ * Result definition (identical to oracle/knn.py): score(q,n) = <q,b_n>/(|q||b_n|) evaluated in
+ * fp64, hits ordered by (score descending, row index ascending).  Returned ids are ROW INDICES
+ * into the bank (the reference's pk restarts per speaker and is not unique, RAG.py:507); ids are
+ * bit-exact w.r.t. that definition: an fp16-MFMA scan proposes candidates, every candidate is
+ * re-scored in fp64, and a query whose candidate set cannot be certified complete (error bound
+ * vs. the gap to the best non-candidate) is re-run through an exact fp64 scan on the GPU.
+ * ------------------------------------------------------------------------------------------ */
+#define ASTTS_DTYPE_F16 1
+#define ASTTS_DTYPE_F32 2
+
+#define ASTTS_METRIC_COSINE 0
+#define ASTTS_METRIC_IP 1 /* reserved: ASTTS_ERR_UNSUPPORTED */
+#define ASTTS_METRIC_L2 2 /* reserved: ASTTS_ERR_UNSUPPORTED */
+
+#define ASTTS_KNN_MAX_K 32
+#define ASTTS_KNN_FORCE_EXACT 1 /* flags: send every query through the exact fp64 scan */
+
+typedef struct astts_knn astts_knn_t;
+
+/* Builds the HBM-resident bank from `bank` ([n,d] row-major device memory of `dtype`).  The
+ * handle keeps its own copy (fp16 scan plane, padded to a multiple of 64 columns; the exact
+ * plane for re-scoring; fp64 row norms).  Synchronises `stream` before returning. */
+int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int32_t metric,
+                     astts_stream_t stream, astts_knn_t** out);
+int astts_knn_destroy(astts_knn_t* h);
+/* n, d, and whether the scan plane is a lossless image of the bank (1) or a rounded one (0). */
+int astts_knn_info(const astts_knn_t* h, int64_t* n, int32_t* d, int32_t* scan_plane_exact);
+/* Bytes of workspace astts_knn_search needs for up to `nq` queries and `k` hits. */
+size_t astts_knn_workspace_bytes(const astts_knn_t* h, int32_t nq, int32_t k);
+/* queries: fp32 [nq,d] device.  out_idx: int64 [nq,k], out_score: fp32 [nq,k] (cosine
+ * similarity, larger = closer; rows beyond min(k,n) hits get idx -1 / score -inf).
+ * workspace: 256-byte aligned device memory of at least astts_knn_workspace_bytes(h,nq,k). */
+int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k,
+                     int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
+                     int32_t flags, astts_stream_t stream);
+/* Number of queries of the last search on `workspace` that took the exact-scan fallback.
+ * Copies one word back and synchronises `stream` (diagnostics; not a launch-path call). */
+int astts_knn_last_fallbacks(const astts_knn_t* h, const void* workspace, astts_stream_t stream,
+                             int32_t* n_fallback_host);
+
+/* Profiling aid for bench.py (roofline of the scan kernel): while enabled, every search brackets its
+ * knn_scan launch(es) with HIP events on the search stream.  _read synchronises, returns the summed
+ * scan time and launch count since the last read, and resets.  Not for production launch paths. */
+int astts_knn_profile_enable(astts_knn_t* h, int32_t on);
+int astts_knn_profile_read(astts_knn_t* h, double* scan_ms_sum, int64_t* scan_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASTTS_H_ */

@@ -1,0 +1,115 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/astts.h declares (no compute
+calls without a GPU), and the host-side logic (Milvus-Lite reader, MilvusClient shim surface)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    syms = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            text = open(os.path.join(inc, fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            syms |= set(re.findall(r"\b(astts_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_library_exports_every_declared_symbol():
+    from astts import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "libastts.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert "astts_knn_search" in syms and len(syms) >= 8
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # the ctypes table mirrors the header one to one
+    import astts.ops  # noqa: F401  (registers its part of the ABI)
+    assert set(_lib.declared_symbols()) == set(syms)
+    lib2 = _lib.load()
+    assert lib2.astts_abi_version() == 1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from astts.knn import StyleBank
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        StyleBank(np.zeros((4, 64), np.float16))
+
+
+def test_milvus_lite_reader_on_shipped_db(golden_dir, real_bank):
+    from astts.milvus_lite import MilvusLiteFile
+
+    f = MilvusLiteFile(os.path.join(golden_dir, "milvus_demo.db"))
+    assert sorted(f.collections()) == ["demo_collection", "embeddings_biographies_collection"]
+    info = f.info("embeddings_biographies_collection")
+    assert info.dim == 6144 and info.metric_type == "COSINE" and info.pk_field == "id"
+    assert info.index_params["index_type"] == "AUTOINDEX"
+    assert [x.name for x in info.fields][:3] == ["id", "vector", "$meta"]
+    v, pks, metas = f.load("embeddings_biographies_collection")
+    assert v.dtype == np.float32 and np.array_equal(v, real_bank.astype(np.float32))
+    assert pks[0] == 1 and len(pks) == 130
+    assert metas[0] == {"file_id": "tonight1_0h2m4dot86s_0h2m7dot13s", "text": "What are you talking about?!"}
+    assert f.info("demo_collection").dim == 768
+    v2, _, _ = f.load("demo_collection")
+    assert v2.shape == (0, 768)
+    with pytest.raises(KeyError):
+        f.info("nope")
+    f.close()
+
+
+def test_milvus_client_surface_cpu(golden_dir):
+    from astts.compat.pymilvus import MilvusClient, MilvusException
+
+    c = MilvusClient(os.path.join(golden_dir, "milvus_demo.db"))
+    assert c.has_collection(collection_name="embeddings_biographies_collection")
+    assert not c.has_collection(collection_name="missing")
+    info = c.get_collection_info("embeddings_biographies_collection")
+    assert info["num_entities"] == 130 and info["fields"][1]["params"]["dim"] == 6144
+    # argument validation happens before any GPU work
+    with pytest.raises(MilvusException):
+        c.search("missing", data=[[0.0] * 6144], limit=1)
+    with pytest.raises(MilvusException):
+        c.search("embeddings_biographies_collection", data=[[0.0] * 10], limit=1)
+    with pytest.raises(MilvusException):
+        c.search("embeddings_biographies_collection", data=[[0.0] * 6144], limit=1, metric_type="L2")
+    with pytest.raises(MilvusException):
+        c.search("embeddings_biographies_collection", data=[[0.0] * 6144], limit=1, anns_field="emb")
+    assert c.search("demo_collection", data=[[0.0] * 768], limit=3) == [[]]  # empty collection
+    # bank-construction calls of RAG.py:49-57,541-544
+    c.create_collection(collection_name="t", dimension=8)
+    r = c.insert(collection_name="t", data=[{"id": 1, "vector": [1.0] * 8, "file_id": "a", "text": "x"}])
+    assert r["insert_count"] == 1
+    with pytest.raises(MilvusException):
+        c.insert(collection_name="t", data=[{"id": 2, "vector": [1.0] * 7}])
+    c.drop_collection("t")
+    assert not c.has_collection("t")
+
+
+def test_compat_install_aliases():
+    import sys
+
+    from astts import compat
+
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "pymilvus" or k.startswith("cosyvoice")}
+    try:
+        compat.install()
+        from pymilvus import MilvusClient  # noqa: F401  (milvus/search_embeddings.py:3)
+        from cosyvoice.cli.cosyvoice import CosyVoice  # noqa: F401  (tts_with_rag.py:1)
+        from cosyvoice.utils.file_utils import load_wav  # noqa: F401  (tts_with_rag.py:2)
+    finally:
+        for k in list(sys.modules):
+            if k == "pymilvus" or k.startswith("cosyvoice"):
+                sys.modules.pop(k)
+        sys.modules.update(saved)

@@ -1,0 +1,215 @@
+"""GPU parity tests for the style-bank kNN: HIP path (through the C ABI) vs oracle/knn.py.
+
+Bar: retrieved ids BIT-EXACT; scores within 1e-6 (the kernel returns the fp64 cosine rounded to
+fp32; the oracle's fp64 value may differ in the last fp64 ulps by summation order).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn as oknn
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-6
+
+
+def _bank(vectors):
+    from astts.knn import StyleBank
+
+    return StyleBank(vectors)
+
+
+def _check(bank_np, q, k, force_exact=False, sb=None):
+    sb = sb or _bank(bank_np)
+    idx, sc = sb.search(q, k, force_exact=force_exact)
+    eidx, esc = oknn.knn_search(bank_np, q, k)
+    kk = eidx.shape[1]
+    assert np.array_equal(idx[:, :kk], eidx), (idx[:, :kk][idx[:, :kk] != eidx], eidx[idx[:, :kk] != eidx])
+    assert np.allclose(sc[:, :kk], esc, atol=SCORE_ATOL, rtol=0)
+    if kk < k:
+        assert np.all(idx[:, kk:] == -1) and np.all(np.isneginf(sc[:, kk:]))
+    return sb
+
+
+def test_real_bank_known_answers(real_bank, kats):
+    sb = _bank(real_bank)
+    assert sb.scan_plane_exact
+    q = real_bank.astype(np.float32)
+    idx, sc = sb.search(q, 5)
+    assert idx.tolist() == kats["self_top5_idx"]            # committed golden ids, bit-exact
+    assert np.allclose(sc, np.asarray(kats["self_top5_score"]), atol=SCORE_ATOL, rtol=0)
+    assert np.array_equal(idx[:, 0], np.arange(130))        # RAG.py:568-582 self-retrieval
+    # the reference's default top_k=3 (search_embeddings.py:64) and top-1 (search_json.py:411)
+    for k in (1, 3):
+        i2, _ = sb.search(q, k)
+        assert i2.tolist() == [r[:k] for r in kats["self_top5_idx"]]
+
+
+def test_real_bank_ablation_queries(real_bank, kats):
+    sb = _bank(real_bank)
+    q = real_bank.astype(np.float32)
+    qb = q.copy()
+    qb[:, :3072] = 0                                        # search_json_ab_bio.py:412 (adversarial near-ties)
+    idx, sc = sb.search(qb, 3)
+    assert idx.tolist() == kats["bio_only_top3_idx"]
+    assert np.allclose(sc, np.asarray(kats["bio_only_top3_score"]), atol=SCORE_ATOL, rtol=0)
+    qe = q.copy()
+    qe[:, 3072:] = 0
+    qe /= np.linalg.norm(qe, axis=1, keepdims=True)         # search_json_ab_text.py:412,420 (L2-normalised)
+    idx, sc = sb.search(qe.astype(np.float32), 3)
+    assert idx.tolist() == kats["emo_only_norm_top3_idx"]
+    assert np.allclose(sc, np.asarray(kats["emo_only_norm_top3_score"]), atol=SCORE_ATOL, rtol=0)
+
+
+def test_fp32_upload_of_exact_bank_matches(real_bank):
+    sb = _bank(real_bank.astype(np.float32))                # FloatVector semantics: fp32 in, fp16-exact detected
+    assert sb.scan_plane_exact
+    _check(real_bank, real_bank[:16].astype(np.float32) * 3.0, 3, sb=sb)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 6144, 8, 3), (1000, 6144, 64, 3), (777, 768, 33, 5),
+                                      (5000, 768, 130, 1), (20000, 256, 256, 3), (300, 100, 7, 8),
+                                      (64, 64, 5, 16), (2000, 6144, 300, 3)])
+def test_synthetic_banks_match_oracle(n, d, nq, k, real_bank):
+    rng = np.random.default_rng(1234)
+    if (n, d) == (1000, 6144):
+        # BASELINE config 2: real rows tiled + perturbed, re-rounded to fp16
+        bank = (real_bank[np.arange(n) % 130].astype(np.float32)
+                + 0.05 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16)
+        rq = np.random.default_rng(0)
+        q = bank[rq.integers(0, n, nq)].astype(np.float32) + 0.5 * rq.standard_normal((nq, d)).astype(np.float32)
+    else:
+        bank = rng.standard_normal((n, d)).astype(np.float16)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+    sb = _check(bank, q, k)
+    assert sb.last_fallbacks() <= nq // 4                    # the certified fast path carries the load
+
+
+def test_exact_path_forced_matches_oracle():
+    rng = np.random.default_rng(7)
+    bank = rng.standard_normal((3000, 512)).astype(np.float16)
+    q = rng.standard_normal((20, 512)).astype(np.float32)
+    sb = _check(bank, q, 4, force_exact=True)
+    assert sb.last_fallbacks() == 20
+    _check(bank, q, 4, force_exact=False, sb=sb)
+
+
+def test_inexact_fp32_bank():
+    rng = np.random.default_rng(3)
+    bank = rng.standard_normal((1500, 384)).astype(np.float32)  # not fp16-representable
+    q = rng.standard_normal((9, 384)).astype(np.float32)
+    sb = _bank(bank)
+    assert not sb.scan_plane_exact
+    _check(bank, q, 3, sb=sb)
+    _check(bank, q, 3, force_exact=True, sb=sb)
+
+
+def test_duplicates_ties_zero_rows_and_small_banks():
+    rng = np.random.default_rng(0)
+    bank = rng.standard_normal((200, 128)).astype(np.float16)
+    for j in range(40):                       # 40 exact copies of row 3: more than the candidate list holds
+        bank[5 * j] = bank[3] if j else bank[0]
+    bank[199] = 0                             # zero row
+    q = np.stack([bank[3], bank[0], np.zeros(128, np.float16), bank[17]]).astype(np.float32)
+    sb = _check(bank, q, 3)
+    assert sb.last_fallbacks() >= 1           # uncertifiable ties must go through the exact scan
+    _check(bank, q, 20, sb=sb)
+    tiny = rng.standard_normal((5, 70)).astype(np.float16)      # n < k, d not a multiple of 64
+    _check(tiny, rng.standard_normal((3, 70)).astype(np.float32), 8)
+    one = rng.standard_normal((1, 33)).astype(np.float16)
+    _check(one, rng.standard_normal((2, 33)).astype(np.float32), 1)
+
+
+def test_query_scale_extremes():
+    rng = np.random.default_rng(5)
+    bank = rng.standard_normal((900, 256)).astype(np.float16)
+    q = rng.standard_normal((6, 256)).astype(np.float32)
+    sb = _bank(bank)
+    for s in (1e-30, 1e-8, 1.0, 1e8, 1e30):
+        _check(bank, q * np.float32(s), 3, sb=sb)
+
+
+def test_device_api_is_async_and_reusable():
+    rng = np.random.default_rng(11)
+    bank = rng.standard_normal((4096, 768)).astype(np.float16)
+    sb = _bank(bank)
+    qs = [torch.from_numpy(rng.standard_normal((8, 768)).astype(np.float32)).cuda() for _ in range(5)]
+    outs = [sb.search_device(q, 3) for q in qs]            # queued back to back, one workspace
+    torch.cuda.synchronize()
+    for q, (i, s) in zip(qs, outs):
+        ei, es = oknn.knn_search(bank, q.cpu().numpy(), 3)
+        assert np.array_equal(i.cpu().numpy(), ei)
+
+
+def test_argument_errors():
+    from astts import _lib
+    from astts.knn import StyleBank
+
+    sb = StyleBank(np.ones((10, 64), np.float16))
+    with pytest.raises(ValueError):
+        sb.search(np.ones((1, 63), np.float32), 3)
+    with pytest.raises(ValueError):
+        sb.search(np.ones((1, 64), np.float32), 0)
+    with pytest.raises(ValueError):
+        sb.search(np.ones((1, 64), np.float32), _lib.KNN_MAX_K + 1)
+    with pytest.raises(_lib.AsttsError):
+        StyleBank(np.full((4, 64), 1e6, np.float32))       # overflows the fp16 scan plane
+    with pytest.raises(_lib.AsttsError):
+        StyleBank(np.ones((4, 64), np.float16), metric="L2")
+
+
+def test_full_size_bank_properties():
+    """BASELINE config 5 size (100k x 6144, Q=256): size-independent properties + oracle on a sample."""
+    n, d, nq, k = 100_000, 6144, 256, 3
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    bank_t = torch.randn((n, d), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    from astts.knn import StyleBank
+
+    sb = StyleBank(bank_t)
+    rows = torch.randint(0, n, (nq,), generator=g, device="cuda")
+    q = bank_t[rows].to(torch.float32)
+    idx, sc = sb.search_device(q, k)
+    torch.cuda.synchronize()
+    assert torch.equal(idx[:, 0], rows)                      # self-retrieval at full size
+    assert torch.allclose(sc[:, 0], torch.ones(nq, device="cuda"), atol=1e-6)
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())             # sorted
+    noisy = q + 0.7 * torch.randn(q.shape, generator=g, device="cuda")
+    i_fast, s_fast = sb.search_device(noisy, k)
+    i_fast, s_fast = i_fast.clone(), s_fast.clone()
+    nfb = sb.last_fallbacks()
+    i_ex, s_ex = sb.search_device(noisy, k, force_exact=True)
+    assert torch.equal(i_fast, i_ex) and torch.equal(s_fast, s_ex)   # certified fast path == exact scan
+    assert nfb <= 8
+    bank_np = bank_t.cpu().numpy()
+    sample = noisy[:3].cpu().numpy()
+    ei, es = oknn.knn_search(bank_np, sample, k)
+    assert np.array_equal(i_fast[:3].cpu().numpy(), ei)
+    assert np.allclose(s_fast[:3].cpu().numpy(), es, atol=SCORE_ATOL, rtol=0)
+
+
+def test_milvus_client_search_end_to_end(golden_dir, kats):
+    """The reference call, verbatim (milvus/search_embeddings.py:15-22), on the shipped DB."""
+    from astts.compat.pymilvus import MilvusClient
+
+    client = MilvusClient(os.path.join(golden_dir, "milvus_demo.db"))
+    meta = json.load(open(os.path.join(golden_dir, "style_bank_meta.json")))
+    bank = np.load(os.path.join(golden_dir, "style_bank_130x6144.f16.npy")).astype(np.float32)
+    embedding = bank[61].tolist()
+    results = client.search(collection_name="embeddings_biographies_collection", data=[embedding],
+                            anns_field="vector", param={"nprobe": 10}, limit=3,
+                            output_fields=["file_id", "text"])
+    assert len(results) == 1 and len(results[0]) == 3
+    assert [h["row"] for h in results[0]] == kats["self_top5_idx"][61][:3]
+    top = results[0][0]
+    assert top["entity"] == meta["rows"][61] and top["id"] == meta["pk"][61]
+    assert abs(top["distance"] - 1.0) < 1e-6
+    assert results[0][0]["distance"] >= results[0][1]["distance"] >= results[0][2]["distance"]
+    # src/search_milvus.py:140-147 form, ndarray query (search_json.py:411), top-1
+    r2 = client.search(collection_name="embeddings_biographies_collection", data=[bank[5]],
+                       anns_field="vector", metric_type="COSINE", limit=1, output_fields=["file_id"])
+    assert r2[0][0]["entity"] == {"file_id": meta["rows"][5]["file_id"]}
+    client.close()

@@ -1,0 +1,74 @@
+"""CPU test of the N>1 path: world_size-2 gloo processes run the query-sharded search + all-gather
+logic of astts.parallel.  The per-rank bank search is the ORACLE here (checker only -- the product's
+search_fn is StyleBank.search_device, which needs a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, k, ret):
+    for p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from astts.parallel import shard_bounds, sharded_search
+    from oracle import knn as oknn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(42)
+    bank = rng.standard_normal((300, 96)).astype(np.float16)
+    q = torch.from_numpy(rng.standard_normal((nq, 96)).astype(np.float32))
+    calls = []
+
+    def search_fn(q_local, kk):
+        calls.append(q_local.shape[0])
+        i, s = oknn.knn_search(bank, q_local.numpy(), kk)
+        return torch.from_numpy(i), torch.from_numpy(s.astype(np.float32))
+
+    idx, sc = sharded_search(search_fn, q, k, dist)
+    b, e, per = shard_bounds(nq, world, rank)
+    assert calls == ([e - b] if e > b else [])          # each rank searched only its shard
+    ei, es = oknn.knn_search(bank, q.numpy(), k)
+    ok = bool(np.array_equal(idx.numpy(), ei)) and bool(np.array_equal(sc.numpy(), es.astype(np.float32)))
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [8, 7, 1])
+def test_sharded_search_world2(nq):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, nq, 3, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_bounds_cover_everything():
+    from astts.parallel import shard_bounds
+
+    for n in (0, 1, 7, 8, 203, 1623):
+        for w in (1, 2, 4, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            covered = [i for b, e, _ in spans for i in range(b, e)]
+            assert covered == list(range(n))
+            assert all(e - b <= per for b, e, per in spans)
+    assert shard_bounds(1623, 8, 0)[2] == 203
