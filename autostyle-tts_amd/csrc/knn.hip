@@ -4,16 +4,14 @@
 // (/root/reference/milvus/search_embeddings.py:15-22, /root/reference/src/search_milvus.py:140-147).
 // Result definition = oracle/knn.py: fp64 cosine, order (score desc, row asc).
 //
-// Pipeline (all on one stream, no host sync, no allocation):
-//   1 knn_prep_queries   fp32 queries -> power-of-two scaled fp16 image + padded fp32 copy + fp64 norms
-//   2 knn_scan           fp16 MFMA (32x32x16) scan of the whole bank: S[q][n] ~ <q,b_n>/|b_n|  (HBM-bound)
-//   3 knn_select         per query: top-C candidates of S by (score desc, row asc)
-//   4 knn_rescore        fp64 cosine of every candidate (one wave per candidate)
-//   5 knn_finalize       order candidates by the fp64 score, emit top-k, CERTIFY the candidate set:
-//                        kth exact score > best possible score of any non-candidate (+ error bound),
-//                        otherwise queue the query for the exact path
-//   6 knn_exact_scan     fp64 cosine of queued queries against every row   (normally zero work)
-//   7 knn_exact_select   exact top-k for queued queries                     (normally zero work)
+// Pipeline (five launches on one stream, no host sync, no allocation):
+//   1 knn_prep_queries     fp32 queries -> power-of-two scaled fp16 image + padded fp32 copy + fp64 norms
+//   2 knn_scan             fp16 MFMA (32x32x16) scan of the whole bank: S[q][n] ~ <q,b_n>/|b_n|  (HBM-bound)
+//   3 knn_select           per query: top-C candidates of S by (score desc, row asc)
+//   4 knn_rescore_finalize fp64 cosine of every candidate (one wave each), order by it, emit top-k and
+//                          CERTIFY the candidate set: kth exact score > best possible score of any
+//                          non-candidate (+ error bound); otherwise queue the query for the exact path
+//   5 knn_exact            fp64 scan + exact top-k for queued queries (normally: every block exits at once)
 //
 // HBM layout: scan plane fp16 [N][Dp] row-major, Dp = D rounded up to 64 (zero filled) so every row
 // is a whole number of 128-byte lines; exact plane = the scan plane when the bank is fp16-exact,
@@ -21,6 +19,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -28,13 +27,9 @@ namespace astts {
 
 static constexpr int kWave = 64;
 static constexpr int kScanThreads = 256;
-static constexpr int kQTile = 32;      // queries per MFMA tile
 static constexpr int kMaxQPerPass = 256;
-
-struct KnnCand64 {
-    double s;
-    int idx;
-};
+static constexpr int kSelTile = 2048;  // scores staged in LDS per selection tile
+static constexpr int kNoIdx = 0x7fffffff;
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -88,10 +83,90 @@ __device__ __forceinline__ double cos_from_parts(double dot, double qn, double b
     return isfinite(c) ? c : 0.0;
 }
 
+// Sorted top-C list distributed over the lanes of one wave: lane i holds the i-th best entry.
+template <typename T>
+struct TopList {
+    T s;
+    int idx;
+    __device__ __forceinline__ void init() {
+        s = -INFINITY;
+        idx = kNoIdx;
+    }
+    // bitonic sort of the 64 per-lane entries, best first
+    __device__ __forceinline__ void sort_desc(int lane) {
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                T os = __shfl_xor(s, j, 64);
+                int oi = __shfl_xor(idx, j, 64);
+                const bool up = (lane & k) == 0;     // this block ends best-first
+                const bool lower = (lane & j) == 0;  // lower lane of the pair
+                const bool other_better = better<T>(os, oi, s, idx);
+                const bool take = (up == lower) ? other_better : !other_better;
+                if (take) {
+                    s = os;
+                    idx = oi;
+                }
+            }
+        }
+    }
+    // insert (xs, xi) into the sorted list of length c (lanes >= c are scratch)
+    __device__ __forceinline__ void insert(T xs, int xi, int lane, int c) {
+        const bool mine_better = better<T>(s, idx, xs, xi) && lane < c;
+        const int pos = __popcll(__ballot(mine_better));
+        T ups = __shfl_up(s, 1, 64);
+        int upi = __shfl_up(idx, 1, 64);
+        if (lane == pos) {
+            s = xs;
+            idx = xi;
+        } else if (lane > pos) {
+            s = ups;
+            idx = upi;
+        }
+    }
+    // every lane offers one entry; those that beat the current c-th best are inserted
+    __device__ __forceinline__ void offer(T vs, int vi, bool valid, int lane, int c) {
+        T ws = __shfl(s, c - 1, 64);
+        int wi = __shfl(idx, c - 1, 64);
+        unsigned long long mask = __ballot(valid && better<T>(vs, vi, ws, wi));
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            T xs = __shfl(vs, src, 64);
+            int xi = __shfl(vi, src, 64);
+            insert(xs, xi, lane, c);
+        }
+    }
+    // first chunk of a wave: the list is empty, so sort the chunk instead of 64 serial inserts
+    __device__ __forceinline__ void seed(T vs, int vi, bool valid, int lane) {
+        s = valid ? vs : (T)-INFINITY;
+        idx = valid ? vi : kNoIdx;
+        sort_desc(lane);
+    }
+};
+
+// merge the per-wave lists (staged in LDS) into wave 0's list
+template <typename T>
+__device__ __forceinline__ void merge_lists(TopList<T>& tl, T* sh_s, int* sh_i, int c) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    sh_s[wid * 64 + lane] = tl.s;
+    sh_i[wid * 64 + lane] = tl.idx;
+    __syncthreads();
+    if (wid == 0) {
+        for (int w = 1; w < nw; ++w) {
+            T v = sh_s[w * 64 + lane];
+            int vi = sh_i[w * 64 + lane];
+            tl.offer(v, vi, lane < c && vi != kNoIdx, lane, c);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// bank construction
+// bank construction: one wave per row -- copy/convert into the padded planes, fp64 norm,
+// exactness + range flags
 // ------------------------------------------------------------------------------------------
-// one wave per row: copy/convert into the padded planes, fp64 norm, exactness + range flags
 template <typename SrcT>
 __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, int dp,
                                _Float16* __restrict__ plane16, float* __restrict__ plane32,
@@ -124,33 +199,27 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
 }
 
 // ------------------------------------------------------------------------------------------
-// 1. query preparation: one block per (padded) query row
+// 1. query preparation: one block per query row; block 0 also clears the fallback counter
 // ------------------------------------------------------------------------------------------
-__global__ void knn_prep_queries(const float* __restrict__ q, int nq, int d, int dp,
-                                 _Float16* __restrict__ qh, float* __restrict__ qf,
-                                 double* __restrict__ qn64, float* __restrict__ qscale) {
+__global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict__ q, int d, int dp,
+                                                        _Float16* __restrict__ qh,
+                                                        float* __restrict__ qf,
+                                                        double* __restrict__ qn64,
+                                                        float* __restrict__ qscale,
+                                                        int* __restrict__ nflag) {
     __shared__ float smax[4];
     __shared__ double ssum[4];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (row == 0 && tid == 0) *nflag = 0;
+    const float* s = q + (int64_t)row * d;
     _Float16* oh = qh + (int64_t)row * dp;
     float* of = qf + (int64_t)row * dp;
-    if (row >= nq) {  // padding rows of the last 32-query tile
-        for (int k = tid; k < dp; k += blockDim.x) {
-            oh[k] = (_Float16)0.0f;
-            of[k] = 0.0f;
-        }
-        if (tid == 0) {
-            qn64[row] = 0.0;
-            qscale[row] = 1.0f;
-        }
-        return;
-    }
-    const float* s = q + (int64_t)row * d;
     float mx = 0.0f;
     double acc = 0.0;
-    for (int k = tid; k < d; k += blockDim.x) {
-        float v = s[k];
+    for (int k = tid; k < dp; k += 256) {
+        float v = (k < d) ? s[k] : 0.0f;
+        of[k] = v;
         mx = fmaxf(mx, fabsf(v));
         acc = fma((double)v, (double)v, acc);
     }
@@ -163,7 +232,7 @@ __global__ void knn_prep_queries(const float* __restrict__ q, int nq, int d, int
     }
     __syncthreads();
     mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-    double tot = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    const double tot = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
     // power-of-two scale that puts max|q| in [2^13, 2^14): exact in fp32, keeps fp16 well inside
     // its normal range so the only rounding is the 11-bit significand
     float scale = 1.0f;
@@ -172,10 +241,9 @@ __global__ void knn_prep_queries(const float* __restrict__ q, int nq, int d, int
         frexpf(mx, &e);  // mx = m * 2^e, m in [0.5,1)
         scale = ldexpf(1.0f, 14 - e);
     }
-    for (int k = tid; k < dp; k += blockDim.x) {
-        float v = (k < d) ? s[k] : 0.0f;
+    for (int k = tid; k < dp; k += 256) {
+        float v = (k < d) ? s[k] : 0.0f;  // second read hits L1/L2
         oh[k] = (_Float16)(v * scale);
-        of[k] = v;
     }
     if (tid == 0) {
         qn64[row] = sqrt(tot);
@@ -189,12 +257,13 @@ __global__ void knn_prep_queries(const float* __restrict__ q, int nq, int d, int
 // line: bytes [64h, 64h+64).  Those are 4 MFMA k-steps of 8 halfs each.  The k order inside a line is
 // a permutation of the natural one, identical for A and B, which a dot product does not see.
 // Block = 4 waves that split the block's K range line by line and reduce through LDS.
+// Query rows past the group's last query are clamped to it (their results are never read).
 // ------------------------------------------------------------------------------------------
 template <int QT, int RT>
 __global__ __launch_bounds__(kScanThreads) void knn_scan(
     const _Float16* __restrict__ bank, const _Float16* __restrict__ qh,
     const float* __restrict__ inv_norm, float* __restrict__ s_part, int64_t n, int dp, int nld,
-    int qpad, int lines_per_split) {
+    int qpad, int nq_group, int lines_per_split) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3][QT*RT*16][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -221,7 +290,11 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
     }
     const _Float16* aptr[QT];
 #pragma unroll
-    for (int a = 0; a < QT; ++a) aptr[a] = qh + (int64_t)(a * 32 + r) * dp + h * 32;
+    for (int a = 0; a < QT; ++a) {
+        int qrow = a * 32 + r;
+        if (qrow >= nq_group) qrow = nq_group - 1;
+        aptr[a] = qh + (int64_t)qrow * dp + h * 32;
+    }
 
     for (int line = line_begin + wid; line < line_end; line += 4) {
         const int koff = line * 64;
@@ -271,7 +344,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
                     for (int w = 0; w < 3; ++w)
                         v += red[(size_t)w * (QT * RT * 16 * 64) + ((a * RT + b) * 16 + i) * 64 + lane];
                     const int qrow = a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // MFMA row = query
-                    if (col < nld)
+                    if (col < nld && qrow < nq_group)
                         s_part[((size_t)blockIdx.y * qpad + qrow) * nld + col] = v * inv;
                 }
             }
@@ -279,136 +352,97 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 }
 
 // ------------------------------------------------------------------------------------------
-// 3. selection: top-C of a score row by (score desc, row asc).  One block per query.
-// Each wave keeps a sorted list distributed over its lanes (lane i = i-th best) and inserts by
-// ballot; wave 0 then merges the four lists.
+// 3. selection: top-C of a score row by (score desc, row asc).  One block (4 waves) per query.
+// The K-split partial planes are summed while a 2048-score tile is staged in LDS (all loads of a
+// tile are independent, so their latency overlaps); each wave then filters its quarter of the tile
+// against its current c-th best and inserts the few survivors.
 // ------------------------------------------------------------------------------------------
-template <typename T>
-struct TopList {
-    T s;
-    int idx;
-    __device__ __forceinline__ void init() {
-        s = -INFINITY;
-        idx = 0x7fffffff;
-    }
-    // insert (xs, xi) into the wave-distributed sorted list of length c
-    __device__ __forceinline__ void insert(T xs, int xi, int lane, int c) {
-        const bool mine_better = better<T>(s, idx, xs, xi) && lane < c;
-        const int pos = __popcll(__ballot(mine_better));
-        T ups = __shfl_up(s, 1, 64);
-        int upi = __shfl_up(idx, 1, 64);
-        if (lane == pos) {
-            s = xs;
-            idx = xi;
-        } else if (lane > pos) {
-            s = ups;
-            idx = upi;
-        }
-    }
-    __device__ __forceinline__ void offer(T vs, int vi, bool valid, int lane, int c) {
-        T ws = __shfl(s, c - 1, 64);
-        int wi = __shfl(idx, c - 1, 64);
-        unsigned long long mask = __ballot(valid && better<T>(vs, vi, ws, wi));
-        while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            T xs = __shfl(vs, src, 64);
-            int xi = __shfl(vi, src, 64);
-            insert(xs, xi, lane, c);
-        }
-    }
-};
-
-template <typename T, typename LoadFn>
-__device__ __forceinline__ void block_select(LoadFn load, int64_t n, int c, T* sh_s, int* sh_i,
-                                             TopList<T>& out) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = blockDim.x >> 6;
-    TopList<T> tl;
-    tl.init();
-    for (int64_t base = (int64_t)wid * 64; base < n; base += (int64_t)nw * 64) {
-        const int64_t i = base + lane;
-        const bool valid = i < n;
-        T v = valid ? load(i) : (T)-INFINITY;
-        tl.offer(v, (int)i, valid, lane, c);
-    }
-    sh_s[wid * 64 + lane] = tl.s;
-    sh_i[wid * 64 + lane] = tl.idx;
-    __syncthreads();
-    if (wid == 0) {
-        for (int w = 1; w < nw; ++w) {
-            T v = sh_s[w * 64 + lane];
-            int vi = sh_i[w * 64 + lane];
-            tl.offer(v, vi, lane < c && vi != 0x7fffffff, lane, c);
-        }
-    }
-    out = tl;
-}
-
 __global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_part, int ksplit,
                                                   int qpad, int nld, int64_t n, int c,
                                                   int* __restrict__ cand_idx,
                                                   float* __restrict__ cand_s) {
+    __shared__ float tile[kSelTile];
     __shared__ float sh_s[256];
     __shared__ int sh_i[256];
     const int q = blockIdx.x;
-    auto load = [&](int64_t i) {
-        float v = 0.0f;
-        for (int ks = 0; ks < ksplit; ++ks) v += s_part[((size_t)ks * qpad + q) * nld + i];
-        return v;
-    };
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t plane = (size_t)qpad * nld;
+    const float* base = s_part + (size_t)q * nld;
     TopList<float> tl;
-    block_select<float>(load, n, c, sh_s, sh_i, tl);
-    if (threadIdx.x < c) {
-        cand_idx[q * 64 + threadIdx.x] = (tl.idx == 0x7fffffff) ? -1 : tl.idx;
-        cand_s[q * 64 + threadIdx.x] = tl.s;
+    tl.init();
+    bool seeded = false;
+    for (int64_t t0 = 0; t0 < n; t0 += kSelTile) {
+        float v[kSelTile / 256];
+#pragma unroll
+        for (int j = 0; j < kSelTile / 256; ++j) v[j] = 0.0f;
+        for (int ks = 0; ks < ksplit; ++ks) {
+#pragma unroll
+            for (int j = 0; j < kSelTile / 256; ++j) {
+                const int64_t i = t0 + j * 256 + tid;
+                if (i < n) v[j] += base[ks * plane + i];
+            }
+        }
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < kSelTile / 256; ++j) tile[j * 256 + tid] = v[j];
+        __syncthreads();
+#pragma unroll 1
+        for (int ch = 0; ch < kSelTile / 256; ++ch) {
+            const int li = wid * (kSelTile / 4) + ch * 64 + lane;
+            const int64_t i = t0 + li;
+            if (t0 + wid * (kSelTile / 4) + ch * 64 >= n) break;  // wave-uniform
+            const bool valid = i < n;
+            const float x = tile[li];
+            if (!seeded) {
+                tl.seed(x, (int)i, valid, lane);
+                seeded = true;
+            } else {
+                tl.offer(x, (int)i, valid, lane, c);
+            }
+        }
+    }
+    merge_lists<float>(tl, sh_s, sh_i, c);
+    if (tid < c) {
+        cand_idx[q * 64 + tid] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        cand_s[q * 64 + tid] = tl.s;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// 4. fp64 re-score: one wave per (query, candidate)
+// 4. fp64 re-score of the candidates (16 waves, one candidate each per round), then wave 0 orders
+// them by the exact score, emits the top-k and certifies the candidate set.
 // ------------------------------------------------------------------------------------------
 template <typename RowT>
-__global__ __launch_bounds__(64) void knn_rescore(const float* __restrict__ qf,
-                                                  const double* __restrict__ qn64,
-                                                  const RowT* __restrict__ plane,
-                                                  const double* __restrict__ norm64, int dp, int c,
-                                                  const int* __restrict__ cand_idx,
-                                                  double* __restrict__ cand_cos) {
-    const int q = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= c) return;
-    const int idx = cand_idx[q * 64 + ci];
-    if (idx < 0) {
-        if (lane == 0) cand_cos[q * 64 + ci] = -INFINITY;
-        return;
+__global__ __launch_bounds__(1024) void knn_rescore_finalize(
+    const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
+    const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
+    const int* __restrict__ cand_idx, const float* __restrict__ cand_s, double err_bound,
+    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
+    int* __restrict__ nflag, int* __restrict__ flagged) {
+    __shared__ double sh_cos[64];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const double qn = qn64[q];
+    for (int ci = wid; ci < c; ci += 16) {
+        const int idx = cand_idx[q * 64 + ci];
+        double cs = -INFINITY;
+        if (idx >= 0) {
+            const double dot = wave_dot64<RowT>(qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
+            cs = cos_from_parts(dot, qn, norm64[idx]);
+        }
+        if (lane == 0) sh_cos[ci] = cs;
     }
-    double dot = wave_dot64<RowT>(qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
-    if (lane == 0) cand_cos[q * 64 + ci] = cos_from_parts(dot, qn64[q], norm64[idx]);
-}
-
-// ------------------------------------------------------------------------------------------
-// 5. finalize: order by fp64 score, emit top-k, certify, queue uncertified queries
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void knn_finalize(const int* __restrict__ cand_idx,
-                                                   const float* __restrict__ cand_s,
-                                                   const double* __restrict__ cand_cos,
-                                                   const double* __restrict__ qn64,
-                                                   const float* __restrict__ qscale, int64_t n,
-                                                   int c, int k, double err_bound, int force_exact,
-                                                   int64_t* __restrict__ out_idx,
-                                                   float* __restrict__ out_score,
-                                                   int* __restrict__ nflag,
-                                                   int* __restrict__ flagged) {
-    const int q = blockIdx.x, lane = threadIdx.x;
+    __syncthreads();
+    if (wid != 0) return;
     const bool valid = lane < c;
-    int idx = valid ? cand_idx[q * 64 + lane] : -1;
-    double cs = (valid && idx >= 0) ? cand_cos[q * 64 + lane] : -INFINITY;
-    float ap = (valid && idx >= 0) ? cand_s[q * 64 + lane] : INFINITY;
+    const int idx = valid ? cand_idx[q * 64 + lane] : -1;
     const bool live = valid && idx >= 0;
+    const double cs = live ? sh_cos[lane] : -INFINITY;
+    const float ap = live ? cand_s[q * 64 + lane] : INFINITY;
     int rank = 0;
     for (int j = 0; j < c; ++j) {
-        double sj = __shfl(cs, j, 64);
-        int ij = __shfl(idx, j, 64);
+        const double sj = __shfl(cs, j, 64);
+        const int ij = __shfl(idx, j, 64);
         if (ij >= 0 && j != lane && better<double>(sj, ij, cs, idx)) ++rank;
     }
     const int kk = (int64_t)k < n ? k : (int)n;  // hits that exist
@@ -420,8 +454,7 @@ __global__ __launch_bounds__(64) void knn_finalize(const int* __restrict__ cand_
         out_idx[(int64_t)q * k + lane] = -1;
         out_score[(int64_t)q * k + lane] = -INFINITY;
     }
-    // certification
-    float tau = ap;  // min approx over live candidates
+    float tau = ap;  // smallest approximate score among the candidates bounds every non-candidate
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tau = fminf(tau, __shfl_xor(tau, off, 64));
     double kth = (live && rank == kk - 1) ? cs : -INFINITY;
@@ -432,61 +465,57 @@ __global__ __launch_bounds__(64) void knn_finalize(const int* __restrict__ cand_
         if (n <= (int64_t)c) {
             certified = true;  // every row is a candidate
         } else {
-            const double denom = (double)qscale[q] * qn64[q];
+            const double denom = (double)qscale[q] * qn;
             const double tau_cos = denom > 0.0 ? (double)tau / denom : INFINITY;
             certified = isfinite(tau_cos) && (kth > tau_cos + err_bound);
         }
         if (!certified || force_exact) {
-            int slot = atomicAdd(nflag, 1);
+            const int slot = atomicAdd(nflag, 1);
             flagged[slot] = q;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// 6./7. exact path for queued queries
+// 5. exact path: block f serves the f-th queued query -- fp64 cosine against every row with the
+// same wave_dot64 as the re-score (so both paths return identical scores), exact top-k.
+// Rare by construction; one block streams the whole bank.
 // ------------------------------------------------------------------------------------------
 template <typename RowT>
-__global__ __launch_bounds__(256) void knn_exact_scan(const float* __restrict__ qf,
-                                                      const double* __restrict__ qn64,
-                                                      const RowT* __restrict__ plane,
-                                                      const double* __restrict__ norm64, int64_t n,
-                                                      int dp, int nld, const int* __restrict__ nflag,
-                                                      const int* __restrict__ flagged,
-                                                      double* __restrict__ s64) {
-    const int nf = *nflag;
-    if (nf == 0) return;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
-    if (row >= n) return;
-    const RowT* rp = plane + row * (int64_t)dp;
-    const double bn = norm64[row];
-    for (int f = 0; f < nf; ++f) {
-        const int q = flagged[f];
-        double dot = wave_dot64<RowT>(qf + (int64_t)q * dp, rp, dp, lane);
-        if (lane == 0) s64[(size_t)f * nld + row] = cos_from_parts(dot, qn64[q], bn);
-    }
-}
-
-__global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict__ s64, int nld,
-                                                        int64_t n, int k,
-                                                        const int* __restrict__ nflag,
-                                                        const int* __restrict__ flagged,
-                                                        int64_t* __restrict__ out_idx,
-                                                        float* __restrict__ out_score) {
+__global__ __launch_bounds__(256) void knn_exact(const float* __restrict__ qf,
+                                                 const double* __restrict__ qn64,
+                                                 const RowT* __restrict__ plane,
+                                                 const double* __restrict__ norm64, int64_t n, int dp,
+                                                 int k, const int* __restrict__ nflag,
+                                                 const int* __restrict__ flagged,
+                                                 int64_t* __restrict__ out_idx,
+                                                 float* __restrict__ out_score) {
     __shared__ double sh_s[256];
     __shared__ int sh_i[256];
     const int f = blockIdx.x;
     if (f >= *nflag) return;
     const int q = flagged[f];
-    const double* row = s64 + (size_t)f * nld;
-    auto load = [&](int64_t i) { return row[i]; };
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* qrow = qf + (int64_t)q * dp;
+    const double qn = qn64[q];
     TopList<double> tl;
-    block_select<double>(load, n, k, sh_s, sh_i, tl);
-    if (threadIdx.x < k) {
-        const bool ok = tl.idx != 0x7fffffff;
-        out_idx[(int64_t)q * k + threadIdx.x] = ok ? tl.idx : -1;
-        out_score[(int64_t)q * k + threadIdx.x] = ok ? (float)tl.s : -INFINITY;
+    tl.init();
+    for (int64_t base = (int64_t)wid * 64; base < n; base += 4 * 64) {
+        double mine = -INFINITY;
+        const int64_t lim = (n - base) < 64 ? (n - base) : 64;
+        for (int j = 0; j < lim; ++j) {
+            const int64_t row = base + j;
+            const double dot = wave_dot64<RowT>(qrow, plane + row * (int64_t)dp, dp, lane);
+            const double cs = cos_from_parts(dot, qn, norm64[row]);
+            if (lane == j) mine = cs;
+        }
+        tl.offer(mine, (int)(base + lane), lane < lim, lane, k);
+    }
+    merge_lists<double>(tl, sh_s, sh_i, k);
+    if (tid < k) {
+        const bool ok = tl.idx != kNoIdx;
+        out_idx[(int64_t)q * k + tid] = ok ? tl.idx : -1;
+        out_score[(int64_t)q * k + tid] = ok ? (float)tl.s : -INFINITY;
     }
 }
 
@@ -517,8 +546,7 @@ namespace {
 
 struct KnnPlan {
     int qt, rt, ksplit, lines_per_split, tiles, qpad, c;
-    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs,
-        off_ccos, off_s64, total;
+    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, total;
 };
 
 KnnPlan make_plan(const astts_knn* h, int nq, int k) {
@@ -535,6 +563,8 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     if (ks_max < 1) ks_max = 1;
     if (ks > ks_max) ks = ks_max;
     if (ks < 1) ks = 1;
+    static const int ks_env = [] { const char* e = getenv("ASTTS_KNN_KSPLIT"); return e ? atoi(e) : 0; }();
+    if (ks_env > 0) ks = ks_env < ks_max ? ks_env : ks_max;  // tuning override
     p.lines_per_split = (int)cdiv(total_lines, ks);
     p.ksplit = (int)cdiv(total_lines, p.lines_per_split);
     p.c = k <= 8 ? 16 : 64;
@@ -544,24 +574,21 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
         o = align_up(o + bytes, 256);
         return at;
     };
-    const int nqpad_all = (int)align_up((size_t)nq, 32) + 32 * 8;  // room for the last group's tile padding
     p.off_nflag = take(256);
     p.off_flagged = take(sizeof(int) * (size_t)nq);
-    p.off_qh = take(sizeof(_Float16) * (size_t)nqpad_all * h->dp);
-    p.off_qf = take(sizeof(float) * (size_t)nqpad_all * h->dp);
-    p.off_qn = take(sizeof(double) * (size_t)nqpad_all);
-    p.off_qscale = take(sizeof(float) * (size_t)nqpad_all);
+    p.off_qh = take(sizeof(_Float16) * (size_t)nq * h->dp);
+    p.off_qf = take(sizeof(float) * (size_t)nq * h->dp);
+    p.off_qn = take(sizeof(double) * (size_t)nq);
+    p.off_qscale = take(sizeof(float) * (size_t)nq);
     p.off_spart = take(sizeof(float) * (size_t)p.ksplit * p.qpad * h->nld);
     p.off_cidx = take(sizeof(int) * (size_t)nq * 64);
     p.off_cs = take(sizeof(float) * (size_t)nq * 64);
-    p.off_ccos = take(sizeof(double) * (size_t)nq * 64);
-    p.off_s64 = take(sizeof(double) * (size_t)nq * h->nld);
     p.total = o;
     return p;
 }
 
 template <int QT, int RT>
-int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, float* spart,
+int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq_group, float* spart,
                 hipStream_t st) {
     dim3 grid(p.tiles, p.ksplit);
     size_t lds = (size_t)3 * QT * RT * 16 * 64 * sizeof(float);
@@ -578,7 +605,7 @@ int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, float*
         }
     }
     hipLaunchKernelGGL((knn_scan<QT, RT>), grid, dim3(kScanThreads), lds, st, h->plane16, qh,
-                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, p.lines_per_split);
+                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -592,7 +619,7 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     ASTTS_REQUIRE(out != nullptr, ASTTS_ERR_INVALID, "astts_knn_create: out is null");
     *out = nullptr;
     ASTTS_REQUIRE(bank != nullptr, ASTTS_ERR_INVALID, "astts_knn_create: bank is null");
-    ASTTS_REQUIRE(n >= 1 && n <= 0x7fffffff - 1024, ASTTS_ERR_INVALID,
+    ASTTS_REQUIRE(n >= 1 && n <= 0x7fffffff - 4096, ASTTS_ERR_INVALID,
                   "astts_knn_create: n=%lld out of range", (long long)n);
     ASTTS_REQUIRE(d >= 1 && d <= (1 << 20), ASTTS_ERR_INVALID, "astts_knn_create: d=%d out of range", d);
     ASTTS_REQUIRE(dtype == ASTTS_DTYPE_F16 || dtype == ASTTS_DTYPE_F32, ASTTS_ERR_INVALID,
@@ -659,7 +686,7 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
         p32 = nullptr;
     }
 #undef KNN_TRY
-    // Error bound of the fp16 scan on the cosine scale (see DESIGN.md "certification"):
+    // Error bound of the fp16 scan on the cosine scale (DESIGN.md "certification"):
     //   query rounded to fp16 (11-bit significand, power-of-two pre-scale): 2^-11 (Cauchy-Schwarz)
     //   fp32 accumulation of dp exact products inside the MFMA chain + cross-wave/ksplit adds: 2*dp*2^-24
     //   bank rounded to fp16 when it is not fp16-exact: 2^-11
@@ -718,13 +745,9 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
     float* spart = (float*)(ws + p.off_spart);
     int* cidx = (int*)(ws + p.off_cidx);
     float* cs = (float*)(ws + p.off_cs);
-    double* ccos = (double*)(ws + p.off_ccos);
-    double* s64 = (double*)(ws + p.off_s64);
 
-    ASTTS_CHECK_HIP(hipMemsetAsync(nflag, 0, 256, st));
-    const int nq_rows = (int)align_up((size_t)nq, 32) + 32 * 8;  // also zero the tile padding rows
-    hipLaunchKernelGGL(knn_prep_queries, dim3(nq_rows), dim3(256), 0, st, queries, nq, h->d, h->dp,
-                       qh, qf, qn, qscale);
+    hipLaunchKernelGGL(knn_prep_queries, dim3(nq), dim3(256), 0, st, queries, h->d, h->dp, qh, qf, qn,
+                       qscale, nflag);
     ASTTS_CHECK_LAUNCH();
 
     for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {
@@ -734,12 +757,12 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
         const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
         if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
         switch (p.qt * 10 + p.rt) {
-            case 11: rc = launch_scan<1, 1>(h, p, qh_g, spart, st); break;
-            case 14: rc = launch_scan<1, 4>(h, p, qh_g, spart, st); break;
-            case 21: rc = launch_scan<2, 1>(h, p, qh_g, spart, st); break;
-            case 22: rc = launch_scan<2, 2>(h, p, qh_g, spart, st); break;
-            case 41: rc = launch_scan<4, 1>(h, p, qh_g, spart, st); break;
-            case 81: rc = launch_scan<8, 1>(h, p, qh_g, spart, st); break;
+            case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, st); break;
+            case 14: rc = launch_scan<1, 4>(h, p, qh_g, qg, spart, st); break;
+            case 21: rc = launch_scan<2, 1>(h, p, qh_g, qg, spart, st); break;
+            case 22: rc = launch_scan<2, 2>(h, p, qh_g, qg, spart, st); break;
+            case 41: rc = launch_scan<4, 1>(h, p, qh_g, qg, spart, st); break;
+            case 81: rc = launch_scan<8, 1>(h, p, qh_g, qg, spart, st); break;
             default:
                 set_error("astts_knn_search: no scan variant for qt=%d rt=%d", p.qt, p.rt);
                 return ASTTS_ERR_INVALID;
@@ -753,29 +776,22 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
                            h->n, p.c, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
         ASTTS_CHECK_LAUNCH();
     }
+    const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
     if (h->exact16) {
-        hipLaunchKernelGGL((knn_rescore<_Float16>), dim3(p.c, nq), dim3(64), 0, st, qf, qn, h->plane16,
-                           h->norm64, h->dp, p.c, cidx, ccos);
+        hipLaunchKernelGGL((knn_rescore_finalize<_Float16>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
+                           h->plane16, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
+                           out_idx, out_score, nflag, flagged);
+        ASTTS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((knn_exact<_Float16>), dim3(nq), dim3(256), 0, st, qf, qn, h->plane16,
+                           h->norm64, h->n, h->dp, k, nflag, flagged, out_idx, out_score);
     } else {
-        hipLaunchKernelGGL((knn_rescore<float>), dim3(p.c, nq), dim3(64), 0, st, qf, qn, h->plane32,
-                           h->norm64, h->dp, p.c, cidx, ccos);
+        hipLaunchKernelGGL((knn_rescore_finalize<float>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
+                           h->plane32, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
+                           out_idx, out_score, nflag, flagged);
+        ASTTS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((knn_exact<float>), dim3(nq), dim3(256), 0, st, qf, qn, h->plane32,
+                           h->norm64, h->n, h->dp, k, nflag, flagged, out_idx, out_score);
     }
-    ASTTS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_finalize, dim3(nq), dim3(64), 0, st, cidx, cs, ccos, qn, qscale, h->n, p.c,
-                       k, h->err_bound, (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0, out_idx, out_score,
-                       nflag, flagged);
-    ASTTS_CHECK_LAUNCH();
-    dim3 egrid((unsigned)cdiv(h->n, 4));
-    if (h->exact16) {
-        hipLaunchKernelGGL((knn_exact_scan<_Float16>), egrid, dim3(256), 0, st, qf, qn, h->plane16,
-                           h->norm64, h->n, h->dp, h->nld, nflag, flagged, s64);
-    } else {
-        hipLaunchKernelGGL((knn_exact_scan<float>), egrid, dim3(256), 0, st, qf, qn, h->plane32,
-                           h->norm64, h->n, h->dp, h->nld, nflag, flagged, s64);
-    }
-    ASTTS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_exact_select, dim3(nq), dim3(256), 0, st, s64, h->nld, h->n, k, nflag,
-                       flagged, out_idx, out_score);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
