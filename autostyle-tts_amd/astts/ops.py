@@ -1,5 +1,292 @@
-"""Host side of the astts_op_* tensor operators (synthesis path).  Filled in as kernels land."""
+"""Host side of the astts_op_* operators: thin ctypes wrappers over libastts.so.
+
+torch is used for device memory and streams only; every function here enqueues hand-written HIP
+kernels on the current stream and returns torch tensors that alias freshly allocated HBM.
+Layout convention: fp32 activations, channels-last ``[B, T, C]`` (or ``[rows, C]``), contiguous.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
 from . import _lib
 
-_SIGS = {}
+_SIGS = {
+    "astts_op_pack_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_gemm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, c_int32, c_float, c_float, c_void_p]),
+    "astts_op_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_groupnorm_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "astts_op_groupnorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                     c_int32, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p]),
+    "astts_op_elementwise": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                       c_int32, c_float, c_float, c_void_p]),
+    "astts_op_embedding": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_interp_linear": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_time_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_attn_relpos": (c_int32, [c_void_p] * 8 + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
+    "astts_op_attn_mha": (c_int32, [c_void_p] * 5 + [c_int32] * 6 + [c_float, c_void_p]),
+    "astts_op_nsf_source_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "astts_op_nsf_source": (c_int32, [c_void_p] * 6 + [c_int32] * 4 + [c_float] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "astts_op_stft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "astts_op_istft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p]),
+    "astts_op_ras_sample": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p]),
+}
 _lib.register_signatures(_SIGS)
+
+ACT = {"none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "mish": 4, "elu": 5, "tanh": 6, "leaky": 7}
+EL_SNAKE, EL_LEAKY, EL_ADD, EL_MUL_ROWMASK, EL_ADD_BC, EL_SCALE, EL_CFG_EULER, EL_MISH, EL_SILU, EL_CLAMP, EL_TANH, EL_ELU = range(12)
+
+
+def _L():
+    return _lib.load()
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.is_cuda and t.dtype == torch.float32, (t.device, t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class PackedWeight:
+    """fp16 weight image for astts_op_gemm: ``[n_pad, taps, cin_pad]`` (K contiguous, zero padded)."""
+
+    def __init__(self, w: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None):
+        """``w``: fp32 ``[n, cin]`` (linear) or ``[n, taps, cin]`` (conv, cin innermost)."""
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        if w.dim() == 2:
+            w = w[:, None, :]
+        assert w.dim() == 3
+        self.n, self.taps, self.cin = (int(s) for s in w.shape)
+        self.cin_pad = _up(self.cin, 64)
+        self.n_pad = _up(self.n, 128)
+        src = w.to(device=device, dtype=torch.float32).contiguous()
+        self.data = torch.empty((self.n_pad, self.taps, self.cin_pad), dtype=torch.float16, device=device)
+        _lib.check(_L().astts_op_pack_weight(src.data_ptr(), self.data.data_ptr(), self.n, self.taps, self.cin,
+                                             self.n_pad, self.cin_pad, _st()))
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def from_conv1d(weight: torch.Tensor, bias=None, device=None) -> "PackedWeight":
+        """torch Conv1d weight ``[cout, cin, k]`` -> taps-major ``[cout, k, cin]``."""
+        return PackedWeight(weight.permute(0, 2, 1).contiguous(), bias, device)
+
+    @staticmethod
+    def from_conv_transpose1d(weight: torch.Tensor, bias, stride: int, device=None) -> "PackedWeight":
+        """torch ConvTranspose1d weight ``[cin, cout, k]`` with k == 2*stride -> phase-decomposed
+        GEMM weight ``[stride*cout, 2, cin]``: output phase r of input step q uses taps
+        x[q] * W[:, :, r] + x[q-1] * W[:, :, r + stride]  (see conv_transpose1d)."""
+        cin, cout, k = (int(s) for s in weight.shape)
+        assert k == 2 * stride, "phase decomposition implemented for kernel == 2*stride"
+        w = weight.to(torch.float32)
+        # gemm taps: tap 0 reads row (q - 1) [pad = 1], tap 1 reads row q
+        w0 = w[:, :, stride:].permute(2, 1, 0)  # [r, cout, cin] for x[q-1]
+        w1 = w[:, :, :stride].permute(2, 1, 0)  # [r, cout, cin] for x[q]
+        packed = torch.stack([w0, w1], dim=2).reshape(stride * cout, 2, cin)  # n = r*cout + co
+        b = None if bias is None else bias.to(torch.float32).repeat(stride)
+        pw = PackedWeight(packed, b, device)
+        pw.ct_stride, pw.ct_cout = stride, cout
+        return pw
+
+
+def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional[torch.Tensor] = None,
+         row_scale: Optional[torch.Tensor] = None, alpha: float = 1.0, slope: float = 0.1,
+         t_in: Optional[int] = None, t_out: Optional[int] = None, stride: int = 1, dil: int = 1, pad: int = 0,
+         out: Optional[torch.Tensor] = None, use_bias: bool = True) -> torch.Tensor:
+    """``x``: ``[..., cin]`` fp32 (rows = batch*time); conv geometry via t_in/t_out/stride/dil/pad."""
+    x = _f32(x)
+    cin = x.shape[-1]
+    assert cin == w.cin, (cin, w.cin)
+    rows_in = x.numel() // cin
+    if t_in is None:
+        t_in = t_out = rows_in
+        batches = 1
+    else:
+        batches = rows_in // t_in
+        assert batches * t_in == rows_in
+    m = batches * t_out
+    if out is None:
+        out = torch.empty((m, w.n), dtype=torch.float32, device=x.device)
+    ldc = out.stride(0) if out.dim() == 2 else out.stride(-2)
+    ldr = 0
+    if residual is not None:
+        residual = _f32(residual)
+        ldr = residual.shape[-1]
+    _lib.check(_L().astts_op_gemm(x.data_ptr(), w.data.data_ptr(), _p(w.bias) if use_bias else None, _p(residual),
+                                  _p(row_scale), out.data_ptr(), m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
+                                  t_in, t_out, stride, dil, pad, ACT[act], alpha, slope, _st()))
+    return out
+
+
+def linear(x: torch.Tensor, w: PackedWeight, act: str = "none", residual=None, alpha: float = 1.0) -> torch.Tensor:
+    y = gemm(x.reshape(-1, x.shape[-1]), w, act=act, residual=None if residual is None else residual.reshape(-1, w.n),
+             alpha=alpha)
+    return y.view(*x.shape[:-1], w.n)
+
+
+def conv1d(x: torch.Tensor, w: PackedWeight, stride: int = 1, dil: int = 1, pad: int = 0, act: str = "none",
+           residual=None, alpha: float = 1.0, slope: float = 0.1) -> torch.Tensor:
+    """``x``: ``[B, T, Cin]`` -> ``[B, T_out, Cout]`` (nn.Conv1d semantics on the time axis)."""
+    b, t, _ = x.shape
+    k = w.taps
+    t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y = gemm(x, w, act=act, residual=residual, alpha=alpha, slope=slope, t_in=t, t_out=t_out, stride=stride, dil=dil, pad=pad)
+    return y.view(b, t_out, w.n)
+
+
+def conv_transpose1d(x: torch.Tensor, w: PackedWeight, padding: int) -> torch.Tensor:
+    """nn.ConvTranspose1d(kernel = 2*stride, stride, padding) on ``[B, T, Cin]`` -> ``[B, stride*T, Cout]``
+    (for padding == stride//2).  Phase decomposition: one GEMM over T+1 steps with two taps producing
+    ``stride`` output phases per step, then a shifted view."""
+    b, t, _ = x.shape
+    s, cout = w.ct_stride, w.ct_cout
+    y = gemm(x, w, t_in=t, t_out=t + 1, stride=1, dil=1, pad=1)  # [B*(T+1), s*cout]
+    y = y.view(b, (t + 1) * s, cout)
+    t_full = (t - 1) * s - 2 * padding + 2 * s
+    return y[:, padding:padding + t_full, :].contiguous()
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    x = _f32(x)
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_L().astts_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                       x.numel() // c, c, c, c, eps, _st()))
+    return y
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-5,
+              lens: Optional[torch.Tensor] = None, mish: bool = False, add_bc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _f32(x)
+    b, t, c = x.shape
+    need = int(_L().astts_op_groupnorm_workspace_bytes(b, t, groups))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(_L().astts_op_groupnorm(x.data_ptr(), _p(lens), gamma.data_ptr(), beta.data_ptr(), _p(add_bc),
+                                       y.data_ptr(), b, t, c, groups, eps, 1 if mish else 0, ws.data_ptr(), need, _st()))
+    return y
+
+
+def elementwise(op: int, x: torch.Tensor, z=None, p0=None, lens=None, s: float = 0.0, s2: float = 0.0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _f32(x)
+    c = x.shape[-1]
+    t = x.shape[-2] if x.dim() >= 2 else 1
+    y = out if out is not None else torch.empty_like(x)
+    _lib.check(_L().astts_op_elementwise(op, x.data_ptr(), _p(z), _p(p0), _p(lens), y.data_ptr(), x.numel(), t, c,
+                                         s, s2, _st()))
+    return y
+
+
+def embedding(table: torch.Tensor, ids: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    ids = ids.to(torch.int32).contiguous()
+    c = table.shape[1]
+    y = torch.empty((*ids.shape, c), dtype=torch.float32, device=table.device)
+    _lib.check(_L().astts_op_embedding(table.data_ptr(), ids.data_ptr(), y.data_ptr(), ids.numel(), c, c,
+                                       table.shape[0], scale, _st()))
+    return y
+
+
+def interp_linear(x: torch.Tensor, t_out: int) -> torch.Tensor:
+    x = _f32(x)
+    b, t, c = x.shape
+    y = torch.empty((b, t_out, c), dtype=torch.float32, device=x.device)
+    _lib.check(_L().astts_op_interp_linear(x.data_ptr(), y.data_ptr(), b, t, t_out, c, _st()))
+    return y
+
+
+def time_embedding(t: torch.Tensor, dim: int, scale: float = 1000.0) -> torch.Tensor:
+    t = _f32(t)
+    y = torch.empty((t.numel(), dim), dtype=torch.float32, device=t.device)
+    _lib.check(_L().astts_op_time_embedding(t.data_ptr(), y.data_ptr(), t.numel(), dim, scale, _st()))
+    return y
+
+
+def attn_relpos(q, k, v, pos, bias_u, bias_v, heads: int, lens=None, q_pos0: int = 0, pos_center: int = 0,
+                causal: bool = False, time_major: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q: [B, Tq, *] (or [Tq, B, *] when time_major) strided view, k/v: [B, Tk, *] / [Tk, B, *];
+    head h occupies columns h*64..h*64+63 of each view."""
+    if time_major:
+        tq, b, tk = q.shape[0], q.shape[1], k.shape[0]
+        ldq, q_bs, ldk, k_bs = q.stride(0), q.stride(1), k.stride(0), k.stride(1)
+        if out is None:
+            out = torch.empty((tq, b, heads * 64), dtype=torch.float32, device=q.device)
+        ldo, o_bs = out.stride(0), out.stride(1)
+    else:
+        b, tq, tk = q.shape[0], q.shape[1], k.shape[1]
+        ldq, q_bs, ldk, k_bs = q.stride(1), q.stride(0), k.stride(1), k.stride(0)
+        if out is None:
+            out = torch.empty((b, tq, heads * 64), dtype=torch.float32, device=q.device)
+        ldo, o_bs = out.stride(1), out.stride(0)
+    assert v.stride() == k.stride()
+    _lib.check(_L().astts_op_attn_relpos(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), bias_u.data_ptr(),
+                                         bias_v.data_ptr(), _p(lens), out.data_ptr(), b, heads, tq, tk, ldq, ldk, ldo,
+                                         pos.stride(0), q_bs, k_bs, o_bs, q_pos0, pos_center, 1 if causal else 0,
+                                         1.0 / math.sqrt(64.0), _st()))
+    return out
+
+
+def attn_mha(q, k, v, heads: int, lens=None) -> torch.Tensor:
+    b, t = q.shape[0], q.shape[1]
+    out = torch.empty((b, t, heads * 64), dtype=torch.float32, device=q.device)
+    assert q.stride(0) == t * q.stride(1) and k.stride(0) == t * k.stride(1)
+    _lib.check(_L().astts_op_attn_mha(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(lens), out.data_ptr(), b, heads, t,
+                                      q.stride(1), k.stride(1), heads * 64, 1.0 / math.sqrt(64.0), _st()))
+    return out
+
+
+def nsf_source(f0, phase0, noise, lin_w, lin_b, upsample: int, sample_rate: float, sine_amp: float, noise_std: float,
+               voiced_threshold: float) -> torch.Tensor:
+    b, tm = f0.shape
+    nh = phase0.shape[1]
+    need = int(_L().astts_op_nsf_source_workspace_bytes(b, tm))
+    ws = torch.empty(need, dtype=torch.uint8, device=f0.device)
+    out = torch.empty((b, tm * upsample), dtype=torch.float32, device=f0.device)
+    _lib.check(_L().astts_op_nsf_source(_f32(f0).data_ptr(), _f32(phase0).data_ptr(), _f32(noise).data_ptr(),
+                                        _f32(lin_w).data_ptr(), _f32(lin_b).data_ptr(), out.data_ptr(), b, tm, upsample,
+                                        nh, sample_rate, sine_amp, noise_std, voiced_threshold, ws.data_ptr(), need, _st()))
+    return out
+
+
+def stft16(x: torch.Tensor) -> torch.Tensor:
+    x = _f32(x)
+    b, n = x.shape
+    y = torch.empty((b, n // 4 + 1, 18), dtype=torch.float32, device=x.device)
+    _lib.check(_L().astts_op_stft16(x.data_ptr(), y.data_ptr(), b, n, _st()))
+    return y
+
+
+def istft16(y: torch.Tensor, mag_clip: float = 100.0, audio_limit: float = 0.99) -> torch.Tensor:
+    y = _f32(y)
+    b, f, _ = y.shape
+    wav = torch.empty((b, 4 * (f - 1)), dtype=torch.float32, device=y.device)
+    _lib.check(_L().astts_op_istft16(y.data_ptr(), wav.data_ptr(), b, f, mag_clip, audio_limit, _st()))
+    return wav
+
+
+def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: float, win_size: int, tau_r: float,
+               eos_id: int, ignore_eos: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    logits = _f32(logits)
+    b, v = logits.shape
+    if out is None:
+        out = torch.empty((b,), dtype=torch.int32, device=logits.device)
+    _lib.check(_L().astts_op_ras_sample(logits.data_ptr(), _p(history), _f32(uniforms).data_ptr(), out.data_ptr(), b, v,
+                                        hist_len, history.stride(0) if history is not None else 0, top_k, top_p,
+                                        win_size, tau_r, eos_id, 1 if ignore_eos else 0, _st()))
+    return out

@@ -1,0 +1,386 @@
+// ops_attention.hip -- attention operators of the synthesis path (gfx950), head dim 64.
+//
+//   attn_relpos         espnet relative-position attention (text encoder, token encoder, LM prefill):
+//                       score(i,j) = ((q_i+u).k_j + (q_i+v).p_{i-j}) / sqrt(dh), optional causal mask.
+//                       LDS-tiled fp32 VALU kernel (exact fp32; sequences here are <= ~500).
+//   attn_relpos_decode  one new query per (batch, head) against the KV cache (LM decode step).
+//   attn_mha_flash      plain masked MHA of the flow estimator's transformer blocks: flash-style,
+//                       fp16 MFMA 32x32x16 with fp32 softmax/accumulate.  S^T = K Q^T keeps the
+//                       query on the lane, so the online softmax is lane-local and P^T feeds the
+//                       second MFMA straight from the accumulator registers (no LDS round trip).
+//
+// Replaces cosyvoice RelPositionMultiHeadedAttention / diffusers Attention inside the reference's
+// CosyVoice calls (tts_with_rag.py:195); third-party code, restated from the published architecture.
+#include "common.h"
+
+namespace astts {
+
+static constexpr int DH = 64;
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_add_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct RelPosArgs {
+    const float* q;    // [B, Tq, ldq]  (+ head*64)
+    const float* k;    // [B, Tk, ldk]
+    const float* v;    // [B, Tk, ldk]
+    const float* pos;  // [2*pos_center+1... rows][H*64]: row (rel + pos_center) holds linear_pos(pe(rel))
+    const float* bias_u;
+    const float* bias_v;
+    const int* lens;   // [B] valid keys (null -> Tk)
+    float* out;        // [B, Tq, ldo]
+    int b, h, tq, tk, ldq, ldk, ldo, ldp;
+    int64_t q_bs, k_bs, o_bs;  // batch strides (elements): batch-major [B,T,*] or time-major [T,B,*] both work
+    int q_pos0;        // absolute position of query row 0 (Tk - Tq for cached decode)
+    int pos_center;
+    int causal;
+    float scale;
+};
+
+static constexpr int RP_QB = 16;  // query rows per block
+static constexpr int RP_KB = 64;  // keys per tile
+static constexpr int RP_LD = 65;  // padded LDS row
+
+__global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
+    __shared__ float sk[RP_KB * RP_LD];
+    __shared__ float sv[RP_KB * DH];
+    __shared__ float sp[(RP_KB + RP_QB - 1) * RP_LD];
+    __shared__ float squ[RP_QB][DH];
+    __shared__ float sqv[RP_QB][DH];
+    __shared__ float sprob[4][RP_KB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int i0 = qt * RP_QB;
+    const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
+    const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
+    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH;
+    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH;
+    // q + u, q + v for the block's query rows
+    for (int e = tid; e < RP_QB * DH; e += 256) {
+        const int r = e >> 6, d = e & 63;
+        const int i = min(i0 + r, a.tq - 1);
+        const float qv = qb[(int64_t)i * a.ldq + d];
+        squ[r][d] = (qv + a.bias_u[head * DH + d]) * a.scale;
+        sqv[r][d] = (qv + a.bias_v[head * DH + d]) * a.scale;
+    }
+    float m_run[4], l_run[4], o_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m_run[r] = -INFINITY;
+        l_run[r] = 0.0f;
+        o_run[r] = 0.0f;
+    }
+    int kmax = len;  // keys needed by this block
+    if (a.causal) kmax = min(len, a.q_pos0 + i0 + RP_QB);
+    for (int j0 = 0; j0 < kmax; j0 += RP_KB) {
+        __syncthreads();
+        for (int e = tid; e < RP_KB * DH; e += 256) {
+            const int r = e >> 6, d = e & 63;
+            const int j = j0 + r;
+            const bool ok = j < len;
+            sk[r * RP_LD + d] = ok ? kb[(int64_t)j * a.ldk + d] : 0.0f;
+            sv[r * DH + d] = ok ? vb[(int64_t)j * a.ldk + d] : 0.0f;
+        }
+        // relative positions needed: rel = (q_pos0 + i) - j, i in [i0, i0+QB), j in [j0, j0+KB)
+        const int rel_min = a.q_pos0 + i0 - (j0 + RP_KB - 1);
+        for (int e = tid; e < (RP_KB + RP_QB - 1) * DH; e += 256) {
+            const int r = e >> 6, d = e & 63;
+            const int row = rel_min + r + a.pos_center;
+            sp[r * RP_LD + d] = a.pos[(int64_t)row * a.ldp + head * DH + d];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wid * 4 + rr;
+            const int i_abs = a.q_pos0 + i0 + r;
+            const int j = j0 + lane;
+            const float* kr = &sk[lane * RP_LD];
+            const float* pr = &sp[(i_abs - j - rel_min) * RP_LD];
+            float s = 0.0f;
+#pragma unroll 16
+            for (int d = 0; d < DH; ++d) s += squ[r][d] * kr[d] + sqv[r][d] * pr[d];
+            const bool valid = j < len && (!a.causal || j <= i_abs);
+            s = valid ? s : -INFINITY;
+            const float m_new = fmaxf(m_run[rr], wave_max_f32(s));
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run[rr] - m_new);
+            const float p = valid ? __expf(s - m_new) : 0.0f;
+            l_run[rr] = l_run[rr] * alpha + wave_add_f32(p);
+            m_run[rr] = m_new;
+            sprob[wid][lane] = p;
+            // LDS write -> read by the same wave: wave-synchronous, make the write visible
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float o = o_run[rr] * alpha;
+#pragma unroll 16
+            for (int jj = 0; jj < RP_KB; ++jj) o += sprob[wid][jj] * sv[jj * DH + lane];
+            o_run[rr] = o;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = i0 + wid * 4 + rr;
+        if (i < a.tq) {
+            const float inv = l_run[rr] > 0.0f ? 1.0f / l_run[rr] : 0.0f;
+            a.out[(int64_t)b * a.o_bs + (int64_t)i * a.ldo + head * DH + lane] = o_run[rr] * inv;
+        }
+    }
+}
+
+// one (batch, head) per block; query = the single new position q_pos0 (== tk - 1 for the LM step)
+__global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
+    extern __shared__ float sc[];  // [tk] scores, then [4][64] partial outputs
+    __shared__ float qu[DH], qv[DH];
+    __shared__ float redm[4], reds[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
+    const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
+    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH;
+    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH;
+    if (tid < DH) {
+        const float x = qb[tid];
+        qu[tid] = (x + a.bias_u[head * DH + tid]) * a.scale;
+        qv[tid] = (x + a.bias_v[head * DH + tid]) * a.scale;
+    }
+    __syncthreads();
+    float mloc = -INFINITY;
+    for (int j = tid; j < len; j += 256) {
+        const float* kr = kb + (int64_t)j * a.ldk;
+        const float* pr = a.pos + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp + head * DH;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) {
+            const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+            const float4 pp = *reinterpret_cast<const float4*>(pr + d);
+            s += qu[d] * kk.x + qu[d + 1] * kk.y + qu[d + 2] * kk.z + qu[d + 3] * kk.w;
+            s += qv[d] * pp.x + qv[d + 1] * pp.y + qv[d + 2] * pp.z + qv[d + 3] * pp.w;
+        }
+        sc[j] = s;
+        mloc = fmaxf(mloc, s);
+    }
+    mloc = wave_max_f32(mloc);
+    if (lane == 0) redm[wid] = mloc;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float sloc = 0.0f;
+    for (int j = tid; j < len; j += 256) {
+        const float p = __expf(sc[j] - m);
+        sc[j] = p;
+        sloc += p;
+    }
+    sloc = wave_add_f32(sloc);
+    if (lane == 0) reds[wid] = sloc;
+    __syncthreads();
+    const float l = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+    // out[d] = sum_j p_j v[j][d]: wave w takes keys j = w (mod 4), lane = d
+    float o = 0.0f;
+    for (int j = wid; j < len; j += 4) o += sc[j] * vb[(int64_t)j * a.ldk + lane];
+    float* part = sc + a.tk;
+    part[wid * DH + lane] = o;
+    __syncthreads();
+    if (wid == 0) {
+        const float tot = (part[lane] + part[DH + lane]) + (part[2 * DH + lane] + part[3 * DH + lane]);
+        a.out[(int64_t)b * a.o_bs + head * DH + lane] = l > 0.0f ? tot / l : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ MFMA flash attention
+struct MhaArgs {
+    const float* q;
+    const float* k;
+    const float* v;
+    const int* lens;  // [B] valid keys
+    float* out;
+    int b, h, t, ldq, ldk, ldo;
+    float scale;
+};
+
+static constexpr int FA_KS = 72;  // halfs per K row in LDS (64 + 8): conflict-free b128 reads
+static constexpr int FA_VS = 40;  // halfs per V^T row in LDS (32 + 8)
+
+__global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 ks[32 * FA_KS];
+    __shared__ __attribute__((aligned(16))) _Float16 vt[DH * FA_VS];
+    __shared__ float so[4][32][DH + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int len = a.lens ? min(a.lens[b], a.t) : a.t;
+    const float* qb = a.q + (int64_t)b * a.t * a.ldq + head * DH;
+    const float* kb = a.k + (int64_t)b * a.t * a.ldk + head * DH;
+    const float* vb = a.v + (int64_t)b * a.t * a.ldk + head * DH;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (c, hh) holds Q[q0+c][16s + 8hh + j] * scale
+    half8 qf[4];
+    {
+        const int qi = min(q0 + c, a.t - 1);
+        const float* qr = qb + (int64_t)qi * a.ldq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s + 8 * hh);
+            const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 8 * hh + 4);
+            qf[s][0] = (_Float16)(x0.x * a.scale); qf[s][1] = (_Float16)(x0.y * a.scale);
+            qf[s][2] = (_Float16)(x0.z * a.scale); qf[s][3] = (_Float16)(x0.w * a.scale);
+            qf[s][4] = (_Float16)(x1.x * a.scale); qf[s][5] = (_Float16)(x1.y * a.scale);
+            qf[s][6] = (_Float16)(x1.z * a.scale); qf[s][7] = (_Float16)(x1.w * a.scale);
+        }
+    }
+    float16v ot[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        ot[0][e] = 0.0f;
+        ot[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int skey = tid >> 3, sd0 = (tid & 7) * 8;  // staging coordinates: key row, first dim
+
+    for (int j0 = 0; j0 < len; j0 += 32) {
+        __syncthreads();
+        {
+            const int j = j0 + skey;
+            float kk[8], vv[8];
+            if (j < len) {
+                const float4 k0 = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk + sd0);
+                const float4 k1 = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk + sd0 + 4);
+                const float4 v0 = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk + sd0);
+                const float4 v1 = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk + sd0 + 4);
+                kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
+                vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    kk[i] = 0.0f;
+                    vv[i] = 0.0f;
+                }
+            }
+            half8 kh;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kh[i] = (_Float16)kk[i];
+            *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = kh;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vt[(sd0 + i) * FA_VS + skey] = (_Float16)vv[i];
+        }
+        __syncthreads();
+        // S^T[key][query] = sum_d K[key][d] Q[query][d]
+        float16v st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8 kf = *reinterpret_cast<const half8*>(&ks[c * FA_KS + 16 * s + 8 * hh]);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            st[e] = key < len ? st[e] : -INFINITY;
+            mloc = fmaxf(mloc, st[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
+        float lloc = 0.0f;
+        half8 pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = (st[e] == -INFINITY) ? 0.0f : __expf(st[e] - m_new);
+            lloc += p;
+            pf[e >> 3][e & 7] = (_Float16)p;
+        }
+        lloc += __shfl_xor(lloc, 32, 64);
+        l_run = l_run * alpha + lloc;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            ot[0][e] *= alpha;
+            ot[1][e] *= alpha;
+        }
+        // O^T[d][query] += V^T[d][key] P^T[key][query]; key order inside a k-step follows the
+        // accumulator layout: element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + 16 * s + 4 * hh];
+                const half4 lo = *reinterpret_cast<const half4*>(vr);
+                const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+                half8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
+            }
+        }
+    }
+    // O^T (dims in registers, query on the lane) -> LDS transpose -> coalesced rows
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            so[wid][c][d] = ot[dt][e] * inv;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < 32; ++r) {
+        const int qi = q0 + r;
+        if (qi < a.t) a.out[((int64_t)b * a.t + qi) * a.ldo + head * DH + lane] = so[wid][r][lane];
+    }
+}
+
+}  // namespace astts
+
+using namespace astts;
+
+extern "C" {
+
+int astts_op_attn_relpos(const float* q, const float* k, const float* v, const float* pos, const float* bias_u,
+                         const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h, int32_t tq,
+                         int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
+                         int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
+                         astts_stream_t stream) {
+    ASTTS_REQUIRE(q && k && v && pos && bias_u && bias_v && out, ASTTS_ERR_INVALID, "astts_op_attn_relpos: null pointer");
+    ASTTS_REQUIRE(b >= 1 && h >= 1 && tq >= 1 && tk >= 1, ASTTS_ERR_INVALID, "astts_op_attn_relpos: bad shape");
+    ASTTS_REQUIRE(q_pos0 + tq - 1 <= pos_center && tk - 1 <= pos_center + q_pos0, ASTTS_ERR_INVALID,
+                  "astts_op_attn_relpos: position table too small (center %d, q_pos0 %d, tq %d, tk %d)", pos_center, q_pos0, tq, tk);
+    RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center, causal, scale};
+    hipStream_t st = (hipStream_t)stream;
+    if (tq == 1) {
+        const size_t lds = ((size_t)tk + 4 * DH) * sizeof(float);
+        ASTTS_REQUIRE(lds <= 60 * 1024, ASTTS_ERR_INVALID, "astts_op_attn_relpos: tk=%d too long for the decode kernel", tk);
+        hipLaunchKernelGGL(attn_relpos_decode, dim3(h, b), dim3(256), lds, st, a);
+    } else {
+        // the tile loader reads rel in [q_pos0+i0-(j0+63), q_pos0+i0+15-j0]; keep that inside the table
+        ASTTS_REQUIRE(pos_center >= tk + RP_KB + RP_QB && pos_center >= q_pos0 + tq + RP_QB, ASTTS_ERR_INVALID,
+                      "astts_op_attn_relpos: pos_center %d must exceed tk/tq by the tile margin", pos_center);
+        hipLaunchKernelGGL(attn_relpos, dim3((tq + RP_QB - 1) / RP_QB, h, b), dim3(256), 0, st, a);
+    }
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
+                      int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream) {
+    ASTTS_REQUIRE(q && k && v && out, ASTTS_ERR_INVALID, "astts_op_attn_mha: null pointer");
+    ASTTS_REQUIRE(b >= 1 && h >= 1 && t >= 1, ASTTS_ERR_INVALID, "astts_op_attn_mha: bad shape");
+    ASTTS_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 &&
+                      ((uintptr_t)v & 15) == 0,
+                  ASTTS_ERR_INVALID, "astts_op_attn_mha: q/k/v must be 16-byte aligned with ld %% 4 == 0");
+    MhaArgs a{q, k, v, lens, out, b, h, t, ldq, ldk, ldo, scale};
+    hipLaunchKernelGGL(attn_mha_flash, dim3((t + 127) / 128, h, b), dim3(256), 0, (hipStream_t)stream, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // extern "C"

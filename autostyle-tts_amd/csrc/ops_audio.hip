@@ -1,0 +1,359 @@
+// ops_audio.hip -- HiFT-vocoder signal operators and the LM's token sampler (gfx950).
+//
+//   nsf_source   f0 -> harmonic sine source + noise -> linear(9->1) -> tanh   (SineGen/SourceModuleHnNSF)
+//   stft16       torch.stft(n_fft=16, hop=4, hann, center/reflect) -> [B, F, 18] (re[0..8], im[0..8])
+//   istft16      magnitude=exp(.), phase=sin(.) -> torch.istft(16, 4, hann) -> clamp       (HiFT head)
+//   ras_sample   repetition-aware top-p/top-k sampling of one speech token per batch row
+//
+// Randomness is INJECTED (initial phases, Gaussian noise, uniforms) so that the CPU oracle and this
+// path can be driven by identical draws.  Replaces third-party cosyvoice.hifigan.generator /
+// cosyvoice.utils.common.ras_sampling arithmetic behind tts_with_rag.py:195.
+#include "common.h"
+
+namespace astts {
+
+static constexpr double kTwoPi = 6.283185307179586476925286766559;
+
+// exclusive prefix sum of f0 over frames, fp64, one block per batch row (frames <= a few thousand)
+__global__ __launch_bounds__(256) void f0_prefix(const float* __restrict__ f0, double* __restrict__ pre, int tm) {
+    __shared__ double carry;
+    __shared__ double buf[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) carry = 0.0;
+    __syncthreads();
+    for (int base = 0; base < tm; base += 256) {
+        const int i = base + tid;
+        const double v = i < tm ? (double)f0[(int64_t)b * tm + i] : 0.0;
+        buf[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+            const double add = tid >= off ? buf[tid - off] : 0.0;
+            __syncthreads();
+            buf[tid] += add;
+            __syncthreads();
+        }
+        if (i < tm) pre[(int64_t)b * tm + i] = carry + buf[tid] - v;
+        __syncthreads();
+        if (tid == 255) carry += buf[255];
+        __syncthreads();
+    }
+}
+
+struct NsfArgs {
+    const float* f0;      // [B, Tm]
+    const double* pre;    // [B, Tm] exclusive prefix of f0
+    const float* phase0;  // [B, H+1] initial phase per harmonic (index 0 forced to 0 by the caller)
+    const float* noise;   // [B, L, H+1] standard normal
+    const float* lin_w;   // [H+1]
+    const float* lin_b;   // [1]
+    float* out;           // [B, L]
+    int b, tm, up, nh;    // up = samples per frame (256), nh = H+1 (9)
+    float sr, sine_amp, noise_std, voiced_thr;
+};
+
+__global__ __launch_bounds__(256) void nsf_source(NsfArgs a) {
+    const int64_t L = (int64_t)a.tm * a.up;
+    const int64_t total = (int64_t)a.b * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int bb = (int)(i / L);
+        const int64_t s = i - (int64_t)bb * L;
+        const int f = (int)(s / a.up);
+        const int r = (int)(s - (int64_t)f * a.up);
+        const float f0 = a.f0[(int64_t)bb * a.tm + f];
+        // cumsum of the nearest-upsampled f0 up to and including sample s (fp64)
+        const double cum = (a.pre[(int64_t)bb * a.tm + f] * (double)a.up + (double)(r + 1) * (double)f0) / (double)a.sr;
+        const float uv = f0 > a.voiced_thr ? 1.0f : 0.0f;
+        const float namp = uv * a.noise_std + (1.0f - uv) * a.sine_amp / 3.0f;
+        float acc = a.lin_b[0];
+        for (int hI = 0; hI < a.nh; ++hI) {
+            double ph = cum * (double)(hI + 1);
+            ph -= floor(ph);
+            const float theta = (float)(kTwoPi * ph);
+            const float sine = a.sine_amp * sinf(theta + a.phase0[bb * a.nh + hI]);
+            const float v = sine * uv + namp * a.noise[i * a.nh + hI];
+            acc += a.lin_w[hI] * v;
+        }
+        a.out[i] = tanhf(acc);
+    }
+}
+
+__device__ __forceinline__ float hann16(int n) {  // periodic Hann, N = 16
+    return 0.5f - 0.5f * cosf((float)(kTwoPi / 16.0) * (float)n);
+}
+
+// x [B, L] -> y [B, F, 18], F = L/4 + 1, frame f covers reflect-padded samples 4f-8 .. 4f+7
+__global__ __launch_bounds__(256) void stft16(const float* __restrict__ x, float* __restrict__ y, int b, int64_t L, int64_t F) {
+    const int64_t total = (int64_t)b * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int bb = (int)(i / F);
+        const int64_t f = i - (int64_t)bb * F;
+        const float* xb = x + (int64_t)bb * L;
+        float w[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            int64_t s = 4 * f - 8 + n;
+            if (s < 0) s = -s;
+            if (s >= L) s = 2 * (L - 1) - s;
+            w[n] = hann16(n) * xb[s];
+        }
+        float* o = y + i * 18;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float re = 0.0f, im = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int ph = (k * n) & 15;
+                const float cs = cosf((float)(kTwoPi / 16.0) * (float)ph);
+                const float sn = sinf((float)(kTwoPi / 16.0) * (float)ph);
+                re += w[n] * cs;
+                im -= w[n] * sn;
+            }
+            o[k] = re;
+            o[9 + k] = im;
+        }
+    }
+}
+
+// y [B, F, 18] (log-magnitude, phase pre-activation) -> wav [B, 4(F-1)], clamped
+__global__ __launch_bounds__(256) void istft16(const float* __restrict__ y, float* __restrict__ wav, int b, int64_t F,
+                                               float mag_clip, float audio_limit) {
+    const int64_t L = 4 * (F - 1);
+    const int64_t total = (int64_t)b * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int bb = (int)(i / L);
+        const int64_t t = i - (int64_t)bb * L;
+        const int64_t tp = t + 8;  // position in the centre-padded signal
+        float num = 0.0f, den = 0.0f;
+        const int64_t f_hi = tp / 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t f = f_hi - q;
+            const int n = (int)(tp - 4 * f);  // 0..15
+            if (f < 0 || f >= F) continue;
+            const float* fr = y + ((int64_t)bb * F + f) * 18;
+            float xs = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float mag = fminf(__expf(fr[k]), mag_clip);
+                const float ph = sinf(fr[9 + k]);
+                const float re = mag * cosf(ph), im = mag * sinf(ph);
+                const int idx = (k * n) & 15;
+                const float cs = cosf((float)(kTwoPi / 16.0) * (float)idx);
+                const float sn = sinf((float)(kTwoPi / 16.0) * (float)idx);
+                const float ck = (k == 0 || k == 8) ? 1.0f : 2.0f;
+                xs += ck * (re * cs - ((k == 0 || k == 8) ? 0.0f : im * sn));
+            }
+            const float wn = hann16(n);
+            num += wn * xs * (1.0f / 16.0f);
+            den += wn * wn;
+        }
+        const float v = den > 1e-11f ? num / den : 0.0f;
+        wav[i] = fminf(fmaxf(v, -audio_limit), audio_limit);
+    }
+}
+
+// ------------------------------------------------------------------ repetition-aware sampling
+// One block per batch row.  Definition (mirrored by oracle/synth.py::ras_sample):
+//   p = softmax(logits) (eos masked when ignore_eos); sort descending (ties: lower id first);
+//   nucleus = shortest prefix with cumulative p >= top_p, at most top_k entries;
+//   token = inverse-CDF pick from the renormalised nucleus with uniform u1;
+//   if token occurs >= win*tau_r times among the last `win` decoded tokens:
+//       token = inverse-CDF pick from the full p (id order) with uniform u2.
+struct SampleArgs {
+    const float* logits;  // [B, V]
+    const int* history;   // [B, hist_ld] decoded tokens so far
+    const float* u;       // [B, 2]
+    int* out;             // [B]
+    int b, v, hist_len, hist_ld, top_k, win, eos, ignore_eos;
+    float top_p, tau_r;
+};
+
+__global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
+    extern __shared__ float prob[];  // [V]
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    __shared__ float top_p_val[64];
+    __shared__ int top_p_idx[64];
+    __shared__ float s_bcast;
+    const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* lg = a.logits + (int64_t)bb * a.v;
+    float mx = -INFINITY;
+    for (int i = tid; i < a.v; i += 256) {
+        float x = lg[i];
+        if (a.ignore_eos && i == a.eos) x = -INFINITY;
+        prob[i] = x;
+        mx = fmaxf(mx, x);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) redv[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = tid; i < a.v; i += 256) {
+        const float e = __expf(prob[i] - mx);
+        prob[i] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) redv[wid] = sum;
+    __syncthreads();
+    const float tot = (redv[0] + redv[1]) + (redv[2] + redv[3]);
+    __syncthreads();
+    const float inv = 1.0f / tot;
+    for (int i = tid; i < a.v; i += 256) prob[i] *= inv;
+    __syncthreads();
+    // top_k rounds of block arg-max (ties -> lower id); taken entries are negated in place
+    const int kk = a.top_k < 64 ? a.top_k : 64;
+    for (int r = 0; r < kk; ++r) {
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < a.v; i += 256) {
+            const float p = prob[i];
+            if (p >= 0.0f && (p > bv || (p == bv && i < bi))) {  // negative = already taken
+                bv = p;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            redv[wid] = bv;
+            redi[wid] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = redv[0];
+            int fi = redi[0];
+            for (int w = 1; w < 4; ++w)
+                if (redv[w] > fv || (redv[w] == fv && redi[w] < fi)) {
+                    fv = redv[w];
+                    fi = redi[w];
+                }
+            top_p_val[r] = fv;
+            top_p_idx[r] = fi;
+            prob[fi] = -fv - 1e-30f;  // mark as taken (negative), restored below
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int r = 0; r < kk; ++r) prob[top_p_idx[r]] = top_p_val[r];
+        // nucleus
+        float cum = 0.0f;
+        int cnt = 0;
+        for (int r = 0; r < kk; ++r) {
+            if (cum < a.top_p && cnt < a.top_k) {
+                cum += top_p_val[r];
+                ++cnt;
+            } else {
+                break;
+            }
+        }
+        const float target = a.u[bb * 2] * cum;
+        float run = 0.0f;
+        int tok = top_p_idx[cnt - 1];
+        for (int r = 0; r < cnt; ++r) {
+            run += top_p_val[r];
+            if (run > target) {
+                tok = top_p_idx[r];
+                break;
+            }
+        }
+        // repetition check over the last `win` decoded tokens
+        int rep = 0;
+        const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
+        for (int i = h0; i < a.hist_len; ++i) rep += (a.history[(int64_t)bb * a.hist_ld + i] == tok) ? 1 : 0;
+        a.out[bb] = tok;
+        s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (s_bcast > 0.5f && tid == 0) {
+        // random sampling from the full distribution, id order, inverse CDF with u2
+        const float target = a.u[bb * 2 + 1];
+        float run = 0.0f;
+        int tok = -1;
+        int last = 0;
+        for (int i = 0; i < a.v; ++i) {
+            const float p = prob[i];
+            if (p > 0.0f) last = i;
+            run += p;
+            if (run > target) {
+                tok = i;
+                break;
+            }
+        }
+        a.out[bb] = tok >= 0 ? tok : last;
+    }
+}
+
+}  // namespace astts
+
+using namespace astts;
+
+static inline int grid_for_a(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" {
+
+size_t astts_op_nsf_source_workspace_bytes(int32_t b, int32_t tm) { return (size_t)b * tm * sizeof(double); }
+
+int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise, const float* lin_w, const float* lin_b,
+                        float* out, int32_t b, int32_t tm, int32_t upsample, int32_t n_harm_plus1, float sample_rate,
+                        float sine_amp, float noise_std, float voiced_threshold, void* workspace, size_t workspace_bytes,
+                        astts_stream_t stream) {
+    ASTTS_REQUIRE(f0 && phase0 && noise && lin_w && lin_b && out && workspace, ASTTS_ERR_INVALID, "astts_op_nsf_source: null pointer");
+    ASTTS_REQUIRE(b >= 1 && tm >= 1 && upsample >= 1 && n_harm_plus1 >= 1 && n_harm_plus1 <= 32, ASTTS_ERR_INVALID,
+                  "astts_op_nsf_source: bad shape");
+    ASTTS_REQUIRE(workspace_bytes >= astts_op_nsf_source_workspace_bytes(b, tm), ASTTS_ERR_WORKSPACE,
+                  "astts_op_nsf_source: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(f0_prefix, dim3(b), dim3(256), 0, st, f0, (double*)workspace, tm);
+    ASTTS_CHECK_LAUNCH();
+    NsfArgs a{f0, (const double*)workspace, phase0, noise, lin_w, lin_b, out, b, tm, upsample, n_harm_plus1,
+              sample_rate, sine_amp, noise_std, voiced_threshold};
+    hipLaunchKernelGGL(nsf_source, dim3(grid_for_a((int64_t)b * tm * upsample)), dim3(256), 0, st, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_stft16(const float* x, float* y, int32_t b, int64_t n_samples, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && y && b >= 1 && n_samples >= 16 && n_samples % 4 == 0, ASTTS_ERR_INVALID, "astts_op_stft16: bad argument");
+    const int64_t F = n_samples / 4 + 1;
+    hipLaunchKernelGGL(stft16, dim3(grid_for_a((int64_t)b * F)), dim3(256), 0, (hipStream_t)stream, x, y, b, n_samples, F);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit,
+                     astts_stream_t stream) {
+    ASTTS_REQUIRE(y && wav && b >= 1 && frames >= 2, ASTTS_ERR_INVALID, "astts_op_istft16: bad argument");
+    hipLaunchKernelGGL(istft16, dim3(grid_for_a((int64_t)b * 4 * (frames - 1))), dim3(256), 0, (hipStream_t)stream, y,
+                       wav, b, frames, mag_clip, audio_limit);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_ras_sample(const float* logits, const int32_t* history, const float* uniforms, int32_t* out_tokens,
+                        int32_t b, int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p,
+                        int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream) {
+    ASTTS_REQUIRE(logits && uniforms && out_tokens && (history || hist_len == 0), ASTTS_ERR_INVALID, "astts_op_ras_sample: null pointer");
+    ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
+                  "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
+    SampleArgs a{logits, history, uniforms, out_tokens, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+// ops_norm_elem.hip -- normalisation, element-wise and data-movement operators of the synthesis
+// path (gfx950).  All activations are fp32, channels-last [B, T, C]: every wave touches whole
+// contiguous rows (coalesced), row reductions are wavefront (64-lane) shuffles.
+//
+// The reference runs these inside cosyvoice (nn.LayerNorm, nn.GroupNorm+Mish of matcha Block1D,
+// Snake / leaky-relu of HiFT, F.interpolate of the length regulator, the CFM Euler update, ...).
+#include "common.h"
+
+namespace astts {
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float mishf(float x) {
+    const float sp = (x > 20.0f) ? x : log1pf(__expf(x));
+    return x * tanhf(sp);
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+__global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      int64_t rows, int c, int ldx, int ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float s = 0.0f;
+    for (int k = lane; k < c; k += 64) s += xr[k];
+    const float mean = wave_sum_f32(s) / (float)c;
+    float v = 0.0f;
+    for (int k = lane; k < c; k += 64) {
+        const float d = xr[k] - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum_f32(v) / (float)c + eps);
+    float* yr = y + row * ldy;
+    for (int k = lane; k < c; k += 64) yr[k] = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+}
+
+// ------------------------------------------------------------------ GroupNorm on [B, T, C]
+// pass 1: per (b, chunk of 64 rows): sum / sum of squares per group over the valid rows
+static constexpr int GN_ROWS = 64;
+
+__global__ __launch_bounds__(256) void groupnorm_stats(const float* __restrict__ x, const int* __restrict__ lens,
+                                                       float* __restrict__ partial, int t, int c, int groups,
+                                                       int nchunks) {
+    extern __shared__ float sh[];  // [2][c]
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int len = lens ? min(lens[b], t) : t;
+    const int t0 = chunk * GN_ROWS;
+    const int t1 = min(t0 + GN_ROWS, len);
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s1 = 0.0f, s2 = 0.0f;
+        const float* p = x + ((int64_t)b * t + t0) * c + ch;
+        for (int r = t0; r < t1; ++r, p += c) {
+            const float v = *p;
+            s1 += v;
+            s2 += v * v;
+        }
+        sh[ch] = s1;
+        sh[c + ch] = s2;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int k = 0; k < cpg; ++k) {
+            s1 += sh[g * cpg + k];
+            s2 += sh[c + g * cpg + k];
+        }
+        float* o = partial + (((int64_t)b * nchunks + chunk) * groups + g) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+
+// pass 2: y = act(gn(x)) * mask(t < len) + add_bc[b, c]
+__global__ __launch_bounds__(256) void groupnorm_apply(const float* __restrict__ x, const int* __restrict__ lens,
+                                                       const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ add_bc, float* __restrict__ y, int t,
+                                                       int c, int groups, int nchunks, float eps, int act_mish) {
+    extern __shared__ float sh[];  // [2][groups]: mean, rstd
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int len = lens ? min(lens[b], t) : t;
+    const int cpg = c / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const float* p = partial + (((int64_t)b * nchunks + k) * groups + g) * 2;
+            s1 += p[0];
+            s2 += p[1];
+        }
+        const double cnt = (double)len * cpg;
+        const double mean = cnt > 0 ? s1 / cnt : 0.0;
+        double var = cnt > 0 ? s2 / cnt - mean * mean : 0.0;
+        if (var < 0) var = 0;
+        sh[g] = (float)mean;
+        sh[groups + g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int t0 = chunk * GN_ROWS;
+    const int t1 = min(t0 + GN_ROWS, t);
+    const int64_t n = (int64_t)(t1 - t0) * c;
+    const int64_t base = ((int64_t)b * t + t0) * c;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int ch = (int)(i % c);
+        const int r = t0 + (int)(i / c);
+        float v = 0.0f;
+        if (r < len) {
+            const int g = ch / cpg;
+            v = (x[base + i] - sh[g]) * sh[groups + g] * gamma[ch] + beta[ch];
+            if (act_mish) v = mishf(v);
+            if (add_bc) v += add_bc[(int64_t)b * c + ch];
+        }
+        y[base + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ element-wise family
+enum ElemOp : int {
+    EL_SNAKE = 0,      // y = x + sin^2(alpha_c x) / (alpha_c + 1e-9)          (p0 = alpha[c])
+    EL_LEAKY = 1,      // y = x > 0 ? x : slope x
+    EL_ADD = 2,        // y = x + s * z
+    EL_MUL_ROWMASK = 3,// y = x * (t < len[b])
+    EL_ADD_BC = 4,     // y = x + v[b, c]
+    EL_SCALE = 5,      // y = s * x
+    EL_CFG_EULER = 6,  // y = x + dt * ((1 + r) * z_cond - r * z_uncond)   z = [2B,...]: cond rows then uncond rows
+    EL_MISH = 7,
+    EL_SILU = 8,
+    EL_CLAMP = 9,      // y = clamp(x, -s, s)
+    EL_TANH = 10,
+    EL_ELU = 11,
+};
+
+struct ElemArgs {
+    const float* x;
+    const float* z;
+    const float* p0;
+    const int* lens;
+    float* y;
+    int64_t total;  // B*T*C
+    int t, c;
+    float s, s2;
+    int op;
+};
+
+__global__ __launch_bounds__(256) void elementwise(ElemArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += stride) {
+        const float x = a.x[i];
+        float y;
+        switch (a.op) {
+            case EL_SNAKE: {
+                const float al = a.p0[i % a.c];
+                const float sn = __sinf(al * x);
+                y = x + sn * sn / (al + 1e-9f);
+                break;
+            }
+            case EL_LEAKY: y = x > 0.0f ? x : x * a.s; break;
+            case EL_ADD: y = x + a.s * a.z[i]; break;
+            case EL_MUL_ROWMASK: {
+                const int64_t row = i / a.c;
+                const int b = (int)(row / a.t), tt = (int)(row % a.t);
+                y = (tt < a.lens[b]) ? x : 0.0f;
+                break;
+            }
+            case EL_ADD_BC: {
+                const int64_t row = i / a.c;
+                y = x + a.p0[(row / a.t) * a.c + (i % a.c)];
+                break;
+            }
+            case EL_SCALE: y = a.s * x; break;
+            case EL_CFG_EULER: y = x + a.s * ((1.0f + a.s2) * a.z[i] - a.s2 * a.z[i + a.total]); break;
+            case EL_MISH: y = mishf(x); break;
+            case EL_SILU: y = x / (1.0f + __expf(-x)); break;
+            case EL_CLAMP: y = fminf(fmaxf(x, -a.s), a.s); break;
+            case EL_TANH: y = tanhf(x); break;
+            case EL_ELU: y = x > 0.0f ? x : (__expf(x) - 1.0f); break;
+            default: y = x;
+        }
+        a.y[i] = y;
+    }
+}
+
+// ------------------------------------------------------------------ embedding gather: y[r, :] = table[ids[r], :] * scale
+__global__ __launch_bounds__(256) void embedding_rows(const float* __restrict__ table, const int* __restrict__ ids,
+                                                      float* __restrict__ y, int64_t rows, int c, int ldy,
+                                                      int vocab, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* src = table + (int64_t)id * c;
+    float* dst = y + row * ldy;
+    for (int k = lane; k < c; k += 64) dst[k] = src[k] * scale;
+}
+
+// ------------------------------------------------------------------ linear interpolation along T (F.interpolate, align_corners=False)
+__global__ __launch_bounds__(256) void interp_linear_rows(const float* __restrict__ x, float* __restrict__ y, int b,
+                                                          int t_in, int t_out, int c) {
+    const int64_t total = (int64_t)b * t_out * c;
+    const float scale = (float)t_in / (float)t_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t row = i / c;
+        const int bb = (int)(row / t_out), to = (int)(row % t_out);
+        float src = ((float)to + 0.5f) * scale - 0.5f;
+        if (src < 0.0f) src = 0.0f;
+        int i0 = (int)src;
+        if (i0 > t_in - 1) i0 = t_in - 1;
+        const int i1 = min(i0 + 1, t_in - 1);
+        const float w1 = src - (float)i0;
+        const float* p = x + (int64_t)bb * t_in * c + ch;
+        y[i] = p[(int64_t)i0 * c] * (1.0f - w1) + p[(int64_t)i1 * c] * w1;
+    }
+}
+
+// ------------------------------------------------------------------ sinusoidal timestep embedding (matcha SinusoidalPosEmb, scale 1000)
+__global__ void time_embedding(const float* __restrict__ t, float* __restrict__ y, int b, int dim, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= b * half) return;
+    const int bb = i / half, k = i % half;
+    const float f = __expf(-logf(10000.0f) * (float)k / (float)(half - 1));
+    const float arg = scale * t[bb] * f;
+    y[(int64_t)bb * dim + k] = sinf(arg);
+    y[(int64_t)bb * dim + half + k] = cosf(arg);
+}
+
+}  // namespace astts
+
+using namespace astts;
+
+static inline int grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" {
+
+int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
+                       int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && gamma && beta && y && rows >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_layernorm: bad argument");
+    hipLaunchKernelGGL(layernorm_rows, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       y, rows, c, ldx, ldy, eps);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups) {
+    return (size_t)b * cdiv(t, GN_ROWS) * groups * 2 * sizeof(float);
+}
+
+int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, const float* beta,
+                       const float* add_bc, float* y, int32_t b, int32_t t, int32_t c, int32_t groups, float eps,
+                       int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && gamma && beta && y && workspace, ASTTS_ERR_INVALID, "astts_op_groupnorm: null pointer");
+    ASTTS_REQUIRE(b >= 1 && t >= 1 && c >= 1 && groups >= 1 && c % groups == 0 && groups <= 256 && c <= 8192,
+                  ASTTS_ERR_INVALID, "astts_op_groupnorm: bad shape b=%d t=%d c=%d groups=%d", b, t, c, groups);
+    const int nch = (int)cdiv(t, GN_ROWS);
+    ASTTS_REQUIRE(workspace_bytes >= astts_op_groupnorm_workspace_bytes(b, t, groups), ASTTS_ERR_WORKSPACE,
+                  "astts_op_groupnorm: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(groupnorm_stats, dim3(b, nch), dim3(256), 2 * c * sizeof(float), st, x, lens, (float*)workspace,
+                       t, c, groups, nch);
+    ASTTS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(groupnorm_apply, dim3(b, nch), dim3(256), 2 * groups * sizeof(float), st, x, lens,
+                       (const float*)workspace, gamma, beta, add_bc, y, t, c, groups, nch, eps, act_mish);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_elementwise(int32_t op, const float* x, const float* z, const float* p0, const int32_t* lens, float* y,
+                         int64_t total, int32_t t, int32_t c, float s, float s2, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && y && total >= 1 && c >= 1 && t >= 1, ASTTS_ERR_INVALID, "astts_op_elementwise: bad argument");
+    ASTTS_REQUIRE(op >= EL_SNAKE && op <= EL_ELU, ASTTS_ERR_INVALID, "astts_op_elementwise: op=%d", op);
+    ASTTS_REQUIRE(!((op == EL_ADD || op == EL_CFG_EULER) && !z), ASTTS_ERR_INVALID, "astts_op_elementwise: z is null");
+    ASTTS_REQUIRE(!((op == EL_SNAKE || op == EL_ADD_BC) && !p0), ASTTS_ERR_INVALID, "astts_op_elementwise: p0 is null");
+    ASTTS_REQUIRE(!(op == EL_MUL_ROWMASK && !lens), ASTTS_ERR_INVALID, "astts_op_elementwise: lens is null");
+    ElemArgs a{x, z, p0, lens, y, total, t, c, s, s2, op};
+    hipLaunchKernelGGL(elementwise, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_embedding(const float* table, const int32_t* ids, float* y, int64_t rows, int32_t c, int32_t ldy,
+                       int32_t vocab, float scale, astts_stream_t stream) {
+    ASTTS_REQUIRE(table && ids && y && rows >= 1 && c >= 1 && vocab >= 1, ASTTS_ERR_INVALID, "astts_op_embedding: bad argument");
+    hipLaunchKernelGGL(embedding_rows, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, table, ids, y,
+                       rows, c, ldy, vocab, scale);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_interp_linear(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
+                           astts_stream_t stream) {
+    ASTTS_REQUIRE(x && y && b >= 1 && t_in >= 1 && t_out >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_interp_linear: bad argument");
+    hipLaunchKernelGGL(interp_linear_rows, dim3(grid_for((int64_t)b * t_out * c)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, b, t_in, t_out, c);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_time_embedding(const float* t, float* y, int32_t b, int32_t dim, float scale, astts_stream_t stream) {
+    ASTTS_REQUIRE(t && y && b >= 1 && dim >= 4 && dim % 2 == 0, ASTTS_ERR_INVALID, "astts_op_time_embedding: bad argument");
+    const int total = b * (dim / 2);
+    hipLaunchKernelGGL(time_embedding, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, y, b, dim, scale);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // extern "C"

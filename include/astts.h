@@ -94,6 +94,82 @@ int astts_knn_last_fallbacks(const astts_knn_t* h, const void* workspace, astts_
 int astts_knn_profile_enable(astts_knn_t* h, int32_t on);
 int astts_knn_profile_read(astts_knn_t* h, double* scan_ms_sum, int64_t* scan_launches);
 
+/* ------------------------------------------------------------------------------------------
+ * Synthesis operators.  Replace the tensor arithmetic executed inside the reference's
+ * cosyvoice.inference_tts_with_st / inference_zero_shot / inference_vc calls (tts_with_rag.py:195,
+ * 133,141; tts_with_style_and_timbre.py:93,47,57).  That arithmetic lives in the authors' private
+ * CosyVoice fork (not vendored): these follow the published CosyVoice-300M architecture.
+ * Activations: fp32, channels-last [B, T, C] row-major.  Weights: fp16 packed by
+ * astts_op_pack_weight.  All launches are asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------ */
+#define ASTTS_ACT_NONE 0
+#define ASTTS_ACT_RELU 1
+#define ASTTS_ACT_SILU 2
+#define ASTTS_ACT_GELU 3
+#define ASTTS_ACT_MISH 4
+#define ASTTS_ACT_ELU 5
+#define ASTTS_ACT_TANH 6
+#define ASTTS_ACT_LEAKY 7
+
+/* fp32 [n, taps, cin] -> fp16 [n_pad, taps, cin_pad], zero padded (n_pad % 128 == 0, cin_pad % 64 == 0). */
+int astts_op_pack_weight(const float* src, void* dst_f16, int32_t n, int32_t taps, int32_t cin,
+                         int32_t n_pad, int32_t cin_pad, astts_stream_t stream);
+/* Implicit GEMM (nn.Linear / nn.Conv1d / phase-decomposed nn.ConvTranspose1d):
+ *   out[m, n] = act(sum_{tap,c} x[b*t_in + t*stride + tap*dil - pad, c] * w[n, tap, c] + bias[n]) * alpha
+ *               * row_scale[m] + residual[m, n],      m = b*t_out + t, zero outside [0, t_in). */
+int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const float* residual,
+                  const float* row_scale, float* out, int64_t m, int32_t n, int32_t cin, int32_t cin_pad,
+                  int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
+                  int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
+                  astts_stream_t stream);
+int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
+                       int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
+size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups);
+/* y = act(GroupNorm(x over the first lens[b] rows)) (+ add_bc[b, c]); rows >= lens[b] are written as 0. */
+int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, const float* beta,
+                       const float* add_bc, float* y, int32_t b, int32_t t, int32_t c, int32_t groups, float eps,
+                       int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream);
+#define ASTTS_EL_SNAKE 0
+#define ASTTS_EL_LEAKY 1
+#define ASTTS_EL_ADD 2
+#define ASTTS_EL_MUL_ROWMASK 3
+#define ASTTS_EL_ADD_BC 4
+#define ASTTS_EL_SCALE 5
+#define ASTTS_EL_CFG_EULER 6
+#define ASTTS_EL_MISH 7
+#define ASTTS_EL_SILU 8
+#define ASTTS_EL_CLAMP 9
+#define ASTTS_EL_TANH 10
+#define ASTTS_EL_ELU 11
+int astts_op_elementwise(int32_t op, const float* x, const float* z, const float* p0, const int32_t* lens, float* y,
+                         int64_t total, int32_t t, int32_t c, float s, float s2, astts_stream_t stream);
+int astts_op_embedding(const float* table, const int32_t* ids, float* y, int64_t rows, int32_t c, int32_t ldy,
+                       int32_t vocab, float scale, astts_stream_t stream);
+int astts_op_interp_linear(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
+                           astts_stream_t stream);
+int astts_op_time_embedding(const float* t, float* y, int32_t b, int32_t dim, float scale, astts_stream_t stream);
+/* espnet relative-position attention, head dim 64; tq == 1 selects the KV-cache decode kernel.
+ * ld* = time-step strides, *_bs = batch strides (elements): batch-major and time-major layouts both work. */
+int astts_op_attn_relpos(const float* q, const float* k, const float* v, const float* pos, const float* bias_u,
+                         const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h, int32_t tq,
+                         int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
+                         int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
+                         astts_stream_t stream);
+/* masked multi-head attention (flash-style MFMA), head dim 64. */
+int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
+                      int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream);
+size_t astts_op_nsf_source_workspace_bytes(int32_t b, int32_t tm);
+int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise, const float* lin_w, const float* lin_b,
+                        float* out, int32_t b, int32_t tm, int32_t upsample, int32_t n_harm_plus1, float sample_rate,
+                        float sine_amp, float noise_std, float voiced_threshold, void* workspace, size_t workspace_bytes,
+                        astts_stream_t stream);
+int astts_op_stft16(const float* x, float* y, int32_t b, int64_t n_samples, astts_stream_t stream);
+int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit,
+                     astts_stream_t stream);
+int astts_op_ras_sample(const float* logits, const int32_t* history, const float* uniforms, int32_t* out_tokens,
+                        int32_t b, int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p,
+                        int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

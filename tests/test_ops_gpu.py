@@ -1,0 +1,273 @@
+"""GPU numerics tests of the astts_op_* HIP operators against plain PyTorch fp32 (CPU) references of
+the same op.  Tolerances: fp16-operand / fp32-accumulate contractions are held to a relative error
+of 2e-3 of the output scale (operand rounding 2^-11); pure fp32 kernels to 1e-5..1e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def h16(t):  # what the kernel sees: fp16-rounded operand
+    return t.half().float()
+
+
+@pytest.mark.parametrize("m,k,n,act", [(1, 1024, 1024, "none"), (8, 1024, 4096, "relu"), (8, 4096, 1024, "none"),
+                                       (16, 320, 1024, "silu"), (32, 192, 80, "none"), (33, 512, 80, "none"),
+                                       (300, 1024, 3072, "none"), (1000, 256, 1024, "gelu"), (5504, 1024, 256, "none"),
+                                       (129, 80, 512, "mish"), (2000, 100, 18, "tanh"), (640, 512, 4097, "none")])
+def test_linear(m, k, n, act):
+    from astts import ops
+
+    g = torch.Generator().manual_seed(m * 7 + n)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    pw = ops.PackedWeight(w, b)
+    y = ops.linear(x.to(DEV), pw, act=act, residual=res.to(DEV), alpha=0.5)
+    ref = F.linear(h16(x), h16(w), b)
+    ref = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "gelu": F.gelu, "mish": F.mish, "tanh": torch.tanh}[act](ref)
+    ref = ref * 0.5 + res
+    assert rel_err(y, ref) < 2e-4          # vs the fp16-rounded-operand reference: only accumulation order differs
+    full = F.linear(x, w, b)
+    full = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "gelu": F.gelu, "mish": F.mish, "tanh": torch.tanh}[act](full) * 0.5 + res
+    assert rel_err(y, full) < 3e-3         # vs full fp32: operand rounding
+
+
+@pytest.mark.parametrize("b,t,cin,cout,k,stride,dil", [(2, 100, 80, 512, 7, 1, 1), (3, 257, 256, 256, 3, 1, 1),
+                                                       (2, 300, 128, 128, 11, 1, 5), (2, 301, 256, 256, 3, 2, 1),
+                                                       (1, 130, 512, 512, 3, 1, 3), (2, 513, 18, 256, 16, 8, 1),
+                                                       (2, 200, 18, 128, 1, 1, 1), (2, 640, 128, 18, 7, 1, 1)])
+def test_conv1d(b, t, cin, cout, k, stride, dil):
+    from astts import ops
+
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    x = torch.randn(b, t, cin, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g)
+    pad = {16: 4}.get(k, dil * (k - 1) // 2)
+    pw = ops.PackedWeight.from_conv1d(w, bias)
+    y = ops.conv1d(x.to(DEV), pw, stride=stride, dil=dil, pad=pad, act="leaky", slope=0.1)
+    ref = F.leaky_relu(F.conv1d(h16(x).transpose(1, 2), h16(w), bias, stride=stride, dilation=dil, padding=pad), 0.1).transpose(1, 2)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-4
+
+
+@pytest.mark.parametrize("b,t,cin,cout,s", [(2, 50, 512, 256, 8), (1, 129, 256, 128, 8), (2, 77, 256, 256, 2)])
+def test_conv_transpose1d(b, t, cin, cout, s):
+    from astts import ops
+
+    g = torch.Generator().manual_seed(s)
+    x = torch.randn(b, t, cin, generator=g)
+    w = torch.randn(cin, cout, 2 * s, generator=g) / math.sqrt(cin * 2)
+    bias = torch.randn(cout, generator=g)
+    pw = ops.PackedWeight.from_conv_transpose1d(w, bias, s)
+    y = ops.conv_transpose1d(x.to(DEV), pw, padding=s // 2)
+    ref = F.conv_transpose1d(h16(x).transpose(1, 2), h16(w), bias, stride=s, padding=s // 2).transpose(1, 2)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-4
+
+
+def test_layernorm_groupnorm():
+    from astts import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 37, 1024, generator=g) * 3 + 1
+    ga, be = torch.randn(1024, generator=g), torch.randn(1024, generator=g)
+    y = ops.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), 1e-5)
+    assert rel_err(y, F.layer_norm(x, (1024,), ga, be, 1e-5)) < 2e-5
+    # GroupNorm(8, 256) + Mish over valid rows only, + per-(b,c) add, masked rows -> 0
+    x = torch.randn(3, 150, 256, generator=g) * 2 - 0.5
+    ga, be = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    add = torch.randn(3, 256, generator=g)
+    lens = torch.tensor([150, 97, 1], dtype=torch.int32)
+    y = ops.groupnorm(x.to(DEV), ga.to(DEV), be.to(DEV), 8, 1e-5, lens=lens.to(DEV), mish=True, add_bc=add.to(DEV)).cpu()
+    for i, L in enumerate(lens.tolist()):
+        ref = F.mish(F.group_norm(x[i:i + 1, :L].transpose(1, 2), 8, ga, be, 1e-5)).transpose(1, 2)[0] + add[i]
+        assert rel_err(y[i, :L], ref) < 5e-5
+        assert float(y[i, L:].abs().max()) == 0.0 if L < 150 else True
+    x = torch.randn(2, 70, 80, generator=g)
+    ga, be = torch.randn(80, generator=g), torch.randn(80, generator=g)
+    y = ops.groupnorm(x.to(DEV), ga.to(DEV), be.to(DEV), 1, 1e-5)
+    assert rel_err(y, F.group_norm(x.transpose(1, 2), 1, ga, be, 1e-5).transpose(1, 2)) < 5e-5
+
+
+def test_elementwise_family():
+    from astts import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 33, 128, generator=g)
+    z = torch.randn(4, 33, 128, generator=g)
+    al = torch.rand(128, generator=g) + 0.1
+    xd, zd = x.to(DEV), z.to(DEV)
+    assert rel_err(ops.elementwise(ops.EL_SNAKE, xd, p0=al.to(DEV)), x + torch.sin(al * x) ** 2 / (al + 1e-9)) < 1e-5
+    assert rel_err(ops.elementwise(ops.EL_LEAKY, xd, s=0.1), F.leaky_relu(x, 0.1)) < 1e-6
+    assert rel_err(ops.elementwise(ops.EL_ADD, xd, z=zd[:2].contiguous(), s=1 / 3), x + z[:2] / 3) < 1e-6
+    lens = torch.tensor([20, 33], dtype=torch.int32)
+    m = (torch.arange(33)[None, :] < lens[:, None]).float()[..., None]
+    assert rel_err(ops.elementwise(ops.EL_MUL_ROWMASK, xd, lens=lens.to(DEV)), x * m) < 1e-7
+    bc = torch.randn(2, 128, generator=g)
+    assert rel_err(ops.elementwise(ops.EL_ADD_BC, xd, p0=bc.to(DEV)), x + bc[:, None, :]) < 1e-6
+    assert rel_err(ops.elementwise(ops.EL_CFG_EULER, xd, z=zd, s=0.07, s2=0.7), x + 0.07 * (1.7 * z[:2] - 0.7 * z[2:])) < 1e-6
+    assert rel_err(ops.elementwise(ops.EL_MISH, xd), F.mish(x)) < 1e-5
+    assert rel_err(ops.elementwise(ops.EL_ELU, xd), F.elu(x)) < 1e-5
+    assert rel_err(ops.elementwise(ops.EL_CLAMP, xd, s=0.99), x.clamp(-0.99, 0.99)) < 1e-7
+
+
+def test_embedding_interp_time():
+    from astts import ops
+
+    g = torch.Generator().manual_seed(2)
+    tab = torch.randn(4096, 512, generator=g)
+    ids = torch.randint(0, 4096, (3, 50), generator=g)
+    assert rel_err(ops.embedding(tab.to(DEV), ids.to(DEV)), tab[ids]) == 0.0
+    x = torch.randn(2, 150, 80, generator=g)
+    for t_out in (258, 430, 75, 150):
+        ref = F.interpolate(x.transpose(1, 2), size=t_out, mode="linear").transpose(1, 2)
+        assert rel_err(ops.interp_linear(x.to(DEV), t_out), ref) < 1e-5
+    t = torch.tensor([0.0, 0.3, 0.97, 1.0])
+    half = 160
+    emb = 1000.0 * t[:, None] * torch.exp(torch.arange(half).float() * -(math.log(10000.0) / (half - 1)))[None, :]
+    ref = torch.cat([emb.sin(), emb.cos()], dim=-1)
+    assert float((ops.time_embedding(t.to(DEV), 320).cpu() - ref).abs().max()) < 2e-3  # fp32 sin/cos of args up to 1000
+
+
+def _relpos_ref(q, k, v, pos_table, pos_center, bu, bv, heads, lens, q_pos0, causal):
+    b, tq, _ = q.shape
+    tk = k.shape[1]
+    qh = q.view(b, tq, heads, 64).transpose(1, 2)
+    kh = k.view(b, tk, heads, 64).transpose(1, 2)
+    vh = v.view(b, tk, heads, 64).transpose(1, 2)
+    i = torch.arange(tq)[:, None] + q_pos0
+    j = torch.arange(tk)[None, :]
+    p = pos_table[(i - j) + pos_center].view(tq, tk, heads, 64).permute(2, 0, 1, 3)  # [h, tq, tk, 64]
+    ac = torch.einsum("bhid,bhjd->bhij", qh + bu.view(1, heads, 1, 64), kh)
+    bd = torch.einsum("bhid,hijd->bhij", qh + bv.view(1, heads, 1, 64), p)
+    s = (ac + bd) / 8.0
+    mask = (j[None] < lens[:, None, None])
+    if causal:
+        mask = mask & (j <= i)[None]
+    s = s.masked_fill(~mask[:, None], float("-inf"))
+    return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), vh).transpose(1, 2).reshape(b, tq, heads * 64)
+
+
+@pytest.mark.parametrize("b,heads,t,causal", [(2, 4, 50, False), (3, 16, 185, True), (2, 8, 400, False)])
+def test_attn_relpos_prefill(b, heads, t, causal):
+    from astts import ops
+
+    g = torch.Generator().manual_seed(t)
+    hd = heads * 64
+    qkv = torch.randn(b, t, 3 * hd, generator=g)
+    center = 700
+    pos = torch.randn(2 * center + 1, hd, generator=g) * 0.5
+    bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
+    lens = torch.tensor([t, max(1, t - 13), max(1, t // 2)][:b], dtype=torch.int32)
+    qd = qkv.to(DEV)
+    out = ops.attn_relpos(qd[..., :hd], qd[..., hd:2 * hd], qd[..., 2 * hd:], pos.to(DEV), bu.to(DEV), bv.to(DEV), heads,
+                          lens=lens.to(DEV), q_pos0=0, pos_center=center, causal=causal).cpu()
+    ref = _relpos_ref(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], pos, center, bu, bv, heads, lens, 0, causal)
+    for i, L in enumerate(lens.tolist()):
+        assert rel_err(out[i, :L], ref[i, :L]) < 1e-4
+
+
+def test_attn_relpos_decode_matches_prefill_row():
+    from astts import ops
+
+    g = torch.Generator().manual_seed(9)
+    b, heads, tk = 8, 16, 333
+    hd = heads * 64
+    kc = torch.randn(b, 512, hd, generator=g)      # KV cache with capacity 512, 333 valid
+    vc = torch.randn(b, 512, hd, generator=g)
+    q = torch.randn(b, 1, hd, generator=g)
+    center = 700
+    pos = torch.randn(2 * center + 1, hd, generator=g) * 0.5
+    bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
+    lens = torch.full((b,), tk, dtype=torch.int32)
+    out = ops.attn_relpos(q.to(DEV), kc.to(DEV), vc.to(DEV), pos.to(DEV), bu.to(DEV), bv.to(DEV), heads,
+                          lens=lens.to(DEV), q_pos0=tk - 1, pos_center=center, causal=False).cpu()
+    ref = _relpos_ref(q, kc[:, :tk], vc[:, :tk], pos, center, bu, bv, heads, lens, tk - 1, False)
+    assert rel_err(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize("b,heads,t", [(2, 8, 344), (3, 8, 688), (1, 2, 31), (2, 4, 129)])
+def test_attn_mha_flash(b, heads, t):
+    from astts import ops
+
+    g = torch.Generator().manual_seed(t)
+    hd = heads * 64
+    qkv = torch.randn(b, t, 3 * hd, generator=g)
+    lens = torch.tensor([t, max(1, t - 40), max(1, t // 3)][:b], dtype=torch.int32)
+    qd = qkv.to(DEV)
+    out = ops.attn_mha(qd[..., :hd], qd[..., hd:2 * hd], qd[..., 2 * hd:], heads, lens=lens.to(DEV)).cpu()
+    q, k, v = (qkv[..., i * hd:(i + 1) * hd].view(b, t, heads, 64).transpose(1, 2) for i in range(3))
+    mask = (torch.arange(t)[None, :] < lens[:, None])[:, None, None, :]
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(b, t, hd)
+    for i, L in enumerate(lens.tolist()):
+        assert rel_err(out[i, :L], ref[i, :L]) < 3e-3   # fp16 operands (Q, K, P, V), fp32 softmax/accumulate
+
+
+def test_stft_istft_nsf():
+    from astts import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 2560, generator=g)
+    win = torch.hann_window(16, periodic=True)
+    spec = torch.stft(x, 16, 4, 16, window=win, return_complex=True)       # [B, 9, F]
+    ref = torch.cat([spec.real, spec.imag], dim=1).transpose(1, 2)         # [B, F, 18]
+    y = ops.stft16(x.to(DEV))
+    assert y.shape == ref.shape and rel_err(y, ref) < 1e-5
+    pre = torch.randn(2, 641, 18, generator=g) * 0.5
+    mag = torch.clip(torch.exp(pre[..., :9]), max=100.0)
+    ph = torch.sin(pre[..., 9:])
+    cplx = torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)).transpose(1, 2)
+    refw = torch.istft(cplx, 16, 4, 16, window=win).clamp(-0.99, 0.99)
+    w = ops.istft16(pre.to(DEV))
+    assert w.shape == refw.shape and float((w.cpu() - refw).abs().max()) < 2e-5
+    # NSF source: fp64 phase accumulation (oracle definition: cumsum in float64)
+    b, tm, up, nh, sr = 2, 40, 256, 9, 22050.0
+    f0 = torch.rand(b, tm, generator=g) * 300
+    f0[:, 5:9] = 0.0                                                        # unvoiced stretch
+    phase0 = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(b, tm * up, nh, generator=g)
+    lw, lb = torch.randn(nh, generator=g) * 0.3, torch.randn(1, generator=g) * 0.1
+    f0u = f0.double().repeat_interleave(up, dim=1)                          # nearest upsample
+    harm = torch.arange(1, nh + 1).double()
+    theta = 2 * math.pi * ((torch.cumsum(f0u / sr, dim=1)[..., None] * harm) % 1.0)
+    sine = 0.1 * torch.sin(theta.float() + phase0[:, None, :])
+    uv = (f0u > 10.0).float()[..., None]
+    src = sine * uv + (uv * 0.003 + (1 - uv) * 0.1 / 3) * noise
+    ref = torch.tanh(src @ lw + lb)
+    out = ops.nsf_source(f0.to(DEV), phase0.to(DEV), noise.to(DEV), lw.to(DEV), lb.to(DEV), up, sr, 0.1, 0.003, 10.0)
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_ras_sample_matches_definition():
+    from astts import ops
+    from oracle import synth as osyn
+
+    g = torch.Generator().manual_seed(4)
+    b, v = 16, 4097
+    logits = torch.randn(b, v, generator=g) * 3
+    hist = torch.randint(0, 4096, (b, 64), generator=g, dtype=torch.int32)
+    u = torch.rand(b, 2, generator=g)
+    for hist_len in (0, 3, 40):
+        for ignore in (True, False):
+            if hist_len >= 3:
+                # force repetition in row 0: make its most likely token fill the window
+                top = int(logits[0].argmax())
+                hist[0, :hist_len] = top
+            out = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, 4096, ignore).cpu()
+            ref = osyn.ras_sample(logits, hist[:, :hist_len], u, 25, 0.8, 10, 0.1, 4096, ignore)
+            assert out.tolist() == ref.tolist()
