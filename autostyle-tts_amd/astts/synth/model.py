@@ -1,0 +1,467 @@
+"""Synthesis engine: acoustic transformer -> flow-matching decoder -> HiFT vocoder on one MI355X.
+
+This is the arithmetic the reference reaches through ``cosyvoice.inference_tts_with_st``
+(/root/reference/tts_with_rag.py:195, tts_with_style_and_timbre.py:93), ``inference_zero_shot``
+(:133 / :47) and ``inference_vc`` (:141 / :57).  Every tensor operation below is a hand-written
+HIP kernel reached through astts.ops (C ABI); torch only owns the HBM buffers, views and
+concatenations.  Activations are fp32 channels-last, weights fp16 (packed once at load), all
+contractions run on fp16 MFMA with fp32 accumulation.
+
+Randomness is injected by the caller (sampling uniforms, CFM start noise, source phases/noise) so
+that the CPU oracle (oracle/synth.py) can be driven with identical draws.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import PackedWeight
+from .config import SynthConfig
+
+SD = Dict[str, torch.Tensor]
+
+
+def _dev(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def rel_pos_table(d: int, max_pos: int) -> torch.Tensor:
+    """Constant sinusoid table (host-side constant generation): rows rel = -max_pos..max_pos."""
+    rel = torch.arange(-max_pos, max_pos + 1, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(2 * max_pos + 1, d)
+    pe[:, 0::2] = torch.sin(rel * div)
+    pe[:, 1::2] = torch.cos(rel * div)
+    return pe
+
+
+class RelPosEncoder:
+    """espnet-style pre-norm encoder with relative-position attention (text encoder, token encoder,
+    and the causal LM body).  Holds one precomputed table ``linear_pos(pe(rel))`` per layer."""
+
+    def __init__(self, sd: SD, prefix: str, heads: int, layers: int, act: str, norm_names: Tuple[str, str],
+                 legacy_embed: bool, causal: bool, eps: float, max_pos: int, device):
+        self.heads, self.layers, self.act, self.causal, self.eps = heads, layers, act, causal, eps
+        self.legacy_embed = legacy_embed
+        self.center = max_pos
+        p = prefix
+        self.d = int(sd[p + ".after_norm.weight"].shape[0])
+        self.embed = PackedWeight(sd[p + ".embed.out.0.weight"], sd[p + ".embed.out.0.bias"], device)
+        self.embed_ln = (_dev(sd[p + ".embed.out.1.weight"], device), _dev(sd[p + ".embed.out.1.bias"], device))
+        self.after = (_dev(sd[p + ".after_norm.weight"], device), _dev(sd[p + ".after_norm.bias"], device))
+        pe = rel_pos_table(self.d, max_pos).to(device)
+        n1, n2 = norm_names
+        self.L: List[dict] = []
+        for i in range(layers):
+            q = f"{p}.encoders.{i}"
+            a = q + ".self_attn"
+            lay = {
+                "n1": (_dev(sd[f"{q}.{n1}.weight"], device), _dev(sd[f"{q}.{n1}.bias"], device)),
+                "n2": (_dev(sd[f"{q}.{n2}.weight"], device), _dev(sd[f"{q}.{n2}.bias"], device)),
+                "wq": PackedWeight(sd[a + ".linear_q.weight"], sd[a + ".linear_q.bias"], device),
+                "wkv": PackedWeight(torch.cat([sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0),
+                                    torch.cat([sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0), device),
+                "wo": PackedWeight(sd[a + ".linear_out.weight"], sd[a + ".linear_out.bias"], device),
+                "w1": PackedWeight(sd[q + ".feed_forward.w_1.weight"], sd[q + ".feed_forward.w_1.bias"], device),
+                "w2": PackedWeight(sd[q + ".feed_forward.w_2.weight"], sd[q + ".feed_forward.w_2.bias"], device),
+                "u": _dev(sd[a + ".pos_bias_u"].reshape(-1), device),
+                "v": _dev(sd[a + ".pos_bias_v"].reshape(-1), device),
+            }
+            lay["pos"] = ops.linear(pe, PackedWeight(sd[a + ".linear_pos.weight"], None, device))
+            self.L.append(lay)
+
+    def embed_in(self, x: torch.Tensor) -> torch.Tensor:
+        h = ops.linear(x, self.embed)
+        h = ops.layernorm(h, *self.embed_ln, self.eps)
+        if self.legacy_embed:
+            # relu then * sqrt(d): relu commutes with the positive scale
+            h = ops.elementwise(ops.EL_LEAKY, h, s=0.0)
+        return ops.elementwise(ops.EL_SCALE, h, s=math.sqrt(self.d))
+
+    def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+        """Batch-major full-sequence pass: x [B, T, in_dim], lens int32 [B] -> [B, T, d]."""
+        h = self.embed_in(x)
+        d = self.d
+        for lay in self.L:
+            n = ops.layernorm(h, *lay["n1"], self.eps)
+            q = ops.linear(n, lay["wq"])
+            kv = ops.linear(n, lay["wkv"])
+            a = ops.attn_relpos(q, kv[..., :d], kv[..., d:], lay["pos"], lay["u"], lay["v"], self.heads, lens=lens,
+                                q_pos0=0, pos_center=self.center, causal=self.causal)
+            h = ops.linear(a, lay["wo"], residual=h)
+            n = ops.layernorm(h, *lay["n2"], self.eps)
+            f = ops.linear(n, lay["w1"], act=self.act)
+            h = ops.linear(f, lay["w2"], residual=h)
+        return ops.layernorm(h, *self.after, self.eps)
+
+
+class AcousticLM:
+    """TransformerLM: text encoder + causal rel-pos transformer with a time-major KV cache
+    ``[T_max, B, 2d]`` per layer (the K|V GEMM writes straight into the cache rows of the new positions)."""
+
+    def __init__(self, sd: SD, cfg: SynthConfig, device):
+        self.cfg, self.device = cfg, device
+        self.text_emb = _dev(sd["text_embedding.weight"], device)
+        self.text_enc = RelPosEncoder(sd, "text_encoder", cfg.lm_heads, cfg.lm_text_layers, "swish",
+                                      ("norm_mha", "norm_ff"), False, True, cfg.ln_eps, cfg.max_positions, device)
+        self.text_aff = PackedWeight(sd["text_encoder_affine_layer.weight"], sd["text_encoder_affine_layer.bias"], device)
+        self.llm_emb = _dev(sd["llm_embedding.weight"], device)
+        self.speech_emb = _dev(sd["speech_embedding.weight"], device)
+        self.spk_aff = PackedWeight(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device)
+        self.body = RelPosEncoder(sd, "llm", cfg.lm_heads, cfg.lm_layers, "relu", ("norm1", "norm2"), True, True,
+                                  cfg.ln_eps, cfg.max_positions, device)
+        self.head = PackedWeight(sd["llm_decoder.weight"], sd["llm_decoder.bias"], device)
+
+    def prefix(self, text: torch.Tensor, text_lens: torch.Tensor, spk: torch.Tensor, prompt_tokens: torch.Tensor) -> torch.Tensor:
+        """-> time-major [S0, B, d]: sos | spk | text_encoder(text) | task_id | speech_emb(prompt)."""
+        b = text.shape[0]
+        te = ops.embedding(self.text_emb, text)
+        enc = ops.linear(self.text_enc.forward(te, text_lens), self.text_aff)
+        spk_n = torch.nn.functional.normalize(spk, dim=1)  # 192-vector per utterance: host-side plumbing
+        spk_e = ops.linear(spk_n, self.spk_aff)[:, None, :]
+        sos = self.llm_emb[0].view(1, 1, -1).expand(b, 1, -1)
+        task = self.llm_emb[1].view(1, 1, -1).expand(b, 1, -1)
+        pe = ops.embedding(self.speech_emb, prompt_tokens)
+        return torch.cat([sos, spk_e, enc, task, pe], dim=1).transpose(0, 1).contiguous()
+
+    def new_cache(self, b: int, t_max: int) -> List[torch.Tensor]:
+        return [torch.empty((t_max, b, 2 * self.body.d), dtype=torch.float32, device=self.device) for _ in self.body.L]
+
+    def forward_new(self, x: torch.Tensor, cache: List[torch.Tensor], pos0: int) -> torch.Tensor:
+        """x: time-major [T, B, d] NEW positions pos0..pos0+T-1 -> hidden [T, B, d]; fills the cache."""
+        body = self.body
+        d = body.d
+        t, b = x.shape[0], x.shape[1]
+        h = body.embed_in(x)
+        tk = pos0 + t
+        lens = torch.full((b,), tk, dtype=torch.int32, device=self.device)
+        for lay, kvc in zip(body.L, cache):
+            n = ops.layernorm(h, *lay["n1"], body.eps)
+            q = ops.linear(n, lay["wq"])
+            ops.gemm(n.view(t * b, d), lay["wkv"], out=kvc[pos0:pos0 + t].view(t * b, 2 * d))
+            kv = kvc[:tk]
+            a = ops.attn_relpos(q, kv[..., :d], kv[..., d:], lay["pos"], lay["u"], lay["v"], body.heads, lens=lens,
+                                q_pos0=pos0, pos_center=body.center, causal=True, time_major=True)
+            h = ops.linear(a, lay["wo"], residual=h)
+            n = ops.layernorm(h, *lay["n2"], body.eps)
+            f = ops.linear(n, lay["w1"], act="relu")
+            h = ops.linear(f, lay["w2"], residual=h)
+        return ops.layernorm(h, *body.after, body.eps)
+
+    def logits(self, hidden_last: torch.Tensor) -> torch.Tensor:
+        return ops.linear(hidden_last, self.head)
+
+    def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
+               forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+        """Fixed-length autoregressive decode, no host synchronisation inside the loop.
+        prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1])."""
+        cfg = self.cfg
+        s0, b = prefix.shape[0], prefix.shape[1]
+        cache = self.new_cache(b, s0 + n_steps)
+        hid = self.forward_new(prefix, cache, 0)
+        cur = self.logits(hid[-1])
+        toks = torch.zeros((b, n_steps), dtype=torch.int32, device=self.device)
+        all_logits = [] if return_logits else None
+        for s in range(n_steps):
+            if return_logits:
+                all_logits.append(cur)
+            tok = ops.ras_sample(cur, toks, s, uniforms[s], cfg.top_k, cfg.top_p, cfg.ras_win, cfg.ras_tau,
+                                 cfg.speech_vocab, ignore_eos)
+            if forced_tokens is not None:
+                tok = forced_tokens[:, s].to(torch.int32).contiguous()
+            toks[:, s] = tok
+            if s + 1 < n_steps:
+                emb = ops.embedding(self.speech_emb, tok)[None]            # [1, B, d]
+                hid = self.forward_new(emb, cache, s0 + s)
+                cur = self.logits(hid[0])
+        if return_logits:
+            return toks, torch.stack(all_logits, dim=1)
+        return toks
+
+
+class _Resnet1D:
+    def __init__(self, sd: SD, p: str, device, groups: int):
+        self.groups = groups
+        self.c1 = PackedWeight.from_conv1d(sd[p + ".block1.block.0.weight"], sd[p + ".block1.block.0.bias"], device)
+        self.g1 = (_dev(sd[p + ".block1.block.1.weight"], device), _dev(sd[p + ".block1.block.1.bias"], device))
+        self.mlp = PackedWeight(sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"], device)
+        self.c2 = PackedWeight.from_conv1d(sd[p + ".block2.block.0.weight"], sd[p + ".block2.block.0.bias"], device)
+        self.g2 = (_dev(sd[p + ".block2.block.1.weight"], device), _dev(sd[p + ".block2.block.1.bias"], device))
+        self.res = PackedWeight.from_conv1d(sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"], device)
+
+    def forward(self, x: torch.Tensor, lens: torch.Tensor, temb_mish: torch.Tensor) -> torch.Tensor:
+        """x must already be zero beyond lens (masked)."""
+        tproj = ops.linear(temb_mish, self.mlp)                                  # [B, C]
+        h = ops.conv1d(x, self.c1, pad=1)
+        h = ops.groupnorm(h, *self.g1, self.groups, 1e-5, lens=lens, mish=True, add_bc=tproj)
+        h = ops.conv1d(h, self.c2, pad=1)
+        h = ops.groupnorm(h, *self.g2, self.groups, 1e-5, lens=lens, mish=True)
+        return ops.conv1d(x, self.res, residual=h)                              # res_conv(x) + h
+
+
+class _TfmBlock:
+    def __init__(self, sd: SD, p: str, heads: int, device):
+        self.heads = heads
+        self.n1 = (_dev(sd[p + ".norm1.weight"], device), _dev(sd[p + ".norm1.bias"], device))
+        self.wqkv = PackedWeight(torch.cat([sd[p + ".attn1.to_q.weight"], sd[p + ".attn1.to_k.weight"],
+                                            sd[p + ".attn1.to_v.weight"]], 0), None, device)
+        self.wo = PackedWeight(sd[p + ".attn1.to_out.0.weight"], sd[p + ".attn1.to_out.0.bias"], device)
+        self.n3 = (_dev(sd[p + ".norm3.weight"], device), _dev(sd[p + ".norm3.bias"], device))
+        self.w1 = PackedWeight(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], device)
+        self.w2 = PackedWeight(sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"], device)
+
+    def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+        hd = self.heads * 64
+        n = ops.layernorm(x, *self.n1, 1e-5)
+        qkv = ops.linear(n, self.wqkv)
+        a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens)
+        x = ops.linear(a, self.wo, residual=x)
+        n = ops.layernorm(x, *self.n3, 1e-5)
+        f = ops.linear(n, self.w1, act="gelu")
+        return ops.linear(f, self.w2, residual=x)
+
+
+class FlowDecoder:
+    """MaskedDiffWithXvec + ConditionalCFM: tokens -> mu -> 10 Euler steps of the U-Net estimator with
+    classifier-free guidance (cond and uncond halves run as one 2B batch)."""
+
+    def __init__(self, sd: SD, cfg: SynthConfig, device):
+        self.cfg, self.device = cfg, device
+        self.tok_emb = _dev(sd["input_embedding.weight"], device)
+        self.spk_aff = PackedWeight(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device)
+        self.enc = RelPosEncoder(sd, "encoder", cfg.flow_heads, cfg.flow_layers, "swish", ("norm_mha", "norm_ff"), False,
+                                 False, cfg.ln_eps, cfg.max_positions, device)
+        self.enc_proj = PackedWeight(sd["encoder_proj.weight"], sd["encoder_proj.bias"], device)
+        self.lr = []
+        for j in range(4):
+            self.lr.append((PackedWeight.from_conv1d(sd[f"length_regulator.model.{3 * j}.weight"],
+                                                     sd[f"length_regulator.model.{3 * j}.bias"], device),
+                            _dev(sd[f"length_regulator.model.{3 * j + 1}.weight"], device),
+                            _dev(sd[f"length_regulator.model.{3 * j + 1}.bias"], device)))
+        self.lr_out = PackedWeight.from_conv1d(sd["length_regulator.model.12.weight"], sd["length_regulator.model.12.bias"], device)
+        e = "decoder.estimator"
+        self.t1 = PackedWeight(sd[e + ".time_mlp.linear_1.weight"], sd[e + ".time_mlp.linear_1.bias"], device)
+        self.t2 = PackedWeight(sd[e + ".time_mlp.linear_2.weight"], sd[e + ".time_mlp.linear_2.bias"], device)
+        ch = cfg.est_channels
+        g = cfg.est_groups
+        self.down, self.mid, self.up = [], [], []
+        for i in range(len(ch)):
+            p = f"{e}.down_blocks.{i}"
+            last = i == len(ch) - 1
+            wname = p + ".2" + ("" if last else ".conv")
+            self.down.append((_Resnet1D(sd, p + ".0", device, g),
+                              [_TfmBlock(sd, f"{p}.1.{j}", cfg.est_heads, device) for j in range(cfg.est_tfm_per_block)],
+                              PackedWeight.from_conv1d(sd[wname + ".weight"], sd[wname + ".bias"], device), last))
+        for i in range(cfg.est_mid_blocks):
+            p = f"{e}.mid_blocks.{i}"
+            self.mid.append((_Resnet1D(sd, p + ".0", device, g),
+                             [_TfmBlock(sd, f"{p}.1.{j}", cfg.est_heads, device) for j in range(cfg.est_tfm_per_block)]))
+        for i in range(len(ch)):
+            p = f"{e}.up_blocks.{i}"
+            last = i == len(ch) - 1
+            if last:
+                w = PackedWeight.from_conv1d(sd[p + ".2.weight"], sd[p + ".2.bias"], device)
+            else:
+                w = PackedWeight.from_conv_transpose1d(sd[p + ".2.conv.weight"], sd[p + ".2.conv.bias"], 2, device)
+            self.up.append((_Resnet1D(sd, p + ".0", device, g),
+                            [_TfmBlock(sd, f"{p}.1.{j}", cfg.est_heads, device) for j in range(cfg.est_tfm_per_block)], w, last))
+        self.fin_c = PackedWeight.from_conv1d(sd[e + ".final_block.block.0.weight"], sd[e + ".final_block.block.0.bias"], device)
+        self.fin_g = (_dev(sd[e + ".final_block.block.1.weight"], device), _dev(sd[e + ".final_block.block.1.bias"], device))
+        self.fin_p = PackedWeight.from_conv1d(sd[e + ".final_proj.weight"], sd[e + ".final_proj.bias"], device)
+
+    # ---- token encoder + length regulator
+    def mu(self, tokens: torch.Tensor, token_lens: torch.Tensor, mel_total: int) -> torch.Tensor:
+        x = ops.embedding(self.tok_emb, tokens.clamp(min=0))
+        x = ops.elementwise(ops.EL_MUL_ROWMASK, x, lens=token_lens)
+        h = ops.linear(self.enc.forward(x, token_lens), self.enc_proj)
+        h = ops.interp_linear(h, mel_total)
+        for w, ga, be in self.lr:
+            h = ops.conv1d(h, w, pad=1)
+            h = ops.groupnorm(h, ga, be, 1, 1e-5, mish=True)
+        return ops.conv1d(h, self.lr_out)
+
+    # ---- one estimator evaluation on a (2B) batch
+    def estimator(self, x, mu, spk, cond, t, lens) -> torch.Tensor:
+        cfg = self.cfg
+        b, T, _ = x.shape
+        temb = ops.time_embedding(t, cfg.est_in)
+        temb = ops.linear(ops.linear(temb, self.t1, act="silu"), self.t2)
+        temb_m = ops.elementwise(ops.EL_MISH, temb)                 # every ResnetBlock1D applies Mish first
+        h = torch.cat([x, mu, spk[:, None, :].expand(b, T, -1), cond], dim=-1)
+        hiddens, lens_stack = [], [lens]
+        for res, tfms, wds, last in self.down:
+            L = lens_stack[-1]
+            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            h = res.forward(h, L, temb_m)
+            for tb in tfms:
+                h = tb.forward(h, L)
+            hiddens.append(h)
+            hm = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            if last:
+                h = ops.conv1d(hm, wds, pad=1)
+                lens_stack.append(L)
+            else:
+                h = ops.conv1d(hm, wds, stride=2, pad=1)
+                lens_stack.append(torch.div(L + 1, 2, rounding_mode="floor").to(torch.int32))
+        L = lens_stack[-1]
+        h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+        for res, tfms in self.mid:
+            h = res.forward(h, L, temb_m)
+            for tb in tfms:
+                h = tb.forward(h, L)
+            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+        lens_stack.pop()
+        for res, tfms, wus, last in self.up:
+            L = lens_stack.pop()
+            skip = hiddens.pop()
+            h = torch.cat([h[:, :skip.shape[1]], skip], dim=-1)
+            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            h = res.forward(h, L, temb_m)
+            for tb in tfms:
+                h = tb.forward(h, L)
+            hm = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            if last:
+                h = ops.conv1d(hm, wus, pad=1)
+            else:
+                h = ops.conv_transpose1d(hm, wus, padding=1)
+        h = ops.elementwise(ops.EL_MUL_ROWMASK, h[:, :T].contiguous(), lens=lens)
+        h = ops.conv1d(h, self.fin_c, pad=1)
+        h = ops.groupnorm(h, *self.fin_g, cfg.est_groups, 1e-5, lens=lens, mish=True)
+        out = ops.conv1d(h, self.fin_p)
+        return ops.elementwise(ops.EL_MUL_ROWMASK, out, lens=lens)
+
+    def decode(self, tokens, token_lens, prompt_mel, spk, z, mel_total: int) -> torch.Tensor:
+        """tokens [B, Tp+Ts], prompt_mel [B, Tm_p, mel], spk [B, spk_dim], z [B, mel_total, mel]
+        -> mel [B, mel_total - Tm_p, mel] (fixed-length batch)."""
+        cfg = self.cfg
+        b = tokens.shape[0]
+        mu = self.mu(tokens, token_lens, mel_total)
+        spk_e = ops.linear(torch.nn.functional.normalize(spk, dim=1), self.spk_aff)
+        tmp = prompt_mel.shape[1]
+        cond = torch.zeros((b, mel_total, cfg.mel), dtype=torch.float32, device=self.device)
+        cond[:, :tmp] = prompt_mel
+        lens2 = torch.full((2 * b,), mel_total, dtype=torch.int32, device=self.device)
+        mu2 = torch.cat([mu, torch.zeros_like(mu)], 0)
+        spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
+        cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
+        n = cfg.cfm_steps
+        ts = 1.0 - torch.cos(torch.linspace(0, 1, n + 1) * 0.5 * math.pi)
+        x = z.clone()
+        for s in range(n):
+            t2 = torch.full((2 * b,), float(ts[s]), dtype=torch.float32, device=self.device)
+            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2)
+            x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s + 1] - ts[s]), s2=cfg.cfg_rate)
+        return x[:, tmp:].contiguous()
+
+
+class _ResBlock:
+    def __init__(self, sd: SD, p: str, k: int, dils, device):
+        self.k, self.dils = k, dils
+        self.c1 = [PackedWeight.from_conv1d(sd[f"{p}.convs1.{j}.weight"], sd[f"{p}.convs1.{j}.bias"], device) for j in range(len(dils))]
+        self.c2 = [PackedWeight.from_conv1d(sd[f"{p}.convs2.{j}.weight"], sd[f"{p}.convs2.{j}.bias"], device) for j in range(len(dils))]
+        self.a1 = [_dev(sd[f"{p}.activations1.{j}.alpha"], device) for j in range(len(dils))]
+        self.a2 = [_dev(sd[f"{p}.activations2.{j}.alpha"], device) for j in range(len(dils))]
+
+    def forward(self, x: torch.Tensor, final_alpha: float = 1.0, accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x + sum of branches; the last conv can fold the 1/3 averaging and the running sum of the
+        parallel resblocks into its epilogue: out = (conv + x) ... handled by the caller via alpha."""
+        k = self.k
+        for j, d in enumerate(self.dils):
+            xt = ops.elementwise(ops.EL_SNAKE, x, p0=self.a1[j])
+            xt = ops.conv1d(xt, self.c1[j], dil=d, pad=d * (k - 1) // 2)
+            xt = ops.elementwise(ops.EL_SNAKE, xt, p0=self.a2[j])
+            x = ops.conv1d(xt, self.c2[j], pad=(k - 1) // 2, residual=x)
+        return x
+
+
+class HiftVocoder:
+    """HiFTGenerator: f0 predictor -> NSF source -> STFT -> conv-transpose / Snake-resblock stack -> iSTFT."""
+
+    def __init__(self, sd: SD, cfg: SynthConfig, device):
+        self.cfg, self.device = cfg, device
+        self.f0_convs = [PackedWeight.from_conv1d(sd[f"f0_predictor.condnet.{2 * j}.weight"], sd[f"f0_predictor.condnet.{2 * j}.bias"], device) for j in range(5)]
+        self.f0_cls = PackedWeight(sd["f0_predictor.classifier.weight"], sd["f0_predictor.classifier.bias"], device)
+        self.src_w = _dev(sd["m_source.l_linear.weight"].reshape(-1), device)
+        self.src_b = _dev(sd["m_source.l_linear.bias"].reshape(-1), device)
+        self.conv_pre = PackedWeight.from_conv1d(sd["conv_pre.weight"], sd["conv_pre.bias"], device)
+        self.ups, self.sdowns, self.sres, self.res = [], [], [], []
+        nk = len(cfg.res_kernels)
+        for i, r in enumerate(cfg.up_rates):
+            self.ups.append(PackedWeight.from_conv_transpose1d(sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], r, device))
+            wd = sd[f"source_downs.{i}.weight"]
+            self.sdowns.append((PackedWeight.from_conv1d(wd, sd[f"source_downs.{i}.bias"], device), int(wd.shape[-1])))
+            self.sres.append(_ResBlock(sd, f"source_resblocks.{i}", cfg.src_res_kernels[i], cfg.res_dils, device))
+            self.res.append([_ResBlock(sd, f"resblocks.{i * nk + kk}", k, cfg.res_dils, device) for kk, k in enumerate(cfg.res_kernels)])
+        self.conv_post = PackedWeight.from_conv1d(sd["conv_post.weight"], sd["conv_post.bias"], device)
+
+    def f0(self, mel: torch.Tensor) -> torch.Tensor:
+        h = mel
+        for w in self.f0_convs:
+            h = ops.conv1d(h, w, pad=1, act="elu")
+        f = ops.linear(h, self.f0_cls)
+        return torch.abs(f.squeeze(-1))  # |.| of a [B, Tm] vector: plumbing
+
+    def source(self, f0: torch.Tensor, phase0: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        return ops.nsf_source(f0.contiguous(), phase0, noise, self.src_w, self.src_b, cfg.upsample_total,
+                              float(cfg.sample_rate), cfg.nsf_alpha, cfg.nsf_sigma, cfg.nsf_voiced_threshold)
+
+    def decode(self, mel: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        s_stft = ops.stft16(source)                                           # [B, F, 18]
+        x = ops.conv1d(mel, self.conv_pre, pad=3)
+        n_up = len(cfg.up_rates)
+        nk = len(cfg.res_kernels)
+        for i, r in enumerate(cfg.up_rates):
+            x = ops.elementwise(ops.EL_LEAKY, x, s=cfg.lrelu_slope)
+            x = ops.conv_transpose1d(x, self.ups[i], padding=r // 2)
+            if i == n_up - 1:
+                x = torch.cat([x[:, 1:2], x], dim=1)                           # ReflectionPad1d((1, 0)): plumbing
+            wd, kd = self.sdowns[i]
+            si = ops.conv1d(s_stft, wd, stride=kd // 2, pad=kd // 4) if kd > 1 else ops.conv1d(s_stft, wd)
+            si = self.sres[i].forward(si)
+            x = ops.elementwise(ops.EL_ADD, x, z=si, s=1.0)
+            xs = None
+            for rb in self.res[i]:
+                y = rb.forward(x)
+                xs = ops.elementwise(ops.EL_SCALE, y, s=1.0 / nk) if xs is None else ops.elementwise(ops.EL_ADD, xs, z=y, s=1.0 / nk)
+            x = xs
+        x = ops.elementwise(ops.EL_LEAKY, x, s=0.01)
+        x = ops.conv1d(x, self.conv_post, pad=3)
+        return ops.istft16(x, 100.0, cfg.audio_limit)
+
+    def forward(self, mel, phase0, noise) -> torch.Tensor:
+        return self.decode(mel, self.source(self.f0(mel), phase0, noise))
+
+
+class SynthEngine:
+    """All three stages on one GPU."""
+
+    def __init__(self, state: Dict[str, SD], cfg: SynthConfig, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("astts.synth needs a ROCm GPU; there is no CPU fallback in the product path")
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.device):
+            self.lm = AcousticLM(state["llm"], cfg, self.device)
+            self.flow = FlowDecoder(state["flow"], cfg, self.device)
+            self.hift = HiftVocoder(state["hift"], cfg, self.device)
+
+    def tts(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int, uniforms, flow_prompt_tokens, flow_prompt_mel,
+            flow_spk, z, phase0, noise, forced_tokens=None):
+        """One fixed-length batch end to end (all inputs on the GPU):
+        LM decode (style-conditioned) -> flow (timbre-conditioned) -> vocoder.  Returns
+        (tokens [B, n_tokens], mel [B, Tm, 80], wav [B, 256*Tm])."""
+        cfg = self.cfg
+        pre = self.lm.prefix(text, text_lens, lm_spk, lm_prompt_tokens)
+        toks = self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
+        all_tok = torch.cat([flow_prompt_tokens.to(torch.int32), toks], dim=1)
+        b = all_tok.shape[0]
+        tok_lens = torch.full((b,), all_tok.shape[1], dtype=torch.int32, device=self.device)
+        mel_total = flow_prompt_mel.shape[1] + cfg.mel_frames_for_tokens(n_tokens)
+        mel = self.flow.decode(all_tok, tok_lens, flow_prompt_mel, flow_spk, z, mel_total)
+        wav = self.hift.forward(mel, phase0, noise)
+        return toks, mel, wav

@@ -1,0 +1,180 @@
+"""GPU parity of the synthesis stages (HIP path through the C ABI) against oracle/synth.py, same seeded
+synthetic weights, same injected randomness.  PARITY UNPINNED w.r.t. the reference (its CosyVoice fork
+is not available): these tests pin the HIP kernels to this build's own fp32 CPU restatement.
+
+Stated tolerances (fp16 weights + fp16 MFMA operands with fp32 accumulation vs an all-fp32 oracle):
+  LM logits           max |d| <= 2e-2 * max|logit|   (teacher-forced, every step)
+  flow mel            max |d| <= 3e-2 * max|mel|     after 10 Euler steps x 2 (CFG) estimator passes
+  vocoder waveform    max |d| <= 2e-2 (full scale 0.99), SNR >= 30 dB
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _cfg_and_weights(seed=0):
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig.tiny()
+    return cfg, make_all(cfg, seed)
+
+
+def _snr_db(ref, out):
+    ref, out = ref.double(), out.double()
+    return float(10 * torch.log10(ref.pow(2).sum() / (ref - out).pow(2).sum().clamp_min(1e-30)))
+
+
+def test_relpos_encoder_matches_oracle():
+    from astts.synth.model import RelPosEncoder
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["flow"]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 70, cfg.flow_dim, generator=g)
+    lens = torch.tensor([70, 55, 9])
+    ref, _ = osyn.relpos_encoder(sd, "encoder", x, lens, cfg.flow_heads, cfg.flow_layers, "swish", ("norm_mha", "norm_ff"),
+                                 False, False, cfg.ln_eps, cfg.max_positions)
+    enc = RelPosEncoder(sd, "encoder", cfg.flow_heads, cfg.flow_layers, "swish", ("norm_mha", "norm_ff"), False, False,
+                        cfg.ln_eps, cfg.max_positions, torch.device(DEV))
+    out = enc.forward(x.to(DEV), lens.to(DEV, torch.int32)).cpu()
+    for i, L in enumerate(lens.tolist()):
+        assert float((out[i, :L] - ref[i, :L]).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_lm_teacher_forced_logits_and_sampling():
+    from astts.synth.model import AcousticLM
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["llm"]
+    g = torch.Generator().manual_seed(1)
+    b, tt, tp, steps = 3, 12, 20, 16
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    pre_ref = osyn.lm_prefix(sd, cfg, text, tlen, spk, prompt)
+    toks_ref, logits_ref = osyn.lm_decode(sd, cfg, pre_ref, steps, u, True, forced)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
+    assert pre.shape == (pre_ref.shape[1], b, cfg.lm_dim)
+    assert float((pre.cpu().transpose(0, 1) - pre_ref).abs().max()) < 2e-2 * float(pre_ref.abs().max())
+    toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
+    scale = float(logits_ref.abs().max())
+    assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * scale
+    assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    # free-running sampling: feed the ORACLE's logits through the HIP sampler step by step (the sampler is
+    # exact given identical logits; free-running token equality is not a stable property across precisions)
+    from astts import ops
+    toks_free, logits_free = osyn.lm_decode(sd, cfg, pre_ref, steps, u, True, None)
+    for s in range(steps):
+        got = ops.ras_sample(logits_free[:, s].to(DEV), toks_free.to(DEV), s, u[s].to(DEV), cfg.top_k, cfg.top_p, cfg.ras_win,
+                             cfg.ras_tau, cfg.speech_vocab, True).cpu()
+        assert got.tolist() == toks_free[:, s].tolist()
+    assert int(toks_free.max()) < cfg.speech_vocab          # EOS is masked in fixed-length decode
+
+
+def test_flow_estimator_and_cfm_match_oracle():
+    from astts.synth.model import FlowDecoder
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["flow"]
+    g = torch.Generator().manual_seed(2)
+    b, tp, ts = 2, 12, 20
+    tmp = cfg.mel_frames_for_tokens(tp)
+    mel_total = tmp + cfg.mel_frames_for_tokens(ts)
+    tokens = torch.randint(0, cfg.speech_vocab, (b, tp + ts), generator=g)
+    tlen = torch.full((b,), tp + ts)
+    prompt_mel = torch.randn(b, tmp, cfg.mel, generator=g)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    z = torch.randn(b, mel_total, cfg.mel, generator=g)
+    fd = FlowDecoder(sd, cfg, torch.device(DEV))
+    # one estimator call with ragged lengths (masking semantics)
+    x = torch.randn(b, mel_total, cfg.mel, generator=g)
+    mu = torch.randn(b, mel_total, cfg.mel, generator=g)
+    cond = torch.randn(b, mel_total, cfg.mel, generator=g)
+    spk_e = torch.randn(b, cfg.mel, generator=g)
+    t = torch.tensor([0.3, 0.8])
+    lens = torch.tensor([mel_total, mel_total - 7])
+    m = (torch.arange(mel_total)[None, :] < lens[:, None]).float()[..., None]
+    ref = osyn.estimator(sd, cfg, x * m, mu * m, spk_e, cond * m, t, lens)
+    out = fd.estimator((x * m).to(DEV), (mu * m).to(DEV), spk_e.to(DEV), (cond * m).to(DEV), t.to(DEV), lens.to(DEV, torch.int32)).cpu()
+    assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    # full CFM solve
+    ref_mel = osyn.flow_decode(sd, cfg, tokens, tlen, prompt_mel, spk, z, mel_total)
+    mel = fd.decode(tokens.to(DEV), tlen.to(DEV, torch.int32), prompt_mel.to(DEV), spk.to(DEV), z.to(DEV), mel_total).cpu()
+    assert mel.shape == ref_mel.shape == (b, mel_total - tmp, cfg.mel)
+    assert float((mel - ref_mel).abs().max()) < 3e-2 * float(ref_mel.abs().max())
+
+
+def test_hift_vocoder_matches_oracle():
+    from astts.synth.model import HiftVocoder
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["hift"]
+    g = torch.Generator().manual_seed(3)
+    b, tm = 2, 24
+    mel = torch.randn(b, tm, cfg.mel, generator=g)
+    nh = cfg.nb_harmonics + 1
+    phase0 = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
+    voc = HiftVocoder(sd, cfg, torch.device(DEV))
+    f0_ref = osyn.hift_f0(sd, cfg, mel)
+    f0 = voc.f0(mel.to(DEV)).cpu()
+    assert float((f0 - f0_ref).abs().max()) < 1e-2 * float(f0_ref.abs().max())
+    # decode from the SAME source signal (the f0 -> phase map amplifies tiny f0 differences over 6k samples)
+    src_ref = osyn.hift_source(sd, cfg, f0_ref, phase0, noise)
+    src = voc.source(f0_ref.to(DEV), phase0.to(DEV), noise.to(DEV)).cpu()
+    assert float((src - src_ref).abs().max()) < 1e-4
+    wav_ref = osyn.hift_decode(sd, cfg, mel, src_ref)
+    wav = voc.decode(mel.to(DEV), src_ref.to(DEV)).cpu()
+    assert wav.shape == wav_ref.shape == (b, tm * cfg.upsample_total)
+    assert float((wav - wav_ref).abs().max()) < 2e-2
+    assert _snr_db(wav_ref, wav) > 30.0
+    assert float(wav.abs().max()) <= cfg.audio_limit + 1e-6
+
+
+def test_engine_end_to_end_shapes_and_stage_parity():
+    from astts.synth.model import SynthEngine
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    eng = SynthEngine(W, cfg, DEV)
+    g = torch.Generator().manual_seed(4)
+    b, tt, tp, ts = 2, 10, 16, 20
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk_s, spk_t = torch.randn(b, cfg.spk_dim, generator=g), torch.randn(b, cfg.spk_dim, generator=g)
+    style_tok = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    timbre_tok = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    tmp = cfg.mel_frames_for_tokens(tp)
+    tm = cfg.mel_frames_for_tokens(ts)
+    timbre_mel = torch.randn(b, tmp, cfg.mel, generator=g)
+    u = torch.rand(ts, b, 2, generator=g)
+    z = torch.randn(b, tmp + tm, cfg.mel, generator=g)
+    nh = cfg.nb_harmonics + 1
+    phase0 = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, ts), generator=g)
+    d = lambda t, dt=None: t.to(DEV) if dt is None else t.to(DEV, dt)
+    toks, mel, wav = eng.tts(d(text), d(tlen, torch.int32), d(spk_s), d(style_tok), ts, d(u), d(timbre_tok), d(timbre_mel),
+                             d(spk_t), d(z), d(phase0), d(noise), forced_tokens=d(forced))
+    assert toks.shape == (b, ts) and mel.shape == (b, tm, cfg.mel) and wav.shape == (b, tm * cfg.upsample_total)
+    # oracle chain with the same forced tokens
+    all_tok = torch.cat([timbre_tok, forced], dim=1)
+    mel_ref = osyn.flow_decode(W["flow"], cfg, all_tok, torch.full((b,), tp + ts), timbre_mel, spk_t, z, tmp + tm)
+    assert float((mel.cpu() - mel_ref).abs().max()) < 3e-2 * float(mel_ref.abs().max())
+    assert torch.isfinite(wav).all() and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
