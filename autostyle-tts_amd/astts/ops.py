@@ -20,6 +20,11 @@ _SIGS = {
     "astts_op_gemm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                 c_int32, c_int32, c_float, c_float, c_void_p]),
+    "astts_op_gemm_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p] + [c_int32] * 10 + [c_float, c_float, c_void_p]),
+    "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
+    "astts_prof_read": (c_int32, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     "astts_op_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_groupnorm_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "astts_op_groupnorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
@@ -37,10 +42,35 @@ _SIGS = {
     "astts_op_istft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p]),
     "astts_op_ras_sample": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p]),
 }
+
+
+class LmConfig(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("d", "heads", "ffn", "layers", "vocab_out", "speech_vocab", "pos_center", "pos_ld",
+                                       "top_k", "ras_win")] + [(n, c_float) for n in ("top_p", "ras_tau", "eps")]
+
+
+class LmGlobals(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("speech_emb", "embed_w", "embed_b", "embed_ln_g", "embed_ln_b", "after_g", "after_b",
+                                        "head_w", "head_b")]
+
+
+class LmLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("n1_g", "n1_b", "wqkv", "bqkv", "wo", "bo", "n2_g", "n2_b", "w1", "b1", "w2", "b2",
+                                        "pos", "bias_u", "bias_v")]
+
+
+_SIGS.update({
+    "astts_op_ras_sample_ex": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p, c_void_p]),
+    "astts_lm_create": (c_int32, [ctypes.POINTER(LmConfig), ctypes.POINTER(LmGlobals), ctypes.POINTER(LmLayer), ctypes.POINTER(c_void_p)]),
+    "astts_lm_destroy": (c_int32, [c_void_p]),
+    "astts_lm_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                  c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+})
 _lib.register_signatures(_SIGS)
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "mish": 4, "elu": 5, "tanh": 6, "leaky": 7}
-EL_SNAKE, EL_LEAKY, EL_ADD, EL_MUL_ROWMASK, EL_ADD_BC, EL_SCALE, EL_CFG_EULER, EL_MISH, EL_SILU, EL_CLAMP, EL_TANH, EL_ELU = range(12)
+EL_SNAKE, EL_LEAKY, EL_ADD, EL_MUL_ROWMASK, EL_ADD_BC, EL_SCALE, EL_CFG_EULER, EL_MISH, EL_SILU, EL_CLAMP, EL_TANH, EL_ELU, EL_RELU_SCALE = range(13)
 
 
 def _L():
@@ -131,6 +161,40 @@ def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional
     _lib.check(_L().astts_op_gemm(x.data_ptr(), w.data.data_ptr(), _p(w.bias) if use_bias else None, _p(residual),
                                   _p(row_scale), out.data_ptr(), m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
                                   t_in, t_out, stride, dil, pad, ACT[act], alpha, slope, _st()))
+    return out
+
+
+PROF_GEMM_TILE, PROF_GEMM_SKINNY, PROF_ATTN_FLASH, PROF_ATTN_DECODE = range(4)
+
+
+def prof_enable(kind: int, on: bool = True, max_launches: int = 8192) -> None:
+    _lib.check(_L().astts_prof_enable(kind, 1 if on else 0, max_launches))
+
+
+def prof_read(kind: int):
+    """-> (ms_sum, launches, work_sum, dropped) since the last read (synchronises)."""
+    ms, work = ctypes.c_double(), ctypes.c_double()
+    n, dropped = c_int64(), c_int64()
+    _lib.check(_L().astts_prof_read(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work), ctypes.byref(dropped)))
+    return float(ms.value), int(n.value), float(work.value), int(dropped.value)
+
+
+def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.Tensor] = None, ln=None, ln_eps: float = 1e-5,
+               act: str = "none", residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               out2: Optional[torch.Tensor] = None, n_split: int = 0, alpha: float = 1.0, slope: float = 0.1,
+               lda: Optional[int] = None) -> torch.Tensor:
+    """Decode-sized GEMM (m <= 32 rows) with optional row gather, LayerNorm prologue and split output.
+    ``x``: [rows, cin] fp32 (``gather`` int32 [m] selects rows); ``out`` [m, n or n_split], ``out2`` [m, n - n_split]
+    (row strides taken from the tensors, so they may be views into larger buffers such as a KV cache)."""
+    n1 = n_split if out2 is not None else w.n
+    if out is None:
+        out = torch.empty((m, n1), dtype=torch.float32, device=x.device)
+    ga, be = (ln if ln is not None else (None, None))
+    _lib.check(_L().astts_op_gemm_fused(x.data_ptr(), _p(gather), _p(ga), _p(be), ln_eps, w.data.data_ptr(), _p(w.bias),
+                                        _p(residual), out.data_ptr(), _p(out2), m, w.n, n_split, w.cin, w.cin_pad,
+                                        lda if lda is not None else x.stride(-2), out.stride(-2),
+                                        out2.stride(-2) if out2 is not None else 0,
+                                        residual.stride(-2) if residual is not None else 0, ACT[act], alpha, slope, _st()))
     return out
 
 

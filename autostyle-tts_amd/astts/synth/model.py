@@ -64,6 +64,8 @@ class RelPosEncoder:
                 "wq": PackedWeight(sd[a + ".linear_q.weight"], sd[a + ".linear_q.bias"], device),
                 "wkv": PackedWeight(torch.cat([sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0),
                                     torch.cat([sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0), device),
+                "wqkv": PackedWeight(torch.cat([sd[a + ".linear_q.weight"], sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0),
+                                     torch.cat([sd[a + ".linear_q.bias"], sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0), device),
                 "wo": PackedWeight(sd[a + ".linear_out.weight"], sd[a + ".linear_out.bias"], device),
                 "w1": PackedWeight(sd[q + ".feed_forward.w_1.weight"], sd[q + ".feed_forward.w_1.bias"], device),
                 "w2": PackedWeight(sd[q + ".feed_forward.w_2.weight"], sd[q + ".feed_forward.w_2.bias"], device),
@@ -154,12 +156,84 @@ class AcousticLM:
     def logits(self, hidden_last: torch.Tensor) -> torch.Tensor:
         return ops.linear(hidden_last, self.head)
 
+    def step_logits(self, tok: torch.Tensor, cache: List[torch.Tensor], pos: int) -> torch.Tensor:
+        """One decode step for B <= 32 utterances with the launch-saving fusions of astts_op_gemm_fused:
+        embedding gather inside the embed GEMM, LayerNorm inside the QKV / FFN-in / head GEMMs, K|V written
+        straight into the cache.  5 launches per layer.  tok int32 [B] -> logits [B, V+1]."""
+        body = self.body
+        d, b = body.d, tok.shape[0]
+        h = ops.gemm_fused(self.speech_emb, body.embed, b, gather=tok)
+        h = ops.layernorm(h, *body.embed_ln, body.eps)
+        h = ops.elementwise(ops.EL_RELU_SCALE, h, s=math.sqrt(d))
+        lens = torch.full((b,), pos + 1, dtype=torch.int32, device=self.device)
+        for lay, kvc in zip(body.L, cache):
+            q = ops.gemm_fused(h, lay["wqkv"], b, ln=lay["n1"], ln_eps=body.eps, out2=kvc[pos], n_split=d)
+            kv = kvc[:pos + 1]
+            a = ops.attn_relpos(q[None], kv[..., :d], kv[..., d:], lay["pos"], lay["u"], lay["v"], body.heads, lens=lens,
+                                q_pos0=pos, pos_center=body.center, causal=True, time_major=True)
+            h = ops.gemm_fused(a[0], lay["wo"], b, residual=h)
+            f = ops.gemm_fused(h, lay["w1"], b, ln=lay["n2"], ln_eps=body.eps, act="relu")
+            h = ops.gemm_fused(f, lay["w2"], b, residual=h)
+        return ops.gemm_fused(h, self.head, b, ln=body.after, ln_eps=body.eps)
+
+    # ---- C++ decode engine (libastts astts_lm_*): same fused step, issued without Python in the loop
+    def _engine(self):
+        if getattr(self, "_eng", None) is None:
+            import ctypes
+
+            from .. import _lib
+            body, cfg = self.body, self.cfg
+            c = ops.LmConfig(body.d, body.heads, cfg.lm_ffn, len(body.L), cfg.speech_vocab + 1, cfg.speech_vocab, body.center,
+                             body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps)
+            g = ops.LmGlobals(self.speech_emb.data_ptr(), body.embed.data.data_ptr(), body.embed.bias.data_ptr(),
+                              body.embed_ln[0].data_ptr(), body.embed_ln[1].data_ptr(), body.after[0].data_ptr(),
+                              body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr())
+            arr = (ops.LmLayer * len(body.L))()
+            for i, L in enumerate(body.L):
+                arr[i] = ops.LmLayer(L["n1"][0].data_ptr(), L["n1"][1].data_ptr(), L["wqkv"].data.data_ptr(), L["wqkv"].bias.data_ptr(),
+                                     L["wo"].data.data_ptr(), L["wo"].bias.data_ptr(), L["n2"][0].data_ptr(), L["n2"][1].data_ptr(),
+                                     L["w1"].data.data_ptr(), L["w1"].bias.data_ptr(), L["w2"].data.data_ptr(), L["w2"].bias.data_ptr(),
+                                     L["pos"].data_ptr(), L["u"].data_ptr(), L["v"].data_ptr())
+            h = ctypes.c_void_p()
+            _lib.check(_lib.load().astts_lm_create(ctypes.byref(c), ctypes.byref(g), arr, ctypes.byref(h)))
+            self._eng = h
+        return self._eng
+
+    def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
+                      forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+        import ctypes
+
+        from .. import _lib
+        lib = _lib.load()
+        eng = self._engine()
+        s0, b = prefix.shape[0], prefix.shape[1]
+        t_max = s0 + n_steps
+        cache = self.new_cache(b, t_max)
+        hid = self.forward_new(prefix, cache, 0)
+        logits0 = self.logits(hid[-1]).contiguous()
+        need = int(lib.astts_lm_workspace_bytes(eng, b))
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        toks = torch.zeros((b, n_steps), dtype=torch.int32, device=self.device)
+        lg_out = torch.empty((b, n_steps, self.cfg.speech_vocab + 1), dtype=torch.float32, device=self.device) if return_logits else None
+        ptrs = (ctypes.c_void_p * len(cache))(*[c.data_ptr() for c in cache])
+        forced = None if forced_tokens is None else forced_tokens.to(torch.int32).contiguous()
+        u = uniforms.to(torch.float32).contiguous()
+        _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, t_max, b, s0, n_steps, u.data_ptr(),
+                                       None if forced is None else forced.data_ptr(), 1 if ignore_eos else 0, toks.data_ptr(),
+                                       None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
+        self._keepalive = (cache, ws, logits0, forced, u)   # buffers referenced by kernels still in flight
+        return (toks, lg_out) if return_logits else toks
+
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
-               forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+               forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True):
         """Fixed-length autoregressive decode, no host synchronisation inside the loop.
         prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1])."""
         cfg = self.cfg
         s0, b = prefix.shape[0], prefix.shape[1]
+        if use_engine and b <= 32:
+            return self.decode_engine(prefix, n_steps, uniforms, ignore_eos, forced_tokens, return_logits)
         cache = self.new_cache(b, s0 + n_steps)
         hid = self.forward_new(prefix, cache, 0)
         cur = self.logits(hid[-1])
@@ -174,9 +248,12 @@ class AcousticLM:
                 tok = forced_tokens[:, s].to(torch.int32).contiguous()
             toks[:, s] = tok
             if s + 1 < n_steps:
-                emb = ops.embedding(self.speech_emb, tok)[None]            # [1, B, d]
-                hid = self.forward_new(emb, cache, s0 + s)
-                cur = self.logits(hid[0])
+                if b <= 32:
+                    cur = self.step_logits(tok.clamp(max=cfg.speech_vocab - 1), cache, s0 + s)
+                else:
+                    emb = ops.embedding(self.speech_emb, tok)[None]        # [1, B, d]
+                    hid = self.forward_new(emb, cache, s0 + s)
+                    cur = self.logits(hid[0])
         if return_logits:
             return toks, torch.stack(all_logits, dim=1)
         return toks

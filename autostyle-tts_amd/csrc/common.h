@@ -13,6 +13,10 @@ namespace astts {
 
 void set_error(const char* fmt, ...);
 
+// bench-only launch profiler (runtime.hip); prof_begin returns true when the launch is being timed
+bool prof_begin(int kind, hipStream_t st, double work);
+void prof_end(int kind, hipStream_t st);
+
 #define ASTTS_CHECK_HIP(expr)                                                              \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \

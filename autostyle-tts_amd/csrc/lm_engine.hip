@@ -1,0 +1,148 @@
+// lm_engine.hip -- autoregressive decode loop of the acoustic transformer, host side in C++.
+//
+// The reference's hot loop #2: one speech token per step, ~50 steps per audio second,
+// inside cosyvoice's TransformerLM.inference (behind tts_with_rag.py:195).  A Python host pays ~10 us
+// per operator call; this engine issues the 5-launches-per-layer fused step (astts_op_gemm_fused,
+// astts_op_attn_relpos, astts_op_ras_sample) straight from C++ with no host synchronisation:
+// sampling, repetition check, EOS masking and the token history all stay on the GPU.
+#include "common.h"
+
+#include <vector>
+
+struct astts_lm {
+    astts_lm_config_t cfg;
+    std::vector<astts_lm_layer_t> layers;
+    astts_lm_globals_t g;
+};
+
+using namespace astts;
+
+extern "C" {
+
+int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* globals, const astts_lm_layer_t* layers,
+                    astts_lm_t** out) {
+    ASTTS_REQUIRE(cfg && globals && layers && out, ASTTS_ERR_INVALID, "astts_lm_create: null argument");
+    ASTTS_REQUIRE(cfg->d >= 64 && cfg->d % 64 == 0 && cfg->heads * 64 == cfg->d, ASTTS_ERR_INVALID,
+                  "astts_lm_create: d=%d heads=%d (head dim must be 64)", cfg->d, cfg->heads);
+    ASTTS_REQUIRE(cfg->layers >= 1 && cfg->ffn >= 64 && cfg->vocab_out >= 2 && cfg->speech_vocab >= 1, ASTTS_ERR_INVALID,
+                  "astts_lm_create: bad sizes");
+    astts_lm* h = new astts_lm();
+    h->cfg = *cfg;
+    h->g = *globals;
+    h->layers.assign(layers, layers + cfg->layers);
+    *out = h;
+    return ASTTS_OK;
+}
+
+int astts_lm_destroy(astts_lm_t* h) {
+    delete h;
+    return ASTTS_OK;
+}
+
+size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
+    if (!h || b < 1 || b > 32) return 0;
+    const size_t d = h->cfg.d;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { o = align_up(o + bytes, 256); };
+    take(sizeof(float) * b * d);                  // h0
+    take(sizeof(float) * b * d);                  // h1
+    take(sizeof(float) * b * d);                  // q
+    take(sizeof(float) * b * d);                  // attn out
+    take(sizeof(float) * b * h->cfg.ffn);         // ffn hidden
+    take(sizeof(float) * b * h->cfg.vocab_out);   // logits
+    take(sizeof(int32_t) * b);                    // token
+    take(sizeof(int32_t) * b);                    // lens
+    return o;
+}
+
+// logits0: [B, vocab_out] logits of the last prefix position (from the prefill); kv_cache[l]: fp32
+// [t_max, B, 2d] time-major, rows [0, pos0) filled by the prefill.  tokens_out: int32 [B, n_steps].
+int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
+                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t ignore_eos,
+                    int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
+                    astts_stream_t stream) {
+    ASTTS_REQUIRE(h && logits0 && kv_cache && uniforms && tokens_out && workspace, ASTTS_ERR_INVALID,
+                  "astts_lm_decode: null argument");
+    ASTTS_REQUIRE(b >= 1 && b <= 32, ASTTS_ERR_INVALID, "astts_lm_decode: b=%d (1..32 per call)", b);
+    ASTTS_REQUIRE(n_steps >= 1 && pos0 >= 1 && pos0 + n_steps - 1 <= t_max, ASTTS_ERR_INVALID,
+                  "astts_lm_decode: pos0=%d n_steps=%d t_max=%d", pos0, n_steps, t_max);
+    ASTTS_REQUIRE(workspace_bytes >= astts_lm_workspace_bytes(h, b) && ((uintptr_t)workspace & 255) == 0,
+                  ASTTS_ERR_WORKSPACE, "astts_lm_decode: workspace too small or misaligned");
+    const astts_lm_config_t& c = h->cfg;
+    const astts_lm_globals_t& g = h->g;
+    hipStream_t st = (hipStream_t)stream;
+    const int d = c.d;
+    const int dpad = (int)align_up((size_t)d, 64), fpad = (int)align_up((size_t)c.ffn, 64);
+    char* ws = (char*)workspace;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        void* p = ws + o;
+        o = align_up(o + bytes, 256);
+        return p;
+    };
+    float* h0 = (float*)take(sizeof(float) * b * d);
+    float* h1 = (float*)take(sizeof(float) * b * d);
+    float* q = (float*)take(sizeof(float) * b * d);
+    float* ao = (float*)take(sizeof(float) * b * d);
+    float* ff = (float*)take(sizeof(float) * b * c.ffn);
+    float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
+    int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
+    int32_t* lens = (int32_t*)take(sizeof(int32_t) * b);
+    const float scale = 0.125f;  // 1/sqrt(64)
+    const int64_t kv_row = (int64_t)b * 2 * d;  // one time step of the time-major cache
+
+    const float* cur = logits0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (logits_out)
+            ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
+                                             cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
+                                             hipMemcpyDeviceToDevice, st));
+        int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, ignore_eos, forced_tokens,
+                                        st);
+        if (rc != ASTTS_OK) return rc;
+        if (s + 1 == n_steps) break;
+        const int pos = pos0 + s;
+        ASTTS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)lens, pos + 1, b, st));
+        // embed: speech_embedding[tok] -> Linear -> LayerNorm -> ReLU * sqrt(d)
+        rc = astts_op_gemm_fused(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, b, d, 0,
+                                 d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
+        if (rc != ASTTS_OK) return rc;
+        rc = astts_op_layernorm(h1, g.embed_ln_g, g.embed_ln_b, h0, b, d, d, d, c.eps, st);
+        if (rc != ASTTS_OK) return rc;
+        rc = astts_op_elementwise(ASTTS_EL_RELU_SCALE, h0, nullptr, nullptr, nullptr, h0, (int64_t)b * d, 1, d, sqrtf((float)d),
+                                  0.f, st);
+        if (rc != ASTTS_OK) return rc;
+        float* x = h0;
+        float* y = h1;
+        for (int l = 0; l < c.layers; ++l) {
+            const astts_lm_layer_t& L = h->layers[l];
+            float* kvc = kv_cache[l];
+            // LN1 + QKV; K|V land in cache row `pos`
+            rc = astts_op_gemm_fused(x, nullptr, L.n1_g, L.n1_b, c.eps, L.wqkv, L.bqkv, nullptr, q, kvc + (int64_t)pos * kv_row,
+                                     b, 3 * d, d, d, dpad, d, d, 2 * d, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_attn_relpos(q, kvc, kvc + d, L.pos, L.bias_u, L.bias_v, lens, ao, b, c.heads, 1, pos + 1,
+                                      /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld, /*q_bs*/ d,
+                                      /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_gemm_fused(ao, nullptr, nullptr, nullptr, 0.f, L.wo, L.bo, x, y, nullptr, b, d, 0, d, dpad, d, d, 0, d,
+                                     ASTTS_ACT_NONE, 1.f, 0.f, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_gemm_fused(y, nullptr, L.n2_g, L.n2_b, c.eps, L.w1, L.b1, nullptr, ff, nullptr, b, c.ffn, 0, d, dpad, d,
+                                     c.ffn, 0, 0, ASTTS_ACT_RELU, 1.f, 0.f, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_gemm_fused(ff, nullptr, nullptr, nullptr, 0.f, L.w2, L.b2, y, x, nullptr, b, d, 0, c.ffn, fpad, c.ffn, d,
+                                     0, d, ASTTS_ACT_NONE, 1.f, 0.f, st);
+            if (rc != ASTTS_OK) return rc;
+        }
+        // after_norm + output head
+        rc = astts_op_gemm_fused(x, nullptr, g.after_g, g.after_b, c.eps, g.head_w, g.head_b, nullptr, lg, nullptr, b, c.vocab_out,
+                                 0, d, dpad, d, c.vocab_out, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
+        if (rc != ASTTS_OK) return rc;
+        cur = lg;
+    }
+    return ASTTS_OK;
+}
+
+}  // extern "C"

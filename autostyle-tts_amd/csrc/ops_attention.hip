@@ -135,37 +135,43 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     }
 }
 
-// one (batch, head) per block; query = the single new position q_pos0 (== tk - 1 for the LM step)
+// one (batch, head) per block; query = the single new position q_pos0 (== tk - 1 for the LM step).
+// 16 lanes share one key: lane sub = lane & 15 owns dims [4 sub, 4 sub + 4), so every wave
+// instruction reads four whole 256-byte K (or V, or position) rows -- fully coalesced.
 __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
-    extern __shared__ float sc[];  // [tk] scores, then [4][64] partial outputs
-    __shared__ float qu[DH], qv[DH];
+    extern __shared__ float sc[];  // [tk] scores, then [16][64] partial outputs
     __shared__ float redm[4], reds[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = lane & 15, grp = tid >> 4;  // 16 key groups per block
     const int head = blockIdx.x, b = blockIdx.y;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
-    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH;
-    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH;
-    if (tid < DH) {
-        const float x = qb[tid];
-        qu[tid] = (x + a.bias_u[head * DH + tid]) * a.scale;
-        qv[tid] = (x + a.bias_v[head * DH + tid]) * a.scale;
+    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH + 4 * sub;
+    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH + 4 * sub;
+    const float* pb = a.pos + head * DH + 4 * sub;
+    float4 qu, qv;
+    {
+        const float4 x = *reinterpret_cast<const float4*>(qb + 4 * sub);
+        const float4 u = *reinterpret_cast<const float4*>(a.bias_u + head * DH + 4 * sub);
+        const float4 v = *reinterpret_cast<const float4*>(a.bias_v + head * DH + 4 * sub);
+        qu = make_float4((x.x + u.x) * a.scale, (x.y + u.y) * a.scale, (x.z + u.z) * a.scale, (x.w + u.w) * a.scale);
+        qv = make_float4((x.x + v.x) * a.scale, (x.y + v.y) * a.scale, (x.z + v.z) * a.scale, (x.w + v.w) * a.scale);
     }
-    __syncthreads();
     float mloc = -INFINITY;
-    for (int j = tid; j < len; j += 256) {
-        const float* kr = kb + (int64_t)j * a.ldk;
-        const float* pr = a.pos + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp + head * DH;
+    for (int j0 = 0; j0 < len; j0 += 16) {
+        const int j = j0 + grp;
         float s = 0.0f;
-#pragma unroll
-        for (int d = 0; d < DH; d += 4) {
-            const float4 kk = *reinterpret_cast<const float4*>(kr + d);
-            const float4 pp = *reinterpret_cast<const float4*>(pr + d);
-            s += qu[d] * kk.x + qu[d + 1] * kk.y + qu[d + 2] * kk.z + qu[d + 3] * kk.w;
-            s += qv[d] * pp.x + qv[d + 1] * pp.y + qv[d + 2] * pp.z + qv[d + 3] * pp.w;
+        if (j < len) {
+            const float4 kk = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk);
+            const float4 pp = *reinterpret_cast<const float4*>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
+            s = qu.x * kk.x + qu.y * kk.y + qu.z * kk.z + qu.w * kk.w + qv.x * pp.x + qv.y * pp.y + qv.z * pp.z + qv.w * pp.w;
         }
-        sc[j] = s;
-        mloc = fmaxf(mloc, s);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (j < len) {
+            if (sub == 0) sc[j] = s;
+            mloc = fmaxf(mloc, s);
+        }
     }
     mloc = wave_max_f32(mloc);
     if (lane == 0) redm[wid] = mloc;
@@ -181,15 +187,21 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
     if (lane == 0) reds[wid] = sloc;
     __syncthreads();
     const float l = (reds[0] + reds[1]) + (reds[2] + reds[3]);
-    // out[d] = sum_j p_j v[j][d]: wave w takes keys j = w (mod 4), lane = d
-    float o = 0.0f;
-    for (int j = wid; j < len; j += 4) o += sc[j] * vb[(int64_t)j * a.ldk + lane];
+    // out[d] = sum_j p_j v[j][d]: key group g takes keys j = g (mod 16)
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = grp; j < len; j += 16) {
+        const float p = sc[j];
+        const float4 vv = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk);
+        o.x += p * vv.x; o.y += p * vv.y; o.z += p * vv.z; o.w += p * vv.w;
+    }
     float* part = sc + a.tk;
-    part[wid * DH + lane] = o;
+    *reinterpret_cast<float4*>(part + grp * DH + 4 * sub) = o;
     __syncthreads();
-    if (wid == 0) {
-        const float tot = (part[lane] + part[DH + lane]) + (part[2 * DH + lane] + part[3 * DH + lane]);
-        a.out[(int64_t)b * a.o_bs + head * DH + lane] = l > 0.0f ? tot / l : 0.0f;
+    if (tid < DH) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) tot += part[g2 * DH + tid];
+        a.out[(int64_t)b * a.o_bs + head * DH + tid] = l > 0.0f ? tot / l : 0.0f;
     }
 }
 
@@ -357,9 +369,13 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
     RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center, causal, scale};
     hipStream_t st = (hipStream_t)stream;
     if (tq == 1) {
-        const size_t lds = ((size_t)tk + 4 * DH) * sizeof(float);
+        const size_t lds = ((size_t)((tk + 3) & ~3) + 16 * DH) * sizeof(float);
         ASTTS_REQUIRE(lds <= 60 * 1024, ASTTS_ERR_INVALID, "astts_op_attn_relpos: tk=%d too long for the decode kernel", tk);
+        a.tk = (tk + 3) & ~3;  // keeps the partial-output area 16-byte aligned (keys are bounded by lens / tk below)
+        if (!lens) { set_error("astts_op_attn_relpos: the decode kernel needs lens"); return ASTTS_ERR_INVALID; }
+        const bool prof = prof_begin(ASTTS_PROF_ATTN_DECODE, st, (double)b * h * tk * DH * 4.0 * 2.0);
         hipLaunchKernelGGL(attn_relpos_decode, dim3(h, b), dim3(256), lds, st, a);
+        if (prof) prof_end(ASTTS_PROF_ATTN_DECODE, st);
     } else {
         // the tile loader reads rel in [q_pos0+i0-(j0+63), q_pos0+i0+15-j0]; keep that inside the table
         ASTTS_REQUIRE(pos_center >= tk + RP_KB + RP_QB && pos_center >= q_pos0 + tq + RP_QB, ASTTS_ERR_INVALID,
@@ -378,7 +394,9 @@ int astts_op_attn_mha(const float* q, const float* k, const float* v, const int3
                       ((uintptr_t)v & 15) == 0,
                   ASTTS_ERR_INVALID, "astts_op_attn_mha: q/k/v must be 16-byte aligned with ld %% 4 == 0");
     MhaArgs a{q, k, v, lens, out, b, h, t, ldq, ldk, ldo, scale};
+    const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, (hipStream_t)stream, 4.0 * (double)b * h * (double)t * t * DH);
     hipLaunchKernelGGL(attn_mha_flash, dim3((t + 127) / 128, h, b), dim3(256), 0, (hipStream_t)stream, a);
+    if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, (hipStream_t)stream);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

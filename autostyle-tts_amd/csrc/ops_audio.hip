@@ -164,6 +164,9 @@ struct SampleArgs {
     const int* history;   // [B, hist_ld] decoded tokens so far
     const float* u;       // [B, 2]
     int* out;             // [B]
+    int* hist_w;          // when set: history[b, hist_len] = token (the engine's on-device token log)
+    const int* forced;    // when set: token = forced[b, hist_len] (teacher forcing), same layout as history
+    int clamp_out;        // out[b] = min(token, clamp_out) (embedding row for the next step); < 0: no clamp
     int b, v, hist_len, hist_ld, top_k, win, eos, ignore_eos;
     float top_p, tau_r;
 };
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     __shared__ float top_p_val[64];
     __shared__ int top_p_idx[64];
     __shared__ float s_bcast;
+    __shared__ int s_tok;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
     float mx = -INFINITY;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
         int rep = 0;
         const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
         for (int i = h0; i < a.hist_len; ++i) rep += (a.history[(int64_t)bb * a.hist_ld + i] == tok) ? 1 : 0;
-        a.out[bb] = tok;
+        s_tok = tok;
         s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
     }
     __syncthreads();
@@ -291,7 +295,14 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
                 break;
             }
         }
-        a.out[bb] = tok >= 0 ? tok : last;
+        s_tok = tok >= 0 ? tok : last;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tok = s_tok;
+        if (a.forced) tok = a.forced[(int64_t)bb * a.hist_ld + a.hist_len];
+        if (a.hist_w) a.hist_w[(int64_t)bb * a.hist_ld + a.hist_len] = tok;
+        a.out[bb] = (a.clamp_out >= 0 && tok > a.clamp_out) ? a.clamp_out : tok;
     }
 }
 
@@ -350,7 +361,21 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(logits && uniforms && out_tokens && (history || hist_len == 0), ASTTS_ERR_INVALID, "astts_op_ras_sample: null pointer");
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
-    SampleArgs a{logits, history, uniforms, out_tokens, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
+    SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+/* Engine form: `history` is read (repetition window) and written at column hist_len; optional teacher forcing. */
+int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* uniforms, int32_t* out_tokens, int32_t b,
+                           int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p, int32_t win_size,
+                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* forced, astts_stream_t stream) {
+    ASTTS_REQUIRE(logits && uniforms && out_tokens && history, ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: null pointer");
+    ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0 && hist_len < hist_ld,
+                  ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
+    SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, b, vocab, hist_len, hist_ld, top_k, win_size,
+                 eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

@@ -8,14 +8,19 @@
 //   m = b*t_out + t,   src_row = b*t_in + t*stride + tap*dil - pad   (zero outside [0, t_in))
 //
 // X: fp32 [B*t_in, lda] channels-last, W: fp16 [n_pad, taps*cin_pad] (K contiguous, zero padded:
-// cin_pad multiple of 32, n_pad multiple of 128), out: fp32 [B*t_out, ldc].
+// cin_pad multiple of 64, n_pad multiple of 128), out: fp32 [B*t_out, ldc].
 // epilogue: (+bias[n]) -> activation -> *alpha -> *row_scale[m] -> +residual[m, n]
 //
-// gemm_tile:   block tile (WM*TM*32) x (WN*TN*32) x 32, 4 waves, v_mfma_f32_32x32x16_f16, fp32->fp16
-//              conversion while staging through LDS (80-byte padded rows: conflict-free b128 reads),
-//              register prefetch of the next K tile under the MFMAs of the current one.
-// gemm_skinny: M <= 32 (decode steps, conditioning MLPs): weights streamed straight to VGPRs, the 4
-//              waves of a block split K line by line and reduce through LDS -- weight-bandwidth bound.
+// gemm_tile:     block tile (WM*TM*32) x (WN*TN*32) x 32, 4 waves, v_mfma_f32_32x32x16_f16, fp32->fp16
+//                conversion while staging through LDS (80-byte padded rows: conflict-free b128 reads),
+//                register prefetch of the next K tile under the MFMAs of the current one.  The tile
+//                shape is picked per call so that the grid covers the 256 CUs.
+// gemm_skinny16: M <= 32 (LM decode steps, conditioning MLPs): weight-bandwidth bound.  One block =
+//                16 output columns, 8 waves that split K line by line, weights streamed straight to
+//                VGPRs (v_mfma_f32_16x16x32_f16), LDS reduction.  Optional fusions that remove whole
+//                launches from the decode step: LayerNorm of the input rows in the prologue, row
+//                gather (embedding lookup), and a second output for the columns >= n_split (the K|V
+//                half of a fused QKV projection lands directly in the KV cache).
 #include "common.h"
 
 namespace astts {
@@ -51,6 +56,13 @@ struct GemmArgs {
     int t_in, t_out, stride, dil, pad;
     int act;
     float alpha, slope;
+    // gemm_skinny16 extras
+    const int* gather;       // [m] row indices into x (embedding lookup) or null
+    const float* ln_gamma;   // LayerNorm over the cin inputs of every row, applied while loading (or null)
+    const float* ln_beta;
+    float ln_eps;
+    float* out2;             // columns >= n_split go to out2[m*ldc2 + n - n_split] (or null)
+    int ldc2, n_split;
 };
 
 static constexpr int BK = 32;
@@ -59,10 +71,9 @@ static constexpr int LDS_ROW = 40;  // halfs per staged row (32 + 8 pad = 80 byt
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_CHUNKS = BM * 2 / 256;  // 16-float chunks per thread for the X tile
-    constexpr int B_CHUNKS = BN * 2 / 256;  // 16-half chunks per thread for the W tile
+    constexpr int A_CH = (BM * 4 + 255) / 256;  // 8-float chunks per thread for the X tile
+    constexpr int B_CH = (BN * 4 + 255) / 256;  // 8-half chunks per thread for the W tile
     static_assert(WM * WN == 4, "4 waves");
-    static_assert(A_CHUNKS >= 1 && (B_CHUNKS >= 1 || BN == 64 || BN == 32), "tile too small");
     __shared__ __attribute__((aligned(16))) _Float16 sa[2][BM * LDS_ROW];
     __shared__ __attribute__((aligned(16))) _Float16 sb[2][BN * LDS_ROW];
 
@@ -75,86 +86,73 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     const int nkt = ktot / BK;
     const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
 
-    // ---- per-thread staging coordinates
-    int a_row[A_CHUNKS], a_seg[A_CHUNKS];
-    int64_t a_base[A_CHUNKS];  // row index of (b, t*stride - pad) in X, before the tap offset
-    int a_t[A_CHUNKS];         // t*stride - pad
-    bool a_live[A_CHUNKS];
+    // ---- per-thread staging coordinates (chunk id -> row = id / 4, k segment = (id % 4) * 8)
+    int a_row[A_CH], a_seg[A_CH], a_t[A_CH];
+    int64_t a_base[A_CH];
+    bool a_live[A_CH];
 #pragma unroll
-    for (int c = 0; c < A_CHUNKS; ++c) {
+    for (int c = 0; c < A_CH; ++c) {
         const int id = tid + c * 256;
-        a_row[c] = id >> 1;
-        a_seg[c] = (id & 1) * 16;
+        a_row[c] = id >> 2;
+        a_seg[c] = (id & 3) * 8;
         const int64_t m = m0 + a_row[c];
-        a_live[c] = m < a.m;
+        a_live[c] = (id < BM * 4) && m < a.m;
         const int64_t b = a_live[c] ? m / a.t_out : 0;
         const int t = a_live[c] ? (int)(m - b * a.t_out) : 0;
         a_t[c] = t * a.stride - a.pad;
         a_base[c] = b * a.t_in;
     }
-    constexpr int BCH = (B_CHUNKS >= 1) ? B_CHUNKS : 1;
-    const bool b_active = (BN * 2 >= 256) || (tid < BN * 2);
-    int b_row[BCH], b_seg[BCH];
+    int b_row[B_CH], b_seg[B_CH];
+    bool b_live[B_CH];
 #pragma unroll
-    for (int c = 0; c < BCH; ++c) {
+    for (int c = 0; c < B_CH; ++c) {
         const int id = tid + c * 256;
-        b_row[c] = id >> 1;
-        b_seg[c] = (id & 1) * 16;
+        b_row[c] = id >> 2;
+        b_seg[c] = (id & 3) * 8;
+        b_live[c] = id < BN * 4;
     }
 
-    float4 ra[A_CHUNKS][4];
-    half8 rb[BCH][2];
+    float4 ra[A_CH][2];
+    half8 rb[B_CH];
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         const int tap = k0 / a.cin_pad;
         const int c0 = k0 - tap * a.cin_pad;
 #pragma unroll
-        for (int c = 0; c < A_CHUNKS; ++c) {
+        for (int c = 0; c < A_CH; ++c) {
             const int ts = a_t[c] + tap * a.dil;
             const bool ok = a_live[c] && ts >= 0 && ts < a.t_in;
             const int ch = c0 + a_seg[c];
             const float* src = a.x + (a_base[c] + ts) * (int64_t)a.lda + ch;
-            if (ok && vec_ok && ch + 16 <= a.cin) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ra[c][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+            if (ok && vec_ok && ch + 8 <= a.cin) {
+                ra[c][0] = *reinterpret_cast<const float4*>(src);
+                ra[c][1] = *reinterpret_cast<const float4*>(src + 4);
             } else {
-                float tmp[16];
+                float tmp[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) tmp[j] = (ok && ch + j < a.cin) ? src[j] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ra[c][j] = make_float4(tmp[4 * j], tmp[4 * j + 1], tmp[4 * j + 2], tmp[4 * j + 3]);
+                for (int j = 0; j < 8; ++j) tmp[j] = (ok && ch + j < a.cin) ? src[j] : 0.0f;
+                ra[c][0] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                ra[c][1] = make_float4(tmp[4], tmp[5], tmp[6], tmp[7]);
             }
         }
-        if (b_active) {
 #pragma unroll
-            for (int c = 0; c < BCH; ++c) {
-                const _Float16* src = a.w + (int64_t)(n0 + b_row[c]) * ktot + k0 + b_seg[c];
-                rb[c][0] = *reinterpret_cast<const half8*>(src);
-                rb[c][1] = *reinterpret_cast<const half8*>(src + 8);
-            }
-        }
+        for (int c = 0; c < B_CH; ++c)
+            if (b_live[c]) rb[c] = *reinterpret_cast<const half8*>(a.w + (int64_t)(n0 + b_row[c]) * ktot + k0 + b_seg[c]);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int c = 0; c < A_CHUNKS; ++c) {
-            half8 h0, h1;
-            h0[0] = (_Float16)ra[c][0].x; h0[1] = (_Float16)ra[c][0].y; h0[2] = (_Float16)ra[c][0].z; h0[3] = (_Float16)ra[c][0].w;
-            h0[4] = (_Float16)ra[c][1].x; h0[5] = (_Float16)ra[c][1].y; h0[6] = (_Float16)ra[c][1].z; h0[7] = (_Float16)ra[c][1].w;
-            h1[0] = (_Float16)ra[c][2].x; h1[1] = (_Float16)ra[c][2].y; h1[2] = (_Float16)ra[c][2].z; h1[3] = (_Float16)ra[c][2].w;
-            h1[4] = (_Float16)ra[c][3].x; h1[5] = (_Float16)ra[c][3].y; h1[6] = (_Float16)ra[c][3].z; h1[7] = (_Float16)ra[c][3].w;
-            _Float16* dst = &sa[buf][a_row[c] * LDS_ROW + a_seg[c]];
-            *reinterpret_cast<half8*>(dst) = h0;
-            *reinterpret_cast<half8*>(dst + 8) = h1;
-        }
-        if (b_active) {
-#pragma unroll
-            for (int c = 0; c < BCH; ++c) {
-                _Float16* dst = &sb[buf][b_row[c] * LDS_ROW + b_seg[c]];
-                *reinterpret_cast<half8*>(dst) = rb[c][0];
-                *reinterpret_cast<half8*>(dst + 8) = rb[c][1];
+        for (int c = 0; c < A_CH; ++c) {
+            if (tid + c * 256 < BM * 4) {
+                half8 hv;
+                hv[0] = (_Float16)ra[c][0].x; hv[1] = (_Float16)ra[c][0].y; hv[2] = (_Float16)ra[c][0].z; hv[3] = (_Float16)ra[c][0].w;
+                hv[4] = (_Float16)ra[c][1].x; hv[5] = (_Float16)ra[c][1].y; hv[6] = (_Float16)ra[c][1].z; hv[7] = (_Float16)ra[c][1].w;
+                *reinterpret_cast<half8*>(&sa[buf][a_row[c] * LDS_ROW + a_seg[c]]) = hv;
             }
         }
+#pragma unroll
+        for (int c = 0; c < B_CH; ++c)
+            if (b_live[c]) *reinterpret_cast<half8*>(&sb[buf][b_row[c] * LDS_ROW + b_seg[c]]) = rb[c];
     };
 
     float16v acc[TM][TN];
@@ -212,62 +210,130 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     }
 }
 
-// M <= 32, no conv addressing (taps == 1, stride 1): out[m, n] for a 32-column slice per block.
-__global__ __launch_bounds__(256) void gemm_skinny(GemmArgs a) {
-    __shared__ float red[3][16][64];
+// ------------------------------------------------------------------------------------------
+// M <= 32, plain (taps == 1): one block = 16 output columns; 8 waves split K by 64-element lines.
+// Lane (c = lane & 15, g = lane >> 4) owns bytes [32g, 32g+32) of row c in every 128-byte weight
+// line: two MFMA 16x16x32 k-steps of 8 halfs each (same permuted k order for X and W).
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
+    __shared__ float red[8][MT][4][64];
+    __shared__ float ln_mu[32], ln_rs[32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
     const int ktot = a.cin_pad;
-    const int lines = ktot >> 6;  // 64-element K lines (cin_pad is a multiple of 64 for this kernel)
-    float16v acc;
+    const int lines = ktot >> 6;
+    const int M = (int)a.m;
+
+    const float* xrow[MT];
+    int mrow[MT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    const int mrow = r < a.m ? r : (int)a.m - 1;
-    const float* xrow = a.x + (int64_t)mrow * a.lda + h * 32;
-    const _Float16* wrow = a.w + (int64_t)(n0 + r) * ktot + h * 32;
-    for (int line = wid; line < lines; line += 4) {
-        const int k0 = line * 64;
-        half8 fb[4], fa[4];
+    for (int t = 0; t < MT; ++t) {
+        int mr = t * 16 + c;
+        if (mr >= M) mr = M - 1;
+        mrow[t] = mr;
+        const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+        xrow[t] = a.x + src * a.lda;
+    }
+    if (a.ln_gamma) {  // LayerNorm statistics of the input rows: wave w takes rows w, w+8, ...
+        for (int mr = wid; mr < M; mr += 8) {
+            const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+            const float* xr = a.x + src * a.lda;
+            float s = 0.0f;
+            for (int k = lane; k < a.cin; k += 64) s += xr[k];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const half8*>(wrow + k0 + i * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = k0 + h * 32 + i * 8;
-            float t[8];
-            if (ch + 8 <= a.cin && (a.lda & 3) == 0) {
-                const float4 v0 = *reinterpret_cast<const float4*>(xrow + k0 + i * 8);
-                const float4 v1 = *reinterpret_cast<const float4*>(xrow + k0 + i * 8 + 4);
-                t[0] = v0.x; t[1] = v0.y; t[2] = v0.z; t[3] = v0.w; t[4] = v1.x; t[5] = v1.y; t[6] = v1.z; t[7] = v1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = (ch + j < a.cin) ? xrow[k0 + i * 8 + j] : 0.0f;
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float mean = s / (float)a.cin;
+            float v = 0.0f;
+            for (int k = lane; k < a.cin; k += 64) {
+                const float d = xr[k] - mean;
+                v += d * d;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fa[i][j] = (_Float16)t[j];
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) {
+                ln_mu[mr] = mean;
+                ln_rs[mr] = rsqrtf(v / (float)a.cin + a.ln_eps);
+            }
+        }
+        __syncthreads();
+    }
+    float mu[MT], rs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        mu[t] = a.ln_gamma ? ln_mu[mrow[t]] : 0.0f;
+        rs[t] = a.ln_gamma ? ln_rs[mrow[t]] : 1.0f;
+    }
+
+    float4v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.0f;
+    const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
+    const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
+
+    for (int line = wid; line < lines; line += 8) {
+        const int k0 = line * 64 + g * 16;
+        half8 fb[2];
+        fb[0] = *reinterpret_cast<const half8*>(wrow + line * 64);
+        fb[1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+        float gam[16], bet[16];
+        if (a.ln_gamma) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = k0 + j < a.cin;
+                gam[j] = ok ? a.ln_gamma[k0 + j] : 0.0f;
+                bet[j] = ok ? a.ln_beta[k0 + j] : 0.0f;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[i], acc, 0, 0, 0);
-    }
-    if (wid > 0) {
+        for (int t = 0; t < MT; ++t) {
+            float xv[16];
+            if (vec_ok && k0 + 16 <= a.cin) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[wid - 1][e][lane] = acc[e];
-    }
-    __syncthreads();
-    if (wid == 0) {
-        const int n = n0 + r;
-        const bool n_ok = n < a.n;
-        const float bias = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(xrow[t] + k0 + 4 * q);
+                    xv[4 * q] = v4.x; xv[4 * q + 1] = v4.y; xv[4 * q + 2] = v4.z; xv[4 * q + 3] = v4.w;
+                }
+            } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
-            float v = acc[e] + red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
-            if (n_ok && m < a.m) {
-                v = apply_act(v + bias, a.act, a.slope) * a.alpha;
-                if (a.row_scale) v *= a.row_scale[m];
-                if (a.residual) v += a.residual[(int64_t)m * a.ldr + n];
-                a.out[(int64_t)m * a.ldc + n] = v;
+                for (int j = 0; j < 16; ++j) xv[j] = (k0 + j < a.cin) ? xrow[t][k0 + j] : 0.0f;
             }
+            half8 fa[2];
+            if (a.ln_gamma) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) fa[j >> 3][j & 7] = (_Float16)((xv[j] - mu[t]) * rs[t] * gam[j] + bet[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) fa[j >> 3][j & 7] = (_Float16)xv[j];
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[1], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wid][t][e][lane] = acc[t][e];
+    __syncthreads();
+    // 16 x 16 (x MT) outputs: thread (t, e, lane) sums the 8 partials of one element
+    for (int o = tid; o < MT * 4 * 64; o += 512) {
+        const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w][t][e][ln];
+        const int n = n0 + (ln & 15);
+        const int m = t * 16 + (ln >> 4) * 4 + e;
+        if (n < a.n && m < M) {
+            v = apply_act(v + (a.bias ? a.bias[n] : 0.0f), a.act, a.slope) * a.alpha;
+            if (a.row_scale) v *= a.row_scale[m];
+            if (a.residual) v += a.residual[(int64_t)m * a.ldr + n];
+            if (a.out2 && n >= a.n_split)
+                a.out2[(int64_t)m * a.ldc2 + (n - a.n_split)] = v;
+            else
+                a.out[(int64_t)m * a.ldc + n] = v;
         }
     }
 }
@@ -287,9 +353,59 @@ __global__ void pack_weight_f16(const float* __restrict__ src, _Float16* __restr
     }
 }
 
+template <int WM, int WN, int TM, int TN>
+static void launch_tile(const GemmArgs& a, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN>), dim3((unsigned)cdiv(a.m, BM), (unsigned)cdiv(a.n, BN)), dim3(256), 0, st, a);
+}
+
+static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
+    if (a.m <= 32 && plain) {
+        const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
+        if (a.m <= 16)
+            hipLaunchKernelGGL((gemm_skinny16<1>), dim3((a.n + 15) / 16), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((gemm_skinny16<2>), dim3((a.n + 15) / 16), dim3(512), 0, st, a);
+        if (prof) prof_end(ASTTS_PROF_GEMM_SKINNY, st);
+        ASTTS_CHECK_LAUNCH();
+        return ASTTS_OK;
+    }
+    ASTTS_REQUIRE(!a.gather && !a.ln_gamma && !a.out2, ASTTS_ERR_INVALID,
+                  "astts_op_gemm_fused: gather / LayerNorm / split output need m <= 32 and a plain (non-conv) GEMM");
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)a.m * a.n * a.cin * a.taps);
+    auto blocks = [&](int bm, int bn) { return cdiv(a.m, bm) * cdiv(a.n, bn); };
+    const int64_t want = 384;  // >= 1.5 blocks per CU
+    if (a.n <= 32) {
+        launch_tile<4, 1, 1, 1>(a, st);
+    } else if (a.n > 64 && blocks(128, 128) >= want) {
+        launch_tile<2, 2, 2, 2>(a, st);
+    } else if (blocks(128, 64) >= want) {
+        launch_tile<2, 2, 2, 1>(a, st);
+    } else {
+        launch_tile<2, 2, 1, 1>(a, st);
+    }
+    if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
 }  // namespace astts
 
 using namespace astts;
+
+static int check_gemm_args(const char* who, const float* x, const void* w, float* out, int64_t m, int32_t n, int32_t cin,
+                           int32_t cin_pad, int32_t taps, int32_t t_in, int32_t t_out, int32_t stride, int32_t dil, int32_t act) {
+    ASTTS_REQUIRE(x && w && out, ASTTS_ERR_INVALID, "%s: null pointer", who);
+    ASTTS_REQUIRE(m >= 1 && n >= 1 && cin >= 1 && taps >= 1, ASTTS_ERR_INVALID, "%s: bad shape m=%lld n=%d cin=%d taps=%d",
+                  who, (long long)m, n, cin, taps);
+    ASTTS_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0, ASTTS_ERR_INVALID,
+                  "%s: cin_pad=%d must be a multiple of 64 and >= cin=%d", who, cin_pad, cin);
+    ASTTS_REQUIRE(t_in >= 1 && t_out >= 1 && m % t_out == 0 && stride >= 1 && dil >= 1, ASTTS_ERR_INVALID,
+                  "%s: bad conv geometry t_in=%d t_out=%d stride=%d dil=%d", who, t_in, t_out, stride, dil);
+    ASTTS_REQUIRE(act >= ACT_NONE && act <= ACT_LEAKY, ASTTS_ERR_INVALID, "%s: act=%d", who, act);
+    return ASTTS_OK;
+}
 
 extern "C" {
 
@@ -312,29 +428,27 @@ int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const fl
                   int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
                   int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
                   astts_stream_t stream) {
-    ASTTS_REQUIRE(x && w_f16 && out, ASTTS_ERR_INVALID, "astts_op_gemm: null pointer");
-    ASTTS_REQUIRE(m >= 1 && n >= 1 && cin >= 1 && taps >= 1, ASTTS_ERR_INVALID,
-                  "astts_op_gemm: bad shape m=%lld n=%d cin=%d taps=%d", (long long)m, n, cin, taps);
-    ASTTS_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0, ASTTS_ERR_INVALID,
-                  "astts_op_gemm: cin_pad=%d must be a multiple of 64 and >= cin=%d", cin_pad, cin);
-    ASTTS_REQUIRE(t_in >= 1 && t_out >= 1 && m % t_out == 0 && stride >= 1 && dil >= 1, ASTTS_ERR_INVALID,
-                  "astts_op_gemm: bad conv geometry t_in=%d t_out=%d stride=%d dil=%d", t_in, t_out, stride, dil);
-    ASTTS_REQUIRE(act >= ACT_NONE && act <= ACT_LEAKY, ASTTS_ERR_INVALID, "astts_op_gemm: act=%d", act);
+    const int rc = check_gemm_args("astts_op_gemm", x, w_f16, out, m, n, cin, cin_pad, taps, t_in, t_out, stride, dil, act);
+    if (rc != ASTTS_OK) return rc;
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, row_scale, out, m, n, cin, cin_pad, taps,
-               lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope};
-    hipStream_t st = (hipStream_t)stream;
-    const bool plain = taps == 1 && stride == 1 && pad == 0 && t_in == t_out;
-    if (m <= 32 && plain) {
-        hipLaunchKernelGGL(gemm_skinny, dim3((n + 31) / 32), dim3(256), 0, st, a);
-    } else if (n <= 32) {
-        hipLaunchKernelGGL((gemm_tile<4, 1, 1, 1>), dim3((unsigned)cdiv(m, 128), (n + 31) / 32), dim3(256), 0, st, a);
-    } else if (n <= 64 || (n % 128 != 0 && n % 128 <= 64 && n < 256)) {
-        hipLaunchKernelGGL((gemm_tile<2, 2, 2, 1>), dim3((unsigned)cdiv(m, 128), (n + 63) / 64), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((gemm_tile<2, 2, 2, 2>), dim3((unsigned)cdiv(m, 128), (n + 127) / 128), dim3(256), 0, st, a);
-    }
-    ASTTS_CHECK_LAUNCH();
-    return ASTTS_OK;
+               lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0};
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const void* w_f16, const float* bias, const float* residual, float* out, float* out2,
+                        int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
+                        int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream) {
+    const int rc = check_gemm_args("astts_op_gemm_fused", x, w_f16, out, m, n, cin, cin_pad, 1, 1, 1, 1, 1, act);
+    if (rc != ASTTS_OK) return rc;
+    ASTTS_REQUIRE(m <= 32, ASTTS_ERR_INVALID, "astts_op_gemm_fused: m=%d > 32", m);
+    ASTTS_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), ASTTS_ERR_INVALID, "astts_op_gemm_fused: gamma/beta");
+    ASTTS_REQUIRE(!out2 || (n_split > 0 && n_split < n), ASTTS_ERR_INVALID, "astts_op_gemm_fused: n_split=%d", n_split);
+    GemmArgs a{x, (const _Float16*)w_f16, bias, residual, nullptr, out, m, n, cin, cin_pad, 1,
+               lda, ldc, ldr, m, m, 1, 1, 0, act, alpha, slope,
+               gather, ln_gamma, ln_beta, ln_eps, out2, ldc2, n_split};
+    return launch_gemm(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -134,6 +134,7 @@ enum ElemOp : int {
     EL_CLAMP = 9,      // y = clamp(x, -s, s)
     EL_TANH = 10,
     EL_ELU = 11,
+    EL_RELU_SCALE = 12,  // y = s * max(x, 0)
 };
 
 struct ElemArgs {
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void elementwise(ElemArgs a) {
             case EL_CLAMP: y = fminf(fmaxf(x, -a.s), a.s); break;
             case EL_TANH: y = tanhf(x); break;
             case EL_ELU: y = x > 0.0f ? x : (__expf(x) - 1.0f); break;
+            case EL_RELU_SCALE: y = a.s * fmaxf(x, 0.0f); break;
             default: y = x;
         }
         a.y[i] = y;
@@ -278,7 +280,7 @@ int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, 
 int astts_op_elementwise(int32_t op, const float* x, const float* z, const float* p0, const int32_t* lens, float* y,
                          int64_t total, int32_t t, int32_t c, float s, float s2, astts_stream_t stream) {
     ASTTS_REQUIRE(x && y && total >= 1 && c >= 1 && t >= 1, ASTTS_ERR_INVALID, "astts_op_elementwise: bad argument");
-    ASTTS_REQUIRE(op >= EL_SNAKE && op <= EL_ELU, ASTTS_ERR_INVALID, "astts_op_elementwise: op=%d", op);
+    ASTTS_REQUIRE(op >= EL_SNAKE && op <= EL_RELU_SCALE, ASTTS_ERR_INVALID, "astts_op_elementwise: op=%d", op);
     ASTTS_REQUIRE(!((op == EL_ADD || op == EL_CFG_EULER) && !z), ASTTS_ERR_INVALID, "astts_op_elementwise: z is null");
     ASTTS_REQUIRE(!((op == EL_SNAKE || op == EL_ADD_BC) && !p0), ASTTS_ERR_INVALID, "astts_op_elementwise: p0 is null");
     ASTTS_REQUIRE(!(op == EL_MUL_ROWMASK && !lens), ASTTS_ERR_INVALID, "astts_op_elementwise: lens is null");

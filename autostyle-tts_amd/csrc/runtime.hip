@@ -1,5 +1,8 @@
-// runtime.hip -- error reporting and ABI version for libastts.so
+// runtime.hip -- error reporting, ABI version, and the bench-only launch profiler of libastts.so
 #include "common.h"
+
+#include <mutex>
+#include <vector>
 
 namespace astts {
 
@@ -12,12 +15,86 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- launch profiler: HIP events on the launch stream around every launch of an enabled kind,
+// plus the algorithmic work (flops or bytes) the caller attributes to the launch.
+struct ProfKind {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+    double work = 0.0;
+    int64_t dropped = 0;
+};
+static ProfKind g_prof[ASTTS_PROF_KINDS];
+static bool g_prof_any = false;
+
+bool prof_begin(int kind, hipStream_t st, double work) {
+    if (!g_prof_any) return false;
+    ProfKind& p = g_prof[kind];
+    if (!p.on) return false;
+    if (p.used + 2 > p.ev.size()) {
+        ++p.dropped;
+        return false;
+    }
+    if (hipEventRecord(p.ev[p.used], st) != hipSuccess) return false;
+    p.work += work;
+    return true;
+}
+
+void prof_end(int kind, hipStream_t st) {
+    ProfKind& p = g_prof[kind];
+    (void)hipEventRecord(p.ev[p.used + 1], st);
+    p.used += 2;
+}
+
 }  // namespace astts
+
+using namespace astts;
 
 extern "C" {
 
 int astts_abi_version(void) { return ASTTS_ABI_VERSION; }
 
 const char* astts_last_error_string(void) { return astts::g_err; }
+
+int astts_prof_enable(int32_t kind, int32_t on, int32_t max_launches) {
+    ASTTS_REQUIRE(kind >= 0 && kind < ASTTS_PROF_KINDS, ASTTS_ERR_INVALID, "astts_prof_enable: kind=%d", kind);
+    ProfKind& p = g_prof[kind];
+    if (on) {
+        const size_t want = (size_t)(max_launches > 0 ? max_launches : 4096) * 2;
+        while (p.ev.size() < want) {
+            hipEvent_t e;
+            ASTTS_CHECK_HIP(hipEventCreate(&e));
+            p.ev.push_back(e);
+        }
+    }
+    p.on = on != 0;
+    p.used = 0;
+    p.work = 0.0;
+    p.dropped = 0;
+    g_prof_any = false;
+    for (auto& k : g_prof) g_prof_any = g_prof_any || k.on;
+    return ASTTS_OK;
+}
+
+int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* work_sum, int64_t* dropped) {
+    ASTTS_REQUIRE(kind >= 0 && kind < ASTTS_PROF_KINDS, ASTTS_ERR_INVALID, "astts_prof_read: kind=%d", kind);
+    ASTTS_REQUIRE(ms_sum && launches && work_sum, ASTTS_ERR_INVALID, "astts_prof_read: null argument");
+    ProfKind& p = g_prof[kind];
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        ASTTS_CHECK_HIP(hipEventSynchronize(p.ev[i + 1]));
+        float ms = 0.f;
+        ASTTS_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        sum += ms;
+    }
+    *ms_sum = sum;
+    *launches = (int64_t)(p.used / 2);
+    *work_sum = p.work;
+    if (dropped) *dropped = p.dropped;
+    p.used = 0;
+    p.work = 0.0;
+    p.dropped = 0;
+    return ASTTS_OK;
+}
 
 }  // extern "C"

@@ -2,13 +2,21 @@
 """bench.py -- headline benchmark of the AutoStyle-TTS hot path on MI355X.
 
 Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``).  Rank 0 prints
-ONE JSON line.  A step = one pass of the hot path over one batch of synthetic input (BASELINE.json
-configs[1]: batch of 8 utterances, 1k-entry style bank).  Inputs are resident in HBM when the timed
-region starts.
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``).  Rank 0 prints ONE
+JSON line.
+
+A step = one pass of the hot path over one batch of synthetic input, BASELINE.json configs[1]
+(SURVEY.md 8d "Config 2"): style-kNN of Q=8 queries against the 1k-entry bank (k=3), then fixed-length
+synthesis of the 8 utterances: Tt=32 text tokens, 3.0 s style/timbre prompts (Tp=150 tokens, Tm_p=258
+mel frames), forced Ts=250 speech tokens (5.0 s -> Tm=430 frames -> L=110080 samples at 22 050 Hz),
+LM decode -> flow matching (10 Euler steps x CFG) -> HiFT vocoder.  Weights are seeded random-init at
+the CosyVoice-300M shapes (no checkpoints exist offline), inputs are resident in HBM when the timed
+region starts, the waveform stays on the GPU.  value = synthesized audio seconds / wall seconds,
+whole job.  The retrieval leg is additionally reported as queries/s (``knn_qps``).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -21,7 +29,8 @@ for _p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 
 
 def make_config2_bank(n=1000, d=6144, seed=1234):
@@ -39,36 +48,82 @@ def make_queries(bank, nq, seed):
     return bank[rows].astype(np.float32) + 0.5 * rng.standard_normal((nq, bank.shape[1])).astype(np.float32)
 
 
-def cpu_baseline_knn(bank16, q, k, budget_s=10.0):
-    """The oracle's CPU leg (kind "port"): fp32 SGEMM scan + fp64 candidate re-score on the host
-    cores, same bank and queries.  Bounded sample: repeats until ~budget_s of CPU time."""
-    from oracle import knn as oknn
+class SynthInputs:
+    """Synthetic fixed-length batch (SURVEY 8d config 2 shapes), all on the GPU."""
 
-    threads = os.cpu_count() or 1
+    def __init__(self, cfg, b, tt, tp, ts, dev, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.b, self.ts = b, ts
+        self.text = torch.randint(0, cfg.text_vocab, (b, tt), device=dev, generator=g)
+        self.tlen = torch.full((b,), tt, dtype=torch.int32, device=dev)
+        self.spk_style = torch.randn(b, cfg.spk_dim, device=dev, generator=g)
+        self.spk_timbre = torch.randn(b, cfg.spk_dim, device=dev, generator=g)
+        self.style_tok = torch.randint(0, cfg.speech_vocab, (b, tp), device=dev, generator=g)
+        self.timbre_tok = torch.randint(0, cfg.speech_vocab, (b, tp), device=dev, generator=g)
+        self.tmp = cfg.mel_frames_for_tokens(tp)
+        self.tm = cfg.mel_frames_for_tokens(ts)
+        self.timbre_mel = torch.randn(b, self.tmp, cfg.mel, device=dev, generator=g)
+        self.u = torch.rand(ts, b, 2, device=dev, generator=g)
+        self.z = torch.randn(b, self.tmp + self.tm, cfg.mel, device=dev, generator=g)
+        nh = cfg.nb_harmonics + 1
+        self.phase0 = (torch.rand(b, nh, device=dev, generator=g) * 2 - 1) * math.pi
+        self.phase0[:, 0] = 0
+        self.noise = torch.randn(b, self.tm * cfg.upsample_total, nh, device=dev, generator=g)
+        self.audio_seconds = b * self.tm * cfg.upsample_total / cfg.sample_rate
+
+
+def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
+    """The oracle (kind "port": this build's fp32 PyTorch-CPU restatement, oracle/) timed on the host cores on a
+    BOUNDED sample of the same workload: one utterance (B=1) at the config-2 shapes but Ts=25 speech tokens
+    (0.5 s of audio) instead of 250, plus the retrieval of the same 8 queries."""
+    from oracle import knn as oknn
+    from oracle import synth as osyn
+
+    threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
-    b32 = bank16.astype(np.float32)
-    inv = (1.0 / np.linalg.norm(b32.astype(np.float64), axis=1)).astype(np.float32)
-    oknn.knn_search_fast_f32(b32, inv, q, k)  # warm
+    g = torch.Generator().manual_seed(0)
+    b, tt, tp, ts = 1, 32, 150, 25
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    tok_p = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    tmp, tm = cfg.mel_frames_for_tokens(tp), cfg.mel_frames_for_tokens(ts)
+    mel_p = torch.randn(b, tmp, cfg.mel, generator=g)
+    u = torch.rand(ts, b, 2, generator=g)
+    z = torch.randn(b, tmp + tm, cfg.mel, generator=g)
+    nh = cfg.nb_harmonics + 1
+    ph = torch.zeros(b, nh)
+    noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < budget_s and reps < 20000:
-        oknn.knn_search_fast_f32(b32, inv, q, k)
-        reps += 1
-    dt = time.perf_counter() - t0
-    return {"value": reps * q.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} searches of Q={q.shape[0]} against the same {bank16.shape[0]}x{bank16.shape[1]} bank "
-                      f"(oracle.knn.knn_search_fast_f32: fp32 GEMM + fp64 re-score, numpy BLAS threads)"}
+    with torch.no_grad():
+        oknn.knn_search_fast_f32(bank16.astype(np.float32),
+                                 (1.0 / np.linalg.norm(bank16.astype(np.float64), axis=1)).astype(np.float32), q_host, k)
+        pre = osyn.lm_prefix(weights["llm"], cfg, text, tlen, spk, tok_p)
+        toks, _ = osyn.lm_decode(weights["llm"], cfg, pre, ts, u, True, None)
+        t1 = time.perf_counter()
+        mel = osyn.flow_decode(weights["flow"], cfg, torch.cat([tok_p, toks.long()], 1), torch.full((b,), tp + ts), mel_p, spk, z, tmp + tm)
+        t2 = time.perf_counter()
+        wav = osyn.hift_forward(weights["hift"], cfg, mel, ph, noise)
+    t3 = time.perf_counter()
+    audio = wav.shape[1] / cfg.sample_rate
+    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "kind": "port",
+            "sample": f"B=1 utterance, Tt={tt}, {tp}-token prompt, Ts={ts} tokens ({audio:.2f} s audio) + kNN of 8 queries; "
+                      f"oracle/ fp32 torch-CPU: lm {t1 - t0:.1f} s, flow {t2 - t1:.1f} s, vocoder {t3 - t2:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bank-rows", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=6144)
-    ap.add_argument("--queries", type=int, default=8)
     ap.add_argument("--topk", type=int, default=3)
+    ap.add_argument("--text-tokens", type=int, default=32)
+    ap.add_argument("--prompt-tokens", type=int, default=150)
+    ap.add_argument("--speech-tokens", type=int, default=250)
+    ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,21 +142,32 @@ def main():
         dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
+    from astts import ops
     from astts.knn import StyleBank
     from astts.parallel import gather_style_ids
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import SynthEngine
+    from astts.synth.weights import make_all
 
+    cfg = SynthConfig(sample_rate=args.sample_rate)
+    weights = make_all(cfg, seed=0)                       # identical on every rank (replicated model)
+    eng = SynthEngine(weights, cfg, dev)
     bank16 = make_config2_bank(args.bank_rows, args.dim)
-    sb = StyleBank(bank16, device=dev)                       # replicated per GPU (12.3 MB)
-    q_host = make_queries(bank16, args.queries, seed=rank)   # this rank's utterance batch
+    sb = StyleBank(bank16, device=dev)                    # replicated per GPU (12.3 MB)
+    q_host = make_queries(bank16, args.batch, seed=rank)  # this rank's utterance batch (weak scaling)
     q_dev = torch.from_numpy(q_host).to(dev)
-    out_idx = torch.empty((args.queries, args.topk), dtype=torch.int64, device=dev)
-    out_sc = torch.empty((args.queries, args.topk), dtype=torch.float32, device=dev)
+    inp = SynthInputs(cfg, args.batch, args.text_tokens, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
+    out_idx = torch.empty((args.batch, args.topk), dtype=torch.int64, device=dev)
+    out_sc = torch.empty((args.batch, args.topk), dtype=torch.float32, device=dev)
+    result = {}
 
     def step():
         sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
-        if dist is not None:
-            return gather_style_ids(out_idx, dist)           # RCCL all-gather of the ids only
-        return out_idx
+        ids = gather_style_ids(out_idx, dist) if dist is not None else out_idx   # RCCL all-gather of the ids only
+        toks, mel, wav = eng.tts(inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok,
+                                 inp.timbre_mel, inp.spk_timbre, inp.z, inp.phase0, inp.noise)
+        result["wav"], result["ids"] = wav, ids
+        return wav
 
     def barrier():
         if dist is not None:
@@ -120,31 +186,74 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    wav_ok = bool(torch.isfinite(result["wav"]).all()) and float(result["wav"].abs().max()) <= cfg.audio_limit + 1e-6
 
-    # roofline of the dominant kernel (knn_scan): HIP events on the search stream, same K steps again
-    sb.profile_enable(True)
-    for _ in range(args.steps):
+    # ---- stage breakdown (one more step with events on the current stream)
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+    e0 = ev()
+    sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
+    e1 = ev()
+    pre = eng.lm.prefix(inp.text, inp.tlen, inp.spk_style, inp.style_tok)
+    toks = eng.lm.decode(pre, inp.ts, inp.u, True)
+    e2 = ev()
+    all_tok = torch.cat([inp.timbre_tok.to(torch.int32), toks], 1)
+    tl = torch.full((inp.b,), all_tok.shape[1], dtype=torch.int32, device=dev)
+    mel = eng.flow.decode(all_tok, tl, inp.timbre_mel, inp.spk_timbre, inp.z, inp.tmp + inp.tm)
+    e3 = ev()
+    eng.hift.forward(mel, inp.phase0, inp.noise)
+    e4 = ev()
+    torch.cuda.synchronize()
+    stages = {"knn_ms": e0.elapsed_time(e1), "lm_ms": e1.elapsed_time(e2), "flow_ms": e2.elapsed_time(e3), "vocoder_ms": e3.elapsed_time(e4)}
+
+    # ---- retrieval leg alone: queries/s
+    for _ in range(50):
         sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
     torch.cuda.synchronize()
-    scan_ms, launches = sb.profile_read()
-    sb.profile_enable(False)
-    # algorithmic bytes per scan launch: N*D*2 (fp16 bank, read once) + Q*D*4 + Q*k*12
-    alg_bytes = args.bank_rows * args.dim * 2 + args.queries * args.dim * 4 + args.queries * args.topk * 12
-    scan_s = scan_ms / 1e3 / max(launches, 1)
-    achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-
-    # parity spot check inside the bench: ids vs oracle for this rank's batch
+    tq = time.perf_counter()
+    nsearch = 500
+    for _ in range(nsearch):
+        sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
+    torch.cuda.synchronize()
+    knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
     from oracle import knn as oknn
 
     eidx, _ = oknn.knn_search(bank16, q_host, args.topk)
     ids_ok = bool(np.array_equal(out_idx.cpu().numpy(), eidx))
 
+    # ---- roofline: HIP events (on the launch stream) around every launch of the profiled kernel kinds, one step
+    kinds = {"gemm_tile": ops.PROF_GEMM_TILE, "gemm_skinny16": ops.PROF_GEMM_SKINNY, "attn_mha_flash": ops.PROF_ATTN_FLASH,
+             "attn_relpos_decode": ops.PROF_ATTN_DECODE}
+    prof = {}
+    for name, kind in kinds.items():        # one kind per pass: event records perturb neighbouring launches
+        ops.prof_enable(kind, True, 40000)
+        step()
+        torch.cuda.synchronize()
+        ms, n, work, dropped = ops.prof_read(kind)
+        ops.prof_enable(kind, False)
+        prof[name] = {"ms_per_step": ms, "launches": n, "work": work, "dropped": dropped}
+    dom = max(prof, key=lambda k: prof[k]["ms_per_step"])
+    p = prof[dom]
+    if dom in ("gemm_tile", "attn_mha_flash"):
+        achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F16_PEAK_TFLOPS}
+    else:
+        achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    roof.update({"traffic": None, "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
+                 "launches_per_step": p["launches"],
+                 "algorithmic_work_per_launch": p["work"] / max(p["launches"], 1),
+                 "all_kinds_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})
+
     if rank == 0:
-        total_q = args.queries * args.steps * world
+        total_audio = inp.audio_seconds * args.steps * world
         res = {
-            "metric": "style-kNN QPS (queries/s), batch-8 IEMOCAP utterances vs 1k-entry style bank",
-            "value": total_q / dt,
-            "unit": "queries/s",
+            "metric": "synthesized audio sec/wall-sec (RTF^-1) + style-kNN QPS, IEMOCAP test batch",
+            "value": total_audio / dt,
+            "unit": "audio-s/wall-s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -152,19 +261,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 scan (fp32 acc) + f64 re-score",
+            "dtype": "f16 MFMA operands, f32 accumulate/activations (kNN: f16 scan + f64 re-score)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] retrieval leg: Q=%d queries x N=%d x D=%d bank, k=%d, per GPU; "
-                                   "synthesis leg not in this revision" % (args.queries, args.bank_rows, args.dim, args.topk),
-                       "parallelism": f"dp{world} (bank replicated, queries sharded, all-gather of ids)"},
+            "config": {"workload": f"BASELINE configs[1]: batch={args.batch} utterances/GPU, kNN Q={args.batch} x N={args.bank_rows} x D={args.dim} k={args.topk}, "
+                                   f"synthesis Tt={args.text_tokens} Tp={args.prompt_tokens} Ts={args.speech_tokens} (fixed-length decode, EOS ignored) "
+                                   f"-> {inp.tm} mel frames -> {inp.tm * cfg.upsample_total} samples @ {cfg.sample_rate} Hz; CosyVoice-300M shapes, random-init weights",
+                       "parallelism": f"dp{world} (model + bank replicated, utterances sharded, all-gather of style ids only)"},
+            "knn_qps": knn_qps,
             "ids_match_oracle": ids_ok,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "knn_scan", "avg_us": scan_s * 1e6, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "waveform_finite_and_clamped": wav_ok,
+            "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline_knn(bank16, q_host, args.topk)
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -44,6 +44,18 @@ typedef void* astts_stream_t; /* hipStream_t */
 int astts_abi_version(void);
 const char* astts_last_error_string(void);
 
+/* Bench-only launch profiler (bench.py's roofline leg): while a kind is enabled, every launch of that
+ * kind is bracketed by HIP events on its own stream and its algorithmic work (flops for GEMM /
+ * attention kinds, bytes for streaming kinds) is accumulated.  _read synchronises those events,
+ * returns the sums since the last read and resets.  Process-global, not thread-safe, off by default. */
+#define ASTTS_PROF_GEMM_TILE 0   /* gemm_tile  (flow estimator / vocoder contractions): work = flops  */
+#define ASTTS_PROF_GEMM_SKINNY 1 /* gemm_skinny (LM decode, M <= 32): work = weight bytes streamed   */
+#define ASTTS_PROF_ATTN_FLASH 2  /* attn_mha_flash: work = flops                                      */
+#define ASTTS_PROF_ATTN_DECODE 3 /* attn_relpos_decode: work = KV-cache bytes read                    */
+#define ASTTS_PROF_KINDS 4
+int astts_prof_enable(int32_t kind, int32_t on, int32_t max_launches);
+int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* work_sum, int64_t* dropped);
+
 /* ------------------------------------------------------------------------------------------
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",
  * metric_type="COSINE", limit=k) -- milvus/search_embeddings.py:15-22.
@@ -122,6 +134,14 @@ int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const fl
                   int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
                   int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
                   astts_stream_t stream);
+/* Decode-sized GEMM (m <= 32, weight-bandwidth bound) with the fusions that take whole launches out of
+ * an LM decode step: optional row gather (x row of output row i = x[gather[i]], i.e. an embedding lookup),
+ * optional LayerNorm(gamma, beta, eps) over the cin inputs of every row applied while loading, and an
+ * optional second destination for the output columns >= n_split (out2[m*ldc2 + n - n_split]). */
+int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const void* w_f16, const float* bias, const float* residual, float* out, float* out2,
+                        int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
+                        int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream);
 int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
                        int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
 size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups);
@@ -141,6 +161,7 @@ int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, 
 #define ASTTS_EL_CLAMP 9
 #define ASTTS_EL_TANH 10
 #define ASTTS_EL_ELU 11
+#define ASTTS_EL_RELU_SCALE 12
 int astts_op_elementwise(int32_t op, const float* x, const float* z, const float* p0, const int32_t* lens, float* y,
                          int64_t total, int32_t t, int32_t c, float s, float s2, astts_stream_t stream);
 int astts_op_embedding(const float* table, const int32_t* ids, float* y, int64_t rows, int32_t c, int32_t ldy,
@@ -169,6 +190,52 @@ int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, floa
 int astts_op_ras_sample(const float* logits, const int32_t* history, const float* uniforms, int32_t* out_tokens,
                         int32_t b, int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p,
                         int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream);
+int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* uniforms, int32_t* out_tokens, int32_t b,
+                           int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p, int32_t win_size,
+                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* forced, astts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Acoustic-transformer decode engine: the autoregressive loop of TransformerLM.inference (one speech
+ * token per step) issued from C++ with no host synchronisation -- 5 launches per layer and step.
+ * All pointers are device pointers that must outlive the handle (weights packed by
+ * astts_op_pack_weight; fp32 biases / norms / tables).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t d, heads, ffn, layers;
+    int32_t vocab_out;    /* speech_vocab + 1 (EOS logit) */
+    int32_t speech_vocab; /* EOS id */
+    int32_t pos_center, pos_ld; /* relative-position tables: row (rel + pos_center), row stride pos_ld floats */
+    int32_t top_k, ras_win;
+    float top_p, ras_tau, eps;
+} astts_lm_config_t;
+typedef struct {
+    const float* speech_emb;                 /* [speech_vocab, d] */
+    const void* embed_w; const float* embed_b;       /* llm.embed.out.0 */
+    const float* embed_ln_g; const float* embed_ln_b; /* llm.embed.out.1 */
+    const float* after_g; const float* after_b;       /* llm.after_norm */
+    const void* head_w; const float* head_b;         /* llm_decoder */
+} astts_lm_globals_t;
+typedef struct {
+    const float* n1_g; const float* n1_b;
+    const void* wqkv; const float* bqkv;             /* [3d, d]: q | k | v */
+    const void* wo; const float* bo;
+    const float* n2_g; const float* n2_b;
+    const void* w1; const float* b1;
+    const void* w2; const float* b2;
+    const float* pos; const float* bias_u; const float* bias_v;
+} astts_lm_layer_t;
+typedef struct astts_lm astts_lm_t;
+int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* globals, const astts_lm_layer_t* layers,
+                    astts_lm_t** out);
+int astts_lm_destroy(astts_lm_t* h);
+size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
+/* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
+ * rows < pos0 filled by the prefill); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
+ * tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL. */
+int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
+                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t ignore_eos,
+                    int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
+                    astts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,33 @@
+import sys, time, math
+sys.path[:0]=['.','autostyle-tts_amd']
+import torch
+from astts.synth.config import SynthConfig
+from astts.synth.weights import make_all
+from astts.synth.model import SynthEngine
+cfg=SynthConfig()
+t0=time.time(); W=make_all(cfg,0); print('weights', time.time()-t0, sum(v.numel() for sd in W.values() for v in sd.values())/1e6,'M params')
+t0=time.time(); eng=SynthEngine(W,cfg,'cuda'); torch.cuda.synchronize(); print('engine', time.time()-t0)
+del W
+g=torch.Generator(device='cuda').manual_seed(0)
+B,Tt,Tp,Ts=8,32,150,250
+dev='cuda'
+text=torch.randint(0,cfg.text_vocab,(B,Tt),device=dev,generator=g); tlen=torch.full((B,),Tt,dtype=torch.int32,device=dev)
+spk_s=torch.randn(B,cfg.spk_dim,device=dev,generator=g); spk_t=torch.randn(B,cfg.spk_dim,device=dev,generator=g)
+style_tok=torch.randint(0,cfg.speech_vocab,(B,Tp),device=dev,generator=g); timbre_tok=torch.randint(0,cfg.speech_vocab,(B,Tp),device=dev,generator=g)
+tmp=cfg.mel_frames_for_tokens(Tp); tm=cfg.mel_frames_for_tokens(Ts)
+timbre_mel=torch.randn(B,tmp,cfg.mel,device=dev,generator=g)
+u=torch.rand(Ts,B,2,device=dev,generator=g); z=torch.randn(B,tmp+tm,cfg.mel,device=dev,generator=g)
+nh=cfg.nb_harmonics+1
+phase0=(torch.rand(B,nh,device=dev,generator=g)*2-1)*math.pi; phase0[:,0]=0
+noise=torch.randn(B,tm*cfg.upsample_total,nh,device=dev,generator=g)
+def ev(): e=torch.cuda.Event(enable_timing=True); e.record(); return e
+for it in range(3):
+    e0=ev(); pre=eng.lm.prefix(text,tlen,spk_s,style_tok); e1=ev()
+    toks=eng.lm.decode(pre,Ts,u,True); e2=ev()
+    all_tok=torch.cat([timbre_tok.to(torch.int32),toks],1); tl=torch.full((B,),all_tok.shape[1],dtype=torch.int32,device=dev)
+    mel=eng.flow.decode(all_tok,tl,timbre_mel,spk_t,z,tmp+tm); e3=ev()
+    wav=eng.hift.forward(mel,phase0,noise); e4=ev()
+    torch.cuda.synchronize()
+    audio=B*wav.shape[1]/cfg.sample_rate
+    tot=e0.elapsed_time(e4)/1e3
+    print(f'iter {it}: prefix {e0.elapsed_time(e1):.1f} ms, decode {e1.elapsed_time(e2):.1f} ms, flow {e2.elapsed_time(e3):.1f} ms, hift {e3.elapsed_time(e4):.1f} ms; audio {audio:.1f}s RTF^-1 {audio/tot:.1f}', 'finite', bool(torch.isfinite(wav).all()), float(wav.abs().max()), float(mel.abs().max()))

@@ -68,10 +68,15 @@ def test_lm_teacher_forced_logits_and_sampling():
     pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
     assert pre.shape == (pre_ref.shape[1], b, cfg.lm_dim)
     assert float((pre.cpu().transpose(0, 1) - pre_ref).abs().max()) < 2e-2 * float(pre_ref.abs().max())
-    toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
     scale = float(logits_ref.abs().max())
-    assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * scale
-    assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    for use_engine in (False, True):      # Python-issued fused step, then the C++ decode engine (astts_lm_decode)
+        toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True, use_engine=use_engine)
+        assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * scale
+        assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    # free-running: engine and Python-issued path take identical kernels in identical order -> identical tokens
+    ta = lm.decode(pre, steps, u.to(DEV), True, None, use_engine=False)
+    tb = lm.decode(pre, steps, u.to(DEV), True, None, use_engine=True)
+    assert torch.equal(ta, tb)
     # free-running sampling: feed the ORACLE's logits through the HIP sampler step by step (the sampler is
     # exact given identical logits; free-running token equality is not a stable property across precisions)
     from astts import ops
