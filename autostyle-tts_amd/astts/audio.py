@@ -1,0 +1,155 @@
+"""Wave-file I/O, resampling and the mel-spectrogram front end (host-side plumbing around the GPU path).
+
+Replaces, for the reference's call surface:
+  cosyvoice.utils.file_utils.load_wav(path, sr)   /root/reference/tts_with_rag.py:2,180-186
+  torchaudio.save(path, tensor[1, L], 22050)      /root/reference/tts_with_rag.py:197,
+                                                  /root/reference/tts_with_style_and_timbre.py:95
+  torchaudio.transforms.Resample(22050 -> 16000)  /root/reference/tts_with_rag.py:137
+torchaudio / soundfile / librosa are not available here, so RIFF parsing, a windowed-sinc polyphase
+resampler and the Slaney mel filter bank are written out.  These stages sit OUTSIDE the measured
+GPU path (frontend features are inputs of the timed region).
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import Tuple
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------ RIFF/WAVE
+def read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """-> (float32 [channels, n] in [-1, 1], sample_rate).  PCM 8/16/24/32-bit and IEEE float 32/64."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos = 12
+    fmt = None
+    pcm = None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _br, _ba, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:  # WAVE_FORMAT_EXTENSIBLE: sub-format tag
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1:
+        if bits == 8:
+            x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif bits == 16:
+            x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
+        elif bits == 24:
+            b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v & 0x800000, v - (1 << 24), v)
+            x = v.astype(np.float32) / 8388608.0
+        elif bits == 32:
+            x = np.frombuffer(pcm, dtype="<i4").astype(np.float32) / 2147483648.0
+        else:
+            raise ValueError(f"{path}: unsupported PCM width {bits}")
+    elif tag == 3:
+        x = np.frombuffer(pcm, dtype="<f4" if bits == 32 else "<f8").astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag}")
+    n = x.size // ch
+    return x[: n * ch].reshape(n, ch).T.copy(), sr
+
+
+def write_wav(path: str, wav, sample_rate: int) -> None:
+    """``wav``: tensor/array [channels, n] (or [n]) float32 -> 32-bit IEEE-float WAVE, the encoding
+    torchaudio.save picks for a float32 tensor."""
+    x = wav.detach().cpu().numpy() if torch.is_tensor(wav) else np.asarray(wav)
+    x = np.atleast_2d(x.astype(np.float32))
+    ch, n = x.shape
+    payload = x.T.astype("<f4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3, ch, sample_rate, sample_rate * ch * 4, ch * 4, 32)
+    fact = struct.pack("<I", n)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact + \
+        b"data" + struct.pack("<I", len(payload)) + payload
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+# ------------------------------------------------------------------------------------------ resampling
+def resample(x: torch.Tensor, sr_in: int, sr_out: int, zeros: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """Band-limited polyphase resampling (Hann-windowed sinc, the torchaudio ``sinc_interp_hann`` recipe).
+    x: [..., n] float32."""
+    if sr_in == sr_out:
+        return x
+    g = math.gcd(sr_in, sr_out)
+    up, down = sr_out // g, sr_in // g
+    base = min(up, down) * rolloff
+    width = int(math.ceil(zeros * down / base))
+    idx = torch.arange(-width, width + down, dtype=torch.float64)[None, :] / down
+    t = (torch.arange(0, -up, -1, dtype=torch.float64)[:, None] / up + idx) * base
+    t = t.clamp(-zeros, zeros)
+    window = torch.cos(t * math.pi / zeros / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / down)
+    kern = kern.to(torch.float32)[:, None, :]                       # [up, 1, k]
+    shape = x.shape
+    xx = x.reshape(-1, 1, shape[-1]).to(torch.float32)
+    xx = torch.nn.functional.pad(xx, (width, width + down))
+    y = torch.nn.functional.conv1d(xx, kern, stride=down)            # [N, up, frames]
+    y = y.transpose(1, 2).reshape(xx.shape[0], -1)
+    n_out = int(math.ceil(up * shape[-1] / down))
+    return y[:, :n_out].reshape(*shape[:-1], n_out)
+
+
+def load_wav(path: str, target_sr: int) -> torch.Tensor:
+    """cosyvoice.utils.file_utils.load_wav: read -> mono (mean over channels) -> resample -> FloatTensor [1, n]."""
+    x, sr = read_wav(path)
+    t = torch.from_numpy(x).mean(dim=0, keepdim=True)
+    if sr != target_sr:
+        t = resample(t, sr, target_sr)
+    return t
+
+
+# ------------------------------------------------------------------------------------------ mel spectrogram
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    mel = f / (200.0 / 3)
+    log_t = f >= 1000.0
+    return np.where(log_t, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) / (np.log(6.4) / 27.0), mel)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f = m * (200.0 / 3)
+    log_t = m >= 15.0
+    return np.where(log_t, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), f)
+
+
+def mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """Slaney-style (area-normalised) triangular filters, the librosa.filters.mel default -> [n_mels, n_fft//2+1]."""
+    freqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    pts = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(pts)
+    ramps = pts[:, None] - freqs[None, :]
+    w = np.maximum(0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    w *= (2.0 / (pts[2:n_mels + 2] - pts[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def mel_spectrogram(wav: torch.Tensor, sr: int = 22050, n_fft: int = 1024, hop: int = 256, win: int = 1024,
+                    n_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0) -> torch.Tensor:
+    """matcha-style log-mel used for the timbre prompt: reflect pad (n_fft-hop)/2, magnitude STFT, Slaney mel,
+    log(clamp(., 1e-5)).  wav [1, n] -> [1, frames, n_mels]."""
+    pad = (n_fft - hop) // 2
+    y = torch.nn.functional.pad(wav[:, None, :], (pad, pad), mode="reflect")[:, 0]
+    spec = torch.stft(y, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False,
+                      return_complex=True)
+    mag = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
+    fb = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+    mel = torch.matmul(fb, mag)
+    return torch.log(torch.clamp(mel, min=1e-5)).transpose(1, 2).contiguous()

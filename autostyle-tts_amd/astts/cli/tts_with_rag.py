@@ -1,0 +1,106 @@
+"""RAG-TTS driver: the build's restatement of /root/reference/tts_with_rag.py (same flags, same JSONL input,
+same output naming and sample rate), running on the MI355X engine through the CosyVoice call surface.
+
+    python -m astts.cli.tts_with_rag --corresponding_json search_results.json --result_dir out
+
+Reference behaviour kept (file:line in /root/reference/tts_with_rag.py):
+  * input = JSONL of retrieval records {zh_text, speaker, retrieved_file_id, retrieved_text, distance, whisper} (:85-94)
+  * speaker in {w1, w2, m1, m2} picks the timbre wav (:66-75); any other speaker is an error (the reference
+    dies with UnboundLocalError, here a KeyError naming the speaker)
+  * whisper rows use one fixed timbre wav (:179-182)
+  * result dir gets a ``_%m%d%H%M`` suffix (:165-168); files ``{cnt}_{style_id}_to_{speaker}_{i}.wav`` at 22 050 Hz (:196-197)
+  * ``--is_exp`` is ``type=bool``: any non-empty string is True (:230); the exp branch needs arguments its parser
+    never defines (dead code in the reference, :98-148) and is not reproduced.
+Additions (the reference hard-codes /apdcephfs_cq10 paths): --model_dir, --timbre_dir, --whisper_timbre_wav.
+"""
+import argparse
+import json
+import os
+from datetime import datetime
+
+REF_TIMBRE_DIR = "/apdcephfs_cq10/share_1615176/cq2/rodenluo/tts_vc/test_data/rag_test/youtube4/timbre"
+REF_MODEL_DIR = "/apdcephfs_cq10/share_1615176/cq2/rodenluo/CosyVoice/pretrained_models/CosyVoice-300M"
+TIMBRE_FILES = {
+    "w1": "engagement_0h0m4dot0s_0h0m9dot51s_w1.wav",
+    "w2": "engagement_0h0m10dot51s_0h0m13dot0s_w2.wav",
+    "m1": "engagement_0h0m16dot73s_0h0m21dot34s_m1.wav",
+    "m2": "engagement_0h0m13dot18s_0h0m16dot73s_m2.wav",
+}
+WHISPER_TIMBRE_FILE = "engagement_0h0m46dot41s_0h0m48dot99s.wav"
+
+
+def get_timbre_wav_path(speaker, timbre_dir=REF_TIMBRE_DIR):
+    if speaker not in TIMBRE_FILES:
+        raise KeyError(f"speaker {speaker!r} has no timbre wav (known: {sorted(TIMBRE_FILES)})")
+    return os.path.join(timbre_dir, TIMBRE_FILES[speaker])
+
+
+def get_text_and_wav(corr_json_path, timbre_dir=REF_TIMBRE_DIR):
+    """JSONL -> work items, field for field as the reference builds them (:77-96)."""
+    data_list = []
+    with open(corr_json_path, "r", encoding="utf-8") as file:
+        for line in file:
+            if not line.strip():
+                continue
+            data = json.loads(line)
+            speaker = data.get("speaker")
+            data_list.append({
+                "is_whisper": data.get("whisper"),
+                "tts_text": data.get("zh_text"),
+                "speaker": speaker,
+                "timbre_wav_path": get_timbre_wav_path(speaker, timbre_dir),
+                "style_wav_path": data.get("retrieved_file_id"),
+                "style_wav_text": data.get("retrieved_text"),
+            })
+    return data_list
+
+
+def output_name(cnt, style_wav_path, speaker, i):
+    style_wav_fileid = os.path.basename(style_wav_path)[:-4]     # the reference strips 4 chars, extension or not (:189)
+    return f"{cnt}_{style_wav_fileid}_to_{speaker}_{i}.wav"
+
+
+def tts_for_infer(args, cosyvoice=None, now=None):
+    from astts import audio
+    from astts.compat.cosyvoice import CosyVoice, load_wav
+
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    result_dir = args.result_dir + "_" + (now or datetime.now()).strftime("%m%d%H%M")
+    os.makedirs(result_dir, exist_ok=True)
+    written = []
+    for cnt, item in enumerate(get_text_and_wav(args.corresponding_json, args.timbre_dir), start=1):
+        print(item)
+        style_wav = load_wav(item["style_wav_path"], 16000)
+        timbre_path = args.whisper_timbre_wav if item["is_whisper"] else item["timbre_wav_path"]
+        timbre_wav = load_wav(timbre_path, 16000)
+        for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
+                                                              timbre_wav, stream=False)):
+            path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
+            audio.write_wav(path, j["tts_speech"], 22050)
+            written.append(path)
+    return written
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Generate vc result from style_dir to timbre_dir.")
+    parser.add_argument("--corresponding_json", required=True, help="include text style timbre information")
+    parser.add_argument("--result_dir", required=True, help="path to save results")
+    parser.add_argument("--is_exp", type=bool, default=False, help="path to save results")
+    parser.add_argument("--model_dir", default=REF_MODEL_DIR)
+    parser.add_argument("--timbre_dir", default=REF_TIMBRE_DIR)
+    parser.add_argument("--whisper_timbre_wav", default=os.path.join(REF_TIMBRE_DIR, WHISPER_TIMBRE_FILE))
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print("flag:", args.is_exp)
+    if args.is_exp:
+        raise SystemExit("--is_exp: the reference's experimental branch reads arguments its own parser never defines "
+                         "(tts_with_rag.py:110-113 vs :224-230); it cannot run there either and is not reproduced")
+    print("---not exp---")
+    return tts_for_infer(args)
+
+
+if __name__ == "__main__":
+    main()

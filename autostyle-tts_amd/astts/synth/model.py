@@ -199,6 +199,15 @@ class AcousticLM:
             self._eng = h
         return self._eng
 
+    @staticmethod
+    def _eos_min(ignore_eos, n_steps: int) -> int:
+        """True -> EOS masked for the whole fixed-length decode; False -> never; int -> masked for that many steps."""
+        if ignore_eos is True:
+            return n_steps
+        if ignore_eos is False:
+            return 0
+        return int(ignore_eos)
+
     def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
                       forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
         import ctypes
@@ -221,7 +230,7 @@ class AcousticLM:
         forced = None if forced_tokens is None else forced_tokens.to(torch.int32).contiguous()
         u = uniforms.to(torch.float32).contiguous()
         _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, t_max, b, s0, n_steps, u.data_ptr(),
-                                       None if forced is None else forced.data_ptr(), 1 if ignore_eos else 0, toks.data_ptr(),
+                                       None if forced is None else forced.data_ptr(), self._eos_min(ignore_eos, n_steps), toks.data_ptr(),
                                        None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
         self._keepalive = (cache, ws, logits0, forced, u)   # buffers referenced by kernels still in flight
         return (toks, lg_out) if return_logits else toks
@@ -243,7 +252,7 @@ class AcousticLM:
             if return_logits:
                 all_logits.append(cur)
             tok = ops.ras_sample(cur, toks, s, uniforms[s], cfg.top_k, cfg.top_p, cfg.ras_win, cfg.ras_tau,
-                                 cfg.speech_vocab, ignore_eos)
+                                 cfg.speech_vocab, s < self._eos_min(ignore_eos, n_steps))
             if forced_tokens is not None:
                 tok = forced_tokens[:, s].to(torch.int32).contiguous()
             toks[:, s] = tok

@@ -17,6 +17,7 @@
 // is a whole number of 128-byte lines; exact plane = the scan plane when the bank is fp16-exact,
 // else fp32 [N][Dp]; fp64 row norms [N]; fp32 inverse norms [N].
 #include "common.h"
+#include "toplist.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -29,16 +30,10 @@ static constexpr int kWave = 64;
 static constexpr int kScanThreads = 256;
 static constexpr int kMaxQPerPass = 256;
 static constexpr int kSelTile = 2048;  // scores staged in LDS per selection tile
-static constexpr int kNoIdx = 0x7fffffff;
 
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ bool better(T sa, int ia, T sb, int ib) {
-    return (sa > sb) || (sa == sb && ia < ib);
-}
-
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -81,86 +76,6 @@ __device__ __forceinline__ double wave_dot64(const float* __restrict__ q, const 
 __device__ __forceinline__ double cos_from_parts(double dot, double qn, double bn) {
     double c = dot / (qn * bn);
     return isfinite(c) ? c : 0.0;
-}
-
-// Sorted top-C list distributed over the lanes of one wave: lane i holds the i-th best entry.
-template <typename T>
-struct TopList {
-    T s;
-    int idx;
-    __device__ __forceinline__ void init() {
-        s = -INFINITY;
-        idx = kNoIdx;
-    }
-    // bitonic sort of the 64 per-lane entries, best first
-    __device__ __forceinline__ void sort_desc(int lane) {
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                T os = __shfl_xor(s, j, 64);
-                int oi = __shfl_xor(idx, j, 64);
-                const bool up = (lane & k) == 0;     // this block ends best-first
-                const bool lower = (lane & j) == 0;  // lower lane of the pair
-                const bool other_better = better<T>(os, oi, s, idx);
-                const bool take = (up == lower) ? other_better : !other_better;
-                if (take) {
-                    s = os;
-                    idx = oi;
-                }
-            }
-        }
-    }
-    // insert (xs, xi) into the sorted list of length c (lanes >= c are scratch)
-    __device__ __forceinline__ void insert(T xs, int xi, int lane, int c) {
-        const bool mine_better = better<T>(s, idx, xs, xi) && lane < c;
-        const int pos = __popcll(__ballot(mine_better));
-        T ups = __shfl_up(s, 1, 64);
-        int upi = __shfl_up(idx, 1, 64);
-        if (lane == pos) {
-            s = xs;
-            idx = xi;
-        } else if (lane > pos) {
-            s = ups;
-            idx = upi;
-        }
-    }
-    // every lane offers one entry; those that beat the current c-th best are inserted
-    __device__ __forceinline__ void offer(T vs, int vi, bool valid, int lane, int c) {
-        T ws = __shfl(s, c - 1, 64);
-        int wi = __shfl(idx, c - 1, 64);
-        unsigned long long mask = __ballot(valid && better<T>(vs, vi, ws, wi));
-        while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            T xs = __shfl(vs, src, 64);
-            int xi = __shfl(vi, src, 64);
-            insert(xs, xi, lane, c);
-        }
-    }
-    // first chunk of a wave: the list is empty, so sort the chunk instead of 64 serial inserts
-    __device__ __forceinline__ void seed(T vs, int vi, bool valid, int lane) {
-        s = valid ? vs : (T)-INFINITY;
-        idx = valid ? vi : kNoIdx;
-        sort_desc(lane);
-    }
-};
-
-// merge the per-wave lists (staged in LDS) into wave 0's list
-template <typename T>
-__device__ __forceinline__ void merge_lists(TopList<T>& tl, T* sh_s, int* sh_i, int c) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = blockDim.x >> 6;
-    sh_s[wid * 64 + lane] = tl.s;
-    sh_i[wid * 64 + lane] = tl.idx;
-    __syncthreads();
-    if (wid == 0) {
-        for (int w = 1; w < nw; ++w) {
-            T v = sh_s[w * 64 + lane];
-            int vi = sh_i[w * 64 + lane];
-            tl.offer(v, vi, lane < c && vi != kNoIdx, lane, c);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -158,19 +158,26 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
         qv = make_float4((x.x + v.x) * a.scale, (x.y + v.y) * a.scale, (x.z + v.z) * a.scale, (x.w + v.w) * a.scale);
     }
     float mloc = -INFINITY;
-    for (int j0 = 0; j0 < len; j0 += 16) {
-        const int j = j0 + grp;
-        float s = 0.0f;
-        if (j < len) {
-            const float4 kk = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk);
-            const float4 pp = *reinterpret_cast<const float4*>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
-            s = qu.x * kk.x + qu.y * kk.y + qu.z * kk.z + qu.w * kk.w + qv.x * pp.x + qv.y * pp.y + qv.z * pp.z + qv.w * pp.w;
+    constexpr int UK = 4;  // keys per 16-lane group and iteration: 8 independent 16-byte loads in flight per lane
+    for (int j0 = 0; j0 < len; j0 += 16 * UK) {
+        float4 kk[UK], pp[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int j = min(j0 + u * 16 + grp, len - 1);  // clamped: always a valid row, masked below
+            kk[u] = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk);
+            pp[u] = *reinterpret_cast<const float4*>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
         }
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (j < len) {
-            if (sub == 0) sc[j] = s;
-            mloc = fmaxf(mloc, s);
+        for (int u = 0; u < UK; ++u) {
+            const int j = j0 + u * 16 + grp;
+            float s = qu.x * kk[u].x + qu.y * kk[u].y + qu.z * kk[u].z + qu.w * kk[u].w + qv.x * pp[u].x + qv.y * pp[u].y +
+                      qv.z * pp[u].z + qv.w * pp[u].w;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (j < len) {
+                if (sub == 0) sc[j] = s;
+                mloc = fmaxf(mloc, s);
+            }
         }
     }
     mloc = wave_max_f32(mloc);
@@ -189,10 +196,20 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
     const float l = (reds[0] + reds[1]) + (reds[2] + reds[3]);
     // out[d] = sum_j p_j v[j][d]: key group g takes keys j = g (mod 16)
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = grp; j < len; j += 16) {
-        const float p = sc[j];
-        const float4 vv = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk);
-        o.x += p * vv.x; o.y += p * vv.y; o.z += p * vv.z; o.w += p * vv.w;
+    for (int j0 = grp; j0 < len; j0 += 16 * UK) {
+        float4 vv[UK];
+        float pw[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int j = j0 + u * 16;
+            const int jc = min(j, len - 1);
+            vv[u] = *reinterpret_cast<const float4*>(vb + (int64_t)jc * a.ldk);
+            pw[u] = j < len ? sc[jc] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            o.x += pw[u] * vv[u].x; o.y += pw[u] * vv[u].y; o.z += pw[u] * vv[u].z; o.w += pw[u] * vv[u].w;
+        }
     }
     float* part = sc + a.tk;
     *reinterpret_cast<float4*>(part + grp * DH + 4 * sub) = o;

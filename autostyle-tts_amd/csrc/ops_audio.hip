@@ -9,6 +9,7 @@
 // path can be driven by identical draws.  Replaces third-party cosyvoice.hifigan.generator /
 // cosyvoice.utils.common.ras_sampling arithmetic behind tts_with_rag.py:195.
 #include "common.h"
+#include "toplist.h"
 
 namespace astts {
 
@@ -174,9 +175,8 @@ struct SampleArgs {
 __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     extern __shared__ float prob[];  // [V]
     __shared__ float redv[4];
-    __shared__ int redi[4];
-    __shared__ float top_p_val[64];
-    __shared__ int top_p_idx[64];
+    __shared__ float sh_s[256];
+    __shared__ int sh_i[256];
     __shared__ float s_bcast;
     __shared__ int s_tok;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -205,58 +205,37 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     if (lane == 0) redv[wid] = sum;
     __syncthreads();
     const float tot = (redv[0] + redv[1]) + (redv[2] + redv[3]);
-    __syncthreads();
     const float inv = 1.0f / tot;
+    __syncthreads();
     for (int i = tid; i < a.v; i += 256) prob[i] *= inv;
     __syncthreads();
-    // top_k rounds of block arg-max (ties -> lower id); taken entries are negated in place
+    // top_k by (p desc, id asc): each wave keeps a sorted list over its 64-entry chunks, wave 0 merges
     const int kk = a.top_k < 64 ? a.top_k : 64;
-    for (int r = 0; r < kk; ++r) {
-        float bv = -1.0f;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < a.v; i += 256) {
-            const float p = prob[i];
-            if (p >= 0.0f && (p > bv || (p == bv && i < bi))) {  // negative = already taken
-                bv = p;
-                bi = i;
-            }
+    TopList<float> tl;
+    tl.init();
+    bool seeded = false;
+    for (int base = wid * 64; base < a.v; base += 256) {
+        const int i = base + lane;
+        const bool valid = i < a.v;
+        const float pv = valid ? prob[i] : -INFINITY;
+        if (!seeded) {
+            tl.seed(pv, i, valid, lane);
+            seeded = true;
+        } else {
+            tl.offer(pv, i, valid, lane, kk);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            redv[wid] = bv;
-            redi[wid] = bi;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float fv = redv[0];
-            int fi = redi[0];
-            for (int w = 1; w < 4; ++w)
-                if (redv[w] > fv || (redv[w] == fv && redi[w] < fi)) {
-                    fv = redv[w];
-                    fi = redi[w];
-                }
-            top_p_val[r] = fv;
-            top_p_idx[r] = fi;
-            prob[fi] = -fv - 1e-30f;  // mark as taken (negative), restored below
-        }
-        __syncthreads();
     }
-    if (tid == 0) {
-        for (int r = 0; r < kk; ++r) prob[top_p_idx[r]] = top_p_val[r];
-        // nucleus
+    merge_lists<float>(tl, sh_s, sh_i, kk);
+    if (wid == 0) {
+        // nucleus: sequential float accumulation in rank order (matches the oracle's definition bit for bit)
         float cum = 0.0f;
         int cnt = 0;
         for (int r = 0; r < kk; ++r) {
+            const float pr = __shfl(tl.s, r, 64);
+            const int ir = __shfl(tl.idx, r, 64);
+            if (ir == kNoIdx) break;
             if (cum < a.top_p && cnt < a.top_k) {
-                cum += top_p_val[r];
+                cum += pr;
                 ++cnt;
             } else {
                 break;
@@ -264,24 +243,26 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
         }
         const float target = a.u[bb * 2] * cum;
         float run = 0.0f;
-        int tok = top_p_idx[cnt - 1];
+        int tok = __shfl(tl.idx, cnt > 0 ? cnt - 1 : 0, 64);
+        bool found = false;
         for (int r = 0; r < cnt; ++r) {
-            run += top_p_val[r];
-            if (run > target) {
-                tok = top_p_idx[r];
-                break;
+            run += __shfl(tl.s, r, 64);
+            if (!found && run > target) {
+                tok = __shfl(tl.idx, r, 64);
+                found = true;
             }
         }
-        // repetition check over the last `win` decoded tokens
-        int rep = 0;
-        const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
-        for (int i = h0; i < a.hist_len; ++i) rep += (a.history[(int64_t)bb * a.hist_ld + i] == tok) ? 1 : 0;
-        s_tok = tok;
-        s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
+        if (lane == 0) {
+            int rep = 0;
+            const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
+            for (int i = h0; i < a.hist_len; ++i) rep += (a.history[(int64_t)bb * a.hist_ld + i] == tok) ? 1 : 0;
+            s_tok = tok;
+            s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
+        }
     }
     __syncthreads();
     if (s_bcast > 0.5f && tid == 0) {
-        // random sampling from the full distribution, id order, inverse CDF with u2
+        // repetition detected: random sampling from the full distribution, id order, inverse CDF with u2
         const float target = a.u[bb * 2 + 1];
         float run = 0.0f;
         int tok = -1;

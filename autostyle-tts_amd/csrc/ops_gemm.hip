@@ -215,36 +215,49 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
 // Lane (c = lane & 15, g = lane >> 4) owns bytes [32g, 32g+32) of row c in every 128-byte weight
 // line: two MFMA 16x16x32 k-steps of 8 halfs each (same permuted k order for X and W).
 // ------------------------------------------------------------------------------------------
+// Structure: (1) every wave issues ALL its weight loads first (up to 8 lines = 16 x 16 B per lane in
+// flight), (2) while they fly, wave w stages input rows w, w+8, ... into LDS as fp16 -- gathered,
+// LayerNorm'ed (two-pass, fp32) and converted once per block instead of once per line --,
+// (3) barrier, MFMAs with A fragments from LDS, (4) cross-wave reduction + epilogue.
+static constexpr int SK_WAVES = 8;
+static constexpr int SK_LINES = 8;  // weight lines prefetched per wave and pass
+
 template <int MT>
 __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
-    __shared__ float red[8][MT][4][64];
-    __shared__ float ln_mu[32], ln_rs[32];
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int ktot = a.cin_pad;
     const int lines = ktot >> 6;
     const int M = (int)a.m;
+    const int xs = ktot + 8;                                 // LDS row stride in halfs (16-byte skew)
+    _Float16* sx = reinterpret_cast<_Float16*>(sk_smem);     // [M][xs]
+    float* red = reinterpret_cast<float*>(sk_smem + (((size_t)M * xs * 2 + 15) & ~(size_t)15));  // [8][MT][4][64]
 
-    const float* xrow[MT];
-    int mrow[MT];
+    const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
+    half8 fb[SK_LINES][2];
+    // (1) first pass of weight loads
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        int mr = t * 16 + c;
-        if (mr >= M) mr = M - 1;
-        mrow[t] = mr;
-        const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
-        xrow[t] = a.x + src * a.lda;
+    for (int i = 0; i < SK_LINES; ++i) {
+        const int line = wid + i * SK_WAVES;
+        if (line < lines) {
+            fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
+            fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+        }
     }
-    if (a.ln_gamma) {  // LayerNorm statistics of the input rows: wave w takes rows w, w+8, ...
-        for (int mr = wid; mr < M; mr += 8) {
-            const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
-            const float* xr = a.x + src * a.lda;
+    // (2) stage x rows (gather + LayerNorm + fp16) : wave w owns rows w, w+8, ...
+    const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && (a.cin & 3) == 0;
+    for (int mr = wid; mr < M; mr += SK_WAVES) {
+        const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+        const float* xr = a.x + src * a.lda;
+        float mean = 0.0f, rstd = 1.0f;
+        if (a.ln_gamma) {
             float s = 0.0f;
             for (int k = lane; k < a.cin; k += 64) s += xr[k];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            const float mean = s / (float)a.cin;
+            mean = s / (float)a.cin;
             float v = 0.0f;
             for (int k = lane; k < a.cin; k += 64) {
                 const float d = xr[k] - mean;
@@ -252,78 +265,88 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) {
-                ln_mu[mr] = mean;
-                ln_rs[mr] = rsqrtf(v / (float)a.cin + a.ln_eps);
+            rstd = rsqrtf(v / (float)a.cin + a.ln_eps);
+        }
+        _Float16* dst = sx + (size_t)mr * xs;
+        if (vec_ok) {
+            for (int k = lane * 4; k < ktot; k += 256) {
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < a.cin) {
+                    v4 = *reinterpret_cast<const float4*>(xr + k);
+                    if (a.ln_gamma) {
+                        const float4 ga = *reinterpret_cast<const float4*>(a.ln_gamma + k);
+                        const float4 be = *reinterpret_cast<const float4*>(a.ln_beta + k);
+                        v4.x = (v4.x - mean) * rstd * ga.x + be.x;
+                        v4.y = (v4.y - mean) * rstd * ga.y + be.y;
+                        v4.z = (v4.z - mean) * rstd * ga.z + be.z;
+                        v4.w = (v4.w - mean) * rstd * ga.w + be.w;
+                    }
+                }
+                half4 h4;
+                h4[0] = (_Float16)v4.x; h4[1] = (_Float16)v4.y; h4[2] = (_Float16)v4.z; h4[3] = (_Float16)v4.w;
+                *reinterpret_cast<half4*>(dst + k) = h4;
+            }
+        } else {
+            for (int k = lane; k < ktot; k += 64) {
+                float v = 0.0f;
+                if (k < a.cin) {
+                    v = xr[k];
+                    if (a.ln_gamma) v = (v - mean) * rstd * a.ln_gamma[k] + a.ln_beta[k];
+                }
+                dst[k] = (_Float16)v;
             }
         }
-        __syncthreads();
     }
-    float mu[MT], rs[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        mu[t] = a.ln_gamma ? ln_mu[mrow[t]] : 0.0f;
-        rs[t] = a.ln_gamma ? ln_rs[mrow[t]] : 1.0f;
-    }
+    __syncthreads();
 
     float4v acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.0f;
-    const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
-    const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
-
-    for (int line = wid; line < lines; line += 8) {
-        const int k0 = line * 64 + g * 16;
-        half8 fb[2];
-        fb[0] = *reinterpret_cast<const half8*>(wrow + line * 64);
-        fb[1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
-        float gam[16], bet[16];
-        if (a.ln_gamma) {
+    const _Float16* arow[MT];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool ok = k0 + j < a.cin;
-                gam[j] = ok ? a.ln_gamma[k0 + j] : 0.0f;
-                bet[j] = ok ? a.ln_beta[k0 + j] : 0.0f;
+    for (int t = 0; t < MT; ++t) {
+        int mr = t * 16 + c;
+        if (mr >= M) mr = M - 1;
+        arow[t] = sx + (size_t)mr * xs + g * 16;
+    }
+    // (3) MFMAs; further passes only when a wave owns more than SK_LINES lines (K > 4096)
+    for (int pass = 0;; ++pass) {
+#pragma unroll
+        for (int i = 0; i < SK_LINES; ++i) {
+            const int line = wid + (pass * SK_LINES + i) * SK_WAVES;
+            if (line < lines) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const half8 fa0 = *reinterpret_cast<const half8*>(arow[t] + line * 64);
+                    const half8 fa1 = *reinterpret_cast<const half8*>(arow[t] + line * 64 + 8);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[i][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[i][1], acc[t], 0, 0, 0);
+                }
             }
         }
+        if (wid + (pass + 1) * SK_LINES * SK_WAVES >= lines) break;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            float xv[16];
-            if (vec_ok && k0 + 16 <= a.cin) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(xrow[t] + k0 + 4 * q);
-                    xv[4 * q] = v4.x; xv[4 * q + 1] = v4.y; xv[4 * q + 2] = v4.z; xv[4 * q + 3] = v4.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) xv[j] = (k0 + j < a.cin) ? xrow[t][k0 + j] : 0.0f;
+        for (int i = 0; i < SK_LINES; ++i) {
+            const int line = wid + ((pass + 1) * SK_LINES + i) * SK_WAVES;
+            if (line < lines) {
+                fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
+                fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
             }
-            half8 fa[2];
-            if (a.ln_gamma) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) fa[j >> 3][j & 7] = (_Float16)((xv[j] - mu[t]) * rs[t] * gam[j] + bet[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) fa[j >> 3][j & 7] = (_Float16)xv[j];
-            }
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[1], acc[t], 0, 0, 0);
         }
     }
+    // (4) reduction + epilogue
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[wid][t][e][lane] = acc[t][e];
+        for (int e = 0; e < 4; ++e) red[((wid * MT + t) * 4 + e) * 64 + lane] = acc[t][e];
     __syncthreads();
-    // 16 x 16 (x MT) outputs: thread (t, e, lane) sums the 8 partials of one element
     for (int o = tid; o < MT * 4 * 64; o += 512) {
         const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[w][t][e][ln];
+        for (int w = 0; w < SK_WAVES; ++w) v += red[((w * MT + t) * 4 + e) * 64 + ln];
         const int n = n0 + (ln & 15);
         const int m = t * 16 + (ln >> 4) * 4 + e;
         if (n < a.n && m < M) {
@@ -336,6 +359,10 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
                 a.out[(int64_t)m * a.ldc + n] = v;
         }
     }
+}
+
+static size_t skinny_lds_bytes(int m, int cin_pad, int mt) {
+    return (((size_t)m * (cin_pad + 8) * 2 + 15) & ~(size_t)15) + (size_t)SK_WAVES * mt * 4 * 64 * sizeof(float);
 }
 
 // fp32 [n, taps, cin] (conv weight already permuted so that cin is innermost) -> fp16 [n_pad, taps, cin_pad]
@@ -363,10 +390,22 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
     if (a.m <= 32 && plain) {
         const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
-        if (a.m <= 16)
-            hipLaunchKernelGGL((gemm_skinny16<1>), dim3((a.n + 15) / 16), dim3(512), 0, st, a);
+        const int mt = a.m <= 16 ? 1 : 2;
+        const size_t lds = skinny_lds_bytes((int)a.m, a.cin_pad, mt);
+        if (lds > 160 * 1024) {
+            set_error("astts_op_gemm: m=%lld x cin_pad=%d does not fit the skinny kernel's LDS image", (long long)a.m, a.cin_pad);
+            return ASTTS_ERR_INVALID;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {  // allow > 64 KiB of dynamic LDS (one-off, outside any captured region in practice)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        if (mt == 1)
+            hipLaunchKernelGGL((gemm_skinny16<1>), dim3((a.n + 15) / 16), dim3(512), lds, st, a);
         else
-            hipLaunchKernelGGL((gemm_skinny16<2>), dim3((a.n + 15) / 16), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((gemm_skinny16<2>), dim3((a.n + 15) / 16), dim3(512), lds, st, a);
         if (prof) prof_end(ASTTS_PROF_GEMM_SKINNY, st);
         ASTTS_CHECK_LAUNCH();
         return ASTTS_OK;

@@ -231,9 +231,11 @@ int astts_lm_destroy(astts_lm_t* h);
 size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
 /* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
  * rows < pos0 filled by the prefill); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
- * tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL. */
+ * tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL.  The EOS logit is masked for the
+ * first eos_min_steps steps (pass n_steps for fixed-length decoding); rows keep decoding after an EOS -- the caller
+ * truncates at the first EOS id (== speech_vocab). */
 int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
-                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t ignore_eos,
+                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
 
