@@ -20,6 +20,9 @@ _SIGS = {
     "astts_op_gemm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                 c_int32, c_int32, c_float, c_float, c_void_p]),
+    "astts_op_gemm_ex": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_int32, c_int32, c_float, c_float, c_void_p]),
     "astts_op_gemm_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p] + [c_int32] * 10 + [c_float, c_float, c_void_p]),
     "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
@@ -35,6 +38,10 @@ _SIGS = {
     "astts_op_interp_linear": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_time_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_attn_relpos": (c_int32, [c_void_p] * 8 + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
+    "astts_op_attn_mha_ex": (c_int32, [c_void_p] * 3 + [c_int32, c_void_p, c_void_p] + [c_int32] * 7 + [c_float, c_void_p]),
+    "astts_op_layernorm_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_groupnorm_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                        c_int32, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p]),
     "astts_op_attn_mha": (c_int32, [c_void_p] * 5 + [c_int32] * 6 + [c_float, c_void_p]),
     "astts_op_nsf_source_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "astts_op_nsf_source": (c_int32, [c_void_p] * 6 + [c_int32] * 4 + [c_float] * 4 + [c_void_p, c_size_t, c_void_p]),
@@ -135,12 +142,18 @@ class PackedWeight:
         return pw
 
 
+def _act_in(t: torch.Tensor) -> torch.Tensor:
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float16), (t.device, t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional[torch.Tensor] = None,
          row_scale: Optional[torch.Tensor] = None, alpha: float = 1.0, slope: float = 0.1,
          t_in: Optional[int] = None, t_out: Optional[int] = None, stride: int = 1, dil: int = 1, pad: int = 0,
-         out: Optional[torch.Tensor] = None, use_bias: bool = True) -> torch.Tensor:
-    """``x``: ``[..., cin]`` fp32 (rows = batch*time); conv geometry via t_in/t_out/stride/dil/pad."""
-    x = _f32(x)
+         out: Optional[torch.Tensor] = None, use_bias: bool = True, out_dtype=torch.float32) -> torch.Tensor:
+    """``x``: ``[..., cin]`` fp32 or fp16 (rows = batch*time); conv geometry via t_in/t_out/stride/dil/pad.
+    ``out_dtype=torch.float16`` when the result only feeds MFMA consumers (another GEMM / attention)."""
+    x = _act_in(x)
     cin = x.shape[-1]
     assert cin == w.cin, (cin, w.cin)
     rows_in = x.numel() // cin
@@ -152,15 +165,16 @@ def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional
         assert batches * t_in == rows_in
     m = batches * t_out
     if out is None:
-        out = torch.empty((m, w.n), dtype=torch.float32, device=x.device)
+        out = torch.empty((m, w.n), dtype=out_dtype, device=x.device)
     ldc = out.stride(0) if out.dim() == 2 else out.stride(-2)
     ldr = 0
     if residual is not None:
         residual = _f32(residual)
         ldr = residual.shape[-1]
-    _lib.check(_L().astts_op_gemm(x.data_ptr(), w.data.data_ptr(), _p(w.bias) if use_bias else None, _p(residual),
-                                  _p(row_scale), out.data_ptr(), m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
-                                  t_in, t_out, stride, dil, pad, ACT[act], alpha, slope, _st()))
+    _lib.check(_L().astts_op_gemm_ex(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, w.data.data_ptr(),
+                                     _p(w.bias) if use_bias else None, _p(residual), _p(row_scale), out.data_ptr(),
+                                     1 if out.dtype == torch.float16 else 0, m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
+                                     t_in, t_out, stride, dil, pad, ACT[act], alpha, slope, _st()))
     return out
 
 
@@ -198,19 +212,21 @@ def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.
     return out
 
 
-def linear(x: torch.Tensor, w: PackedWeight, act: str = "none", residual=None, alpha: float = 1.0) -> torch.Tensor:
+def linear(x: torch.Tensor, w: PackedWeight, act: str = "none", residual=None, alpha: float = 1.0,
+           out_dtype=torch.float32) -> torch.Tensor:
     y = gemm(x.reshape(-1, x.shape[-1]), w, act=act, residual=None if residual is None else residual.reshape(-1, w.n),
-             alpha=alpha)
+             alpha=alpha, out_dtype=out_dtype)
     return y.view(*x.shape[:-1], w.n)
 
 
 def conv1d(x: torch.Tensor, w: PackedWeight, stride: int = 1, dil: int = 1, pad: int = 0, act: str = "none",
-           residual=None, alpha: float = 1.0, slope: float = 0.1) -> torch.Tensor:
+           residual=None, alpha: float = 1.0, slope: float = 0.1, out_dtype=torch.float32) -> torch.Tensor:
     """``x``: ``[B, T, Cin]`` -> ``[B, T_out, Cout]`` (nn.Conv1d semantics on the time axis)."""
     b, t, _ = x.shape
     k = w.taps
     t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
-    y = gemm(x, w, act=act, residual=residual, alpha=alpha, slope=slope, t_in=t, t_out=t_out, stride=stride, dil=dil, pad=pad)
+    y = gemm(x, w, act=act, residual=residual, alpha=alpha, slope=slope, t_in=t, t_out=t_out, stride=stride, dil=dil, pad=pad,
+             out_dtype=out_dtype)
     return y.view(b, t_out, w.n)
 
 
@@ -226,24 +242,26 @@ def conv_transpose1d(x: torch.Tensor, w: PackedWeight, padding: int) -> torch.Te
     return y[:, padding:padding + t_full, :].contiguous()
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype=torch.float32) -> torch.Tensor:
     x = _f32(x)
     c = x.shape[-1]
-    y = torch.empty_like(x)
-    _lib.check(_L().astts_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                       x.numel() // c, c, c, c, eps, _st()))
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_L().astts_op_layernorm_ex(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                          1 if out_dtype == torch.float16 else 0, x.numel() // c, c, c, c, eps, _st()))
     return y
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-5,
-              lens: Optional[torch.Tensor] = None, mish: bool = False, add_bc: Optional[torch.Tensor] = None) -> torch.Tensor:
+              lens: Optional[torch.Tensor] = None, mish: bool = False, add_bc: Optional[torch.Tensor] = None,
+              out_dtype=torch.float32) -> torch.Tensor:
     x = _f32(x)
     b, t, c = x.shape
     need = int(_L().astts_op_groupnorm_workspace_bytes(b, t, groups))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    y = torch.empty_like(x)
-    _lib.check(_L().astts_op_groupnorm(x.data_ptr(), _p(lens), gamma.data_ptr(), beta.data_ptr(), _p(add_bc),
-                                       y.data_ptr(), b, t, c, groups, eps, 1 if mish else 0, ws.data_ptr(), need, _st()))
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_L().astts_op_groupnorm_ex(x.data_ptr(), _p(lens), gamma.data_ptr(), beta.data_ptr(), _p(add_bc),
+                                          y.data_ptr(), 1 if out_dtype == torch.float16 else 0, b, t, c, groups, eps,
+                                          1 if mish else 0, ws.data_ptr(), need, _st()))
     return y
 
 
@@ -306,12 +324,14 @@ def attn_relpos(q, k, v, pos, bias_u, bias_v, heads: int, lens=None, q_pos0: int
     return out
 
 
-def attn_mha(q, k, v, heads: int, lens=None) -> torch.Tensor:
+def attn_mha(q, k, v, heads: int, lens=None, out_dtype=torch.float32) -> torch.Tensor:
+    """q/k/v: [B, T, *] strided views (fp32 or fp16, e.g. thirds of a fused qkv buffer)."""
     b, t = q.shape[0], q.shape[1]
-    out = torch.empty((b, t, heads * 64), dtype=torch.float32, device=q.device)
-    assert q.stride(0) == t * q.stride(1) and k.stride(0) == t * k.stride(1)
-    _lib.check(_L().astts_op_attn_mha(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(lens), out.data_ptr(), b, heads, t,
-                                      q.stride(1), k.stride(1), heads * 64, 1.0 / math.sqrt(64.0), _st()))
+    out = torch.empty((b, t, heads * 64), dtype=out_dtype, device=q.device)
+    assert q.stride(0) == t * q.stride(1) and k.stride(0) == t * k.stride(1) and q.dtype == k.dtype == v.dtype
+    _lib.check(_L().astts_op_attn_mha_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), 1 if q.dtype == torch.float16 else 0,
+                                         _p(lens), out.data_ptr(), 1 if out_dtype == torch.float16 else 0, b, heads, t,
+                                         q.stride(1), k.stride(1), heads * 64, 1.0 / math.sqrt(64.0), _st()))
     return out
 
 

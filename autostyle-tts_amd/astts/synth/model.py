@@ -282,8 +282,8 @@ class _Resnet1D:
         """x must already be zero beyond lens (masked)."""
         tproj = ops.linear(temb_mish, self.mlp)                                  # [B, C]
         h = ops.conv1d(x, self.c1, pad=1)
-        h = ops.groupnorm(h, *self.g1, self.groups, 1e-5, lens=lens, mish=True, add_bc=tproj)
-        h = ops.conv1d(h, self.c2, pad=1)
+        h = ops.groupnorm(h, *self.g1, self.groups, 1e-5, lens=lens, mish=True, add_bc=tproj, out_dtype=torch.float16)
+        h = ops.conv1d(h, self.c2, pad=1)                                       # fp16 in: only consumer is the MFMA
         h = ops.groupnorm(h, *self.g2, self.groups, 1e-5, lens=lens, mish=True)
         return ops.conv1d(x, self.res, residual=h)                              # res_conv(x) + h
 
@@ -301,12 +301,13 @@ class _TfmBlock:
 
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
         hd = self.heads * 64
-        n = ops.layernorm(x, *self.n1, 1e-5)
-        qkv = ops.linear(n, self.wqkv)
-        a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens)
+        f16 = torch.float16   # everything between two residual adds feeds MFMA operands only: fp16 in HBM
+        n = ops.layernorm(x, *self.n1, 1e-5, out_dtype=f16)
+        qkv = ops.linear(n, self.wqkv, out_dtype=f16)
+        a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens, out_dtype=f16)
         x = ops.linear(a, self.wo, residual=x)
-        n = ops.layernorm(x, *self.n3, 1e-5)
-        f = ops.linear(n, self.w1, act="gelu")
+        n = ops.layernorm(x, *self.n3, 1e-5, out_dtype=f16)
+        f = ops.linear(n, self.w1, act="gelu", out_dtype=f16)
         return ops.linear(f, self.w2, residual=x)
 
 

@@ -224,11 +224,11 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
 
 // ------------------------------------------------------------------ MFMA flash attention
 struct MhaArgs {
-    const float* q;
-    const float* k;
-    const float* v;
+    const void* q;   // fp32 or fp16 (IN16), [B, T, ldq]
+    const void* k;
+    const void* v;
     const int* lens;  // [B] valid keys
-    float* out;
+    void* out;        // fp32 or fp16 (OUT16)
     int b, h, t, ldq, ldk, ldo;
     float scale;
 };
@@ -236,6 +236,21 @@ struct MhaArgs {
 static constexpr int FA_KS = 72;  // halfs per K row in LDS (64 + 8): conflict-free b128 reads
 static constexpr int FA_VS = 40;  // halfs per V^T row in LDS (32 + 8)
 
+template <bool IN16>
+__device__ __forceinline__ void load8(const void* base, int64_t off, float* dst) {
+    if constexpr (IN16) {
+        const half8 hv = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(base) + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = (float)hv[i];
+    } else {
+        const float* p = reinterpret_cast<const float*>(base) + off;
+        const float4 a0 = *reinterpret_cast<const float4*>(p);
+        const float4 a1 = *reinterpret_cast<const float4*>(p + 4);
+        dst[0] = a0.x; dst[1] = a0.y; dst[2] = a0.z; dst[3] = a0.w; dst[4] = a1.x; dst[5] = a1.y; dst[6] = a1.z; dst[7] = a1.w;
+    }
+}
+
+template <bool IN16, bool OUT16>
 __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 ks[32 * FA_KS];
     __shared__ __attribute__((aligned(16))) _Float16 vt[DH * FA_VS];
@@ -245,23 +260,19 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * 128 + wid * 32;
     const int len = a.lens ? min(a.lens[b], a.t) : a.t;
-    const float* qb = a.q + (int64_t)b * a.t * a.ldq + head * DH;
-    const float* kb = a.k + (int64_t)b * a.t * a.ldk + head * DH;
-    const float* vb = a.v + (int64_t)b * a.t * a.ldk + head * DH;
+    const int64_t qb = (int64_t)b * a.t * a.ldq + head * DH;
+    const int64_t kb = (int64_t)b * a.t * a.ldk + head * DH;
 
     // Q fragments (B operand of S^T = K Q^T): lane (c, hh) holds Q[q0+c][16s + 8hh + j] * scale
     half8 qf[4];
     {
         const int qi = min(q0 + c, a.t - 1);
-        const float* qr = qb + (int64_t)qi * a.ldq;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s + 8 * hh);
-            const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 8 * hh + 4);
-            qf[s][0] = (_Float16)(x0.x * a.scale); qf[s][1] = (_Float16)(x0.y * a.scale);
-            qf[s][2] = (_Float16)(x0.z * a.scale); qf[s][3] = (_Float16)(x0.w * a.scale);
-            qf[s][4] = (_Float16)(x1.x * a.scale); qf[s][5] = (_Float16)(x1.y * a.scale);
-            qf[s][6] = (_Float16)(x1.z * a.scale); qf[s][7] = (_Float16)(x1.w * a.scale);
+            float x[8];
+            load8<IN16>(a.q, qb + (int64_t)qi * a.ldq + 16 * s + 8 * hh, x);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[s][i] = (_Float16)(x[i] * a.scale);
         }
     }
     float16v ot[2];
@@ -279,12 +290,8 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
             const int j = j0 + skey;
             float kk[8], vv[8];
             if (j < len) {
-                const float4 k0 = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk + sd0);
-                const float4 k1 = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk + sd0 + 4);
-                const float4 v0 = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk + sd0);
-                const float4 v1 = *reinterpret_cast<const float4*>(vb + (int64_t)j * a.ldk + sd0 + 4);
-                kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
-                vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+                load8<IN16>(a.k, kb + (int64_t)j * a.ldk + sd0, kk);
+                load8<IN16>(a.v, kb + (int64_t)j * a.ldk + sd0, vv);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -364,7 +371,13 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     __builtin_amdgcn_wave_barrier();
     for (int r = 0; r < 32; ++r) {
         const int qi = q0 + r;
-        if (qi < a.t) a.out[((int64_t)b * a.t + qi) * a.ldo + head * DH + lane] = so[wid][r][lane];
+        if (qi < a.t) {
+            const int64_t o = ((int64_t)b * a.t + qi) * a.ldo + head * DH + lane;
+            if constexpr (OUT16)
+                reinterpret_cast<_Float16*>(a.out)[o] = (_Float16)so[wid][r][lane];
+            else
+                reinterpret_cast<float*>(a.out)[o] = so[wid][r][lane];
+        }
     }
 }
 
@@ -403,19 +416,35 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
     return ASTTS_OK;
 }
 
-int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
-                      int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream) {
+int astts_op_attn_mha_ex(const void* q, const void* k, const void* v, int32_t in_f16, const int32_t* lens, void* out,
+                         int32_t out_f16, int32_t b, int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                         astts_stream_t stream) {
     ASTTS_REQUIRE(q && k && v && out, ASTTS_ERR_INVALID, "astts_op_attn_mha: null pointer");
     ASTTS_REQUIRE(b >= 1 && h >= 1 && t >= 1, ASTTS_ERR_INVALID, "astts_op_attn_mha: bad shape");
-    ASTTS_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 &&
+    const int al = in_f16 ? 7 : 3;
+    ASTTS_REQUIRE((ldq & al) == 0 && (ldk & al) == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 &&
                       ((uintptr_t)v & 15) == 0,
-                  ASTTS_ERR_INVALID, "astts_op_attn_mha: q/k/v must be 16-byte aligned with ld %% 4 == 0");
+                  ASTTS_ERR_INVALID, "astts_op_attn_mha: q/k/v must be 16-byte aligned with 16-byte row strides");
     MhaArgs a{q, k, v, lens, out, b, h, t, ldq, ldk, ldo, scale};
-    const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, (hipStream_t)stream, 4.0 * (double)b * h * (double)t * t * DH);
-    hipLaunchKernelGGL(attn_mha_flash, dim3((t + 127) / 128, h, b), dim3(256), 0, (hipStream_t)stream, a);
-    if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((t + 127) / 128, h, b);
+    const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, st, 4.0 * (double)b * h * (double)t * t * DH);
+    if (in_f16 && out_f16)
+        hipLaunchKernelGGL((attn_mha_flash<true, true>), grid, dim3(256), 0, st, a);
+    else if (in_f16)
+        hipLaunchKernelGGL((attn_mha_flash<true, false>), grid, dim3(256), 0, st, a);
+    else if (out_f16)
+        hipLaunchKernelGGL((attn_mha_flash<false, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((attn_mha_flash<false, false>), grid, dim3(256), 0, st, a);
+    if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
+}
+
+int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
+                      int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream) {
+    return astts_op_attn_mha_ex(q, k, v, 0, lens, out, 0, b, h, t, ldq, ldk, ldo, scale, stream);
 }
 
 }  // extern "C"

@@ -63,19 +63,26 @@ struct GemmArgs {
     float ln_eps;
     float* out2;             // columns >= n_split go to out2[m*ldc2 + n - n_split] (or null)
     int ldc2, n_split;
+    int x_f16, out_f16;      // activations in / out as fp16 (ld* are then in halfs)
 };
 
 static constexpr int BK = 32;
 static constexpr int LDS_ROW = 40;  // halfs per staged row (32 + 8 pad = 80 bytes)
 
-template <int WM, int WN, int TM, int TN>
+// A16: the activations arrive as fp16 (written by a producer whose only consumers are MFMA operands:
+// LayerNorm / GroupNorm / attention / a previous GEMM), so staging is a plain 16-byte copy.
+template <int WM, int WN, int TM, int TN, bool A16>
 __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_CH = (BM * 4 + 255) / 256;  // 8-float chunks per thread for the X tile
+    constexpr int A_CH = (BM * 4 + 255) / 256;  // 8-element chunks per thread for the X tile
     constexpr int B_CH = (BN * 4 + 255) / 256;  // 8-half chunks per thread for the W tile
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) _Float16 sa[2][BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) _Float16 sb[2][BN * LDS_ROW];
+    constexpr int STAGE_HALFS = 2 * (BM + BN) * LDS_ROW;
+    constexpr int EPI_W = 32 * TN + 4;           // padded fp32 row of a wave's 32 x (32*TN) output slab
+    static_assert(4 * 32 * EPI_W * 4 <= STAGE_HALFS * 2, "epilogue slab must fit in the staging LDS");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[STAGE_HALFS];
+    _Float16* sa0 = smem;                         // [2][BM * LDS_ROW]
+    _Float16* sb0 = smem + 2 * BM * LDS_ROW;      // [2][BN * LDS_ROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -84,9 +91,9 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     const int n0 = blockIdx.y * BN;
     const int ktot = a.taps * a.cin_pad;
     const int nkt = ktot / BK;
-    const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
+    const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
+    const bool vec_ok = A16 ? ((a.lda & 7) == 0 && ((uintptr_t)a.x & 15) == 0) : ((a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0);
 
-    // ---- per-thread staging coordinates (chunk id -> row = id / 4, k segment = (id % 4) * 8)
     int a_row[A_CH], a_seg[A_CH], a_t[A_CH];
     int64_t a_base[A_CH];
     bool a_live[A_CH];
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
         b_live[c] = id < BN * 4;
     }
 
-    float4 ra[A_CH][2];
+    half8 ra[A_CH];
     half8 rb[B_CH];
 
     auto load_tile = [&](int kt) {
@@ -124,16 +131,26 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
             const int ts = a_t[c] + tap * a.dil;
             const bool ok = a_live[c] && ts >= 0 && ts < a.t_in;
             const int ch = c0 + a_seg[c];
-            const float* src = a.x + (a_base[c] + ts) * (int64_t)a.lda + ch;
-            if (ok && vec_ok && ch + 8 <= a.cin) {
-                ra[c][0] = *reinterpret_cast<const float4*>(src);
-                ra[c][1] = *reinterpret_cast<const float4*>(src + 4);
+            const int64_t off = (a_base[c] + ts) * (int64_t)a.lda + ch;
+            if constexpr (A16) {
+                if (ok && vec_ok && ch + 8 <= a.cin) {
+                    ra[c] = *reinterpret_cast<const half8*>(x16 + off);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ra[c][j] = (ok && ch + j < a.cin) ? x16[off + j] : (_Float16)0.0f;
+                }
             } else {
                 float tmp[8];
+                if (ok && vec_ok && ch + 8 <= a.cin) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
+                    const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
+                    tmp[0] = v0.x; tmp[1] = v0.y; tmp[2] = v0.z; tmp[3] = v0.w; tmp[4] = v1.x; tmp[5] = v1.y; tmp[6] = v1.z; tmp[7] = v1.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = (ok && ch + j < a.cin) ? src[j] : 0.0f;
-                ra[c][0] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                ra[c][1] = make_float4(tmp[4], tmp[5], tmp[6], tmp[7]);
+                    for (int j = 0; j < 8; ++j) tmp[j] = (ok && ch + j < a.cin) ? a.x[off + j] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ra[c][j] = (_Float16)tmp[j];
             }
         }
 #pragma unroll
@@ -142,17 +159,11 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int c = 0; c < A_CH; ++c) {
-            if (tid + c * 256 < BM * 4) {
-                half8 hv;
-                hv[0] = (_Float16)ra[c][0].x; hv[1] = (_Float16)ra[c][0].y; hv[2] = (_Float16)ra[c][0].z; hv[3] = (_Float16)ra[c][0].w;
-                hv[4] = (_Float16)ra[c][1].x; hv[5] = (_Float16)ra[c][1].y; hv[6] = (_Float16)ra[c][1].z; hv[7] = (_Float16)ra[c][1].w;
-                *reinterpret_cast<half8*>(&sa[buf][a_row[c] * LDS_ROW + a_seg[c]]) = hv;
-            }
-        }
+        for (int c = 0; c < A_CH; ++c)
+            if (tid + c * 256 < BM * 4) *reinterpret_cast<half8*>(&sa0[buf * BM * LDS_ROW + a_row[c] * LDS_ROW + a_seg[c]]) = ra[c];
 #pragma unroll
         for (int c = 0; c < B_CH; ++c)
-            if (b_live[c]) *reinterpret_cast<half8*>(&sb[buf][b_row[c] * LDS_ROW + b_seg[c]]) = rb[c];
+            if (b_live[c]) *reinterpret_cast<half8*>(&sb0[buf * BN * LDS_ROW + b_row[c] * LDS_ROW + b_seg[c]]) = rb[c];
     };
 
     float16v acc[TM][TN];
@@ -169,15 +180,17 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);
+        const _Float16* sa = sa0 + buf * BM * LDS_ROW;
+        const _Float16* sb = sb0 + buf * BN * LDS_ROW;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const half8*>(&sa[buf][((wm * TM + i) * 32 + r) * LDS_ROW + ks * 16 + h * 8]);
+                fa[i] = *reinterpret_cast<const half8*>(&sa[((wm * TM + i) * 32 + r) * LDS_ROW + ks * 16 + h * 8]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const half8*>(&sb[buf][((wn * TN + j) * 32 + r) * LDS_ROW + ks * 16 + h * 8]);
+                fb[j] = *reinterpret_cast<const half8*>(&sb[((wn * TN + j) * 32 + r) * LDS_ROW + ks * 16 + h * 8]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -188,25 +201,83 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns column n (coalesced 128-byte rows), 16 rows per accumulator
+    // ---- epilogue.  The accumulator layout (column on the lane, 16 rows in registers) would cost 16*TM*TN
+    // four-byte stores per lane; instead each wave transposes one 32 x (32*TN) slab at a time through its own
+    // LDS region and stores whole 16-byte vectors (store-issue bound otherwise: 2-3x the main loop).
+    float* slab = reinterpret_cast<float*>(smem) + wid * 32 * EPI_W;
+    constexpr int VPR = 8 * TN;            // float4 vectors per slab row
+    constexpr int RPI = 64 / VPR;          // rows per wave-instruction
+    const int vq = lane % VPR, vr = lane / VPR;
+    _Float16* out16 = reinterpret_cast<_Float16*>(a.out);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + r;
-        const bool n_ok = n < a.n;
-        const float bias = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n_ok && m < a.m) {
-                    float v = apply_act(acc[i][j][e] + bias, a.act, a.slope) * a.alpha;
-                    if (a.row_scale) v *= a.row_scale[m];
-                    if (a.residual) v += a.residual[m * a.ldr + n];
-                    a.out[m * a.ldc + n] = v;
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[i][j][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int nb = n0 + wn * TN * 32 + vq * 4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) {
+            bias4.x = nb < a.n ? a.bias[nb] : 0.f;
+            bias4.y = nb + 1 < a.n ? a.bias[nb + 1] : 0.f;
+            bias4.z = nb + 2 < a.n ? a.bias[nb + 2] : 0.f;
+            bias4.w = nb + 3 < a.n ? a.bias[nb + 3] : 0.f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += RPI) {
+            const int row = rr + vr;
+            const int64_t m = m0 + (wm * TM + i) * 32 + row;
+            float4 v = *reinterpret_cast<const float4*>(&slab[row * EPI_W + vq * 4]);
+            if (m < a.m && nb < a.n) {
+                v.x = apply_act(v.x + bias4.x, a.act, a.slope) * a.alpha;
+                v.y = apply_act(v.y + bias4.y, a.act, a.slope) * a.alpha;
+                v.z = apply_act(v.z + bias4.z, a.act, a.slope) * a.alpha;
+                v.w = apply_act(v.w + bias4.w, a.act, a.slope) * a.alpha;
+                if (a.row_scale) {
+                    const float rs = a.row_scale[m];
+                    v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+                }
+                const bool full = nb + 4 <= a.n;
+                if (a.residual) {
+                    const float* rp = a.residual + m * a.ldr + nb;
+                    if (full && (a.ldr & 3) == 0) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    } else {
+                        v.x += rp[0];
+                        if (nb + 1 < a.n) v.y += rp[1];
+                        if (nb + 2 < a.n) v.z += rp[2];
+                        if (nb + 3 < a.n) v.w += rp[3];
+                    }
+                }
+                if (a.out_f16) {
+                    _Float16* op = out16 + m * a.ldc + nb;
+                    if (full && (a.ldc & 3) == 0) {
+                        half4 h4;
+                        h4[0] = (_Float16)v.x; h4[1] = (_Float16)v.y; h4[2] = (_Float16)v.z; h4[3] = (_Float16)v.w;
+                        *reinterpret_cast<half4*>(op) = h4;
+                    } else {
+                        op[0] = (_Float16)v.x;
+                        if (nb + 1 < a.n) op[1] = (_Float16)v.y;
+                        if (nb + 2 < a.n) op[2] = (_Float16)v.z;
+                        if (nb + 3 < a.n) op[3] = (_Float16)v.w;
+                    }
+                } else {
+                    float* op = a.out + m * a.ldc + nb;
+                    if (full && (a.ldc & 3) == 0) {
+                        *reinterpret_cast<float4*>(op) = v;
+                    } else {
+                        op[0] = v.x;
+                        if (nb + 1 < a.n) op[1] = v.y;
+                        if (nb + 2 < a.n) op[2] = v.z;
+                        if (nb + 3 < a.n) op[3] = v.w;
+                    }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -251,42 +322,68 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     for (int mr = wid; mr < M; mr += SK_WAVES) {
         const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
         const float* xr = a.x + src * a.lda;
-        float mean = 0.0f, rstd = 1.0f;
-        if (a.ln_gamma) {
-            float s = 0.0f;
-            for (int k = lane; k < a.cin; k += 64) s += xr[k];
+        _Float16* dst = sx + (size_t)mr * xs;
+        if (vec_ok && ktot <= 4096) {
+            // single pass: the row lives in registers (<= 16 float4 per lane); every block re-reads the same few
+            // input rows, so one 16-byte request per 4 elements instead of three scalar passes matters (L2 hot spot)
+            constexpr int MAXV = 16;
+            float4 v[MAXV];
+            const int nv = (ktot + 255) >> 8;
+            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            mean = s / (float)a.cin;
-            float v = 0.0f;
-            for (int k = lane; k < a.cin; k += 64) {
-                const float d = xr[k] - mean;
-                v += d * d;
+            for (int i = 0; i < MAXV; ++i) {
+                const int k = lane * 4 + i * 256;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nv && k < a.cin) v[i] = *reinterpret_cast<const float4*>(xr + k);
+                s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+            float mean = 0.0f, rstd = 1.0f;
+            if (a.ln_gamma) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    s1 += __shfl_xor(s1, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                mean = s1 / (float)a.cin;
+                const float var = fmaxf(s2 / (float)a.cin - mean * mean, 0.0f);
+                rstd = rsqrtf(var + a.ln_eps);
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            rstd = rsqrtf(v / (float)a.cin + a.ln_eps);
-        }
-        _Float16* dst = sx + (size_t)mr * xs;
-        if (vec_ok) {
-            for (int k = lane * 4; k < ktot; k += 256) {
-                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < a.cin) {
-                    v4 = *reinterpret_cast<const float4*>(xr + k);
-                    if (a.ln_gamma) {
+            for (int i = 0; i < MAXV; ++i) {
+                const int k = lane * 4 + i * 256;
+                if (i < nv && k < ktot) {
+                    float4 o = v[i];
+                    if (a.ln_gamma && k < a.cin) {
                         const float4 ga = *reinterpret_cast<const float4*>(a.ln_gamma + k);
                         const float4 be = *reinterpret_cast<const float4*>(a.ln_beta + k);
-                        v4.x = (v4.x - mean) * rstd * ga.x + be.x;
-                        v4.y = (v4.y - mean) * rstd * ga.y + be.y;
-                        v4.z = (v4.z - mean) * rstd * ga.z + be.z;
-                        v4.w = (v4.w - mean) * rstd * ga.w + be.w;
+                        o.x = (o.x - mean) * rstd * ga.x + be.x;
+                        o.y = (o.y - mean) * rstd * ga.y + be.y;
+                        o.z = (o.z - mean) * rstd * ga.z + be.z;
+                        o.w = (o.w - mean) * rstd * ga.w + be.w;
                     }
+                    half4 h4;
+                    h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+                    *reinterpret_cast<half4*>(dst + k) = h4;
                 }
-                half4 h4;
-                h4[0] = (_Float16)v4.x; h4[1] = (_Float16)v4.y; h4[2] = (_Float16)v4.z; h4[3] = (_Float16)v4.w;
-                *reinterpret_cast<half4*>(dst + k) = h4;
             }
         } else {
+            float mean = 0.0f, rstd = 1.0f;
+            if (a.ln_gamma) {
+                float s = 0.0f;
+                for (int k = lane; k < a.cin; k += 64) s += xr[k];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+                mean = s / (float)a.cin;
+                float vv = 0.0f;
+                for (int k = lane; k < a.cin; k += 64) {
+                    const float d = xr[k] - mean;
+                    vv += d * d;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) vv += __shfl_xor(vv, off, 64);
+                rstd = rsqrtf(vv / (float)a.cin + a.ln_eps);
+            }
             for (int k = lane; k < ktot; k += 64) {
                 float v = 0.0f;
                 if (k < a.cin) {
@@ -383,12 +480,16 @@ __global__ void pack_weight_f16(const float* __restrict__ src, _Float16* __restr
 template <int WM, int WN, int TM, int TN>
 static void launch_tile(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN>), dim3((unsigned)cdiv(a.m, BM), (unsigned)cdiv(a.n, BN)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)cdiv(a.m, BM), (unsigned)cdiv(a.n, BN));
+    if (a.x_f16)
+        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, a);
 }
 
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
-    if (a.m <= 32 && plain) {
+    if (a.m <= 32 && plain && !a.x_f16 && !a.out_f16) {
         const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
         const int mt = a.m <= 16 ? 1 : 2;
         const size_t lds = skinny_lds_bytes((int)a.m, a.cin_pad, mt);
@@ -471,7 +572,20 @@ int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const fl
     if (rc != ASTTS_OK) return rc;
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, row_scale, out, m, n, cin, cin_pad, taps,
                lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
-               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0};
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, 0, 0};
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual,
+                     const float* row_scale, void* out, int32_t out_f16, int64_t m, int32_t n, int32_t cin, int32_t cin_pad,
+                     int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
+                     int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
+                     astts_stream_t stream) {
+    const int rc = check_gemm_args("astts_op_gemm_ex", (const float*)x, w_f16, (float*)out, m, n, cin, cin_pad, taps, t_in, t_out, stride, dil, act);
+    if (rc != ASTTS_OK) return rc;
+    GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, row_scale, (float*)out, m, n, cin, cin_pad, taps,
+               lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0};
     return launch_gemm(a, (hipStream_t)stream);
 }
 
@@ -486,7 +600,7 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
     ASTTS_REQUIRE(!out2 || (n_split > 0 && n_split < n), ASTTS_ERR_INVALID, "astts_op_gemm_fused: n_split=%d", n_split);
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, nullptr, out, m, n, cin, cin_pad, 1,
                lda, ldc, ldr, m, m, 1, 1, 0, act, alpha, slope,
-               gather, ln_gamma, ln_beta, ln_eps, out2, ldc2, n_split};
+               gather, ln_gamma, ln_beta, ln_eps, out2, ldc2, n_split, 0, 0};
     return launch_gemm(a, (hipStream_t)stream);
 }
 

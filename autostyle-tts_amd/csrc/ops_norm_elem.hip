@@ -20,13 +20,58 @@ __device__ __forceinline__ float mishf(float x) {
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
+// The row is read once into registers (c <= 2048, c % 4 == 0: 16-byte loads), statistics by 64-lane shuffles,
+// output fp32 or fp16 (fp16 when the only consumer is an MFMA operand).
+template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      const float* __restrict__ beta, OutT* __restrict__ y,
                                                       int64_t rows, int c, int ldx, int ldy, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * ldx;
+    OutT* yr = y + row * ldy;
+    if ((c & 3) == 0 && c <= 2048 && (ldx & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+        constexpr int MAXV = 8;
+        float4 v[MAXV];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int k = lane * 4 + i * 256;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < c) v[i] = *reinterpret_cast<const float4*>(xr + k);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wave_sum_f32(s) / (float)c;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < c) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum_f32(q) / (float)c + eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < c) {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + k);
+                const float4 be = *reinterpret_cast<const float4*>(beta + k);
+                const float o0 = (v[i].x - mean) * rstd * ga.x + be.x, o1 = (v[i].y - mean) * rstd * ga.y + be.y;
+                const float o2 = (v[i].z - mean) * rstd * ga.z + be.z, o3 = (v[i].w - mean) * rstd * ga.w + be.w;
+                if constexpr (sizeof(OutT) == 2) {
+                    half4 h4;
+                    h4[0] = (_Float16)o0; h4[1] = (_Float16)o1; h4[2] = (_Float16)o2; h4[3] = (_Float16)o3;
+                    *reinterpret_cast<half4*>(yr + k) = h4;
+                } else {
+                    *reinterpret_cast<float4*>(yr + k) = make_float4(o0, o1, o2, o3);
+                }
+            }
+        }
+        return;
+    }
     float s = 0.0f;
     for (int k = lane; k < c; k += 64) s += xr[k];
     const float mean = wave_sum_f32(s) / (float)c;
@@ -36,8 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
         v += d * d;
     }
     const float rstd = rsqrtf(wave_sum_f32(v) / (float)c + eps);
-    float* yr = y + row * ldy;
-    for (int k = lane; k < c; k += 64) yr[k] = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+    for (int k = lane; k < c; k += 64) yr[k] = (OutT)((xr[k] - mean) * rstd * gamma[k] + beta[k]);
 }
 
 // ------------------------------------------------------------------ GroupNorm on [B, T, C]
@@ -77,11 +121,13 @@ __global__ __launch_bounds__(256) void groupnorm_stats(const float* __restrict__
     }
 }
 
-// pass 2: y = act(gn(x)) * mask(t < len) + add_bc[b, c]
+// pass 2: y = act(gn(x)) * mask(t < len) + add_bc[b, c].  Thread = 4 consecutive channels (per-channel scale and
+// shift folded once), loop over the chunk's rows: no per-element division, 16-byte accesses when c % 4 == 0.
+template <typename OutT>
 __global__ __launch_bounds__(256) void groupnorm_apply(const float* __restrict__ x, const int* __restrict__ lens,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ add_bc, float* __restrict__ y, int t,
+                                                       const float* __restrict__ add_bc, OutT* __restrict__ y, int t,
                                                        int c, int groups, int nchunks, float eps, int act_mish) {
     extern __shared__ float sh[];  // [2][groups]: mean, rstd
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -104,6 +150,39 @@ __global__ __launch_bounds__(256) void groupnorm_apply(const float* __restrict__
     __syncthreads();
     const int t0 = chunk * GN_ROWS;
     const int t1 = min(t0 + GN_ROWS, t);
+    if ((c & 3) == 0 && (cpg & 3) == 0) {
+        const int cv = c >> 2;                       // float4 columns
+        const int rstep = 256 / cv > 0 ? 256 / cv : 1;
+        for (int col = threadIdx.x % cv, r0 = threadIdx.x / cv; col < cv && r0 < rstep; col += 256) {
+            const int ch = col * 4;
+            const int g = ch / cpg;
+            const float mean = sh[g], rstd = sh[groups + g];
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+            const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+            const float4 sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+            const float4 sf = make_float4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add_bc) ad = *reinterpret_cast<const float4*>(add_bc + (int64_t)b * c + ch);
+            for (int r = t0 + r0; r < t1; r += rstep) {
+                const int64_t off = ((int64_t)b * t + r) * c + ch;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < len) {
+                    const float4 v = *reinterpret_cast<const float4*>(x + off);
+                    o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
+                    if (act_mish) o = make_float4(mishf(o.x), mishf(o.y), mishf(o.z), mishf(o.w));
+                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                }
+                if constexpr (sizeof(OutT) == 2) {
+                    half4 h4;
+                    h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+                    *reinterpret_cast<half4*>(y + off) = h4;
+                } else {
+                    *reinterpret_cast<float4*>(y + off) = o;
+                }
+            }
+        }
+        return;
+    }
     const int64_t n = (int64_t)(t1 - t0) * c;
     const int64_t base = ((int64_t)b * t + t0) * c;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
@@ -116,7 +195,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply(const float* __restrict__
             if (act_mish) v = mishf(v);
             if (add_bc) v += add_bc[(int64_t)b * c + ch];
         }
-        y[base + i] = v;
+        y[base + i] = (OutT)v;
     }
 }
 
@@ -245,13 +324,22 @@ static inline int grid_for(int64_t total) {
 
 extern "C" {
 
-int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
-                       int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
+int astts_op_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
+                          int32_t c, int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
     ASTTS_REQUIRE(x && gamma && beta && y && rows >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_layernorm: bad argument");
-    hipLaunchKernelGGL(layernorm_rows, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       y, rows, c, ldx, ldy, eps);
+    if (out_f16)
+        hipLaunchKernelGGL((layernorm_rows<_Float16>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           gamma, beta, (_Float16*)y, rows, c, ldx, ldy, eps);
+    else
+        hipLaunchKernelGGL((layernorm_rows<float>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                           beta, (float*)y, rows, c, ldx, ldy, eps);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
+}
+
+int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
+                       int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
+    return astts_op_layernorm_ex(x, gamma, beta, y, 0, rows, c, ldx, ldy, eps, stream);
 }
 
 size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups) {
@@ -261,6 +349,12 @@ size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups) 
 int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, const float* beta,
                        const float* add_bc, float* y, int32_t b, int32_t t, int32_t c, int32_t groups, float eps,
                        int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream) {
+    return astts_op_groupnorm_ex(x, lens, gamma, beta, add_bc, y, 0, b, t, c, groups, eps, act_mish, workspace, workspace_bytes, stream);
+}
+
+int astts_op_groupnorm_ex(const float* x, const int32_t* lens, const float* gamma, const float* beta,
+                          const float* add_bc, void* y, int32_t out_f16, int32_t b, int32_t t, int32_t c, int32_t groups,
+                          float eps, int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream) {
     ASTTS_REQUIRE(x && gamma && beta && y && workspace, ASTTS_ERR_INVALID, "astts_op_groupnorm: null pointer");
     ASTTS_REQUIRE(b >= 1 && t >= 1 && c >= 1 && groups >= 1 && c % groups == 0 && groups <= 256 && c <= 8192,
                   ASTTS_ERR_INVALID, "astts_op_groupnorm: bad shape b=%d t=%d c=%d groups=%d", b, t, c, groups);
@@ -271,8 +365,12 @@ int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, 
     hipLaunchKernelGGL(groupnorm_stats, dim3(b, nch), dim3(256), 2 * c * sizeof(float), st, x, lens, (float*)workspace,
                        t, c, groups, nch);
     ASTTS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(groupnorm_apply, dim3(b, nch), dim3(256), 2 * groups * sizeof(float), st, x, lens,
-                       (const float*)workspace, gamma, beta, add_bc, y, t, c, groups, nch, eps, act_mish);
+    if (out_f16)
+        hipLaunchKernelGGL((groupnorm_apply<_Float16>), dim3(b, nch), dim3(256), 2 * groups * sizeof(float), st, x, lens,
+                           (const float*)workspace, gamma, beta, add_bc, (_Float16*)y, t, c, groups, nch, eps, act_mish);
+    else
+        hipLaunchKernelGGL((groupnorm_apply<float>), dim3(b, nch), dim3(256), 2 * groups * sizeof(float), st, x, lens,
+                           (const float*)workspace, gamma, beta, add_bc, (float*)y, t, c, groups, nch, eps, act_mish);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -134,6 +134,13 @@ int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const fl
                   int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
                   int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
                   astts_stream_t stream);
+/* Same contraction with fp16 activation input and/or output (x_f16 / out_f16 != 0; lda / ldc then count halfs).
+ * A producer whose only consumers are MFMA operands writes fp16, halving its store and the consumer's load. */
+int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual,
+                     const float* row_scale, void* out, int32_t out_f16, int64_t m, int32_t n, int32_t cin, int32_t cin_pad,
+                     int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
+                     int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
+                     astts_stream_t stream);
 /* Decode-sized GEMM (m <= 32, weight-bandwidth bound) with the fusions that take whole launches out of
  * an LM decode step: optional row gather (x row of output row i = x[gather[i]], i.e. an embedding lookup),
  * optional LayerNorm(gamma, beta, eps) over the cin inputs of every row applied while loading, and an
@@ -144,6 +151,12 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
                         int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream);
 int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
                        int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
+/* _ex forms: out_f16 != 0 writes fp16 (ldy in halfs) for outputs whose only consumers are MFMA operands. */
+int astts_op_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
+                          int32_t c, int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
+int astts_op_groupnorm_ex(const float* x, const int32_t* lens, const float* gamma, const float* beta,
+                          const float* add_bc, void* y, int32_t out_f16, int32_t b, int32_t t, int32_t c, int32_t groups,
+                          float eps, int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream);
 size_t astts_op_groupnorm_workspace_bytes(int32_t b, int32_t t, int32_t groups);
 /* y = act(GroupNorm(x over the first lens[b] rows)) (+ add_bc[b, c]); rows >= lens[b] are written as 0. */
 int astts_op_groupnorm(const float* x, const int32_t* lens, const float* gamma, const float* beta,
@@ -179,6 +192,9 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
 /* masked multi-head attention (flash-style MFMA), head dim 64. */
 int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
                       int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream);
+int astts_op_attn_mha_ex(const void* q, const void* k, const void* v, int32_t in_f16, const int32_t* lens, void* out,
+                         int32_t out_f16, int32_t b, int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                         astts_stream_t stream);
 size_t astts_op_nsf_source_workspace_bytes(int32_t b, int32_t tm);
 int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise, const float* lin_w, const float* lin_b,
                         float* out, int32_t b, int32_t tm, int32_t upsample, int32_t n_harm_plus1, float sample_rate,
