@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
             bias4.z = nb + 2 < a.n ? a.bias[nb + 2] : 0.f;
             bias4.w = nb + 3 < a.n ? a.bias[nb + 3] : 0.f;
         }
-#pragma unroll
+#pragma unroll 1  // rolled on purpose: the activation switch must appear once, not 32 times (I-cache: 148 KB -> ~12 KB)
         for (int rr = 0; rr < 32; rr += RPI) {
             const int row = rr + vr;
             const int64_t m = m0 + (wm * TM + i) * 32 + row;
