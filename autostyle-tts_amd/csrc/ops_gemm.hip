@@ -66,16 +66,19 @@ struct GemmArgs {
     int x_f16, out_f16;      // activations in / out as fp16 (ld* are then in halfs)
 };
 
-static constexpr int BK = 32;
-static constexpr int LDS_ROW = 40;  // halfs per staged row (32 + 8 pad = 80 bytes)
-
 // A16: the activations arrive as fp16 (written by a producer whose only consumers are MFMA operands:
 // LayerNorm / GroupNorm / attention / a previous GEMM), so staging is a plain 16-byte copy.
-template <int WM, int WN, int TM, int TN, bool A16>
+// BKT: K elements staged per iteration (32 / 64 / 128).  These GEMMs run at ~1-2 blocks per CU, so the
+// bytes in flight that hide HBM/L2 latency must come from inside the block: a wide K tile keeps
+// (BM + BN) * BKT * 2 bytes of loads outstanding per block and halves / quarters the barrier count.
+template <int WM, int WN, int TM, int TN, bool A16, int BKT>
 __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_CH = (BM * 4 + 255) / 256;  // 8-element chunks per thread for the X tile
-    constexpr int B_CH = (BN * 4 + 255) / 256;  // 8-half chunks per thread for the W tile
+    constexpr int BK = BKT;
+    constexpr int LDS_ROW = BKT + 8;              // halfs per staged row: (2*BKT + 16) bytes = odd multiple of 16
+    constexpr int CPR = BKT / 8;                  // 8-element chunks per row
+    constexpr int A_CH = (BM * CPR + 255) / 256;
+    constexpr int B_CH = (BN * CPR + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int STAGE_HALFS = 2 * (BM + BN) * LDS_ROW;
     constexpr int EPI_W = 32 * TN + 4;           // padded fp32 row of a wave's 32 x (32*TN) output slab
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
         const int id = tid + c * 256;
-        a_row[c] = id >> 2;
-        a_seg[c] = (id & 3) * 8;
+        a_row[c] = id / CPR;
+        a_seg[c] = (id % CPR) * 8;
         const int64_t m = m0 + a_row[c];
-        a_live[c] = (id < BM * 4) && m < a.m;
+        a_live[c] = (id < BM * CPR) && m < a.m;
         const int64_t b = a_live[c] ? m / a.t_out : 0;
         const int t = a_live[c] ? (int)(m - b * a.t_out) : 0;
         a_t[c] = t * a.stride - a.pad;
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
         const int id = tid + c * 256;
-        b_row[c] = id >> 2;
-        b_seg[c] = (id & 3) * 8;
-        b_live[c] = id < BN * 4;
+        b_row[c] = id / CPR;
+        b_seg[c] = (id % CPR) * 8;
+        b_live[c] = id < BN * CPR;
     }
 
     half8 ra[A_CH];
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < A_CH; ++c)
-            if (tid + c * 256 < BM * 4) *reinterpret_cast<half8*>(&sa0[buf * BM * LDS_ROW + a_row[c] * LDS_ROW + a_seg[c]]) = ra[c];
+            if (tid + c * 256 < BM * CPR) *reinterpret_cast<half8*>(&sa0[buf * BM * LDS_ROW + a_row[c] * LDS_ROW + a_seg[c]]) = ra[c];
 #pragma unroll
         for (int c = 0; c < B_CH; ++c)
             if (b_live[c]) *reinterpret_cast<half8*>(&sb0[buf * BN * LDS_ROW + b_row[c] * LDS_ROW + b_seg[c]]) = rb[c];
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
         const _Float16* sa = sa0 + buf * BM * LDS_ROW;
         const _Float16* sb = sb0 + buf * BN * LDS_ROW;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             half8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -477,14 +480,14 @@ __global__ void pack_weight_f16(const float* __restrict__ src, _Float16* __restr
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BKT>
 static void launch_tile(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const dim3 grid((unsigned)cdiv(a.m, BM), (unsigned)cdiv(a.n, BN));
     if (a.x_f16)
-        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, true, BKT>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, false, BKT>), grid, dim3(256), 0, st, a);
 }
 
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
@@ -516,14 +519,18 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)a.m * a.n * a.cin * a.taps);
     auto blocks = [&](int bm, int bn) { return cdiv(a.m, bm) * cdiv(a.n, bn); };
     const int64_t want = 384;  // >= 1.5 blocks per CU
+    // K tile: cin_pad is a multiple of 64, so 64 never straddles a tap; 128 needs cin_pad % 128 == 0
+    const bool k128 = (a.cin_pad % 128) == 0 && a.taps * a.cin_pad >= 256;
     if (a.n <= 32) {
-        launch_tile<4, 1, 1, 1>(a, st);
+        launch_tile<4, 1, 1, 1, 64>(a, st);
     } else if (a.n > 64 && blocks(128, 128) >= want) {
-        launch_tile<2, 2, 2, 2>(a, st);
+        launch_tile<2, 2, 2, 2, 32>(a, st);   // measured: the 128x128 tile is fastest at BK=32 (2+ blocks/CU, small K)
     } else if (blocks(128, 64) >= want) {
-        launch_tile<2, 2, 2, 1>(a, st);
+        launch_tile<2, 2, 2, 1, 32>(a, st);
+    } else if (k128) {
+        launch_tile<2, 2, 1, 1, 128>(a, st);
     } else {
-        launch_tile<2, 2, 1, 1>(a, st);
+        launch_tile<2, 2, 1, 1, 64>(a, st);
     }
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
