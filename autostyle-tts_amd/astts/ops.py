@@ -24,7 +24,9 @@ _SIGS = {
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_int32, c_float, c_float, c_void_p]),
     "astts_op_gemm_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p] + [c_int32] * 10 + [c_float, c_float, c_void_p]),
+                                      c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p]),
+    "astts_op_attn_relpos_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                          c_void_p] + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_prof_read": (c_int32, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
@@ -53,7 +55,8 @@ _SIGS = {
 
 class LmConfig(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("d", "heads", "ffn", "layers", "vocab_out", "speech_vocab", "pos_center", "pos_ld",
-                                       "top_k", "ras_win")] + [(n, c_float) for n in ("top_p", "ras_tau", "eps")]
+                                       "top_k", "ras_win")] + [(n, c_float) for n in ("top_p", "ras_tau", "eps")] + \
+               [("kv_f16", c_int32), ("pos_f16", c_int32)]
 
 
 class LmGlobals(ctypes.Structure):
@@ -205,7 +208,8 @@ def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.
         out = torch.empty((m, n1), dtype=torch.float32, device=x.device)
     ga, be = (ln if ln is not None else (None, None))
     _lib.check(_L().astts_op_gemm_fused(x.data_ptr(), _p(gather), _p(ga), _p(be), ln_eps, w.data.data_ptr(), _p(w.bias),
-                                        _p(residual), out.data_ptr(), _p(out2), m, w.n, n_split, w.cin, w.cin_pad,
+                                        _p(residual), out.data_ptr(), _p(out2),
+                                        1 if (out2 is not None and out2.dtype == torch.float16) else 0, m, w.n, n_split, w.cin, w.cin_pad,
                                         lda if lda is not None else x.stride(-2), out.stride(-2),
                                         out2.stride(-2) if out2 is not None else 0,
                                         residual.stride(-2) if residual is not None else 0, ACT[act], alpha, slope, _st()))
@@ -316,11 +320,12 @@ def attn_relpos(q, k, v, pos, bias_u, bias_v, heads: int, lens=None, q_pos0: int
         if out is None:
             out = torch.empty((b, tq, heads * 64), dtype=torch.float32, device=q.device)
         ldo, o_bs = out.stride(1), out.stride(0)
-    assert v.stride() == k.stride()
-    _lib.check(_L().astts_op_attn_relpos(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), bias_u.data_ptr(),
-                                         bias_v.data_ptr(), _p(lens), out.data_ptr(), b, heads, tq, tk, ldq, ldk, ldo,
-                                         pos.stride(0), q_bs, k_bs, o_bs, q_pos0, pos_center, 1 if causal else 0,
-                                         1.0 / math.sqrt(64.0), _st()))
+    assert v.stride() == k.stride() and k.dtype == v.dtype
+    _lib.check(_L().astts_op_attn_relpos_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), 1 if k.dtype == torch.float16 else 0,
+                                            pos.data_ptr(), 1 if pos.dtype == torch.float16 else 0, bias_u.data_ptr(),
+                                            bias_v.data_ptr(), _p(lens), out.data_ptr(), b, heads, tq, tk, ldq, ldk, ldo,
+                                            pos.stride(0), q_bs, k_bs, o_bs, q_pos0, pos_center, 1 if causal else 0,
+                                            1.0 / math.sqrt(64.0), _st()))
     return out
 
 

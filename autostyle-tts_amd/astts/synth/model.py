@@ -43,7 +43,7 @@ class RelPosEncoder:
     and the causal LM body).  Holds one precomputed table ``linear_pos(pe(rel))`` per layer."""
 
     def __init__(self, sd: SD, prefix: str, heads: int, layers: int, act: str, norm_names: Tuple[str, str],
-                 legacy_embed: bool, causal: bool, eps: float, max_pos: int, device):
+                 legacy_embed: bool, causal: bool, eps: float, max_pos: int, device, pos_dtype=torch.float32):
         self.heads, self.layers, self.act, self.causal, self.eps = heads, layers, act, causal, eps
         self.legacy_embed = legacy_embed
         self.center = max_pos
@@ -72,7 +72,7 @@ class RelPosEncoder:
                 "u": _dev(sd[a + ".pos_bias_u"].reshape(-1), device),
                 "v": _dev(sd[a + ".pos_bias_v"].reshape(-1), device),
             }
-            lay["pos"] = ops.linear(pe, PackedWeight(sd[a + ".linear_pos.weight"], None, device))
+            lay["pos"] = ops.linear(pe, PackedWeight(sd[a + ".linear_pos.weight"], None, device), out_dtype=pos_dtype)
             self.L.append(lay)
 
     def embed_in(self, x: torch.Tensor) -> torch.Tensor:
@@ -113,8 +113,9 @@ class AcousticLM:
         self.llm_emb = _dev(sd["llm_embedding.weight"], device)
         self.speech_emb = _dev(sd["speech_embedding.weight"], device)
         self.spk_aff = PackedWeight(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device)
+        # the LM body re-reads its position tables and KV cache every decode step: both live in HBM as fp16
         self.body = RelPosEncoder(sd, "llm", cfg.lm_heads, cfg.lm_layers, "relu", ("norm1", "norm2"), True, True,
-                                  cfg.ln_eps, cfg.max_positions, device)
+                                  cfg.ln_eps, cfg.max_positions, device, pos_dtype=torch.float16)
         self.head = PackedWeight(sd["llm_decoder.weight"], sd["llm_decoder.bias"], device)
 
     def prefix(self, text: torch.Tensor, text_lens: torch.Tensor, spk: torch.Tensor, prompt_tokens: torch.Tensor) -> torch.Tensor:
@@ -130,7 +131,7 @@ class AcousticLM:
         return torch.cat([sos, spk_e, enc, task, pe], dim=1).transpose(0, 1).contiguous()
 
     def new_cache(self, b: int, t_max: int) -> List[torch.Tensor]:
-        return [torch.empty((t_max, b, 2 * self.body.d), dtype=torch.float32, device=self.device) for _ in self.body.L]
+        return [torch.empty((t_max, b, 2 * self.body.d), dtype=torch.float16, device=self.device) for _ in self.body.L]
 
     def forward_new(self, x: torch.Tensor, cache: List[torch.Tensor], pos0: int) -> torch.Tensor:
         """x: time-major [T, B, d] NEW positions pos0..pos0+T-1 -> hidden [T, B, d]; fills the cache."""
@@ -184,7 +185,7 @@ class AcousticLM:
             from .. import _lib
             body, cfg = self.body, self.cfg
             c = ops.LmConfig(body.d, body.heads, cfg.lm_ffn, len(body.L), cfg.speech_vocab + 1, cfg.speech_vocab, body.center,
-                             body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps)
+                             body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps, 1, 1)
             g = ops.LmGlobals(self.speech_emb.data_ptr(), body.embed.data.data_ptr(), body.embed.bias.data_ptr(),
                               body.embed_ln[0].data_ptr(), body.embed_ln[1].data_ptr(), body.after[0].data_ptr(),
                               body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr())

@@ -55,9 +55,9 @@ size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
     return o;
 }
 
-// logits0: [B, vocab_out] logits of the last prefix position (from the prefill); kv_cache[l]: fp32
-// [t_max, B, 2d] time-major, rows [0, pos0) filled by the prefill.  tokens_out: int32 [B, n_steps].
-int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
+// logits0: [B, vocab_out] logits of the last prefix position (from the prefill); kv_cache[l]: fp32 or fp16
+// (cfg.kv_f16) [t_max, B, 2d] time-major, rows [0, pos0) filled by the prefill.  tokens_out: int32 [B, n_steps].
+int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
                     int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream) {
@@ -105,7 +105,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache,
         const int pos = pos0 + s;
         ASTTS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)lens, pos + 1, b, st));
         // embed: speech_embedding[tok] -> Linear -> LayerNorm -> ReLU * sqrt(d)
-        rc = astts_op_gemm_fused(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, b, d, 0,
+        rc = astts_op_gemm_fused(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, 0, b, d, 0,
                                  d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
         if (rc != ASTTS_OK) return rc;
         rc = astts_op_layernorm(h1, g.embed_ln_g, g.embed_ln_b, h0, b, d, d, d, c.eps, st);
@@ -117,27 +117,29 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache,
         float* y = h1;
         for (int l = 0; l < c.layers; ++l) {
             const astts_lm_layer_t& L = h->layers[l];
-            float* kvc = kv_cache[l];
+            char* kvc = (char*)kv_cache[l];
+            const size_t esz = c.kv_f16 ? 2 : 4;
             // LN1 + QKV; K|V land in cache row `pos`
-            rc = astts_op_gemm_fused(x, nullptr, L.n1_g, L.n1_b, c.eps, L.wqkv, L.bqkv, nullptr, q, kvc + (int64_t)pos * kv_row,
-                                     b, 3 * d, d, d, dpad, d, d, 2 * d, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
-            if (rc != ASTTS_OK) return rc;
-            rc = astts_op_attn_relpos(q, kvc, kvc + d, L.pos, L.bias_u, L.bias_v, lens, ao, b, c.heads, 1, pos + 1,
-                                      /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld, /*q_bs*/ d,
-                                      /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
-            if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(ao, nullptr, nullptr, nullptr, 0.f, L.wo, L.bo, x, y, nullptr, b, d, 0, d, dpad, d, d, 0, d,
+            rc = astts_op_gemm_fused(x, nullptr, L.n1_g, L.n1_b, c.eps, L.wqkv, L.bqkv, nullptr, q,
+                                     kvc + (size_t)pos * kv_row * esz, c.kv_f16, b, 3 * d, d, d, dpad, d, d, 2 * d, 0,
                                      ASTTS_ACT_NONE, 1.f, 0.f, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(y, nullptr, L.n2_g, L.n2_b, c.eps, L.w1, L.b1, nullptr, ff, nullptr, b, c.ffn, 0, d, dpad, d,
+            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, lens, ao, b,
+                                         c.heads, 1, pos + 1, /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld,
+                                         /*q_bs*/ d, /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_gemm_fused(ao, nullptr, nullptr, nullptr, 0.f, L.wo, L.bo, x, y, nullptr, 0, b, d, 0, d, dpad, d, d, 0, d,
+                                     ASTTS_ACT_NONE, 1.f, 0.f, st);
+            if (rc != ASTTS_OK) return rc;
+            rc = astts_op_gemm_fused(y, nullptr, L.n2_g, L.n2_b, c.eps, L.w1, L.b1, nullptr, ff, nullptr, 0, b, c.ffn, 0, d, dpad, d,
                                      c.ffn, 0, 0, ASTTS_ACT_RELU, 1.f, 0.f, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(ff, nullptr, nullptr, nullptr, 0.f, L.w2, L.b2, y, x, nullptr, b, d, 0, c.ffn, fpad, c.ffn, d,
+            rc = astts_op_gemm_fused(ff, nullptr, nullptr, nullptr, 0.f, L.w2, L.b2, y, x, nullptr, 0, b, d, 0, c.ffn, fpad, c.ffn, d,
                                      0, d, ASTTS_ACT_NONE, 1.f, 0.f, st);
             if (rc != ASTTS_OK) return rc;
         }
         // after_norm + output head
-        rc = astts_op_gemm_fused(x, nullptr, g.after_g, g.after_b, c.eps, g.head_w, g.head_b, nullptr, lg, nullptr, b, c.vocab_out,
+        rc = astts_op_gemm_fused(x, nullptr, g.after_g, g.after_b, c.eps, g.head_w, g.head_b, nullptr, lg, nullptr, 0, b, c.vocab_out,
                                  0, d, dpad, d, c.vocab_out, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
         if (rc != ASTTS_OK) return rc;
         cur = lg;

@@ -30,9 +30,9 @@ __device__ __forceinline__ float wave_add_f32(float v) {
 
 struct RelPosArgs {
     const float* q;    // [B, Tq, ldq]  (+ head*64)
-    const float* k;    // [B, Tk, ldk]
-    const float* v;    // [B, Tk, ldk]
-    const float* pos;  // [2*pos_center+1... rows][H*64]: row (rel + pos_center) holds linear_pos(pe(rel))
+    const void* k;     // [B, Tk, ldk]  fp32, or fp16 when kv_f16 (the KV cache)
+    const void* v;     // [B, Tk, ldk]
+    const void* pos;   // [2*pos_center+1 rows][H*64]: row (rel + pos_center) holds linear_pos(pe(rel)); fp32 or fp16
     const float* bias_u;
     const float* bias_v;
     const int* lens;   // [B] valid keys (null -> Tk)
@@ -43,12 +43,24 @@ struct RelPosArgs {
     int pos_center;
     int causal;
     float scale;
+    int kv_f16, pos_f16;
 };
+
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T* p) {
+    if constexpr (sizeof(T) == 2) {
+        const half4 h = *reinterpret_cast<const half4*>(p);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
 
 static constexpr int RP_QB = 16;  // query rows per block
 static constexpr int RP_KB = 64;  // keys per tile
 static constexpr int RP_LD = 65;  // padded LDS row
 
+template <typename KVT, typename PT>
 __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     __shared__ float sk[RP_KB * RP_LD];
     __shared__ float sv[RP_KB * DH];
@@ -61,8 +73,9 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     const int i0 = qt * RP_QB;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
-    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH;
-    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH;
+    const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH;
+    const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH;
+    const PT* posb = reinterpret_cast<const PT*>(a.pos);
     // q + u, q + v for the block's query rows
     for (int e = tid; e < RP_QB * DH; e += 256) {
         const int r = e >> 6, d = e & 63;
@@ -86,15 +99,15 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
             const int r = e >> 6, d = e & 63;
             const int j = j0 + r;
             const bool ok = j < len;
-            sk[r * RP_LD + d] = ok ? kb[(int64_t)j * a.ldk + d] : 0.0f;
-            sv[r * DH + d] = ok ? vb[(int64_t)j * a.ldk + d] : 0.0f;
+            sk[r * RP_LD + d] = ok ? (float)kb[(int64_t)j * a.ldk + d] : 0.0f;
+            sv[r * DH + d] = ok ? (float)vb[(int64_t)j * a.ldk + d] : 0.0f;
         }
         // relative positions needed: rel = (q_pos0 + i) - j, i in [i0, i0+QB), j in [j0, j0+KB)
         const int rel_min = a.q_pos0 + i0 - (j0 + RP_KB - 1);
         for (int e = tid; e < (RP_KB + RP_QB - 1) * DH; e += 256) {
             const int r = e >> 6, d = e & 63;
             const int row = rel_min + r + a.pos_center;
-            sp[r * RP_LD + d] = a.pos[(int64_t)row * a.ldp + head * DH + d];
+            sp[r * RP_LD + d] = (float)posb[(int64_t)row * a.ldp + head * DH + d];
         }
         __syncthreads();
 #pragma unroll
@@ -135,20 +148,25 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     }
 }
 
-// one (batch, head) per block; query = the single new position q_pos0 (== tk - 1 for the LM step).
-// 16 lanes share one key: lane sub = lane & 15 owns dims [4 sub, 4 sub + 4), so every wave
-// instruction reads four whole 256-byte K (or V, or position) rows -- fully coalesced.
-__global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
-    extern __shared__ float sc[];  // [tk] scores, then [16][64] partial outputs
-    __shared__ float redm[4], reds[4];
+// one (batch, head) per block (512 threads); query = the single new position q_pos0 (== tk - 1 for the LM step).
+// 16 lanes share one key: lane sub = lane & 15 owns dims [4 sub, 4 sub + 4), so every wave instruction reads four
+// whole K (or V, or position) rows -- fully coalesced.  32 key groups x DK keys each per pass keep up to
+// 2*DK 8/16-byte loads in flight per lane: the ~400 cached keys of a step take two passes instead of 25.
+static constexpr int DG = 32;  // key groups per block
+static constexpr int DK = 8;   // keys per group and pass
+
+template <typename KVT, typename PT>
+__global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
+    extern __shared__ float sc[];  // [tk] scores, then [DG][64] partial outputs
+    __shared__ float redm[8], reds[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int sub = lane & 15, grp = tid >> 4;  // 16 key groups per block
+    const int sub = lane & 15, grp = tid >> 4;
     const int head = blockIdx.x, b = blockIdx.y;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
-    const float* kb = a.k + (int64_t)b * a.k_bs + head * DH + 4 * sub;
-    const float* vb = a.v + (int64_t)b * a.k_bs + head * DH + 4 * sub;
-    const float* pb = a.pos + head * DH + 4 * sub;
+    const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
+    const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
+    const PT* pb = reinterpret_cast<const PT*>(a.pos) + head * DH + 4 * sub;
     float4 qu, qv;
     {
         const float4 x = *reinterpret_cast<const float4*>(qb + 4 * sub);
@@ -158,18 +176,17 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
         qv = make_float4((x.x + v.x) * a.scale, (x.y + v.y) * a.scale, (x.z + v.z) * a.scale, (x.w + v.w) * a.scale);
     }
     float mloc = -INFINITY;
-    constexpr int UK = 4;  // keys per 16-lane group and iteration: 8 independent 16-byte loads in flight per lane
-    for (int j0 = 0; j0 < len; j0 += 16 * UK) {
-        float4 kk[UK], pp[UK];
+    for (int j0 = 0; j0 < len; j0 += DG * DK) {
+        float4 kk[DK], pp[DK];
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int j = min(j0 + u * 16 + grp, len - 1);  // clamped: always a valid row, masked below
-            kk[u] = *reinterpret_cast<const float4*>(kb + (int64_t)j * a.ldk);
-            pp[u] = *reinterpret_cast<const float4*>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
+        for (int u = 0; u < DK; ++u) {
+            const int j = min(j0 + u * DG + grp, len - 1);  // clamped: always a valid row, masked below
+            kk[u] = ld4<KVT>(kb + (int64_t)j * a.ldk);
+            pp[u] = ld4<PT>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
         }
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int j = j0 + u * 16 + grp;
+        for (int u = 0; u < DK; ++u) {
+            const int j = j0 + u * DG + grp;
             float s = qu.x * kk[u].x + qu.y * kk[u].y + qu.z * kk[u].z + qu.w * kk[u].w + qv.x * pp[u].x + qv.y * pp[u].y +
                       qv.z * pp[u].z + qv.w * pp[u].w;
 #pragma unroll
@@ -183,9 +200,11 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
     mloc = wave_max_f32(mloc);
     if (lane == 0) redm[wid] = mloc;
     __syncthreads();
-    const float m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float m = redm[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, redm[w]);
     float sloc = 0.0f;
-    for (int j = tid; j < len; j += 256) {
+    for (int j = tid; j < len; j += 512) {
         const float p = __expf(sc[j] - m);
         sc[j] = p;
         sloc += p;
@@ -193,21 +212,23 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
     sloc = wave_add_f32(sloc);
     if (lane == 0) reds[wid] = sloc;
     __syncthreads();
-    const float l = (reds[0] + reds[1]) + (reds[2] + reds[3]);
-    // out[d] = sum_j p_j v[j][d]: key group g takes keys j = g (mod 16)
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = grp; j0 < len; j0 += 16 * UK) {
-        float4 vv[UK];
-        float pw[UK];
+    float l = 0.0f;
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int j = j0 + u * 16;
+    for (int w = 0; w < 8; ++w) l += reds[w];
+    // out[d] = sum_j p_j v[j][d]: key group g takes keys j = g (mod DG)
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = grp; j0 < len; j0 += DG * DK) {
+        float4 vv[DK];
+        float pw[DK];
+#pragma unroll
+        for (int u = 0; u < DK; ++u) {
+            const int j = j0 + u * DG;
             const int jc = min(j, len - 1);
-            vv[u] = *reinterpret_cast<const float4*>(vb + (int64_t)jc * a.ldk);
+            vv[u] = ld4<KVT>(vb + (int64_t)jc * a.ldk);
             pw[u] = j < len ? sc[jc] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
+        for (int u = 0; u < DK; ++u) {
             o.x += pw[u] * vv[u].x; o.y += pw[u] * vv[u].y; o.z += pw[u] * vv[u].z; o.w += pw[u] * vv[u].w;
         }
     }
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_relpos_decode(RelPosArgs a) {
     if (tid < DH) {
         float tot = 0.0f;
 #pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) tot += part[g2 * DH + tid];
+        for (int g2 = 0; g2 < DG; ++g2) tot += part[g2 * DH + tid];
         a.out[(int64_t)b * a.o_bs + head * DH + tid] = l > 0.0f ? tot / l : 0.0f;
     }
 }
@@ -387,33 +408,57 @@ using namespace astts;
 
 extern "C" {
 
-int astts_op_attn_relpos(const float* q, const float* k, const float* v, const float* pos, const float* bias_u,
-                         const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h, int32_t tq,
-                         int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
-                         int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
-                         astts_stream_t stream) {
+int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_t kv_f16, const void* pos, int32_t pos_f16,
+                            const float* bias_u, const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h,
+                            int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs,
+                            int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
+                            astts_stream_t stream) {
     ASTTS_REQUIRE(q && k && v && pos && bias_u && bias_v && out, ASTTS_ERR_INVALID, "astts_op_attn_relpos: null pointer");
     ASTTS_REQUIRE(b >= 1 && h >= 1 && tq >= 1 && tk >= 1, ASTTS_ERR_INVALID, "astts_op_attn_relpos: bad shape");
     ASTTS_REQUIRE(q_pos0 + tq - 1 <= pos_center && tk - 1 <= pos_center + q_pos0, ASTTS_ERR_INVALID,
                   "astts_op_attn_relpos: position table too small (center %d, q_pos0 %d, tq %d, tk %d)", pos_center, q_pos0, tq, tk);
-    RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center, causal, scale};
+    RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center,
+                 causal, scale, kv_f16 ? 1 : 0, pos_f16 ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
+    const int variant = (kv_f16 ? 2 : 0) | (pos_f16 ? 1 : 0);
     if (tq == 1) {
-        const size_t lds = ((size_t)((tk + 3) & ~3) + 16 * DH) * sizeof(float);
+        a.tk = (tk + 3) & ~3;  // keeps the partial-output area 16-byte aligned (keys are bounded by lens)
+        const size_t lds = ((size_t)a.tk + DG * DH) * sizeof(float);
         ASTTS_REQUIRE(lds <= 60 * 1024, ASTTS_ERR_INVALID, "astts_op_attn_relpos: tk=%d too long for the decode kernel", tk);
-        a.tk = (tk + 3) & ~3;  // keeps the partial-output area 16-byte aligned (keys are bounded by lens / tk below)
-        if (!lens) { set_error("astts_op_attn_relpos: the decode kernel needs lens"); return ASTTS_ERR_INVALID; }
-        const bool prof = prof_begin(ASTTS_PROF_ATTN_DECODE, st, (double)b * h * tk * DH * 4.0 * 2.0);
-        hipLaunchKernelGGL(attn_relpos_decode, dim3(h, b), dim3(256), lds, st, a);
+        ASTTS_REQUIRE(lens != nullptr, ASTTS_ERR_INVALID, "astts_op_attn_relpos: the decode kernel needs lens");
+        const int esz = kv_f16 ? 2 : 4;
+        const bool prof = prof_begin(ASTTS_PROF_ATTN_DECODE, st, (double)b * h * tk * DH * esz * 2.0);
+        const dim3 grid(h, b);
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((attn_relpos_decode<float, float>), grid, dim3(512), lds, st, a); break;
+            case 1: hipLaunchKernelGGL((attn_relpos_decode<float, _Float16>), grid, dim3(512), lds, st, a); break;
+            case 2: hipLaunchKernelGGL((attn_relpos_decode<_Float16, float>), grid, dim3(512), lds, st, a); break;
+            default: hipLaunchKernelGGL((attn_relpos_decode<_Float16, _Float16>), grid, dim3(512), lds, st, a); break;
+        }
         if (prof) prof_end(ASTTS_PROF_ATTN_DECODE, st);
     } else {
         // the tile loader reads rel in [q_pos0+i0-(j0+63), q_pos0+i0+15-j0]; keep that inside the table
         ASTTS_REQUIRE(pos_center >= tk + RP_KB + RP_QB && pos_center >= q_pos0 + tq + RP_QB, ASTTS_ERR_INVALID,
                       "astts_op_attn_relpos: pos_center %d must exceed tk/tq by the tile margin", pos_center);
-        hipLaunchKernelGGL(attn_relpos, dim3((tq + RP_QB - 1) / RP_QB, h, b), dim3(256), 0, st, a);
+        const dim3 grid((tq + RP_QB - 1) / RP_QB, h, b);
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((attn_relpos<float, float>), grid, dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((attn_relpos<float, _Float16>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((attn_relpos<_Float16, float>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((attn_relpos<_Float16, _Float16>), grid, dim3(256), 0, st, a); break;
+        }
     }
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
+}
+
+int astts_op_attn_relpos(const float* q, const float* k, const float* v, const float* pos, const float* bias_u,
+                         const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h, int32_t tq,
+                         int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
+                         int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
+                         astts_stream_t stream) {
+    return astts_op_attn_relpos_ex(q, k, v, 0, pos, 0, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs,
+                                   o_bs, q_pos0, pos_center, causal, scale, stream);
 }
 
 int astts_op_attn_mha_ex(const void* q, const void* k, const void* v, int32_t in_f16, const int32_t* lens, void* out,

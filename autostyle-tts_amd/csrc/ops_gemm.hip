@@ -64,6 +64,7 @@ struct GemmArgs {
     float* out2;             // columns >= n_split go to out2[m*ldc2 + n - n_split] (or null)
     int ldc2, n_split;
     int x_f16, out_f16;      // activations in / out as fp16 (ld* are then in halfs)
+    int out2_f16;            // skinny kernel: the split destination (KV cache) is fp16
 };
 
 // A16: the activations arrive as fp16 (written by a producer whose only consumers are MFMA operands:
@@ -309,6 +310,20 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     _Float16* sx = reinterpret_cast<_Float16*>(sk_smem);     // [M][xs]
     float* red = reinterpret_cast<float*>(sk_smem + (((size_t)M * xs * 2 + 15) & ~(size_t)15));  // [8][MT][4][64]
 
+    // epilogue operands of this thread's output element (threads < MT*256), requested before anything else so
+    // their round trip overlaps the weight stream instead of trailing the reduction
+    float e_bias = 0.0f, e_res = 0.0f;
+    {
+        const int o = tid;
+        if (o < MT * 256) {
+            const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
+            const int n = n0 + (ln & 15), m = t * 16 + (ln >> 4) * 4 + e;
+            if (n < a.n && m < M) {
+                if (a.bias) e_bias = a.bias[n];
+                if (a.residual) e_res = a.residual[(int64_t)m * a.ldr + n];
+            }
+        }
+    }
     const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
     half8 fb[SK_LINES][2];
     // (1) first pass of weight loads
@@ -442,7 +457,8 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[((wid * MT + t) * 4 + e) * 64 + lane] = acc[t][e];
     __syncthreads();
-    for (int o = tid; o < MT * 4 * 64; o += 512) {
+    if (tid < MT * 256) {   // MT*256 outputs <= 512 threads: one element each
+        const int o = tid;
         const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
         float v = 0.0f;
 #pragma unroll
@@ -450,13 +466,17 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
         const int n = n0 + (ln & 15);
         const int m = t * 16 + (ln >> 4) * 4 + e;
         if (n < a.n && m < M) {
-            v = apply_act(v + (a.bias ? a.bias[n] : 0.0f), a.act, a.slope) * a.alpha;
+            v = apply_act(v + e_bias, a.act, a.slope) * a.alpha;
             if (a.row_scale) v *= a.row_scale[m];
-            if (a.residual) v += a.residual[(int64_t)m * a.ldr + n];
-            if (a.out2 && n >= a.n_split)
-                a.out2[(int64_t)m * a.ldc2 + (n - a.n_split)] = v;
-            else
+            v += e_res;
+            if (a.out2 && n >= a.n_split) {
+                if (a.out2_f16)
+                    reinterpret_cast<_Float16*>(a.out2)[(int64_t)m * a.ldc2 + (n - a.n_split)] = (_Float16)v;
+                else
+                    a.out2[(int64_t)m * a.ldc2 + (n - a.n_split)] = v;
+            } else {
                 a.out[(int64_t)m * a.ldc + n] = v;
+            }
         }
     }
 }
@@ -579,7 +599,7 @@ int astts_op_gemm(const float* x, const void* w_f16, const float* bias, const fl
     if (rc != ASTTS_OK) return rc;
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, row_scale, out, m, n, cin, cin_pad, taps,
                lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
-               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, 0, 0};
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, 0, 0, 0};
     return launch_gemm(a, (hipStream_t)stream);
 }
 
@@ -592,12 +612,12 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
     if (rc != ASTTS_OK) return rc;
     GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, row_scale, (float*)out, m, n, cin, cin_pad, taps,
                lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
-               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0};
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
     return launch_gemm(a, (hipStream_t)stream);
 }
 
 int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                        const void* w_f16, const float* bias, const float* residual, float* out, float* out2,
+                        const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
                         int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
                         int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream) {
     const int rc = check_gemm_args("astts_op_gemm_fused", x, w_f16, out, m, n, cin, cin_pad, 1, 1, 1, 1, 1, act);
@@ -607,7 +627,7 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
     ASTTS_REQUIRE(!out2 || (n_split > 0 && n_split < n), ASTTS_ERR_INVALID, "astts_op_gemm_fused: n_split=%d", n_split);
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, nullptr, out, m, n, cin, cin_pad, 1,
                lda, ldc, ldr, m, m, 1, 1, 0, act, alpha, slope,
-               gather, ln_gamma, ln_beta, ln_eps, out2, ldc2, n_split, 0, 0};
+               gather, ln_gamma, ln_beta, ln_eps, (float*)out2, ldc2, n_split, 0, 0, out2_f16 ? 1 : 0};
     return launch_gemm(a, (hipStream_t)stream);
 }
 

@@ -144,9 +144,9 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
 /* Decode-sized GEMM (m <= 32, weight-bandwidth bound) with the fusions that take whole launches out of
  * an LM decode step: optional row gather (x row of output row i = x[gather[i]], i.e. an embedding lookup),
  * optional LayerNorm(gamma, beta, eps) over the cin inputs of every row applied while loading, and an
- * optional second destination for the output columns >= n_split (out2[m*ldc2 + n - n_split]). */
+ * optional second destination for the output columns >= n_split (out2[m*ldc2 + n - n_split], fp32 or fp16). */
 int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                        const void* w_f16, const float* bias, const float* residual, float* out, float* out2,
+                        const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
                         int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
                         int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream);
 int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
@@ -189,6 +189,12 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
                          int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
                          int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
                          astts_stream_t stream);
+/* _ex: K/V (e.g. a KV cache) and/or the position table may be fp16 (ldk / k_bs / ldp then count halfs). */
+int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_t kv_f16, const void* pos, int32_t pos_f16,
+                            const float* bias_u, const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h,
+                            int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs,
+                            int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
+                            astts_stream_t stream);
 /* masked multi-head attention (flash-style MFMA), head dim 64. */
 int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
                       int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream);
@@ -223,6 +229,7 @@ typedef struct {
     int32_t pos_center, pos_ld; /* relative-position tables: row (rel + pos_center), row stride pos_ld floats */
     int32_t top_k, ras_win;
     float top_p, ras_tau, eps;
+    int32_t kv_f16, pos_f16; /* KV cache / position tables stored as fp16 */
 } astts_lm_config_t;
 typedef struct {
     const float* speech_emb;                 /* [speech_vocab, d] */
@@ -246,11 +253,11 @@ int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* glob
 int astts_lm_destroy(astts_lm_t* h);
 size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
 /* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
- * rows < pos0 filled by the prefill); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
+ * rows < pos0 filled by the prefill; fp16 when cfg.kv_f16); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
  * tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL.  The EOS logit is masked for the
  * first eos_min_steps steps (pass n_steps for fixed-length decoding); rows keep decoding after an EOS -- the caller
  * truncates at the first EOS id (== speech_vocab). */
-int astts_lm_decode(astts_lm_t* h, const float* logits0, float* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
+int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
                     int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
