@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
 static constexpr int SK_WAVES = 8;
 static constexpr int SK_LINES = 8;  // weight lines prefetched per wave and pass
 
-template <int MT>
+template <int MT, int XV>
 __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -310,23 +310,30 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     _Float16* sx = reinterpret_cast<_Float16*>(sk_smem);     // [M][xs]
     float* red = reinterpret_cast<float*>(sk_smem + (((size_t)M * xs * 2 + 15) & ~(size_t)15));  // [8][MT][4][64]
 
-    // epilogue operands of this thread's output element (threads < MT*256), requested before anything else so
-    // their round trip overlaps the weight stream instead of trailing the reduction
-    float e_bias = 0.0f, e_res = 0.0f;
-    {
-        const int o = tid;
-        if (o < MT * 256) {
-            const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
-            const int n = n0 + (ln & 15), m = t * 16 + (ln >> 4) * 4 + e;
-            if (n < a.n && m < M) {
-                if (a.bias) e_bias = a.bias[n];
-                if (a.residual) e_res = a.residual[(int64_t)m * a.ldr + n];
-            }
+    // Load ORDER matters: vmcnt retires in issue order, so whatever is needed first must be issued first.
+    //   (0) this wave's first input row (L2-resident, needed for the LayerNorm right away)
+    //   (1) the wave's weight lines (HBM, consumed after the barrier)
+    //   (2) the epilogue operands (bias / residual, consumed last)
+    // XV == 4: rows of <= 1024 inputs live in registers (prefetched, single-pass LayerNorm).  XV == 16 (K up to 4096,
+    // the FFN-out GEMM): rows are staged in rolled 16-byte pieces (no LayerNorm on that path; it falls back to scalar).
+    const bool al_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && (a.cin & 3) == 0;
+    const bool vec_ok = XV == 4 && al_ok && ktot <= 1024;
+    const bool vec_wide = XV != 4 && al_ok && !a.ln_gamma;
+    constexpr int MAXV = 4;
+    const int nv = (ktot + 255) >> 8;
+    float4 v0[MAXV];
+    if (vec_ok && wid < M) {
+        const int64_t src = a.gather ? (int64_t)a.gather[wid] : (int64_t)wid;
+        const float* xr = a.x + src * a.lda;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int k = lane * 4 + i * 256;
+            v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nv && k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
         }
     }
     const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
     half8 fb[SK_LINES][2];
-    // (1) first pass of weight loads
 #pragma unroll
     for (int i = 0; i < SK_LINES; ++i) {
         const int line = wid + i * SK_WAVES;
@@ -335,56 +342,75 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
             fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
         }
     }
-    // (2) stage x rows (gather + LayerNorm + fp16) : wave w owns rows w, w+8, ...
-    const bool vec_ok = (a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && (a.cin & 3) == 0;
-    for (int mr = wid; mr < M; mr += SK_WAVES) {
+    float e_bias = 0.0f, e_res = 0.0f;
+    if (tid < MT * 256) {
+        const int t = tid / 256, e = (tid >> 6) & 3, ln = tid & 63;
+        const int n = n0 + (ln & 15), m = t * 16 + (ln >> 4) * 4 + e;
+        if (n < a.n && m < M) {
+            if (a.bias) e_bias = a.bias[n];
+            if (a.residual) e_res = a.residual[(int64_t)m * a.ldr + n];
+        }
+    }
+    // stage x rows (gather + LayerNorm + fp16): wave w owns rows w, w+8, ...
+    auto stage_row = [&](float4 (&v)[MAXV], _Float16* dst) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        float mean = 0.0f, rstd = 1.0f;
+        if (a.ln_gamma) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s1 += __shfl_xor(s1, off, 64);
+                s2 += __shfl_xor(s2, off, 64);
+            }
+            mean = s1 / (float)a.cin;
+            const float var = fmaxf(s2 / (float)a.cin - mean * mean, 0.0f);
+            rstd = rsqrtf(var + a.ln_eps);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (i < nv && k < ktot) {
+                float4 o = v[i];
+                if (a.ln_gamma && k < a.cin) {
+                    const float4 ga = *reinterpret_cast<const float4*>(a.ln_gamma + k);
+                    const float4 be = *reinterpret_cast<const float4*>(a.ln_beta + k);
+                    o.x = (o.x - mean) * rstd * ga.x + be.x;
+                    o.y = (o.y - mean) * rstd * ga.y + be.y;
+                    o.z = (o.z - mean) * rstd * ga.z + be.z;
+                    o.w = (o.w - mean) * rstd * ga.w + be.w;
+                }
+                half4 h4;
+                h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+                *reinterpret_cast<half4*>(dst + k) = h4;
+            }
+        }
+    };
+    if (vec_ok && wid < M) stage_row(v0, sx + (size_t)wid * xs);   // the prefetched row
+    for (int mr = vec_ok ? wid + SK_WAVES : wid; mr < M; mr += SK_WAVES) {
         const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
         const float* xr = a.x + src * a.lda;
         _Float16* dst = sx + (size_t)mr * xs;
-        if (vec_ok && ktot <= 4096) {
-            // single pass: the row lives in registers (<= 16 float4 per lane); every block re-reads the same few
-            // input rows, so one 16-byte request per 4 elements instead of three scalar passes matters (L2 hot spot)
-            constexpr int MAXV = 16;
-            float4 v[MAXV];
-            const int nv = (ktot + 255) >> 8;
-            float s1 = 0.0f, s2 = 0.0f;
+        if (vec_wide) {
+#pragma unroll 4
+            for (int k = lane * 4; k < ktot; k += 256) {
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < a.cin) v4 = *reinterpret_cast<const float4*>(xr + k);
+                half4 h4;
+                h4[0] = (_Float16)v4.x; h4[1] = (_Float16)v4.y; h4[2] = (_Float16)v4.z; h4[3] = (_Float16)v4.w;
+                *reinterpret_cast<half4*>(dst + k) = h4;
+            }
+        } else if (vec_ok) {
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int k = lane * 4 + i * 256;
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < nv && k < a.cin) v[i] = *reinterpret_cast<const float4*>(xr + k);
-                s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nv && k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
             }
-            float mean = 0.0f, rstd = 1.0f;
-            if (a.ln_gamma) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    s1 += __shfl_xor(s1, off, 64);
-                    s2 += __shfl_xor(s2, off, 64);
-                }
-                mean = s1 / (float)a.cin;
-                const float var = fmaxf(s2 / (float)a.cin - mean * mean, 0.0f);
-                rstd = rsqrtf(var + a.ln_eps);
-            }
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int k = lane * 4 + i * 256;
-                if (i < nv && k < ktot) {
-                    float4 o = v[i];
-                    if (a.ln_gamma && k < a.cin) {
-                        const float4 ga = *reinterpret_cast<const float4*>(a.ln_gamma + k);
-                        const float4 be = *reinterpret_cast<const float4*>(a.ln_beta + k);
-                        o.x = (o.x - mean) * rstd * ga.x + be.x;
-                        o.y = (o.y - mean) * rstd * ga.y + be.y;
-                        o.z = (o.z - mean) * rstd * ga.z + be.z;
-                        o.w = (o.w - mean) * rstd * ga.w + be.w;
-                    }
-                    half4 h4;
-                    h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
-                    *reinterpret_cast<half4*>(dst + k) = h4;
-                }
-            }
+            stage_row(v0, dst);
         } else {
             float mean = 0.0f, rstd = 1.0f;
             if (a.ln_gamma) {
@@ -522,14 +548,22 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
         static bool attr_set = false;
         if (!attr_set) {  // allow > 64 KiB of dynamic LDS (one-off, outside any captured region in practice)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (mt == 1)
-            hipLaunchKernelGGL((gemm_skinny16<1>), dim3((a.n + 15) / 16), dim3(512), lds, st, a);
+        const dim3 grid((a.n + 15) / 16);
+        const bool small_k = a.cin_pad <= 1024;   // row of <= 4 float4 per lane: a quarter of the staging registers
+        if (mt == 1 && small_k)
+            hipLaunchKernelGGL((gemm_skinny16<1, 4>), grid, dim3(512), lds, st, a);
+        else if (mt == 1)
+            hipLaunchKernelGGL((gemm_skinny16<1, 16>), grid, dim3(512), lds, st, a);
+        else if (small_k)
+            hipLaunchKernelGGL((gemm_skinny16<2, 4>), grid, dim3(512), lds, st, a);
         else
-            hipLaunchKernelGGL((gemm_skinny16<2>), dim3((a.n + 15) / 16), dim3(512), lds, st, a);
+            hipLaunchKernelGGL((gemm_skinny16<2, 16>), grid, dim3(512), lds, st, a);
         if (prof) prof_end(ASTTS_PROF_GEMM_SKINNY, st);
         ASTTS_CHECK_LAUNCH();
         return ASTTS_OK;
