@@ -543,13 +543,155 @@ class SynthEngine:
         """One fixed-length batch end to end (all inputs on the GPU):
         LM decode (style-conditioned) -> flow (timbre-conditioned) -> vocoder.  Returns
         (tokens [B, n_tokens], mel [B, Tm, 80], wav [B, 256*Tm])."""
-        cfg = self.cfg
+        toks = self.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, forced_tokens)
+        mel, wav = self.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
+        return toks, mel, wav
+
+    # the two halves of tts(): the latency-bound autoregressive stage and the throughput-bound rendering stage
+    def tts_tokens(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int, uniforms, forced_tokens=None) -> torch.Tensor:
         pre = self.lm.prefix(text, text_lens, lm_spk, lm_prompt_tokens)
-        toks = self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
+        return self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
+
+    def tts_render(self, toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise):
+        cfg = self.cfg
         all_tok = torch.cat([flow_prompt_tokens.to(torch.int32), toks], dim=1)
         b = all_tok.shape[0]
         tok_lens = torch.full((b,), all_tok.shape[1], dtype=torch.int32, device=self.device)
-        mel_total = flow_prompt_mel.shape[1] + cfg.mel_frames_for_tokens(n_tokens)
+        mel_total = flow_prompt_mel.shape[1] + cfg.mel_frames_for_tokens(toks.shape[1])
         mel = self.flow.decode(all_tok, tok_lens, flow_prompt_mel, flow_spk, z, mel_total)
         wav = self.hift.forward(mel, phase0, noise)
+        return mel, wav
+
+
+class PipelinedSynth:
+    """Two-stage software pipeline over consecutive batches on two HIP streams of one GPU.
+
+    The LM decode is a chain of ~19k small dependent launches (latency-bound: it leaves most CUs idle), the
+    flow + vocoder stage is throughput-bound.  Running stage 1 of batch i (high-priority stream) while stage 2 of
+    batch i-1 runs on a second stream overlaps the two; an event hands the tokens over.  ``submit`` enqueues batch i
+    and returns the result of batch i-1 (None for the first call); ``drain`` returns the last one.  Nothing here
+    synchronises the host."""
+
+    def __init__(self, engine: "SynthEngine"):
+        self.eng = engine
+        dev = engine.device
+        with torch.cuda.device(dev):
+            self.s_lm = torch.cuda.Stream(device=dev, priority=-1)
+            self.s_render = torch.cuda.Stream(device=dev)
+        self._pending = None
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=1)
+
+    def _render(self, pending):
+        toks, ev, rargs = pending
+        with torch.cuda.stream(self.s_render):
+            self.s_render.wait_event(ev)
+            toks.record_stream(self.s_render)
+            mel, wav = self.eng.tts_render(toks, *rargs)
         return toks, mel, wav
+
+    def submit(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel,
+               flow_spk, z, phase0, noise):
+        cur = torch.cuda.current_stream(self.eng.device)
+        self.s_lm.wait_stream(cur)
+        self.s_render.wait_stream(cur)
+
+        def lm_stage():
+            # the decode loop is issued from C++ (ctypes drops the GIL): it enqueues in parallel with the Python-issued
+            # render stage of the previous batch
+            with torch.cuda.device(self.eng.device), torch.cuda.stream(self.s_lm):
+                toks = self.eng.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
+                ev = torch.cuda.Event()
+                ev.record(self.s_lm)
+            return toks, ev
+
+        fut = self._pool.submit(lm_stage)
+        done = self._render(self._pending) if self._pending is not None else None
+        toks, ev = fut.result()
+        self._pending = (toks, ev, (flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise))
+        return done
+
+    def drain(self):
+        done = self._render(self._pending) if self._pending is not None else None
+        self._pending = None
+        cur = torch.cuda.current_stream(self.eng.device)
+        cur.wait_stream(self.s_lm)
+        cur.wait_stream(self.s_render)
+        return done
+
+
+class GraphPipelinedSynth:
+    """PipelinedSynth with both stages captured into hipGraphs (torch.cuda.CUDAGraph) for FIXED shapes.
+
+    The LM stage is ~19k launches and the render stage ~6k operator calls per batch: issued eagerly they cost the
+    host ~140 ms + ~85 ms, which is what bounds the two-stream pipeline.  Captured once, a stage replays with one
+    host call.  Two instances of each graph (even / odd batches) give the two batches in flight their own KV
+    caches, token and activation buffers.  ``inputs`` are the resident tensors the graphs read (update them in place
+    between submits to change the batch); outputs of batch i live in ``self.out[i % 2]`` until batch i+2 replays."""
+
+    def __init__(self, engine: "SynthEngine", inputs):
+        self.eng = engine
+        dev = engine.device
+        (text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel, flow_spk, z,
+         phase0, noise) = inputs
+        with torch.cuda.device(dev):
+            self.s_lm = torch.cuda.Stream(device=dev, priority=-1)
+            self.s_render = torch.cuda.Stream(device=dev)
+            self.g_lm, self.g_render, self.out = [], [], []
+            self.ev_lm = [torch.cuda.Event() for _ in range(2)]
+            self.ev_render = [torch.cuda.Event() for _ in range(2)]
+            torch.cuda.synchronize(dev)
+            # warm both stages once on the capture streams (lazy one-off initialisation must not land in a capture)
+            with torch.cuda.stream(self.s_lm):
+                toks = engine.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
+                engine.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
+            torch.cuda.synchronize(dev)
+            for _p in range(2):
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=self.s_lm):
+                    toks = engine.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=self.s_render):
+                    mel, wav = engine.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
+                self.g_lm.append(g1)
+                self.g_render.append(g2)
+                self.out.append((toks, mel, wav))
+            torch.cuda.synchronize(dev)
+        self._i = 0
+        self._pending = None   # parity whose render stage has not been enqueued yet
+
+    def _enqueue_render(self, p):
+        with torch.cuda.stream(self.s_render):
+            self.s_render.wait_event(self.ev_lm[p])
+            self.g_render[p].replay()
+            self.ev_render[p].record(self.s_render)
+
+    def submit(self):
+        """Enqueue the LM stage of the next batch and the render stage of the previous one; returns the parity slot of
+        the batch whose render was just enqueued (or None)."""
+        p = self._i & 1
+        cur = torch.cuda.current_stream(self.eng.device)
+        self.s_lm.wait_stream(cur)
+        with torch.cuda.stream(self.s_lm):
+            if self._i >= 2:
+                self.s_lm.wait_event(self.ev_render[p])      # batch i-2 has finished reading this slot's tokens
+            self.g_lm[p].replay()
+            self.ev_lm[p].record(self.s_lm)
+        done = None
+        if self._pending is not None:
+            self._enqueue_render(self._pending)
+            done = self._pending
+        self._pending = p
+        self._i += 1
+        return done
+
+    def drain(self):
+        done = None
+        if self._pending is not None:
+            self._enqueue_render(self._pending)
+            done = self._pending
+            self._pending = None
+        cur = torch.cuda.current_stream(self.eng.device)
+        cur.wait_stream(self.s_lm)
+        cur.wait_stream(self.s_render)
+        return done

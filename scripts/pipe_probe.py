@@ -1,0 +1,56 @@
+import sys, time, math
+sys.path[:0] = ['.', 'autostyle-tts_amd']
+import torch
+from astts.synth.config import SynthConfig
+from astts.synth.weights import make_all
+from astts.synth.model import SynthEngine, PipelinedSynth, GraphPipelinedSynth
+cfg = SynthConfig(); W = make_all(cfg, 0); eng = SynthEngine(W, cfg, 'cuda'); del W
+g = torch.Generator(device='cuda').manual_seed(0)
+B, Tt, Tp, Ts = 8, 32, 150, 250
+dev = 'cuda'
+text = torch.randint(0, cfg.text_vocab, (B, Tt), device=dev, generator=g); tlen = torch.full((B,), Tt, dtype=torch.int32, device=dev)
+spk_s = torch.randn(B, cfg.spk_dim, device=dev, generator=g); spk_t = torch.randn(B, cfg.spk_dim, device=dev, generator=g)
+style_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=dev, generator=g); timbre_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=dev, generator=g)
+tmp = cfg.mel_frames_for_tokens(Tp); tm = cfg.mel_frames_for_tokens(Ts)
+timbre_mel = torch.randn(B, tmp, cfg.mel, device=dev, generator=g)
+u = torch.rand(Ts, B, 2, device=dev, generator=g); z = torch.randn(B, tmp + tm, cfg.mel, device=dev, generator=g)
+nh = cfg.nb_harmonics + 1
+phase0 = (torch.rand(B, nh, device=dev, generator=g) * 2 - 1) * math.pi; phase0[:, 0] = 0
+noise = torch.randn(B, tm * cfg.upsample_total, nh, device=dev, generator=g)
+args = (text, tlen, spk_s, style_tok, Ts, u, timbre_tok, timbre_mel, spk_t, z, phase0, noise)
+for _ in range(2): ref = eng.tts(*args)
+torch.cuda.synchronize()
+K = 6
+t0 = time.perf_counter()
+for _ in range(K): out = eng.tts(*args)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+audio = B * ref[2].shape[1] / cfg.sample_rate
+print(f'sequential: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
+pipe = PipelinedSynth(eng)
+for _ in range(2): pipe.submit(*args)
+pipe.drain(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+outs = []
+for _ in range(K):
+    r = pipe.submit(*args)
+    if r is not None: outs.append(r)
+outs.append(pipe.drain())
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f'pipelined : {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}  results {len(outs)}')
+print('identical to sequential:', all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in outs))
+gp = GraphPipelinedSynth(eng, args)
+for _ in range(3): gp.submit()
+gp.drain(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K): gp.submit()
+gp.drain()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f'graph pipelined: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
+print('identical to sequential:', all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in gp.out))
+# host-side enqueue cost of each stage (no sync inside)
+torch.cuda.synchronize()
+for _ in range(2):
+    t0 = time.perf_counter(); toks = eng.tts_tokens(text, tlen, spk_s, style_tok, Ts, u); t1 = time.perf_counter()
+    mel, wav = eng.tts_render(toks, timbre_tok, timbre_mel, spk_t, z, phase0, noise); t2 = time.perf_counter()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f'host enqueue: tokens {1e3 * (t1 - t0):.1f} ms, render {1e3 * (t2 - t1):.1f} ms, then wait {1e3 * (t3 - t2):.1f} ms')
