@@ -564,26 +564,33 @@ class SynthEngine:
 
 
 class PipelinedSynth:
-    """Two-stage software pipeline over consecutive batches on two HIP streams of one GPU.
+    """Software pipeline over consecutive (independent) batches on several HIP streams of one GPU.
 
     The LM decode is a chain of ~19k small dependent launches (latency-bound: it leaves most CUs idle), the
-    flow + vocoder stage is throughput-bound.  Running stage 1 of batch i (high-priority stream) while stage 2 of
-    batch i-1 runs on a second stream overlaps the two; an event hands the tokens over.  ``submit`` enqueues batch i
-    and returns the result of batch i-1 (None for the first call); ``drain`` returns the last one.  Nothing here
-    synchronises the host."""
+    flow + vocoder stage is throughput-bound.  ``lm_depth`` decode chains run concurrently on their own high-priority
+    streams, each enqueued by its own host thread (the decode loop is C++: ctypes drops the GIL), while the render
+    stage of an earlier batch runs on a further stream; an event hands each batch's tokens over.
+    ``submit`` enqueues batch i and returns the (toks, mel, wav) of the batch whose render stage it enqueued
+    (None while the pipeline fills); ``drain`` enqueues what is left and returns those results.  Nothing here
+    synchronises the host with the GPU."""
 
-    def __init__(self, engine: "SynthEngine"):
+    def __init__(self, engine: "SynthEngine", lm_depth: int = 2):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
         self.eng = engine
+        self.depth = max(1, int(lm_depth))
         dev = engine.device
         with torch.cuda.device(dev):
-            self.s_lm = torch.cuda.Stream(device=dev, priority=-1)
+            self.s_lm = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.depth)]
             self.s_render = torch.cuda.Stream(device=dev)
-        self._pending = None
-        from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pool = ThreadPoolExecutor(max_workers=self.depth)
+        self._fifo = deque()
+        self._i = 0
 
-    def _render(self, pending):
-        toks, ev, rargs = pending
+    def _render(self, item):
+        fut, rargs = item
+        toks, ev = fut.result()
         with torch.cuda.stream(self.s_render):
             self.s_render.wait_event(ev)
             toks.record_stream(self.s_render)
@@ -593,31 +600,32 @@ class PipelinedSynth:
     def submit(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel,
                flow_spk, z, phase0, noise):
         cur = torch.cuda.current_stream(self.eng.device)
-        self.s_lm.wait_stream(cur)
+        stream = self.s_lm[self._i % self.depth]
+        self._i += 1
+        stream.wait_stream(cur)
         self.s_render.wait_stream(cur)
 
         def lm_stage():
-            # the decode loop is issued from C++ (ctypes drops the GIL): it enqueues in parallel with the Python-issued
-            # render stage of the previous batch
-            with torch.cuda.device(self.eng.device), torch.cuda.stream(self.s_lm):
+            with torch.cuda.device(self.eng.device), torch.cuda.stream(stream):
                 toks = self.eng.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
                 ev = torch.cuda.Event()
-                ev.record(self.s_lm)
+                ev.record(stream)
             return toks, ev
 
-        fut = self._pool.submit(lm_stage)
-        done = self._render(self._pending) if self._pending is not None else None
-        toks, ev = fut.result()
-        self._pending = (toks, ev, (flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise))
-        return done
+        self._fifo.append((self._pool.submit(lm_stage), (flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)))
+        if len(self._fifo) > self.depth:
+            return self._render(self._fifo.popleft())
+        return None
 
     def drain(self):
-        done = self._render(self._pending) if self._pending is not None else None
-        self._pending = None
+        out = []
+        while self._fifo:
+            out.append(self._render(self._fifo.popleft()))
         cur = torch.cuda.current_stream(self.eng.device)
-        cur.wait_stream(self.s_lm)
+        for st in self.s_lm:
+            cur.wait_stream(st)
         cur.wait_stream(self.s_render)
-        return done
+        return out
 
 
 class GraphPipelinedSynth:

@@ -87,7 +87,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     float* ff = (float*)take(sizeof(float) * b * c.ffn);
     float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
     int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
-    int32_t* lens = (int32_t*)take(sizeof(int32_t) * b);
+    (void)take(sizeof(int32_t) * b);  // reserved
     const float scale = 0.125f;  // 1/sqrt(64)
     const int64_t kv_row = (int64_t)b * 2 * d;  // one time step of the time-major cache
 
@@ -103,7 +103,6 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
         if (rc != ASTTS_OK) return rc;
         if (s + 1 == n_steps) break;
         const int pos = pos0 + s;
-        ASTTS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)lens, pos + 1, b, st));
         // embed: speech_embedding[tok] -> Linear -> LayerNorm -> ReLU * sqrt(d)
         rc = astts_op_gemm_fused(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, 0, b, d, 0,
                                  d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
@@ -124,7 +123,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                                      kvc + (size_t)pos * kv_row * esz, c.kv_f16, b, 3 * d, d, d, dpad, d, d, 2 * d, 0,
                                      ASTTS_ACT_NONE, 1.f, 0.f, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, lens, ao, b,
+            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, /*lens: every row has pos + 1 keys*/ nullptr, ao, b,
                                          c.heads, 1, pos + 1, /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld,
                                          /*q_bs*/ d, /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
             if (rc != ASTTS_OK) return rc;

@@ -44,6 +44,7 @@ struct RelPosArgs {
     int causal;
     float scale;
     int kv_f16, pos_f16;
+    int len_all;       // decode kernel: number of valid keys when lens == null (same for every batch row)
 };
 
 template <typename T>
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane & 15, grp = tid >> 4;
     const int head = blockIdx.x, b = blockIdx.y;
-    const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
+    const int len = a.lens ? min(a.lens[b], a.len_all) : a.len_all;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
@@ -418,14 +419,13 @@ int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_
     ASTTS_REQUIRE(q_pos0 + tq - 1 <= pos_center && tk - 1 <= pos_center + q_pos0, ASTTS_ERR_INVALID,
                   "astts_op_attn_relpos: position table too small (center %d, q_pos0 %d, tq %d, tk %d)", pos_center, q_pos0, tq, tk);
     RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center,
-                 causal, scale, kv_f16 ? 1 : 0, pos_f16 ? 1 : 0};
+                 causal, scale, kv_f16 ? 1 : 0, pos_f16 ? 1 : 0, tk};
     hipStream_t st = (hipStream_t)stream;
     const int variant = (kv_f16 ? 2 : 0) | (pos_f16 ? 1 : 0);
     if (tq == 1) {
         a.tk = (tk + 3) & ~3;  // keeps the partial-output area 16-byte aligned (keys are bounded by lens)
         const size_t lds = ((size_t)a.tk + DG * DH) * sizeof(float);
         ASTTS_REQUIRE(lds <= 60 * 1024, ASTTS_ERR_INVALID, "astts_op_attn_relpos: tk=%d too long for the decode kernel", tk);
-        ASTTS_REQUIRE(lens != nullptr, ASTTS_ERR_INVALID, "astts_op_attn_relpos: the decode kernel needs lens");
         const int esz = kv_f16 ? 2 : 4;
         const bool prof = prof_begin(ASTTS_PROF_ATTN_DECODE, st, (double)b * h * tk * DH * esz * 2.0);
         const dim3 grid(h, b);

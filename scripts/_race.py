@@ -1,0 +1,37 @@
+import sys, time, math
+sys.path[:0] = ['.', 'autostyle-tts_amd']
+import torch
+from astts.synth.config import SynthConfig
+from astts.synth.weights import make_all
+from astts.synth.model import SynthEngine, PipelinedSynth
+cfg = SynthConfig(); W = make_all(cfg, 0); eng = SynthEngine(W, cfg, 'cuda'); del W
+g = torch.Generator(device='cuda').manual_seed(0)
+B, Tt, Tp, Ts = 8, 32, 150, 250
+dev = 'cuda'
+text = torch.randint(0, cfg.text_vocab, (B, Tt), device=dev, generator=g); tlen = torch.full((B,), Tt, dtype=torch.int32, device=dev)
+spk_s = torch.randn(B, cfg.spk_dim, device=dev, generator=g); spk_t = torch.randn(B, cfg.spk_dim, device=dev, generator=g)
+style_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=dev, generator=g); timbre_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=dev, generator=g)
+tmp = cfg.mel_frames_for_tokens(Tp); tm = cfg.mel_frames_for_tokens(Ts)
+timbre_mel = torch.randn(B, tmp, cfg.mel, device=dev, generator=g)
+u = torch.rand(Ts, B, 2, device=dev, generator=g); z = torch.randn(B, tmp + tm, cfg.mel, device=dev, generator=g)
+nh = cfg.nb_harmonics + 1
+phase0 = (torch.rand(B, nh, device=dev, generator=g) * 2 - 1) * math.pi; phase0[:, 0] = 0
+noise = torch.randn(B, tm * cfg.upsample_total, nh, device=dev, generator=g)
+args = (text, tlen, spk_s, style_tok, Ts, u, timbre_tok, timbre_mel, spk_t, z, phase0, noise)
+ref = eng.tts(*args); torch.cuda.synchronize()
+bad = 0
+for rep in range(4):
+    for depth in (1, 2, 3):
+        pipe = PipelinedSynth(eng, lm_depth=depth)
+        outs = []
+        for _ in range(12):
+            r = pipe.submit(*args)
+            if r is not None: outs.append(r)
+        outs += pipe.drain(); torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            tok_ok = bool(torch.equal(o[0], ref[0])); mel_d = float((o[1] - ref[1]).abs().max()); wav_d = float((o[2] - ref[2]).abs().max())
+            if not tok_ok or mel_d > 0 or wav_d > 0:
+                bad += 1
+                first = int((o[0] != ref[0]).any(0).nonzero()[0]) if not tok_ok else -1
+                print(f'rep {rep} depth {depth} batch {i}: toks {tok_ok} (first differing step {first}) mel diff {mel_d:.3g} wav diff {wav_d:.3g}')
+print('mismatching batches:', bad)

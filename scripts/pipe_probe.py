@@ -26,18 +26,21 @@ for _ in range(K): out = eng.tts(*args)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 audio = B * ref[2].shape[1] / cfg.sample_rate
 print(f'sequential: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
-pipe = PipelinedSynth(eng)
-for _ in range(2): pipe.submit(*args)
-pipe.drain(); torch.cuda.synchronize()
-t0 = time.perf_counter()
-outs = []
-for _ in range(K):
-    r = pipe.submit(*args)
-    if r is not None: outs.append(r)
-outs.append(pipe.drain())
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f'pipelined : {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}  results {len(outs)}')
-print('identical to sequential:', all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in outs))
+for depth in (1, 2, 3):
+    pipe = PipelinedSynth(eng, lm_depth=depth)
+    for _ in range(3): pipe.submit(*args)
+    pipe.drain(); torch.cuda.synchronize()
+    K = 12
+    t0 = time.perf_counter()
+    outs = []
+    for _ in range(K):
+        r = pipe.submit(*args)
+        if r is not None: outs.append(r)
+    outs += pipe.drain()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ok = all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in outs)
+    print(f'pipelined depth {depth}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}  results {len(outs)} identical {ok}')
+K = 6
 gp = GraphPipelinedSynth(eng, args)
 for _ in range(3): gp.submit()
 gp.drain(); torch.cuda.synchronize()

@@ -183,3 +183,43 @@ def test_engine_end_to_end_shapes_and_stage_parity():
     mel_ref = osyn.flow_decode(W["flow"], cfg, all_tok, torch.full((b,), tp + ts), timbre_mel, spk_t, z, tmp + tm)
     assert float((mel.cpu() - mel_ref).abs().max()) < 3e-2 * float(mel_ref.abs().max())
     assert torch.isfinite(wav).all() and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
+
+
+def test_pipelined_batches_are_bit_identical_to_sequential():
+    """Software pipeline over independent batches (2 decode chains + render stream in flight): every batch must equal
+    the sequential result bit for bit, for every batch, repeatedly (guards cross-stream hand-over and buffer reuse)."""
+    from astts.synth.model import PipelinedSynth, SynthEngine
+
+    cfg, W = _cfg_and_weights()
+    eng = SynthEngine(W, cfg, DEV)
+    g = torch.Generator().manual_seed(7)
+    b, tt, tp, ts = 4, 10, 16, 40
+    d = lambda t, dt=None: t.to(DEV) if dt is None else t.to(DEV, dt)
+    tmp, tm = cfg.mel_frames_for_tokens(tp), cfg.mel_frames_for_tokens(ts)
+    nh = cfg.nb_harmonics + 1
+    batches = []
+    for _ in range(3):     # three different batches cycled through the pipeline
+        ph = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+        ph[:, 0] = 0
+        batches.append((d(torch.randint(0, cfg.text_vocab, (b, tt), generator=g)), d(torch.full((b,), tt), torch.int32),
+                        d(torch.randn(b, cfg.spk_dim, generator=g)), d(torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)), ts,
+                        d(torch.rand(ts, b, 2, generator=g)), d(torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)),
+                        d(torch.randn(b, tmp, cfg.mel, generator=g)), d(torch.randn(b, cfg.spk_dim, generator=g)),
+                        d(torch.randn(b, tmp + tm, cfg.mel, generator=g)), d(ph),
+                        d(torch.randn(b, tm * cfg.upsample_total, nh, generator=g))))
+    refs = [eng.tts(*a) for a in batches]
+    torch.cuda.synchronize()
+    for depth in (1, 2, 3):
+        pipe = PipelinedSynth(eng, lm_depth=depth)
+        outs = []
+        n = 18
+        for i in range(n):
+            r = pipe.submit(*batches[i % 3])
+            if r is not None:
+                outs.append(r)
+        outs += pipe.drain()
+        torch.cuda.synchronize()
+        assert len(outs) == n
+        for i, o in enumerate(outs):
+            ref = refs[i % 3]
+            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, i)
