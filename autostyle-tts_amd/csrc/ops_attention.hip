@@ -255,8 +255,9 @@ struct MhaArgs {
     float scale;
 };
 
-static constexpr int FA_KS = 72;  // halfs per K row in LDS (64 + 8): conflict-free b128 reads
-static constexpr int FA_VS = 40;  // halfs per V^T row in LDS (32 + 8)
+static constexpr int FA_KT = 64;  // keys per staged tile (two 32-key MFMA sub-tiles)
+static constexpr int FA_KS = 72;  // halfs per K row in LDS (64 dims + 8): conflict-free b128 reads
+static constexpr int FA_VS = 72;  // halfs per V^T row in LDS (64 keys + 8)
 
 template <bool IN16>
 __device__ __forceinline__ void load8(const void* base, int64_t off, float* dst) {
@@ -272,9 +273,25 @@ __device__ __forceinline__ void load8(const void* base, int64_t off, float* dst)
     }
 }
 
+template <bool IN16>
+__device__ __forceinline__ half8 load8h(const void* base, int64_t off) {
+    if constexpr (IN16) {
+        return *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(base) + off);
+    } else {
+        float t[8];
+        load8<false>(base, off, t);
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (_Float16)t[i];
+        return h;
+    }
+}
+
+// Block = 4 waves x 32 queries.  Per 64-key tile: barrier, registers -> LDS, barrier, issue the NEXT tile's global
+// loads, then two 32-key sub-tiles of {S^T = K Q^T (4 MFMA), lane-local online softmax, O^T += V^T P^T (4 MFMA)}.
 template <bool IN16, bool OUT16>
 __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 ks[32 * FA_KS];
+    __shared__ __attribute__((aligned(16))) _Float16 ks[FA_KT * FA_KS];
     __shared__ __attribute__((aligned(16))) _Float16 vt[DH * FA_VS];
     __shared__ float so[4][32][DH + 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -304,79 +321,82 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
         ot[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const int skey = tid >> 3, sd0 = (tid & 7) * 8;  // staging coordinates: key row, first dim
+    const int skey = tid >> 2, sd0 = (tid & 3) * 16;  // staging coordinates: key row (0..63), first of 16 dims
+    half8 rk[2], rv[2];
+    auto prefetch = [&](int j0) {
+        const int j = min(j0 + skey, len - 1);         // clamped; keys >= len are masked in the scores
+        const int64_t off = kb + (int64_t)j * a.ldk + sd0;
+        rk[0] = load8h<IN16>(a.k, off);
+        rk[1] = load8h<IN16>(a.k, off + 8);
+        rv[0] = load8h<IN16>(a.v, off);
+        rv[1] = load8h<IN16>(a.v, off + 8);
+    };
+    if (len > 0) prefetch(0);
 
-    for (int j0 = 0; j0 < len; j0 += 32) {
+    for (int j0 = 0; j0 < len; j0 += FA_KT) {
         __syncthreads();
-        {
-            const int j = j0 + skey;
-            float kk[8], vv[8];
-            if (j < len) {
-                load8<IN16>(a.k, kb + (int64_t)j * a.ldk + sd0, kk);
-                load8<IN16>(a.v, kb + (int64_t)j * a.ldk + sd0, vv);
-            } else {
+        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = rk[0];
+        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    kk[i] = 0.0f;
-                    vv[i] = 0.0f;
-                }
+        for (int i = 0; i < 8; ++i) {
+            vt[(sd0 + i) * FA_VS + skey] = rv[0][i];
+            vt[(sd0 + 8 + i) * FA_VS + skey] = rv[1][i];
+        }
+        __syncthreads();
+        if (j0 + FA_KT < len) prefetch(j0 + FA_KT);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + sub * 32;
+            if (jb >= len) break;   // block-uniform
+            // S^T[key][query] = sum_d K[key][d] Q[query][d]
+            float16v st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8 kf = *reinterpret_cast<const half8*>(&ks[(sub * 32 + c) * FA_KS + 16 * s + 8 * hh]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
             }
-            half8 kh;
+            float mloc = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kh[i] = (_Float16)kk[i];
-            *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = kh;
+            for (int e = 0; e < 16; ++e) {
+                const int key = jb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                st[e] = key < len ? st[e] : -INFINITY;
+                mloc = fmaxf(mloc, st[e]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
+            float lloc = 0.0f;
+            half8 pf[2];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) vt[(sd0 + i) * FA_VS + skey] = (_Float16)vv[i];
-        }
-        __syncthreads();
-        // S^T[key][query] = sum_d K[key][d] Q[query][d]
-        float16v st;
+            for (int e = 0; e < 16; ++e) {
+                const float p = (st[e] == -INFINITY) ? 0.0f : __expf(st[e] - m_new);
+                lloc += p;
+                pf[e >> 3][e & 7] = (_Float16)p;
+            }
+            lloc += __shfl_xor(lloc, 32, 64);
+            l_run = l_run * alpha + lloc;
+            m_run = m_new;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+            for (int e = 0; e < 16; ++e) {
+                ot[0][e] *= alpha;
+                ot[1][e] *= alpha;
+            }
+            // O^T[d][query] += V^T[d][key] P^T[key][query]; key order inside a k-step follows the
+            // accumulator layout: element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const half8 kf = *reinterpret_cast<const half8*>(&ks[c * FA_KS + 16 * s + 8 * hh]);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
-        }
-        float mloc = -INFINITY;
+            for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            st[e] = key < len ? st[e] : -INFINITY;
-            mloc = fmaxf(mloc, st[e]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
-        float lloc = 0.0f;
-        half8 pf[2];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = (st[e] == -INFINITY) ? 0.0f : __expf(st[e] - m_new);
-            lloc += p;
-            pf[e >> 3][e & 7] = (_Float16)p;
-        }
-        lloc += __shfl_xor(lloc, 32, 64);
-        l_run = l_run * alpha + lloc;
-        m_run = m_new;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            ot[0][e] *= alpha;
-            ot[1][e] *= alpha;
-        }
-        // O^T[d][query] += V^T[d][key] P^T[key][query]; key order inside a k-step follows the
-        // accumulator layout: element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + 16 * s + 4 * hh];
-                const half4 lo = *reinterpret_cast<const half4*>(vr);
-                const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
-                half8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + sub * 32 + 16 * s + 4 * hh];
+                    const half4 lo = *reinterpret_cast<const half4*>(vr);
+                    const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+                    half8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
+                }
             }
         }
     }

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
         const float* xr = a.x + src * a.lda;
         _Float16* dst = sx + (size_t)mr * xs;
         if (vec_wide) {
-#pragma unroll 4
+#pragma unroll 8  // 8 independent 16-byte loads in flight per lane (a 4096-wide row = 2 round trips)
             for (int k = lane * 4; k < ktot; k += 256) {
                 float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < a.cin) v4 = *reinterpret_cast<const float4*>(xr + k);
