@@ -13,9 +13,12 @@
 //                          non-candidate (+ error bound); otherwise queue the query for the exact path
 //   5 knn_exact            fp64 scan + exact top-k for queued queries (normally: every block exits at once)
 //
-// HBM layout: scan plane fp16 [N][Dp] row-major, Dp = D rounded up to 64 (zero filled) so every row
-// is a whole number of 128-byte lines; exact plane = the scan plane when the bank is fp16-exact,
-// else fp32 [N][Dp]; fp64 row norms [N]; fp32 inverse norms [N].
+// HBM layout: the SCAN plane is stored pre-tiled in the order the scan consumes it -- fp16
+// [N/32 row tiles][Dp/64 lines][4 k-steps][64 lanes][8 halfs]: one (row tile, line) block is a contiguous 4 KB, one
+// wave instruction reads a contiguous 1 KB (lane (r, h) of k-step i holds bank[32*rt + r][64*line + 32*h + 8*i .. +8]),
+// so the whole scan is sequential streaming instead of 32 rows 2*Dp bytes apart.  Dp = D rounded up to 64, rows
+// padded to a multiple of 32 with zeros.  The EXACT plane (fp64 re-score / exact path) stays row-major [N][Dp]:
+// fp16 when the bank is fp16-exact, else fp32.  fp64 row norms [N]; fp32 inverse norms [N].
 #include "common.h"
 #include "toplist.h"
 
@@ -84,9 +87,9 @@ __device__ __forceinline__ double cos_from_parts(double dot, double qn, double b
 // ------------------------------------------------------------------------------------------
 template <typename SrcT>
 __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, int dp,
-                               _Float16* __restrict__ plane16, float* __restrict__ plane32,
-                               double* __restrict__ norm64, float* __restrict__ inv_norm,
-                               int* __restrict__ flags /* [0]=inexact, [1]=overflow */) {
+                               _Float16* __restrict__ scan_tiled, _Float16* __restrict__ plane16,
+                               float* __restrict__ plane32, double* __restrict__ norm64,
+                               float* __restrict__ inv_norm, int* __restrict__ flags /* [0]=inexact, [1]=overflow */) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -101,6 +104,12 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
         if (!isfinite(back) || !isfinite(v)) overflow = true;
         plane16[row * (int64_t)dp + k] = h;
         if (plane32) plane32[row * (int64_t)dp + k] = v;
+        {   // tiled scan image
+            const int64_t rt = row >> 5;
+            const int r = (int)(row & 31), line = k >> 6, kk = k & 63;
+            const int hh = kk >> 5, i = (kk & 31) >> 3, j = kk & 7;
+            scan_tiled[((rt * (dp >> 6) + line) << 11) + i * 512 + (hh * 32 + r) * 8 + j] = h;
+        }
         acc = fma((double)v, (double)v, acc);
     }
     acc = wave_sum_f64(acc);
@@ -116,7 +125,7 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
 // ------------------------------------------------------------------------------------------
 // 1. query preparation: one block per query row; block 0 also clears the fallback counter
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict__ q, int d, int dp,
+__global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict__ q, int nq, int d, int dp,
                                                         _Float16* __restrict__ qh,
                                                         float* __restrict__ qf,
                                                         double* __restrict__ qn64,
@@ -127,8 +136,16 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (row == 0 && tid == 0) *nflag = 0;
+    if (row >= nq) {  // zero rows completing the last 32-query tile
+        const int qt = row >> 5, r = row & 31;
+        _Float16* tb = qh + (int64_t)qt * (dp >> 6) * 2048;
+        for (int k = tid; k < dp; k += 256) {
+            const int line = k >> 6, kk = k & 63;
+            tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8 + (kk & 7)] = (_Float16)0.0f;
+        }
+        return;
+    }
     const float* s = q + (int64_t)row * d;
-    _Float16* oh = qh + (int64_t)row * dp;
     float* of = qf + (int64_t)row * dp;
     float mx = 0.0f;
     double acc = 0.0;
@@ -156,9 +173,14 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
         frexpf(mx, &e);  // mx = m * 2^e, m in [0.5,1)
         scale = ldexpf(1.0f, 14 - e);
     }
-    for (int k = tid; k < dp; k += 256) {
-        float v = (k < d) ? s[k] : 0.0f;  // second read hits L1/L2
-        oh[k] = (_Float16)(v * scale);
+    {   // tiled fp16 image, same (row tile, line, k-step, lane) order as the bank's scan plane
+        const int qt = row >> 5, r = row & 31;
+        _Float16* tb = qh + (int64_t)qt * (dp >> 6) * 2048;
+        for (int k = tid; k < dp; k += 256) {
+            float v = (k < d) ? s[k] : 0.0f;  // second read hits L1/L2
+            const int line = k >> 6, kk = k & 63;
+            tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8 + (kk & 7)] = (_Float16)(v * scale);
+        }
     }
     if (tid == 0) {
         qn64[row] = sqrt(tot);
@@ -196,35 +218,28 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
+    // tiled planes: block (tile, line) = 2048 halfs; k-step i of lane l at i*512 + l*8
     const _Float16* bptr[RT];
 #pragma unroll
-    for (int b = 0; b < RT; ++b) {
-        int64_t row = row0 + b * 32 + r;
-        if (row >= n) row = n - 1;  // clamp: valid memory, masked at the store
-        bptr[b] = bank + row * (int64_t)dp + h * 32;
-    }
+    for (int b = 0; b < RT; ++b) bptr[b] = bank + ((int64_t)(blockIdx.x * RT + b) * total_lines << 11) + lane * 8;
     const _Float16* aptr[QT];
 #pragma unroll
-    for (int a = 0; a < QT; ++a) {
-        int qrow = a * 32 + r;
-        if (qrow >= nq_group) qrow = nq_group - 1;
-        aptr[a] = qh + (int64_t)qrow * dp + h * 32;
-    }
+    for (int a = 0; a < QT; ++a) aptr[a] = qh + ((int64_t)a * total_lines << 11) + lane * 8;
 
     for (int line = line_begin + wid; line < line_end; line += 4) {
-        const int koff = line * 64;
+        const int64_t koff = (int64_t)line << 11;
         half8 bf[RT][4];
         half8 af[QT][4];
 #pragma unroll
         for (int b = 0; b < RT; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                bf[b][i] = *reinterpret_cast<const half8*>(bptr[b] + koff + i * 8);
+                bf[b][i] = *reinterpret_cast<const half8*>(bptr[b] + koff + i * 512);
 #pragma unroll
         for (int a = 0; a < QT; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                af[a][i] = *reinterpret_cast<const half8*>(aptr[a] + koff + i * 8);
+                af[a][i] = *reinterpret_cast<const half8*>(aptr[a] + koff + i * 512);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 // against its current c-th best and inserts the few survivors.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_part, int ksplit,
-                                                  int qpad, int nld, int64_t n, int c,
+                                                  int qpad, int nld, int64_t n_all, int c, int seg_len,
                                                   int* __restrict__ cand_idx,
                                                   float* __restrict__ cand_s) {
     __shared__ float tile[kSelTile];
@@ -283,10 +298,13 @@ __global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_pa
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t plane = (size_t)qpad * nld;
     const float* base = s_part + (size_t)q * nld;
+    // this block's segment of the row: [seg0, n)
+    const int64_t seg0 = (int64_t)blockIdx.y * seg_len;
+    const int64_t n = (seg0 + seg_len < n_all) ? seg0 + seg_len : n_all;
     TopList<float> tl;
     tl.init();
     bool seeded = false;
-    for (int64_t t0 = 0; t0 < n; t0 += kSelTile) {
+    for (int64_t t0 = seg0; t0 < n; t0 += kSelTile) {
         float v[kSelTile / 256];
 #pragma unroll
         for (int j = 0; j < kSelTile / 256; ++j) v[j] = 0.0f;
@@ -318,8 +336,31 @@ __global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_pa
     }
     merge_lists<float>(tl, sh_s, sh_i, c);
     if (tid < c) {
-        cand_idx[q * 64 + tid] = (tl.idx == kNoIdx) ? -1 : tl.idx;
-        cand_s[q * 64 + tid] = tl.s;
+        const size_t o = ((size_t)q * gridDim.y + blockIdx.y) * 64 + tid;
+        cand_idx[o] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        cand_s[o] = tl.s;
+    }
+}
+
+// merge the per-segment candidate lists of one query (one wave) into the final top-C
+__global__ __launch_bounds__(64) void knn_select_merge(const int* __restrict__ seg_idx, const float* __restrict__ seg_s,
+                                                       int nseg, int c, int* __restrict__ cand_idx,
+                                                       float* __restrict__ cand_s) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    TopList<float> tl;
+    tl.init();
+    for (int sg = 0; sg < nseg; ++sg) {
+        const size_t o = ((size_t)q * nseg + sg) * 64 + lane;
+        const int vi = lane < c ? seg_idx[o] : -1;
+        const float v = lane < c ? seg_s[o] : -INFINITY;
+        if (sg == 0)
+            tl.seed(v, vi, vi >= 0, lane);
+        else
+            tl.offer(v, vi, vi >= 0, lane, c);
+    }
+    if (lane < c) {
+        cand_idx[q * 64 + lane] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        cand_s[q * 64 + lane] = tl.s;
     }
 }
 
@@ -446,7 +487,8 @@ struct astts_knn {
     int d = 0, dp = 0, nld = 0;
     int metric = 0;
     bool exact16 = true;          // scan plane is a lossless image of the bank
-    _Float16* plane16 = nullptr;  // [n][dp]
+    _Float16* scan = nullptr;     // tiled scan plane [ceil(n/128)*4 row tiles][dp/64][4][64][8]
+    _Float16* plane16 = nullptr;  // [n][dp] row-major (exact plane when exact16)
     float* plane32 = nullptr;     // [n][dp], only when !exact16
     double* norm64 = nullptr;     // [n]
     float* inv_norm = nullptr;    // [n]
@@ -460,8 +502,8 @@ struct astts_knn {
 namespace {
 
 struct KnnPlan {
-    int qt, rt, ksplit, lines_per_split, tiles, qpad, c;
-    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, total;
+    int qt, rt, ksplit, lines_per_split, tiles, qpad, c, nseg, seg_len;
+    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, total;
 };
 
 KnnPlan make_plan(const astts_knn* h, int nq, int k) {
@@ -483,6 +525,12 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.lines_per_split = (int)cdiv(total_lines, ks);
     p.ksplit = (int)cdiv(total_lines, p.lines_per_split);
     p.c = k <= 8 ? 16 : 64;
+    // selection segments: one block per (query, 8192-score segment), at most 64 segments per query
+    p.nseg = (int)cdiv(h->n, 8192);
+    if (p.nseg > 64) p.nseg = 64;
+    if (p.nseg < 1) p.nseg = 1;
+    p.seg_len = (int)align_up((size_t)cdiv(h->n, p.nseg), 64);
+    p.nseg = (int)cdiv(h->n, p.seg_len);
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t at = o;
@@ -491,13 +539,15 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     };
     p.off_nflag = take(256);
     p.off_flagged = take(sizeof(int) * (size_t)nq);
-    p.off_qh = take(sizeof(_Float16) * (size_t)nq * h->dp);
+    p.off_qh = take(sizeof(_Float16) * (align_up((size_t)nq, 32) + 256) * h->dp);  // whole 32-query tiles (+ one group's tail)
     p.off_qf = take(sizeof(float) * (size_t)nq * h->dp);
     p.off_qn = take(sizeof(double) * (size_t)nq);
     p.off_qscale = take(sizeof(float) * (size_t)nq);
     p.off_spart = take(sizeof(float) * (size_t)p.ksplit * p.qpad * h->nld);
     p.off_cidx = take(sizeof(int) * (size_t)nq * 64);
     p.off_cs = take(sizeof(float) * (size_t)nq * 64);
+    p.off_sidx = take(sizeof(int) * (size_t)kMaxQPerPass * p.nseg * 64);
+    p.off_ss = take(sizeof(float) * (size_t)kMaxQPerPass * p.nseg * 64);
     p.total = o;
     return p;
 }
@@ -519,7 +569,7 @@ int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq
             once = true;
         }
     }
-    hipLaunchKernelGGL((knn_scan<QT, RT>), grid, dim3(kScanThreads), lds, st, h->plane16, qh,
+    hipLaunchKernelGGL((knn_scan<QT, RT>), grid, dim3(kScanThreads), lds, st, h->scan, qh,
                        h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
@@ -566,6 +616,9 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
             return fail(ASTTS_ERR_HIP);                                                      \
         }                                                                                    \
     } while (0)
+    const size_t scan_rows = align_up((size_t)n, 128);  // every row tile a scan block may touch exists
+    KNN_TRY(hipMalloc(&h->scan, sizeof(_Float16) * scan_rows * h->dp));
+    KNN_TRY(hipMemsetAsync(h->scan, 0, sizeof(_Float16) * scan_rows * h->dp, st));
     KNN_TRY(hipMalloc(&h->plane16, sizeof(_Float16) * (size_t)n * h->dp));
     KNN_TRY(hipMalloc(&h->norm64, sizeof(double) * (size_t)n));
     KNN_TRY(hipMalloc(&h->inv_norm, sizeof(float) * (size_t)n));
@@ -576,10 +629,10 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     if (dtype == ASTTS_DTYPE_F32) {
         KNN_TRY(hipMalloc(&p32, sizeof(float) * (size_t)n * h->dp));
         hipLaunchKernelGGL((knn_build_bank<float>), grid, dim3(256), 0, st, (const float*)bank, n, d,
-                           h->dp, h->plane16, p32, h->norm64, h->inv_norm, flags);
+                           h->dp, h->scan, h->plane16, p32, h->norm64, h->inv_norm, flags);
     } else {
         hipLaunchKernelGGL((knn_build_bank<_Float16>), grid, dim3(256), 0, st, (const _Float16*)bank,
-                           n, d, h->dp, h->plane16, (float*)nullptr, h->norm64, h->inv_norm, flags);
+                           n, d, h->dp, h->scan, h->plane16, (float*)nullptr, h->norm64, h->inv_norm, flags);
     }
     KNN_TRY(hipGetLastError());
     int hf[2] = {0, 0};
@@ -614,6 +667,7 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
 
 int astts_knn_destroy(astts_knn_t* h) {
     if (!h) return ASTTS_OK;
+    if (h->scan) (void)hipFree(h->scan);
     if (h->plane16) (void)hipFree(h->plane16);
     if (h->plane32) (void)hipFree(h->plane32);
     if (h->norm64) (void)hipFree(h->norm64);
@@ -660,9 +714,11 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
     float* spart = (float*)(ws + p.off_spart);
     int* cidx = (int*)(ws + p.off_cidx);
     float* cs = (float*)(ws + p.off_cs);
+    int* sidx = (int*)(ws + p.off_sidx);
+    float* ss = (float*)(ws + p.off_ss);
 
-    hipLaunchKernelGGL(knn_prep_queries, dim3(nq), dim3(256), 0, st, queries, h->d, h->dp, qh, qf, qn,
-                       qscale, nflag);
+    hipLaunchKernelGGL(knn_prep_queries, dim3((unsigned)align_up((size_t)nq, 32)), dim3(256), 0, st, queries, nq, h->d, h->dp,
+                       qh, qf, qn, qscale, nflag);
     ASTTS_CHECK_LAUNCH();
 
     for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {
@@ -687,9 +743,18 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
             ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_used += 2;
         }
-        hipLaunchKernelGGL(knn_select, dim3(qg), dim3(256), 0, st, spart, p.ksplit, p.qpad, h->nld,
-                           h->n, p.c, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
-        ASTTS_CHECK_LAUNCH();
+        if (p.nseg == 1) {
+            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(256), 0, st, spart, p.ksplit, p.qpad, h->nld,
+                               h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
+            ASTTS_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(256), 0, st, spart, p.ksplit, p.qpad, h->nld,
+                               h->n, p.c, p.seg_len, sidx, ss);
+            ASTTS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(knn_select_merge, dim3(qg), dim3(64), 0, st, sidx, ss, p.nseg, p.c,
+                               cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
+            ASTTS_CHECK_LAUNCH();
+        }
     }
     const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
     if (h->exact16) {
