@@ -26,7 +26,7 @@ _SIGS = {
     "astts_op_gemm_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p]),
     "astts_op_attn_relpos_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
-                                          c_void_p] + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
+                                          c_void_p, c_void_p] + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_prof_read": (c_int32, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
@@ -74,7 +74,7 @@ _SIGS.update({
     "astts_lm_create": (c_int32, [ctypes.POINTER(LmConfig), ctypes.POINTER(LmGlobals), ctypes.POINTER(LmLayer), ctypes.POINTER(c_void_p)]),
     "astts_lm_destroy": (c_int32, [c_void_p]),
     "astts_lm_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
-    "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_void_p,
+    "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                   c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 })
 _lib.register_signatures(_SIGS)
@@ -305,7 +305,8 @@ def time_embedding(t: torch.Tensor, dim: int, scale: float = 1000.0) -> torch.Te
 
 
 def attn_relpos(q, k, v, pos, bias_u, bias_v, heads: int, lens=None, q_pos0: int = 0, pos_center: int = 0,
-                causal: bool = False, time_major: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                causal: bool = False, time_major: bool = False, out: Optional[torch.Tensor] = None,
+                key_start: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q: [B, Tq, *] (or [Tq, B, *] when time_major) strided view, k/v: [B, Tk, *] / [Tk, B, *];
     head h occupies columns h*64..h*64+63 of each view."""
     if time_major:
@@ -323,7 +324,7 @@ def attn_relpos(q, k, v, pos, bias_u, bias_v, heads: int, lens=None, q_pos0: int
     assert v.stride() == k.stride() and k.dtype == v.dtype
     _lib.check(_L().astts_op_attn_relpos_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), 1 if k.dtype == torch.float16 else 0,
                                             pos.data_ptr(), 1 if pos.dtype == torch.float16 else 0, bias_u.data_ptr(),
-                                            bias_v.data_ptr(), _p(lens), out.data_ptr(), b, heads, tq, tk, ldq, ldk, ldo,
+                                            bias_v.data_ptr(), _p(lens), _p(key_start), out.data_ptr(), b, heads, tq, tk, ldq, ldk, ldo,
                                             pos.stride(0), q_bs, k_bs, o_bs, q_pos0, pos_center, 1 if causal else 0,
                                             1.0 / math.sqrt(64.0), _st()))
     return out

@@ -133,7 +133,35 @@ class AcousticLM:
     def new_cache(self, b: int, t_max: int) -> List[torch.Tensor]:
         return [torch.empty((t_max, b, 2 * self.body.d), dtype=torch.float16, device=self.device) for _ in self.body.L]
 
-    def forward_new(self, x: torch.Tensor, cache: List[torch.Tensor], pos0: int) -> torch.Tensor:
+    def prefix_ragged(self, texts: List[torch.Tensor], spk: torch.Tensor, prompts: List[torch.Tensor]):
+        """Ragged batch: row i has its own text length and prompt length.  Rows are LEFT-padded to the longest
+        prefix (relative-position attention is translation invariant, so masking the pad keys is exact):
+        -> (prefix [S0, B, d] time-major, key_start int32 [B])."""
+        b = len(texts)
+        dev = self.device
+        tl = [int(t.numel()) for t in texts]
+        tmax = max(tl)
+        text = torch.zeros((b, tmax), dtype=torch.int64, device=dev)
+        for i, t in enumerate(texts):
+            text[i, :tl[i]] = t.to(dev).view(-1)
+        text_lens = torch.tensor(tl, dtype=torch.int32, device=dev)
+        te = ops.embedding(self.text_emb, text)
+        enc = ops.linear(self.text_enc.forward(te, text_lens), self.text_aff)      # suffix padding + causal: exact
+        spk_e = ops.linear(torch.nn.functional.normalize(spk.to(dev), dim=1), self.spk_aff)
+        s0 = [2 + tl[i] + 1 + int(prompts[i].numel()) for i in range(b)]
+        smax = max(s0)
+        pre = torch.zeros((b, smax, self.body.d), dtype=torch.float32, device=dev)
+        for i in range(b):                                                          # host-side assembly (plumbing)
+            o = smax - s0[i]
+            pre[i, o] = self.llm_emb[0]
+            pre[i, o + 1] = spk_e[i]
+            pre[i, o + 2:o + 2 + tl[i]] = enc[i, :tl[i]]
+            pre[i, o + 2 + tl[i]] = self.llm_emb[1]
+            pre[i, o + 3 + tl[i]:] = ops.embedding(self.speech_emb, prompts[i].to(dev).view(1, -1))[0]
+        key_start = torch.tensor([smax - s for s in s0], dtype=torch.int32, device=dev)
+        return pre.transpose(0, 1).contiguous(), key_start
+
+    def forward_new(self, x: torch.Tensor, cache: List[torch.Tensor], pos0: int, key_start: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: time-major [T, B, d] NEW positions pos0..pos0+T-1 -> hidden [T, B, d]; fills the cache."""
         body = self.body
         d = body.d
@@ -147,7 +175,7 @@ class AcousticLM:
             ops.gemm(n.view(t * b, d), lay["wkv"], out=kvc[pos0:pos0 + t].view(t * b, 2 * d))
             kv = kvc[:tk]
             a = ops.attn_relpos(q, kv[..., :d], kv[..., d:], lay["pos"], lay["u"], lay["v"], body.heads, lens=lens,
-                                q_pos0=pos0, pos_center=body.center, causal=True, time_major=True)
+                                q_pos0=pos0, pos_center=body.center, causal=True, time_major=True, key_start=key_start)
             h = ops.linear(a, lay["wo"], residual=h)
             n = ops.layernorm(h, *lay["n2"], body.eps)
             f = ops.linear(n, lay["w1"], act="relu")
@@ -157,7 +185,7 @@ class AcousticLM:
     def logits(self, hidden_last: torch.Tensor) -> torch.Tensor:
         return ops.linear(hidden_last, self.head)
 
-    def step_logits(self, tok: torch.Tensor, cache: List[torch.Tensor], pos: int) -> torch.Tensor:
+    def step_logits(self, tok: torch.Tensor, cache: List[torch.Tensor], pos: int, key_start: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One decode step for B <= 32 utterances with the launch-saving fusions of astts_op_gemm_fused:
         embedding gather inside the embed GEMM, LayerNorm inside the QKV / FFN-in / head GEMMs, K|V written
         straight into the cache.  5 launches per layer.  tok int32 [B] -> logits [B, V+1]."""
@@ -171,7 +199,7 @@ class AcousticLM:
             q = ops.gemm_fused(h, lay["wqkv"], b, ln=lay["n1"], ln_eps=body.eps, out2=kvc[pos], n_split=d)
             kv = kvc[:pos + 1]
             a = ops.attn_relpos(q[None], kv[..., :d], kv[..., d:], lay["pos"], lay["u"], lay["v"], body.heads, lens=lens,
-                                q_pos0=pos, pos_center=body.center, causal=True, time_major=True)
+                                q_pos0=pos, pos_center=body.center, causal=True, time_major=True, key_start=key_start)
             h = ops.gemm_fused(a[0], lay["wo"], b, residual=h)
             f = ops.gemm_fused(h, lay["w1"], b, ln=lay["n2"], ln_eps=body.eps, act="relu")
             h = ops.gemm_fused(f, lay["w2"], b, residual=h)
@@ -210,7 +238,8 @@ class AcousticLM:
         return int(ignore_eos)
 
     def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
-                      forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+                      forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False,
+                      key_start: Optional[torch.Tensor] = None):
         import ctypes
 
         from .. import _lib
@@ -219,7 +248,7 @@ class AcousticLM:
         s0, b = prefix.shape[0], prefix.shape[1]
         t_max = s0 + n_steps
         cache = self.new_cache(b, t_max)
-        hid = self.forward_new(prefix, cache, 0)
+        hid = self.forward_new(prefix, cache, 0, key_start)
         logits0 = self.logits(hid[-1]).contiguous()
         need = int(lib.astts_lm_workspace_bytes(eng, b))
         ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
@@ -230,22 +259,35 @@ class AcousticLM:
         ptrs = (ctypes.c_void_p * len(cache))(*[c.data_ptr() for c in cache])
         forced = None if forced_tokens is None else forced_tokens.to(torch.int32).contiguous()
         u = uniforms.to(torch.float32).contiguous()
-        _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, t_max, b, s0, n_steps, u.data_ptr(),
+        _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, None if key_start is None else key_start.data_ptr(), t_max, b,
+                                       s0, n_steps, u.data_ptr(),
                                        None if forced is None else forced.data_ptr(), self._eos_min(ignore_eos, n_steps), toks.data_ptr(),
                                        None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
-        self._keepalive = (cache, ws, logits0, forced, u)   # buffers referenced by kernels still in flight
+        self._keepalive = (cache, ws, logits0, forced, u, key_start)   # buffers referenced by kernels still in flight
         return (toks, lg_out) if return_logits else toks
 
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
-               forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True):
+               forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True,
+               key_start: Optional[torch.Tensor] = None):
         """Fixed-length autoregressive decode, no host synchronisation inside the loop.
         prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1])."""
         cfg = self.cfg
         s0, b = prefix.shape[0], prefix.shape[1]
         if use_engine and b <= 32:
-            return self.decode_engine(prefix, n_steps, uniforms, ignore_eos, forced_tokens, return_logits)
+            return self.decode_engine(prefix, n_steps, uniforms, ignore_eos, forced_tokens, return_logits, key_start)
+        if use_engine:
+            # larger batches (BASELINE config 3: 64 long-form utterances): independent rows, decoded 32 at a time
+            outs = []
+            for b0 in range(0, b, 32):
+                sl = slice(b0, min(b0 + 32, b))
+                outs.append(self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(), ignore_eos,
+                                               None if forced_tokens is None else forced_tokens[sl], return_logits,
+                                               None if key_start is None else key_start[sl].contiguous()))
+            if return_logits:
+                return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+            return torch.cat(outs, 0)
         cache = self.new_cache(b, s0 + n_steps)
-        hid = self.forward_new(prefix, cache, 0)
+        hid = self.forward_new(prefix, cache, 0, key_start)
         cur = self.logits(hid[-1])
         toks = torch.zeros((b, n_steps), dtype=torch.int32, device=self.device)
         all_logits = [] if return_logits else None
@@ -259,10 +301,10 @@ class AcousticLM:
             toks[:, s] = tok
             if s + 1 < n_steps:
                 if b <= 32:
-                    cur = self.step_logits(tok.clamp(max=cfg.speech_vocab - 1), cache, s0 + s)
+                    cur = self.step_logits(tok.clamp(max=cfg.speech_vocab - 1), cache, s0 + s, key_start)
                 else:
                     emb = ops.embedding(self.speech_emb, tok)[None]        # [1, B, d]
-                    hid = self.forward_new(emb, cache, s0 + s)
+                    hid = self.forward_new(emb, cache, s0 + s, key_start)
                     cur = self.logits(hid[0])
         if return_logits:
             return toks, torch.stack(all_logits, dim=1)

@@ -57,8 +57,8 @@ size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
 
 // logits0: [B, vocab_out] logits of the last prefix position (from the prefill); kv_cache[l]: fp32 or fp16
 // (cfg.kv_f16) [t_max, B, 2d] time-major, rows [0, pos0) filled by the prefill.  tokens_out: int32 [B, n_steps].
-int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
-                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
+int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
+                    int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream) {
     ASTTS_REQUIRE(h && logits0 && kv_cache && uniforms && tokens_out && workspace, ASTTS_ERR_INVALID,
@@ -123,7 +123,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                                      kvc + (size_t)pos * kv_row * esz, c.kv_f16, b, 3 * d, d, d, dpad, d, d, 2 * d, 0,
                                      ASTTS_ACT_NONE, 1.f, 0.f, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, /*lens: every row has pos + 1 keys*/ nullptr, ao, b,
+            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, /*lens: every row has pos + 1 keys*/ nullptr, key_start, ao, b,
                                          c.heads, 1, pos + 1, /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld,
                                          /*q_bs*/ d, /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
             if (rc != ASTTS_OK) return rc;

@@ -45,6 +45,7 @@ struct RelPosArgs {
     float scale;
     int kv_f16, pos_f16;
     int len_all;       // decode kernel: number of valid keys when lens == null (same for every batch row)
+    const int* kstart; // [B] first valid key (left-padded rows: keys < kstart are masked) or null
 };
 
 template <typename T>
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * RP_QB;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
+    const int ks0 = a.kstart ? a.kstart[b] : 0;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     }
     int kmax = len;  // keys needed by this block
     if (a.causal) kmax = min(len, a.q_pos0 + i0 + RP_QB);
-    for (int j0 = 0; j0 < kmax; j0 += RP_KB) {
+    for (int j0 = (ks0 / RP_KB) * RP_KB; j0 < kmax; j0 += RP_KB) {
         __syncthreads();
         for (int e = tid; e < RP_KB * DH; e += 256) {
             const int r = e >> 6, d = e & 63;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
             float s = 0.0f;
 #pragma unroll 16
             for (int d = 0; d < DH; ++d) s += squ[r][d] * kr[d] + sqv[r][d] * pr[d];
-            const bool valid = j < len && (!a.causal || j <= i_abs);
+            const bool valid = j >= ks0 && j < len && (!a.causal || j <= i_abs);
             s = valid ? s : -INFINITY;
             const float m_new = fmaxf(m_run[rr], wave_max_f32(s));
             const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run[rr] - m_new);
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
     const int sub = lane & 15, grp = tid >> 4;
     const int head = blockIdx.x, b = blockIdx.y;
     const int len = a.lens ? min(a.lens[b], a.len_all) : a.len_all;
+    const int ks0 = a.kstart ? min(a.kstart[b], len - 1) : 0;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
         qv = make_float4((x.x + v.x) * a.scale, (x.y + v.y) * a.scale, (x.z + v.z) * a.scale, (x.w + v.w) * a.scale);
     }
     float mloc = -INFINITY;
-    for (int j0 = 0; j0 < len; j0 += DG * DK) {
+    for (int j0 = ks0; j0 < len; j0 += DG * DK) {
         float4 kk[DK], pp[DK];
 #pragma unroll
         for (int u = 0; u < DK; ++u) {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) m = fmaxf(m, redm[w]);
     float sloc = 0.0f;
-    for (int j = tid; j < len; j += 512) {
+    for (int j = ks0 + tid; j < len; j += 512) {
         const float p = __expf(sc[j] - m);
         sc[j] = p;
         sloc += p;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
     for (int w = 0; w < 8; ++w) l += reds[w];
     // out[d] = sum_j p_j v[j][d]: key group g takes keys j = g (mod DG)
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = grp; j0 < len; j0 += DG * DK) {
+    for (int j0 = ks0 + grp; j0 < len; j0 += DG * DK) {
         float4 vv[DK];
         float pw[DK];
 #pragma unroll
@@ -430,16 +433,16 @@ using namespace astts;
 extern "C" {
 
 int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_t kv_f16, const void* pos, int32_t pos_f16,
-                            const float* bias_u, const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h,
-                            int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs,
-                            int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
-                            astts_stream_t stream) {
+                            const float* bias_u, const float* bias_v, const int32_t* lens, const int32_t* key_start, float* out,
+                            int32_t b, int32_t h, int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp,
+                            int64_t q_bs, int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal,
+                            float scale, astts_stream_t stream) {
     ASTTS_REQUIRE(q && k && v && pos && bias_u && bias_v && out, ASTTS_ERR_INVALID, "astts_op_attn_relpos: null pointer");
     ASTTS_REQUIRE(b >= 1 && h >= 1 && tq >= 1 && tk >= 1, ASTTS_ERR_INVALID, "astts_op_attn_relpos: bad shape");
     ASTTS_REQUIRE(q_pos0 + tq - 1 <= pos_center && tk - 1 <= pos_center + q_pos0, ASTTS_ERR_INVALID,
                   "astts_op_attn_relpos: position table too small (center %d, q_pos0 %d, tq %d, tk %d)", pos_center, q_pos0, tq, tk);
     RelPosArgs a{q, k, v, pos, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs, o_bs, q_pos0, pos_center,
-                 causal, scale, kv_f16 ? 1 : 0, pos_f16 ? 1 : 0, tk};
+                 causal, scale, kv_f16 ? 1 : 0, pos_f16 ? 1 : 0, tk, key_start};
     hipStream_t st = (hipStream_t)stream;
     const int variant = (kv_f16 ? 2 : 0) | (pos_f16 ? 1 : 0);
     if (tq == 1) {
@@ -477,7 +480,7 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
                          int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
                          int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
                          astts_stream_t stream) {
-    return astts_op_attn_relpos_ex(q, k, v, 0, pos, 0, bias_u, bias_v, lens, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs,
+    return astts_op_attn_relpos_ex(q, k, v, 0, pos, 0, bias_u, bias_v, lens, nullptr, out, b, h, tq, tk, ldq, ldk, ldo, ldp, q_bs, k_bs,
                                    o_bs, q_pos0, pos_center, causal, scale, stream);
 }
 

@@ -189,12 +189,14 @@ int astts_op_attn_relpos(const float* q, const float* k, const float* v, const f
                          int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs, int64_t k_bs,
                          int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
                          astts_stream_t stream);
-/* _ex: K/V (e.g. a KV cache) and/or the position table may be fp16 (ldk / k_bs / ldp then count halfs). */
+/* _ex: K/V (e.g. a KV cache) and/or the position table may be fp16 (ldk / k_bs / ldp then count halfs).
+ * key_start[b] (or NULL): first valid key of row b -- rows of a ragged batch are LEFT-padded to a common length
+ * (relative positions make that exact) and keys < key_start[b] are masked. */
 int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_t kv_f16, const void* pos, int32_t pos_f16,
-                            const float* bias_u, const float* bias_v, const int32_t* lens, float* out, int32_t b, int32_t h,
-                            int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp, int64_t q_bs,
-                            int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal, float scale,
-                            astts_stream_t stream);
+                            const float* bias_u, const float* bias_v, const int32_t* lens, const int32_t* key_start, float* out,
+                            int32_t b, int32_t h, int32_t tq, int32_t tk, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldp,
+                            int64_t q_bs, int64_t k_bs, int64_t o_bs, int32_t q_pos0, int32_t pos_center, int32_t causal,
+                            float scale, astts_stream_t stream);
 /* masked multi-head attention (flash-style MFMA), head dim 64. */
 int astts_op_attn_mha(const float* q, const float* k, const float* v, const int32_t* lens, float* out, int32_t b,
                       int32_t h, int32_t t, int32_t ldq, int32_t ldk, int32_t ldo, float scale, astts_stream_t stream);
@@ -254,11 +256,11 @@ int astts_lm_destroy(astts_lm_t* h);
 size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
 /* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
  * rows < pos0 filled by the prefill; fp16 when cfg.kv_f16); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
- * tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL.  The EOS logit is masked for the
+ * key_start int32 [b] or NULL (left-padded ragged prefixes); tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL.  The EOS logit is masked for the
  * first eos_min_steps steps (pass n_steps for fixed-length decoding); rows keep decoding after an EOS -- the caller
  * truncates at the first EOS id (== speech_vocab). */
-int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, int32_t t_max, int32_t b, int32_t pos0,
-                    int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
+int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
+                    int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
 

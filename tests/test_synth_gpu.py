@@ -223,3 +223,60 @@ def test_pipelined_batches_are_bit_identical_to_sequential():
         for i, o in enumerate(outs):
             ref = refs[i % 3]
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, i)
+
+
+def test_large_batch_is_decoded_in_groups_of_32():
+    """B > 32 (BASELINE config 3 shape class): rows are independent, so decoding 40 rows in groups must equal
+    decoding each group alone, and the forced-token logits must still match the oracle on a sample of rows."""
+    from astts.synth.model import AcousticLM
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["llm"]
+    g = torch.Generator().manual_seed(11)
+    b, tt, tp, steps = 40, 9, 14, 6
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
+    toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
+    assert toks.shape == (b, steps) and torch.equal(toks.cpu(), forced.to(torch.int32))
+    rows = [0, 31, 32, 39]
+    pre_ref = osyn.lm_prefix(sd, cfg, text[rows], tlen[rows], spk[rows], prompt[rows])
+    _, logits_ref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, rows], True, forced[rows])
+    assert float((logits.cpu()[rows] - logits_ref).abs().max()) < 2e-2 * float(logits_ref.abs().max())
+    free = lm.decode(pre, steps, u.to(DEV), True, None)
+    alone = lm.decode(pre[:, 32:].contiguous(), steps, u[:, 32:].contiguous().to(DEV), True, None)
+    assert torch.equal(free[32:], alone)
+
+
+def test_ragged_lm_batch_equals_one_at_a_time():
+    """Rows with different text / prompt lengths in ONE left-padded batch must reproduce the oracle run one utterance
+    at a time (the only way the reference runs): teacher-forced logits per row, both decode paths."""
+    from astts.synth.model import AcousticLM
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["llm"]
+    g = torch.Generator().manual_seed(21)
+    shapes = [(5, 9), (17, 30), (11, 3), (1, 22)]        # (text tokens, prompt tokens) per row
+    steps = 7
+    texts = [torch.randint(0, cfg.text_vocab, (tt,), generator=g) for tt, _ in shapes]
+    prompts = [torch.randint(0, cfg.speech_vocab, (tp,), generator=g) for _, tp in shapes]
+    b = len(shapes)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre, ks = lm.prefix_ragged(texts, spk, prompts)
+    assert ks.tolist() == [max(3 + tt + tp for tt, tp in shapes) - (3 + tt + tp) for tt, tp in shapes]
+    for use_engine in (False, True):
+        toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True, use_engine=use_engine, key_start=ks)
+        for i in range(b):
+            pre_ref = osyn.lm_prefix(sd, cfg, texts[i][None], torch.tensor([shapes[i][0]]), spk[i:i + 1], prompts[i][None])
+            _, lref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, i:i + 1], True, forced[i:i + 1])
+            assert float((logits[i].cpu() - lref[0]).abs().max()) < 2e-2 * float(lref.abs().max()), (use_engine, i)
