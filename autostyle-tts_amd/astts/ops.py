@@ -38,6 +38,7 @@ _SIGS = {
                                        c_int32, c_float, c_float, c_void_p]),
     "astts_op_embedding": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_interp_linear": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_interp_linear_ex": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "astts_op_time_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_attn_relpos": (c_int32, [c_void_p] * 8 + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_op_attn_mha_ex": (c_int32, [c_void_p] * 3 + [c_int32, c_void_p, c_void_p] + [c_int32] * 7 + [c_float, c_void_p]),
@@ -289,11 +290,14 @@ def embedding(table: torch.Tensor, ids: torch.Tensor, scale: float = 1.0) -> tor
     return y
 
 
-def interp_linear(x: torch.Tensor, t_out: int) -> torch.Tensor:
+def interp_linear(x: torch.Tensor, t_out: int, in_lens: Optional[torch.Tensor] = None,
+                  out_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.interpolate(mode="linear") along T; with in_lens / out_lens each row is resampled from its own valid length
+    to its own output length (ragged batch), zeros beyond."""
     x = _f32(x)
     b, t, c = x.shape
     y = torch.empty((b, t_out, c), dtype=torch.float32, device=x.device)
-    _lib.check(_L().astts_op_interp_linear(x.data_ptr(), y.data_ptr(), b, t, t_out, c, _st()))
+    _lib.check(_L().astts_op_interp_linear_ex(x.data_ptr(), y.data_ptr(), b, t, t_out, c, _p(in_lens), _p(out_lens), _st()))
     return y
 
 

@@ -403,15 +403,17 @@ class FlowDecoder:
         self.fin_p = PackedWeight.from_conv1d(sd[e + ".final_proj.weight"], sd[e + ".final_proj.bias"], device)
 
     # ---- token encoder + length regulator
-    def mu(self, tokens: torch.Tensor, token_lens: torch.Tensor, mel_total: int) -> torch.Tensor:
+    def mu(self, tokens: torch.Tensor, token_lens: torch.Tensor, mel_total: int, mel_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mel_lens (ragged batch): row b is regulated from token_lens[b] tokens to mel_lens[b] frames, zeros beyond."""
         x = ops.embedding(self.tok_emb, tokens.clamp(min=0))
         x = ops.elementwise(ops.EL_MUL_ROWMASK, x, lens=token_lens)
         h = ops.linear(self.enc.forward(x, token_lens), self.enc_proj)
-        h = ops.interp_linear(h, mel_total)
+        h = ops.interp_linear(h, mel_total, in_lens=None if mel_lens is None else token_lens, out_lens=mel_lens)
         for w, ga, be in self.lr:
             h = ops.conv1d(h, w, pad=1)
-            h = ops.groupnorm(h, ga, be, 1, 1e-5, mish=True)
-        return ops.conv1d(h, self.lr_out)
+            h = ops.groupnorm(h, ga, be, 1, 1e-5, lens=mel_lens, mish=True)      # writes 0 beyond the row's length
+        h = ops.conv1d(h, self.lr_out)
+        return h if mel_lens is None else ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=mel_lens)
 
     # ---- one estimator evaluation on a (2B) batch
     def estimator(self, x, mu, spk, cond, t, lens) -> torch.Tensor:
@@ -485,6 +487,41 @@ class FlowDecoder:
             d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2)
             x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s + 1] - ts[s]), s2=cfg.cfg_rate)
         return x[:, tmp:].contiguous()
+
+
+    def decode_ragged(self, tokens: List[torch.Tensor], prompt_mels: List[torch.Tensor], spk: torch.Tensor,
+                      zs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Ragged batch: row i = (prompt + generated tokens [Ti], prompt mel [Tm_p_i, mel], noise z [mel_total_i, mel]).
+        Padded to the longest row, every stage masked by the row lengths -> list of mels [mel_total_i - Tm_p_i, mel],
+        each equal to running that utterance alone."""
+        cfg, dev = self.cfg, self.device
+        b = len(tokens)
+        tl = [int(t.numel()) for t in tokens]
+        tmp = [int(m.shape[0]) for m in prompt_mels]
+        mt = [int(z.shape[0]) for z in zs]
+        tmax, mmax = max(tl), max(mt)
+        tok = torch.zeros((b, tmax), dtype=torch.int32, device=dev)
+        cond = torch.zeros((b, mmax, cfg.mel), dtype=torch.float32, device=dev)
+        x = torch.zeros((b, mmax, cfg.mel), dtype=torch.float32, device=dev)
+        for i in range(b):
+            tok[i, :tl[i]] = tokens[i].to(dev).view(-1)
+            cond[i, :tmp[i]] = prompt_mels[i].to(dev)
+            x[i, :mt[i]] = zs[i].to(dev)
+        tok_lens = torch.tensor(tl, dtype=torch.int32, device=dev)
+        mel_lens = torch.tensor(mt, dtype=torch.int32, device=dev)
+        mu = self.mu(tok, tok_lens, mmax, mel_lens)
+        spk_e = ops.linear(torch.nn.functional.normalize(spk.to(dev), dim=1), self.spk_aff)
+        lens2 = torch.cat([mel_lens, mel_lens])
+        mu2 = torch.cat([mu, torch.zeros_like(mu)], 0)
+        spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
+        cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
+        n = cfg.cfm_steps
+        ts = 1.0 - torch.cos(torch.linspace(0, 1, n + 1) * 0.5 * math.pi)
+        for s_ in range(n):
+            t2 = torch.full((2 * b,), float(ts[s_]), dtype=torch.float32, device=dev)
+            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2)
+            x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s_ + 1] - ts[s_]), s2=cfg.cfg_rate)
+        return [x[i, tmp[i]:mt[i]].contiguous() for i in range(b)]
 
 
 class _ResBlock:

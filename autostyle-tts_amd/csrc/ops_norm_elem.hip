@@ -282,21 +282,30 @@ __global__ __launch_bounds__(256) void embedding_rows(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ linear interpolation along T (F.interpolate, align_corners=False)
+// in_lens / out_lens (nullable): per-row valid lengths of a ragged batch -- row b is resampled from its own in_lens[b]
+// steps to its own out_lens[b] steps (exactly F.interpolate on that row alone); outputs beyond out_lens[b] are 0.
 __global__ __launch_bounds__(256) void interp_linear_rows(const float* __restrict__ x, float* __restrict__ y, int b,
-                                                          int t_in, int t_out, int c) {
-    const int64_t total = (int64_t)b * t_out * c;
-    const float scale = (float)t_in / (float)t_out;
+                                                          int t_in_max, int t_out_max, int c,
+                                                          const int* __restrict__ in_lens, const int* __restrict__ out_lens) {
+    const int64_t total = (int64_t)b * t_out_max * c;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const int64_t row = i / c;
-        const int bb = (int)(row / t_out), to = (int)(row % t_out);
+        const int bb = (int)(row / t_out_max), to = (int)(row % t_out_max);
+        const int t_in = in_lens ? min(in_lens[bb], t_in_max) : t_in_max;
+        const int t_out = out_lens ? min(out_lens[bb], t_out_max) : t_out_max;
+        if (to >= t_out || t_in < 1) {
+            y[i] = 0.0f;
+            continue;
+        }
+        const float scale = (float)t_in / (float)t_out;
         float src = ((float)to + 0.5f) * scale - 0.5f;
         if (src < 0.0f) src = 0.0f;
         int i0 = (int)src;
         if (i0 > t_in - 1) i0 = t_in - 1;
         const int i1 = min(i0 + 1, t_in - 1);
         const float w1 = src - (float)i0;
-        const float* p = x + (int64_t)bb * t_in * c + ch;
+        const float* p = x + (int64_t)bb * t_in_max * c + ch;
         y[i] = p[(int64_t)i0 * c] * (1.0f - w1) + p[(int64_t)i1 * c] * w1;
     }
 }
@@ -397,13 +406,18 @@ int astts_op_embedding(const float* table, const int32_t* ids, float* y, int64_t
     return ASTTS_OK;
 }
 
-int astts_op_interp_linear(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
-                           astts_stream_t stream) {
+int astts_op_interp_linear_ex(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
+                              const int32_t* in_lens, const int32_t* out_lens, astts_stream_t stream) {
     ASTTS_REQUIRE(x && y && b >= 1 && t_in >= 1 && t_out >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_interp_linear: bad argument");
     hipLaunchKernelGGL(interp_linear_rows, dim3(grid_for((int64_t)b * t_out * c)), dim3(256), 0, (hipStream_t)stream, x,
-                       y, b, t_in, t_out, c);
+                       y, b, t_in, t_out, c, in_lens, out_lens);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
+}
+
+int astts_op_interp_linear(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
+                           astts_stream_t stream) {
+    return astts_op_interp_linear_ex(x, y, b, t_in, t_out, c, nullptr, nullptr, stream);
 }
 
 int astts_op_time_embedding(const float* t, float* y, int32_t b, int32_t dim, float scale, astts_stream_t stream) {

@@ -181,6 +181,9 @@ int astts_op_embedding(const float* table, const int32_t* ids, float* y, int64_t
                        int32_t vocab, float scale, astts_stream_t stream);
 int astts_op_interp_linear(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
                            astts_stream_t stream);
+/* ragged form: row b is resampled from in_lens[b] to out_lens[b] steps (rows padded to t_in / t_out); NULL = uniform. */
+int astts_op_interp_linear_ex(const float* x, float* y, int32_t b, int32_t t_in, int32_t t_out, int32_t c,
+                              const int32_t* in_lens, const int32_t* out_lens, astts_stream_t stream);
 int astts_op_time_embedding(const float* t, float* y, int32_t b, int32_t dim, float scale, astts_stream_t stream);
 /* espnet relative-position attention, head dim 64; tq == 1 selects the KV-cache decode kernel.
  * ld* = time-step strides, *_bs = batch strides (elements): batch-major and time-major layouts both work. */

@@ -280,3 +280,28 @@ def test_ragged_lm_batch_equals_one_at_a_time():
             pre_ref = osyn.lm_prefix(sd, cfg, texts[i][None], torch.tensor([shapes[i][0]]), spk[i:i + 1], prompts[i][None])
             _, lref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, i:i + 1], True, forced[i:i + 1])
             assert float((logits[i].cpu() - lref[0]).abs().max()) < 2e-2 * float(lref.abs().max()), (use_engine, i)
+
+
+def test_ragged_flow_batch_equals_one_at_a_time():
+    """Flow-matching decode of a ragged batch (different token counts, prompt lengths, output lengths) == each utterance
+    decoded alone by the oracle."""
+    from astts.synth.model import FlowDecoder
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    sd = W["flow"]
+    g = torch.Generator().manual_seed(31)
+    shapes = [(12, 20), (5, 33), (21, 8)]                 # (prompt tokens, generated tokens)
+    toks, pmels, zs = [], [], []
+    for tp, tg in shapes:
+        tmp, tm = cfg.mel_frames_for_tokens(tp), cfg.mel_frames_for_tokens(tg)
+        toks.append(torch.randint(0, cfg.speech_vocab, (tp + tg,), generator=g))
+        pmels.append(torch.randn(tmp, cfg.mel, generator=g))
+        zs.append(torch.randn(tmp + tm, cfg.mel, generator=g))
+    spk = torch.randn(len(shapes), cfg.spk_dim, generator=g)
+    fd = FlowDecoder(sd, cfg, torch.device(DEV))
+    mels = fd.decode_ragged(toks, pmels, spk, zs)
+    for i, (tp, tg) in enumerate(shapes):
+        ref = osyn.flow_decode(sd, cfg, toks[i][None], torch.tensor([tp + tg]), pmels[i][None], spk[i:i + 1], zs[i][None], zs[i].shape[0])[0]
+        assert mels[i].shape == ref.shape
+        assert float((mels[i].cpu() - ref).abs().max()) < 3e-2 * float(ref.abs().max()), i
