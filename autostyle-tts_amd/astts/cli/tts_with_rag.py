@@ -11,7 +11,9 @@ Reference behaviour kept (file:line in /root/reference/tts_with_rag.py):
   * result dir gets a ``_%m%d%H%M`` suffix (:165-168); files ``{cnt}_{style_id}_to_{speaker}_{i}.wav`` at 22 050 Hz (:196-197)
   * ``--is_exp`` is ``type=bool``: any non-empty string is True (:230); the exp branch needs arguments its parser
     never defines (dead code in the reference, :98-148) and is not reproduced.
-Additions (the reference hard-codes /apdcephfs_cq10 paths): --model_dir, --timbre_dir, --whisper_timbre_wav.
+Additions (the reference hard-codes /apdcephfs_cq10 paths): --model_dir, --timbre_dir, --whisper_timbre_wav, and
+--batch_size N: rows are independent, so N of them share one ragged GPU batch (left-padded LM prefixes, per-row EOS
+windows, masked flow matching); file names and contents layout are unchanged.
 """
 import argparse
 import json
@@ -68,16 +70,35 @@ def tts_for_infer(args, cosyvoice=None, now=None):
     result_dir = args.result_dir + "_" + (now or datetime.now()).strftime("%m%d%H%M")
     os.makedirs(result_dir, exist_ok=True)
     written = []
-    for cnt, item in enumerate(get_text_and_wav(args.corresponding_json, args.timbre_dir), start=1):
-        print(item)
+    items = get_text_and_wav(args.corresponding_json, args.timbre_dir)
+
+    def wavs_of(item):
         style_wav = load_wav(item["style_wav_path"], 16000)
         timbre_path = args.whisper_timbre_wav if item["is_whisper"] else item["timbre_wav_path"]
-        timbre_wav = load_wav(timbre_path, 16000)
-        for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
-                                                              timbre_wav, stream=False)):
-            path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
-            audio.write_wav(path, j["tts_speech"], 22050)
-            written.append(path)
+        return style_wav, load_wav(timbre_path, 16000)
+
+    bs = max(1, int(getattr(args, "batch_size", 1)))
+    if bs == 1:     # the reference's schedule: one utterance at a time (tts_with_rag.py:172-197)
+        for cnt, item in enumerate(items, start=1):
+            print(item)
+            style_wav, timbre_wav = wavs_of(item)
+            for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
+                                                                  timbre_wav, stream=False)):
+                path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
+                audio.write_wav(path, j["tts_speech"], 22050)
+                written.append(path)
+        return written
+    # batched schedule: same files, same names; rows are independent so they share ragged GPU batches
+    for c0 in range(0, len(items), bs):
+        chunk = items[c0:c0 + bs]
+        for item in chunk:
+            print(item)
+        reqs = [(it["tts_text"], it["style_wav_text"], *wavs_of(it)) for it in chunk]
+        for k, segs in enumerate(cosyvoice.inference_tts_with_st_batch(reqs, max_batch=bs)):
+            for i, j in enumerate(segs):
+                path = os.path.join(result_dir, output_name(c0 + k + 1, chunk[k]["style_wav_path"], chunk[k]["speaker"], i))
+                audio.write_wav(path, j["tts_speech"], 22050)
+                written.append(path)
     return written
 
 
@@ -89,6 +110,7 @@ def build_parser():
     parser.add_argument("--model_dir", default=REF_MODEL_DIR)
     parser.add_argument("--timbre_dir", default=REF_TIMBRE_DIR)
     parser.add_argument("--whisper_timbre_wav", default=os.path.join(REF_TIMBRE_DIR, WHISPER_TIMBRE_FILE))
+    parser.add_argument("--batch_size", type=int, default=1, help="rows synthesised per ragged GPU batch (1 = the reference's schedule)")
     return parser
 
 

@@ -100,6 +100,69 @@ class CosyVoice:
         wav = eng.hift.forward(mel, phase0.to(dev), noise.to(dev))
         return wav.cpu()
 
+    # ------------------------------------------------------------------ ragged batches (many segments in one pass)
+    def synthesize_batch(self, requests, max_batch: int = 32):
+        """``requests``: list of (text_ids [1, Tt] = prompt text + segment text, n_segment_text_tokens, lm_prompt,
+        flow_prompt).  All segments go through ONE left-padded LM batch (per-row EOS window, tokens truncated at
+        each row's EOS), one ragged flow-matching batch and the vocoder.  Returns one FloatTensor[1, n] per request,
+        each what the one-at-a-time path produces for that segment up to sampling draws."""
+        cfg, dev, eng = self.cfg, self.device, self.engine
+        out = [None] * len(requests)
+        for g0 in range(0, len(requests), max_batch):
+            grp = requests[g0:g0 + max_batch]
+            b = len(grp)
+            texts = [r[0].view(-1) for r in grp]
+            spk_lm = torch.cat([r[2].spk_embedding for r in grp], 0)
+            pre, ks = eng.lm.prefix_ragged(texts, spk_lm, [r[2].speech_tokens.view(-1) for r in grp])
+            min_len = [self.min_token_text_ratio * r[1] for r in grp]
+            cap = cfg.max_positions - pre.shape[0] - 100
+            max_len = [max(min(self.max_token_text_ratio * r[1], cap), m + 1) for r, m in zip(grp, min_len)]
+            n_steps = max(max_len)
+            u = torch.rand(n_steps, b, 2, generator=self._gen).to(dev)
+            eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
+            toks = eng.lm.decode(pre, n_steps, u, ignore_eos=eos_min, key_start=ks).cpu()       # one sync per group
+            gen_tokens = []
+            for i in range(b):
+                row = toks[i, :max_len[i]]
+                eos = (row >= cfg.speech_vocab).nonzero()
+                n = int(eos[0]) if eos.numel() else max_len[i]
+                gen_tokens.append(row[:max(n, 1)].to(torch.int32))
+            all_tok, pmels, zs, draws = [], [], [], []
+            for i, r in enumerate(grp):
+                fp = r[3]
+                n_gen = cfg.mel_frames_for_tokens(int(gen_tokens[i].numel()))
+                tmp = int(fp.mel.shape[1])
+                _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen)
+                all_tok.append(torch.cat([fp.speech_tokens.view(-1).to(torch.int32), gen_tokens[i]]))
+                pmels.append(fp.mel[0])
+                zs.append(z[0])
+                draws.append((phase0, noise))
+            spk_flow = torch.cat([r[3].spk_embedding for r in grp], 0)
+            mels = eng.flow.decode_ragged(all_tok, pmels, spk_flow, zs)
+            for i in range(b):      # vocoder per row: its conv stack has no length masks (3 % of the time)
+                wav = eng.hift.forward(mels[i][None], draws[i][0].to(dev), draws[i][1].to(dev))
+                out[g0 + i] = wav.cpu()
+        return out
+
+    def inference_tts_with_st_batch(self, items, max_batch: int = 32):
+        """Batched form of inference_tts_with_st for drivers that know all their work up front
+        (tts_with_rag.py:172 loops 64 rows one by one).  ``items``: list of (tts_text, style_text, style_wav_16k,
+        timbre_wav_16k) -> list (per item) of lists (per text segment) of {'tts_speech': FloatTensor[1, n]}."""
+        fe = self.frontend
+        reqs, owner = [], []
+        for k, (tts_text, style_text, style_wav, timbre_wav) in enumerate(items):
+            style, timbre = fe.prompt(style_wav), fe.prompt(timbre_wav)
+            style_ids = fe.text_ids(style_text)
+            for seg in text_normalize(tts_text, fe.tokenizer, split=True):
+                seg_ids = fe.text_ids(seg)
+                reqs.append((torch.cat([style_ids, seg_ids], dim=1), seg_ids.shape[1], style, timbre))
+                owner.append(k)
+        wavs = self.synthesize_batch(reqs, max_batch)
+        out = [[] for _ in items]
+        for k, w in zip(owner, wavs):
+            out[k].append({"tts_speech": w})
+        return out
+
     # ------------------------------------------------------------------ public generators
     def inference_tts_with_st(self, tts_text: str, style_text: str, style_wav_16k: torch.Tensor,
                               timbre_wav_16k: torch.Tensor, stream: bool = False) -> Iterator[Dict[str, torch.Tensor]]:

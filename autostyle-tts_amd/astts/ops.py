@@ -71,12 +71,12 @@ class LmLayer(ctypes.Structure):
 
 
 _SIGS.update({
-    "astts_op_ras_sample_ex": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p, c_void_p]),
+    "astts_op_ras_sample_ex": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "astts_lm_create": (c_int32, [ctypes.POINTER(LmConfig), ctypes.POINTER(LmGlobals), ctypes.POINTER(LmLayer), ctypes.POINTER(c_void_p)]),
     "astts_lm_destroy": (c_int32, [c_void_p]),
     "astts_lm_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
-                                  c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 })
 _lib.register_signatures(_SIGS)
 

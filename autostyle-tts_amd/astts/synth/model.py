@@ -230,7 +230,10 @@ class AcousticLM:
 
     @staticmethod
     def _eos_min(ignore_eos, n_steps: int) -> int:
-        """True -> EOS masked for the whole fixed-length decode; False -> never; int -> masked for that many steps."""
+        """True -> EOS masked for the whole fixed-length decode; False -> never; int -> masked for that many steps;
+        int32 device tensor [B] -> per-row step counts (handled by the engine; scalar fallback 0)."""
+        if torch.is_tensor(ignore_eos):
+            return 0
         if ignore_eos is True:
             return n_steps
         if ignore_eos is False:
@@ -261,9 +264,10 @@ class AcousticLM:
         u = uniforms.to(torch.float32).contiguous()
         _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, None if key_start is None else key_start.data_ptr(), t_max, b,
                                        s0, n_steps, u.data_ptr(),
-                                       None if forced is None else forced.data_ptr(), self._eos_min(ignore_eos, n_steps), toks.data_ptr(),
+                                       None if forced is None else forced.data_ptr(), self._eos_min(ignore_eos, n_steps),
+                                       ignore_eos.data_ptr() if torch.is_tensor(ignore_eos) else None, toks.data_ptr(),
                                        None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
-        self._keepalive = (cache, ws, logits0, forced, u, key_start)   # buffers referenced by kernels still in flight
+        self._keepalive = (cache, ws, logits0, forced, u, key_start, ignore_eos)   # buffers referenced by kernels still in flight
         return (toks, lg_out) if return_logits else toks
 
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
@@ -280,7 +284,8 @@ class AcousticLM:
             outs = []
             for b0 in range(0, b, 32):
                 sl = slice(b0, min(b0 + 32, b))
-                outs.append(self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(), ignore_eos,
+                outs.append(self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(),
+                                               ignore_eos[sl].contiguous() if torch.is_tensor(ignore_eos) else ignore_eos,
                                                None if forced_tokens is None else forced_tokens[sl], return_logits,
                                                None if key_start is None else key_start[sl].contiguous()))
             if return_logits:

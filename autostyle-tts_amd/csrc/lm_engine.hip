@@ -59,7 +59,7 @@ size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
 // (cfg.kv_f16) [t_max, B, 2d] time-major, rows [0, pos0) filled by the prefill.  tokens_out: int32 [B, n_steps].
 int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
                     int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
-                    int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
+                    const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream) {
     ASTTS_REQUIRE(h && logits0 && kv_cache && uniforms && tokens_out && workspace, ASTTS_ERR_INVALID,
                   "astts_lm_decode: null argument");
@@ -98,7 +98,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                                              cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
                                              hipMemcpyDeviceToDevice, st));
         int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
-                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, s < eos_min_steps ? 1 : 0, forced_tokens,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, s < eos_min_steps ? 1 : 0, eos_min_rows, forced_tokens,
                                         st);
         if (rc != ASTTS_OK) return rc;
         if (s + 1 == n_steps) break;

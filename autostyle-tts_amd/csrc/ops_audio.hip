@@ -168,6 +168,7 @@ struct SampleArgs {
     int* hist_w;          // when set: history[b, hist_len] = token (the engine's on-device token log)
     const int* forced;    // when set: token = forced[b, hist_len] (teacher forcing), same layout as history
     int clamp_out;        // out[b] = min(token, clamp_out) (embedding row for the next step); < 0: no clamp
+    const int* eos_min_rows;  // when set: EOS is masked for row b while hist_len < eos_min_rows[b] (ragged batches)
     int b, v, hist_len, hist_ld, top_k, win, eos, ignore_eos;
     float top_p, tau_r;
 };
@@ -181,10 +182,11 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     __shared__ int s_tok;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
+    const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
     float mx = -INFINITY;
     for (int i = tid; i < a.v; i += 256) {
         float x = lg[i];
-        if (a.ignore_eos && i == a.eos) x = -INFINITY;
+        if (mask_eos && i == a.eos) x = -INFINITY;
         prob[i] = x;
         mx = fmaxf(mx, x);
     }
@@ -342,7 +344,7 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(logits && uniforms && out_tokens && (history || hist_len == 0), ASTTS_ERR_INVALID, "astts_op_ras_sample: null pointer");
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
-    SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
+    SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, nullptr, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
@@ -351,11 +353,12 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
 /* Engine form: `history` is read (repetition window) and written at column hist_len; optional teacher forcing. */
 int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* uniforms, int32_t* out_tokens, int32_t b,
                            int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p, int32_t win_size,
-                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* forced, astts_stream_t stream) {
+                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* eos_min_rows, const int32_t* forced,
+                           astts_stream_t stream) {
     ASTTS_REQUIRE(logits && uniforms && out_tokens && history, ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: null pointer");
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0 && hist_len < hist_ld,
                   ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
-    SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, b, vocab, hist_len, hist_ld, top_k, win_size,
+    SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();

@@ -219,7 +219,8 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
                         int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream);
 int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* uniforms, int32_t* out_tokens, int32_t b,
                            int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p, int32_t win_size,
-                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* forced, astts_stream_t stream);
+                           float tau_r, int32_t eos_id, int32_t ignore_eos, const int32_t* eos_min_rows, const int32_t* forced,
+                           astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Acoustic-transformer decode engine: the autoregressive loop of TransformerLM.inference (one speech
@@ -260,11 +261,12 @@ size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
 /* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
  * rows < pos0 filled by the prefill; fp16 when cfg.kv_f16); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;
  * key_start int32 [b] or NULL (left-padded ragged prefixes); tokens_out int32 [b, n_steps]; logits_out [b, n_steps, vocab_out] or NULL.  The EOS logit is masked for the
- * first eos_min_steps steps (pass n_steps for fixed-length decoding); rows keep decoding after an EOS -- the caller
+ * first eos_min_steps steps (pass n_steps for fixed-length decoding), or per row for eos_min_rows[b] steps when that
+ * device array is given (ragged batches); rows keep decoding after an EOS -- the caller
  * truncates at the first EOS id (== speech_vocab). */
 int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
                     int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
-                    int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
+                    const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
 
 #ifdef __cplusplus

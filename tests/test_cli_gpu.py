@@ -91,6 +91,17 @@ def test_tts_with_rag_driver_end_to_end(cosy, tmp_path, golden_dir):
         assert f"{cnt}_{fid}_to_{r['speaker']}_0.wav" in names
     x, sr = audio.read_wav(written[0])
     assert sr == 22050 and x.shape[0] == 1 and np.isfinite(x).all() and np.abs(x).max() <= 0.99 + 1e-6
+    # batched schedule (--batch_size): same file names; every row's duration stays inside its own 2x..20x window
+    args_b = drv.build_parser().parse_args(["--corresponding_json", str(corr), "--result_dir", str(tmp_path / "resb"), "--batch_size", "3",
+                                            "--timbre_dir", str(timbre_dir), "--whisper_timbre_wav", str(timbre_dir / drv.WHISPER_TIMBRE_FILE)])
+    written_b = drv.tts_for_infer(args_b, cosyvoice=cosy, now=now)
+    assert [os.path.basename(w) for w in written_b] == names
+    for w, r in zip(written_b, picked):
+        xb, srb = audio.read_wav(w)
+        n_text = len(r["zh_text"].encode())
+        frames = xb.shape[1] // cosy.cfg.upsample_total
+        assert srb == 22050 and np.isfinite(xb).all() and np.abs(xb).max() <= 0.99 + 1e-6
+        assert cosy.cfg.mel_frames_for_tokens(2 * n_text) <= frames <= cosy.cfg.mel_frames_for_tokens(20 * n_text)
 
 
 def test_tts_with_style_and_timbre_driver(cosy, tmp_path):
