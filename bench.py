@@ -260,7 +260,14 @@ def main():
     else:
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
-    roof.update({"traffic": None, "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE; cannot be collected inside this run)
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        pass
+    roof.update({"traffic": traffic, "traffic_source": "profiles/r01_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
+                 "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
                  "launches_per_step": p["launches"],
                  "algorithmic_work_per_launch": p["work"] / max(p["launches"], 1),
                  "all_kinds_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})

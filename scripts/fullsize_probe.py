@@ -1,4 +1,4 @@
-import sys, time, math
+import sys, time, math, os
 sys.path[:0]=['.','autostyle-tts_amd']
 import torch
 from astts.synth.config import SynthConfig
@@ -9,7 +9,7 @@ t0=time.time(); W=make_all(cfg,0); print('weights', time.time()-t0, sum(v.numel(
 t0=time.time(); eng=SynthEngine(W,cfg,'cuda'); torch.cuda.synchronize(); print('engine', time.time()-t0)
 del W
 g=torch.Generator(device='cuda').manual_seed(0)
-B,Tt,Tp,Ts=8,32,150,250
+B,Tt,Tp,Ts=8,32,150,int(os.environ.get('PROBE_TS','250'))
 dev='cuda'
 text=torch.randint(0,cfg.text_vocab,(B,Tt),device=dev,generator=g); tlen=torch.full((B,),Tt,dtype=torch.int32,device=dev)
 spk_s=torch.randn(B,cfg.spk_dim,device=dev,generator=g); spk_t=torch.randn(B,cfg.spk_dim,device=dev,generator=g)
@@ -21,7 +21,7 @@ nh=cfg.nb_harmonics+1
 phase0=(torch.rand(B,nh,device=dev,generator=g)*2-1)*math.pi; phase0[:,0]=0
 noise=torch.randn(B,tm*cfg.upsample_total,nh,device=dev,generator=g)
 def ev(): e=torch.cuda.Event(enable_timing=True); e.record(); return e
-for it in range(3):
+for it in range(int(os.environ.get('PROBE_ITERS','3'))):
     e0=ev(); pre=eng.lm.prefix(text,tlen,spk_s,style_tok); e1=ev()
     toks=eng.lm.decode(pre,Ts,u,True); e2=ev()
     all_tok=torch.cat([timbre_tok.to(torch.int32),toks],1); tl=torch.full((B,),all_tok.shape[1],dtype=torch.int32,device=dev)
