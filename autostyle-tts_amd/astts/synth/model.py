@@ -421,9 +421,15 @@ class FlowDecoder:
         return h if mel_lens is None else ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=mel_lens)
 
     # ---- one estimator evaluation on a (2B) batch
-    def estimator(self, x, mu, spk, cond, t, lens) -> torch.Tensor:
+    def estimator(self, x, mu, spk, cond, t, lens, full: bool = False) -> torch.Tensor:
+        """``full``: every row uses all T frames (fixed-length batch) -- the length masks are identities and are
+        not launched."""
         cfg = self.cfg
         b, T, _ = x.shape
+        if full:
+            _mask = lambda h, L: h
+        else:
+            _mask = lambda h, L: ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
         temb = ops.time_embedding(t, cfg.est_in)
         temb = ops.linear(ops.linear(temb, self.t1, act="silu"), self.t2)
         temb_m = ops.elementwise(ops.EL_MISH, temb)                 # every ResnetBlock1D applies Mish first
@@ -431,12 +437,12 @@ class FlowDecoder:
         hiddens, lens_stack = [], [lens]
         for res, tfms, wds, last in self.down:
             L = lens_stack[-1]
-            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            h = _mask(h, L)
             h = res.forward(h, L, temb_m)
             for tb in tfms:
                 h = tb.forward(h, L)
             hiddens.append(h)
-            hm = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            hm = _mask(h, L)
             if last:
                 h = ops.conv1d(hm, wds, pad=1)
                 lens_stack.append(L)
@@ -444,31 +450,31 @@ class FlowDecoder:
                 h = ops.conv1d(hm, wds, stride=2, pad=1)
                 lens_stack.append(torch.div(L + 1, 2, rounding_mode="floor").to(torch.int32))
         L = lens_stack[-1]
-        h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+        h = _mask(h, L)
         for res, tfms in self.mid:
             h = res.forward(h, L, temb_m)
             for tb in tfms:
                 h = tb.forward(h, L)
-            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            h = _mask(h, L)
         lens_stack.pop()
         for res, tfms, wus, last in self.up:
             L = lens_stack.pop()
             skip = hiddens.pop()
             h = torch.cat([h[:, :skip.shape[1]], skip], dim=-1)
-            h = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            h = _mask(h, L)
             h = res.forward(h, L, temb_m)
             for tb in tfms:
                 h = tb.forward(h, L)
-            hm = ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
+            hm = _mask(h, L)
             if last:
                 h = ops.conv1d(hm, wus, pad=1)
             else:
                 h = ops.conv_transpose1d(hm, wus, padding=1)
-        h = ops.elementwise(ops.EL_MUL_ROWMASK, h[:, :T].contiguous(), lens=lens)
+        h = _mask(h[:, :T].contiguous(), lens)
         h = ops.conv1d(h, self.fin_c, pad=1)
         h = ops.groupnorm(h, *self.fin_g, cfg.est_groups, 1e-5, lens=lens, mish=True)
         out = ops.conv1d(h, self.fin_p)
-        return ops.elementwise(ops.EL_MUL_ROWMASK, out, lens=lens)
+        return _mask(out, lens)
 
     def decode(self, tokens, token_lens, prompt_mel, spk, z, mel_total: int) -> torch.Tensor:
         """tokens [B, Tp+Ts], prompt_mel [B, Tm_p, mel], spk [B, spk_dim], z [B, mel_total, mel]
@@ -489,7 +495,7 @@ class FlowDecoder:
         x = z.clone()
         for s in range(n):
             t2 = torch.full((2 * b,), float(ts[s]), dtype=torch.float32, device=self.device)
-            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2)
+            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2, full=True)
             x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s + 1] - ts[s]), s2=cfg.cfg_rate)
         return x[:, tmp:].contiguous()
 

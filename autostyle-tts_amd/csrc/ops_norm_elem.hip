@@ -199,6 +199,84 @@ __global__ __launch_bounds__(256) void groupnorm_apply(const float* __restrict__
     }
 }
 
+// single-kernel GroupNorm: one block per (batch row, group) keeps its [len x cpg] tile in LDS -- the input is read
+// once, statistics are the exact two-pass form, one launch instead of two.  Used when the tile fits (<= 150 KB).
+template <typename OutT>
+__global__ __launch_bounds__(512) void groupnorm_fused(const float* __restrict__ x, const int* __restrict__ lens,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ add_bc, OutT* __restrict__ y, int t,
+                                                       int c, int groups, float eps, int act_mish) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [len][cpg]
+    __shared__ float red[16];
+    __shared__ float s_mean, s_rstd;
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int len = lens ? min(lens[b], t) : t;
+    const int cpg = c / groups, cv = cpg >> 2;                      // float4 columns per row
+    const int nvec = len * cv;
+    const float* xb = x + (int64_t)b * t * c + g * cpg;
+    float s = 0.0f;
+    for (int i = tid; i < nvec; i += 512) {
+        const int r = i / cv, q = i - r * cv;
+        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * c + q * 4);
+        *reinterpret_cast<float4*>(tile + (size_t)i * 4) = v;
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = wave_sum_f32(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < 8; ++w) tot += red[w];
+        s_mean = nvec > 0 ? tot / (float)(nvec * 4) : 0.0f;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    float q2 = 0.0f;
+    for (int i = tid; i < nvec; i += 512) {
+        const float4 v = *reinterpret_cast<const float4*>(tile + (size_t)i * 4);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    q2 = wave_sum_f32(q2);
+    if (lane == 0) red[8 + wid] = q2;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < 8; ++w) tot += red[8 + w];
+        s_rstd = rsqrtf((nvec > 0 ? tot / (float)(nvec * 4) : 0.0f) + eps);
+    }
+    __syncthreads();
+    const float rstd = s_rstd;
+    OutT* yb = y + (int64_t)b * t * c + g * cpg;
+    const int total = t * cv;                                       // rows beyond len are written as zeros
+    for (int i = tid; i < total; i += 512) {
+        const int r = i / cv, q = i - r * cv;
+        const int ch = g * cpg + q * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < len) {
+            const float4 v = *reinterpret_cast<const float4*>(tile + (size_t)i * 4);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+            const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+            o = make_float4((v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
+                            (v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w);
+            if (act_mish) o = make_float4(mishf(o.x), mishf(o.y), mishf(o.z), mishf(o.w));
+            if (add_bc) {
+                const float4 ad = *reinterpret_cast<const float4*>(add_bc + (int64_t)b * c + ch);
+                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+            }
+        }
+        OutT* op = yb + (int64_t)r * c + q * 4;
+        if constexpr (sizeof(OutT) == 2) {
+            half4 h4;
+            h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+            *reinterpret_cast<half4*>(op) = h4;
+        } else {
+            *reinterpret_cast<float4*>(op) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ element-wise family
 enum ElemOp : int {
     EL_SNAKE = 0,      // y = x + sin^2(alpha_c x) / (alpha_c + 1e-9)          (p0 = alpha[c])
@@ -371,6 +449,24 @@ int astts_op_groupnorm_ex(const float* x, const int32_t* lens, const float* gamm
     ASTTS_REQUIRE(workspace_bytes >= astts_op_groupnorm_workspace_bytes(b, t, groups), ASTTS_ERR_WORKSPACE,
                   "astts_op_groupnorm: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    const int cpg = c / groups;
+    const size_t tile_bytes = (size_t)t * cpg * sizeof(float);
+    if ((cpg & 3) == 0 && (c & 3) == 0 && tile_bytes <= 150 * 1024 && ((uintptr_t)x & 15) == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&groupnorm_fused<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&groupnorm_fused<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set = true;
+        }
+        if (out_f16)
+            hipLaunchKernelGGL((groupnorm_fused<_Float16>), dim3(b, groups), dim3(512), tile_bytes, st, x, lens, gamma, beta, add_bc,
+                               (_Float16*)y, t, c, groups, eps, act_mish);
+        else
+            hipLaunchKernelGGL((groupnorm_fused<float>), dim3(b, groups), dim3(512), tile_bytes, st, x, lens, gamma, beta, add_bc,
+                               (float*)y, t, c, groups, eps, act_mish);
+        ASTTS_CHECK_LAUNCH();
+        return ASTTS_OK;
+    }
     hipLaunchKernelGGL(groupnorm_stats, dim3(b, nch), dim3(256), 2 * c * sizeof(float), st, x, lens, (float*)workspace,
                        t, c, groups, nch);
     ASTTS_CHECK_LAUNCH();
