@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     __shared__ int sh_i[256];
     __shared__ float s_bcast;
     __shared__ int s_tok;
+    __shared__ unsigned hist[2048];
+    __shared__ int s_sel_bin, s_sel_rem, s_cnt;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
     const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
@@ -211,23 +213,88 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     __syncthreads();
     for (int i = tid; i < a.v; i += 256) prob[i] *= inv;
     __syncthreads();
-    // top_k by (p desc, id asc): each wave keeps a sorted list over its 64-entry chunks, wave 0 merges
+    // top_k by (p desc, id asc).  Fast path: the exact kk-th largest probability by a 3-pass radix select on the float
+    // bits (LDS histograms), then the <= 64 entries >= it are gathered and sorted by one wave.  If ties push the
+    // gather past 64 entries (e.g. fewer than kk non-zero probabilities) the general chunked path below runs instead.
     const int kk = a.top_k < 64 ? a.top_k : 64;
     TopList<float> tl;
     tl.init();
-    bool seeded = false;
-    for (int base = wid * 64; base < a.v; base += 256) {
-        const int i = base + lane;
-        const bool valid = i < a.v;
-        const float pv = valid ? prob[i] : -INFINITY;
-        if (!seeded) {
-            tl.seed(pv, i, valid, lane);
-            seeded = true;
-        } else {
-            tl.offer(pv, i, valid, lane, kk);
+    {
+        unsigned prefix = 0u, known = 0u;
+        int remaining = kk < a.v ? kk : a.v;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+            const int bins = pass == 2 ? 1024 : 2048;
+            for (int i = tid; i < bins; i += 256) hist[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < a.v; i += 256) {
+                const unsigned key = __float_as_uint(prob[i]);
+                if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
+            }
+            __syncthreads();
+            if (wid == 0) {
+                const int per = bins >> 6;
+                unsigned local = 0u;
+                for (int j = 0; j < per; ++j) local += hist[lane * per + j];
+                unsigned incl = local;                       // sum over lanes >= lane
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned tv = __shfl_down(incl, off, 64);
+                    if (lane + off < 64) incl += tv;
+                }
+                const unsigned above = incl - local;
+                if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
+                    unsigned acc = above;
+                    for (int j = per - 1; j >= 0; --j) {
+                        const unsigned hcount = hist[lane * per + j];
+                        if (acc + hcount >= (unsigned)remaining) {
+                            s_sel_bin = lane * per + j;
+                            s_sel_rem = remaining - (int)acc;
+                            break;
+                        }
+                        acc += hcount;
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_sel_bin << shift;
+            known |= (unsigned)(bins - 1) << shift;
+            remaining = s_sel_rem;
+            __syncthreads();
         }
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int i = tid; i < a.v; i += 256) {
+            if (__float_as_uint(prob[i]) >= prefix) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < 64) {
+                    sh_s[pos] = prob[i];
+                    sh_i[pos] = i;
+                }
+            }
+        }
+        __syncthreads();
     }
-    merge_lists<float>(tl, sh_s, sh_i, kk);
+    const bool fast = s_cnt <= 64;
+    if (fast) {
+        if (wid == 0) tl.seed(sh_s[lane], sh_i[lane], lane < s_cnt, lane);   // sort fixes the order whatever the gather order was
+    } else {
+        bool seeded = false;
+        for (int base = wid * 64; base < a.v; base += 256) {
+            const int i = base + lane;
+            const bool valid = i < a.v;
+            const float pv = valid ? prob[i] : -INFINITY;
+            if (!seeded) {
+                tl.seed(pv, i, valid, lane);
+                seeded = true;
+            } else {
+                tl.offer(pv, i, valid, lane, kk);
+            }
+        }
+        __syncthreads();
+        merge_lists<float>(tl, sh_s, sh_i, kk);
+    }
     if (wid == 0) {
         // nucleus: sequential float accumulation in rank order (matches the oracle's definition bit for bit)
         float cum = 0.0f;

@@ -271,3 +271,15 @@ def test_ras_sample_matches_definition():
             out = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, 4096, ignore).cpu()
             ref = osyn.ras_sample(logits, hist[:, :hist_len], u, 25, 0.8, 10, 0.1, 4096, ignore)
             assert out.tolist() == ref.tolist()
+    # degenerate distributions: fewer non-zero probabilities than top_k (ties at p == 0 -> the general path), and
+    # exact ties among the top entries (order by id)
+    lg2 = torch.full((4, v), float("-inf"))
+    lg2[0, [5, 77, 4000]] = torch.tensor([1.0, 1.0, 0.5])
+    lg2[1, 123] = 0.0
+    lg2[2, :40] = 2.0                       # 40-way exact tie
+    lg2[3] = torch.randn(v, generator=g)
+    lg2[3, 1000:1030] = lg2[3].max() + 1.0  # 30-way tie at the top
+    for uu in (torch.tensor([[0.0, 0.0]] * 4), torch.tensor([[0.999, 0.5]] * 4), torch.rand(4, 2, generator=g)):
+        out = ops.ras_sample(lg2.to(DEV), hist[:4].contiguous().to(DEV), 0, uu.to(DEV), 25, 0.8, 10, 0.1, 4096, False).cpu()
+        ref = osyn.ras_sample(lg2, hist[:4, :0], uu, 25, 0.8, 10, 0.1, 4096, False)
+        assert out.tolist() == ref.tolist()
