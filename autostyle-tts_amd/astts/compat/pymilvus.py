@@ -29,7 +29,7 @@ from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
-from ..milvus_lite import MilvusLiteFile
+from ..milvus_lite import MilvusLiteFile, MilvusLiteWriter
 
 
 class MilvusException(Exception):
@@ -70,8 +70,12 @@ class _Collection:
 
 
 class MilvusClient:
-    def __init__(self, uri: str = "./milvus_demo.db", **_kwargs):
+    def __init__(self, uri: str = "./milvus_demo.db", persist: bool = True, **_kwargs):
+        """``uri`` is a Milvus-Lite file path, loaded if it exists.  As with pymilvus, create_collection / insert /
+        drop_collection are written through to that file (created on first write) unless ``persist=False``."""
         self.uri = uri
+        self._persist = bool(persist) and "://" not in uri
+        self._writer: Optional[MilvusLiteWriter] = None
         self._colls: Dict[str, _Collection] = {}
         if os.path.exists(uri):
             f = MilvusLiteFile(uri)
@@ -88,6 +92,11 @@ class MilvusClient:
                     self._colls[name] = c
             finally:
                 f.close()
+
+    def _file(self) -> Optional[MilvusLiteWriter]:
+        if self._persist and self._writer is None:
+            self._writer = MilvusLiteWriter(self.uri)
+        return self._writer
 
     # ------------------------------------------------------------------ collection management
     def has_collection(self, collection_name: str, **_kw) -> bool:
@@ -130,14 +139,23 @@ class MilvusClient:
             return
         self._colls[collection_name] = _Collection(collection_name, int(dimension), metric_type,
                                                    primary_field_name, vector_field_name)
+        if self._file():
+            self._file().create_collection(collection_name, int(dimension), metric_type, primary_field_name,
+                                           vector_field_name)
 
     def drop_collection(self, collection_name: str, **_kw) -> None:
-        self._colls.pop(collection_name, None)
+        if self._colls.pop(collection_name, None) is not None and self._file():
+            self._file().drop_collection(collection_name)
 
     def insert(self, collection_name: str, data, **_kw) -> Dict[str, Any]:
         c = self._get(collection_name)
         rows = [data] if isinstance(data, dict) else list(data)
         ids = []
+        first_new = len(c.pks)
+        for r in rows:      # validate the whole request before any row lands (a bad row rejects the request)
+            if np.asarray(r[c.vector_field]).shape != (c.dim,):
+                raise MilvusException(1100, f"the dim ({np.asarray(r[c.vector_field]).size}) of field data"
+                                            f"({c.vector_field}) is not equal to schema dim ({c.dim})")
         for r in rows:
             vec = np.asarray(r[c.vector_field], dtype=np.float32)
             if vec.shape != (c.dim,):
@@ -149,6 +167,9 @@ class MilvusClient:
             ids.append(pk)
             c.metas.append({k: v for k, v in r.items() if k not in (c.vector_field, c.pk_field)})
         c._bank = None
+        if self._file():
+            self._file().insert(c.name, ((c.pks[i], c.vectors[i], c.metas[i]) for i in range(first_new, len(c.pks))),
+                                c.pk_field, c.vector_field)
         return {"insert_count": len(rows), "ids": ids}
 
     # ------------------------------------------------------------------ search (the hot path)
@@ -197,3 +218,6 @@ class MilvusClient:
             if c._bank is not None:
                 c._bank.close()
                 c._bank = None
+        if self._writer is not None:
+            self._writer.close()
+            self._writer = None

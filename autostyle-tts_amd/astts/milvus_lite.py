@@ -1,4 +1,4 @@
-"""Reader for the Milvus-Lite (2.4-era) on-disk format: one SQLite file, one table per
+"""Reader and writer for the Milvus-Lite (2.4-era) on-disk format: one SQLite file, one table per
 collection, one protobuf ``InsertRequest``-style blob per row.
 
 This is the storage format behind ``MilvusClient("milvus_demo.db")`` in the reference
@@ -262,3 +262,154 @@ class MilvusLiteFile:
         d = info.dim
         v = np.stack(vecs).astype(np.float32) if vecs else np.zeros((0, d), np.float32)
         return v, np.asarray(pks, dtype=np.int64), metas
+
+
+# ----------------------------------------------------------------------------- writer
+# The inverse of the reader above, so that banks built through ``MilvusClient.create_collection`` / ``insert``
+# (the reference's bank builder, /root/reference/milvus/RAG.py:49-57,541-544) persist in the same file
+# format the shipped milvus_demo.db uses.  tests/test_oracle_knn.py re-encodes every schema / index / row
+# blob of that file and requires the bytes to be identical.
+def _enc_varint(v: int) -> bytes:
+    if v < 0:
+        v += 1 << 64
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _enc_key(fno: int, wt: int) -> bytes:
+    return _enc_varint((fno << 3) | wt)
+
+
+def _enc_bytes(fno: int, payload: bytes) -> bytes:
+    return _enc_key(fno, 2) + _enc_varint(len(payload)) + payload
+
+
+def _enc_uint(fno: int, v: int) -> bytes:
+    return _enc_key(fno, 0) + _enc_varint(v)
+
+
+def _enc_kv(fno: int, k: str, v: str) -> bytes:
+    return _enc_bytes(fno, _enc_bytes(1, k.encode("utf-8")) + _enc_bytes(2, v.encode("utf-8")))
+
+
+def encode_schema(name: str, dim: int, pk_field: str = "id", vector_field: str = "vector") -> bytes:
+    """CollectionSchema of a quick-setup collection (int64 pk, float vector, dynamic ``$meta``, plus the two
+    system fields RowID / Timestamp), proto3 encoding (zero-valued scalars are omitted)."""
+    def fschema(fid, fname, dtype, primary=False, desc="", params=(), dynamic=False):
+        b = b""
+        if fid:
+            b += _enc_uint(1, fid)
+        b += _enc_bytes(2, fname.encode("utf-8"))
+        if primary:
+            b += _enc_uint(3, 1)
+        if desc:
+            b += _enc_bytes(4, desc.encode("utf-8"))
+        b += _enc_uint(5, dtype)
+        for k, v in params:
+            b += _enc_kv(6, k, v)
+        if dynamic:
+            b += _enc_uint(12, 1)
+        return _enc_bytes(4, b)
+
+    out = _enc_bytes(1, name.encode("utf-8"))
+    out += fschema(100, pk_field, DT_INT64, primary=True)
+    out += fschema(101, vector_field, DT_FLOAT_VECTOR, params=(("dim", str(int(dim))),))
+    out += fschema(102, "$meta", DT_JSON, desc="dynamic schema", dynamic=True)
+    out += fschema(0, "RowID", DT_INT64, desc="row id")
+    out += fschema(1, "Timestamp", DT_INT64, desc="time stamp")
+    out += _enc_uint(5, 1)          # enable_dynamic_field
+    return out
+
+
+def encode_index(dim: int, metric_type: str = "COSINE", vector_field: str = "vector", index_id: int = 0,
+                 index_type: str = "AUTOINDEX", m: int = 18, ef_construction: int = 240) -> bytes:
+    out = _enc_uint(1, 101) + _enc_uint(2, index_id) + _enc_bytes(3, vector_field.encode("utf-8"))
+    out += _enc_kv(5, "M", str(m)) + _enc_kv(5, "efConstruction", str(ef_construction))
+    out += _enc_kv(5, "index_type", index_type) + _enc_kv(5, "metric_type", metric_type)
+    out += _enc_kv(5, "dim", str(int(dim)))
+    out += _enc_uint(6, 1)
+    return out
+
+
+def encode_row(pk: int, vector: np.ndarray, meta: Dict[str, Any], row_id: int, timestamp: int,
+               pk_field: str = "id", vector_field: str = "vector") -> bytes:
+    """One single-row InsertRequest-style blob (see the module docstring for the layout)."""
+    def longs(fid, fname, val):
+        sc = _enc_bytes(3, _enc_bytes(1, _enc_varint(int(val))))
+        b = _enc_uint(1, DT_INT64) + _enc_bytes(2, fname.encode("utf-8")) + _enc_bytes(3, sc)
+        if fid:
+            b += _enc_uint(5, fid)
+        return _enc_bytes(1, b)
+
+    vec = np.ascontiguousarray(vector, dtype="<f4").reshape(-1)
+    vf = _enc_uint(1, vec.size) + _enc_bytes(2, _enc_bytes(1, vec.tobytes()))
+    vb = _enc_uint(1, DT_FLOAT_VECTOR) + _enc_bytes(2, vector_field.encode("utf-8")) + _enc_bytes(4, vf) + _enc_uint(5, 101)
+    # ujson conventions, as the shipped file shows them: compact separators, raw UTF-8, "/" written "\\/"
+    payload = json.dumps(meta, separators=(",", ":"), ensure_ascii=False).replace("/", "\\/").encode("utf-8")
+    jb = _enc_uint(1, DT_JSON) + _enc_bytes(2, b"$meta") + _enc_bytes(3, _enc_bytes(9, _enc_bytes(1, payload))) + _enc_uint(5, 102)
+    out = longs(100, pk_field, pk) + _enc_bytes(1, vb) + _enc_bytes(1, jb)
+    out += longs(0, "RowID", row_id) + longs(1, "Timestamp", timestamp)
+    out += _enc_uint(2, 1)          # num_rows
+    return out
+
+
+class MilvusLiteWriter:
+    """Creates / appends to a Milvus-Lite SQLite file (same tables and blobs as the shipped milvus_demo.db)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._con = sqlite3.connect(path)
+        self._con.execute("CREATE TABLE IF NOT EXISTS collection_meta (id INTEGER PRIMARY KEY, collection_name "
+                          "VARCHAR(1024), meta_type VARCHAR(1024), blob_field BLOB, string_field VARCHAR(1024))")
+        self._con.commit()
+        self._tick = 0
+
+    def close(self) -> None:
+        self._con.commit()
+        self._con.close()
+
+    def _hybrid_ts(self) -> int:
+        import time
+        self._tick += 1
+        return (int(time.time() * 1000) << 18) + (self._tick & 0x3FFFF)       # TSO layout: physical ms << 18 | logical
+
+    def has_collection(self, name: str) -> bool:
+        cur = self._con.execute("select 1 from collection_meta where collection_name = ? limit 1", (name,))
+        return cur.fetchone() is not None
+
+    def create_collection(self, name: str, dim: int, metric_type: str = "COSINE", pk_field: str = "id",
+                          vector_field: str = "vector") -> None:
+        if '"' in name:
+            raise ValueError("collection name must not contain quotes")
+        if self.has_collection(name):
+            return
+        import random
+        ins = "insert into collection_meta (collection_name, meta_type, blob_field, string_field) values (?,?,?,?)"
+        self._con.execute(ins, (name, "schema", encode_schema(name, dim, pk_field, vector_field), pk_field))
+        self._con.execute(ins, (name, "index", encode_index(dim, metric_type.upper(), vector_field,
+                                                            random.getrandbits(62)), vector_field))
+        self._con.execute(f'CREATE TABLE IF NOT EXISTS "{name}" (id INTEGER PRIMARY KEY, milvus_id VARCHAR(1024), data BLOB)')
+        self._con.commit()
+
+    def drop_collection(self, name: str) -> None:
+        if '"' in name:
+            raise ValueError("collection name must not contain quotes")
+        self._con.execute("delete from collection_meta where collection_name = ?", (name,))
+        self._con.execute(f'DROP TABLE IF EXISTS "{name}"')
+        self._con.commit()
+
+    def insert(self, name: str, rows, pk_field: str = "id", vector_field: str = "vector") -> None:
+        """``rows``: iterable of (pk, vector, meta dict)."""
+        recs = []
+        for pk, vec, meta in rows:
+            ts = self._hybrid_ts()
+            recs.append((str(int(pk)), encode_row(pk, vec, meta, ts, ts, pk_field, vector_field)))
+        self._con.executemany(f'insert into "{name}" (milvus_id, data) values (?,?)', recs)
+        self._con.commit()

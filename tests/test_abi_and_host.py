@@ -1,6 +1,7 @@
 """CPU tests: the C-ABI library loads and exports every symbol include/astts.h declares (no compute
 calls without a GPU), and the host-side logic (Milvus-Lite reader, MilvusClient shim surface)."""
 import ctypes
+import json
 import os
 import re
 
@@ -69,10 +70,14 @@ def test_milvus_lite_reader_on_shipped_db(golden_dir, real_bank):
     f.close()
 
 
-def test_milvus_client_surface_cpu(golden_dir):
+def test_milvus_client_surface_cpu(golden_dir, tmp_path):
+    import shutil
+
     from astts.compat.pymilvus import MilvusClient, MilvusException
 
-    c = MilvusClient(os.path.join(golden_dir, "milvus_demo.db"))
+    db = str(tmp_path / "milvus_demo.db")        # writes go through to the file: work on a copy
+    shutil.copy(os.path.join(golden_dir, "milvus_demo.db"), db)
+    c = MilvusClient(db)
     assert c.has_collection(collection_name="embeddings_biographies_collection")
     assert not c.has_collection(collection_name="missing")
     info = c.get_collection_info("embeddings_biographies_collection")
@@ -95,6 +100,69 @@ def test_milvus_client_surface_cpu(golden_dir):
         c.insert(collection_name="t", data=[{"id": 2, "vector": [1.0] * 7}])
     c.drop_collection("t")
     assert not c.has_collection("t")
+    c.close()
+
+
+def test_milvus_lite_writer_reproduces_shipped_blobs(golden_dir):
+    """Re-encoding the schema, index and all 130 row blobs of the shipped DB gives the same BYTES."""
+    import sqlite3
+
+    from astts import milvus_lite as ml
+
+    con = sqlite3.connect(f"file:{os.path.join(golden_dir, 'milvus_demo.db')}?mode=ro&immutable=1", uri=True)
+    con.text_factory = bytes
+    n_meta = 0
+    for name, mt, blob, sf in con.execute("select collection_name, meta_type, blob_field, string_field from collection_meta"):
+        name = name.decode()
+        if mt == b"schema":
+            _, fields = ml._parse_schema(blob)
+            dim = int([f for f in fields if f.data_type == ml.DT_FLOAT_VECTOR][0].params["dim"])
+            assert ml.encode_schema(name, dim) == blob and sf == b"id"
+        else:
+            p = ml._parse_index(blob)
+            assert ml.encode_index(int(p["dim"]), p["metric_type"], index_id=ml._first(blob, 2)) == blob and sf == b"vector"
+        n_meta += 1
+    assert n_meta == 4
+    n = 0
+    for mid, blob in con.execute('select milvus_id, data from "embeddings_biographies_collection" order by id'):
+        r = ml.parse_row(blob)
+        assert ml.encode_row(r["id"], r["vector"], r["$meta"], r["RowID"], r["Timestamp"]) == blob
+        assert mid.decode() == str(r["id"])
+        n += 1
+    assert n == 130
+    con.close()
+
+
+def test_milvus_client_persists_bank_like_rag_py(tmp_path, real_bank, golden_dir):
+    """RAG.py:49-57,541-544: create_collection + insert into a fresh file; a new client sees the same bank."""
+    from astts.compat.pymilvus import MilvusClient
+    from astts.milvus_lite import MilvusLiteFile
+
+    meta = json.load(open(os.path.join(golden_dir, "style_bank_meta.json")))
+    db = str(tmp_path / "fresh.db")
+    c = MilvusClient(db)
+    assert not c.has_collection(collection_name="bank")
+    c.create_collection(collection_name="bank", dimension=6144)
+    c.create_collection(collection_name="scratch", dimension=4, metric_type="IP")
+    data = [{"id": i + 1, "vector": real_bank[i].astype(np.float32).tolist(), **meta["rows"][i]} for i in range(20)]
+    assert c.insert(collection_name="bank", data=data[:12])["insert_count"] == 12
+    assert c.insert(collection_name="bank", data=data[12:])["ids"] == list(range(13, 21))
+    c.insert(collection_name="scratch", data={"id": 7, "vector": [1, 2, 3, 4], "tag": "a/b \u00e9"})
+    c.drop_collection("scratch")
+    c.close()
+    f = MilvusLiteFile(db)
+    assert f.collections() == ["bank"]
+    info = f.info("bank")
+    assert info.dim == 6144 and info.metric_type == "COSINE" and info.pk_field == "id"
+    v, pks, metas = f.load("bank")
+    assert np.array_equal(v, real_bank[:20].astype(np.float32)) and list(pks) == list(range(1, 21))
+    assert metas == meta["rows"][:20]
+    f.close()
+    c2 = MilvusClient(db)
+    assert c2.get_collection_info("bank")["num_entities"] == 20
+    c2.insert(collection_name="bank", data=[{"id": 21, "vector": real_bank[20].astype(np.float32).tolist(), "text": "x"}])
+    c2.close()
+    assert MilvusClient(db, persist=False).get_collection_info("bank")["num_entities"] == 21
 
 
 def test_compat_install_aliases():
