@@ -539,11 +539,12 @@ static void launch_tile(const GemmArgs& a, hipStream_t st) {
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
     if (a.m <= 32 && plain && !a.x_f16 && !a.out_f16) {
-        const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
-        const int mt = a.m <= 16 ? 1 : 2;
-        const size_t lds = skinny_lds_bytes((int)a.m, a.cin_pad, mt);
-        if (lds > 160 * 1024) {
-            set_error("astts_op_gemm: m=%lld x cin_pad=%d does not fit the skinny kernel's LDS image", (long long)a.m, a.cin_pad);
+        // the block keeps its m rows of x as an fp16 image in LDS: rows are taken in chunks that fit 160 KB
+        // (only m > 16 with K > 2048 needs two passes, e.g. the FFN-out projection of a 32-row decode group)
+        int rows = (int)a.m;
+        while (rows > 1 && skinny_lds_bytes(rows, a.cin_pad, rows <= 16 ? 1 : 2) > 160 * 1024) rows = rows > 16 ? 16 : rows / 2;
+        if (skinny_lds_bytes(rows, a.cin_pad, 1) > 160 * 1024) {
+            set_error("astts_op_gemm: cin_pad=%d does not fit the skinny kernel's LDS image", a.cin_pad);
             return ASTTS_ERR_INVALID;
         }
         static bool attr_set = false;
@@ -556,15 +557,27 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
         const dim3 grid((a.n + 15) / 16);
         const bool small_k = a.cin_pad <= 1024;   // row of <= 4 float4 per lane: a quarter of the staging registers
-        if (mt == 1 && small_k)
-            hipLaunchKernelGGL((gemm_skinny16<1, 4>), grid, dim3(512), lds, st, a);
-        else if (mt == 1)
-            hipLaunchKernelGGL((gemm_skinny16<1, 16>), grid, dim3(512), lds, st, a);
-        else if (small_k)
-            hipLaunchKernelGGL((gemm_skinny16<2, 4>), grid, dim3(512), lds, st, a);
-        else
-            hipLaunchKernelGGL((gemm_skinny16<2, 16>), grid, dim3(512), lds, st, a);
-        if (prof) prof_end(ASTTS_PROF_GEMM_SKINNY, st);
+        for (int r0 = 0; r0 < (int)a.m; r0 += rows) {
+            GemmArgs c = a;
+            c.m = (int)a.m - r0 < rows ? (int)a.m - r0 : rows;
+            if (c.gather) c.gather += r0; else c.x += (int64_t)r0 * a.lda;
+            if (c.residual) c.residual += (int64_t)r0 * a.ldr;
+            if (c.row_scale) c.row_scale += r0;
+            c.out += (int64_t)r0 * a.ldc;
+            if (c.out2) c.out2 = a.out2_f16 ? (float*)((_Float16*)a.out2 + (int64_t)r0 * a.ldc2) : a.out2 + (int64_t)r0 * a.ldc2;
+            const int mt = c.m <= 16 ? 1 : 2;
+            const size_t lds = skinny_lds_bytes((int)c.m, a.cin_pad, mt);
+            const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
+            if (mt == 1 && small_k)
+                hipLaunchKernelGGL((gemm_skinny16<1, 4>), grid, dim3(512), lds, st, c);
+            else if (mt == 1)
+                hipLaunchKernelGGL((gemm_skinny16<1, 16>), grid, dim3(512), lds, st, c);
+            else if (small_k)
+                hipLaunchKernelGGL((gemm_skinny16<2, 4>), grid, dim3(512), lds, st, c);
+            else
+                hipLaunchKernelGGL((gemm_skinny16<2, 16>), grid, dim3(512), lds, st, c);
+            if (prof) prof_end(ASTTS_PROF_GEMM_SKINNY, st);
+        }
         ASTTS_CHECK_LAUNCH();
         return ASTTS_OK;
     }

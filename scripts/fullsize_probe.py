@@ -9,7 +9,7 @@ t0=time.time(); W=make_all(cfg,0); print('weights', time.time()-t0, sum(v.numel(
 t0=time.time(); eng=SynthEngine(W,cfg,'cuda'); torch.cuda.synchronize(); print('engine', time.time()-t0)
 del W
 g=torch.Generator(device='cuda').manual_seed(0)
-B,Tt,Tp,Ts=8,32,150,int(os.environ.get('PROBE_TS','250'))
+B,Tt,Tp,Ts=int(os.environ.get('PROBE_B','8')),32,150,int(os.environ.get('PROBE_TS','250'))
 dev='cuda'
 text=torch.randint(0,cfg.text_vocab,(B,Tt),device=dev,generator=g); tlen=torch.full((B,),Tt,dtype=torch.int32,device=dev)
 spk_s=torch.randn(B,cfg.spk_dim,device=dev,generator=g); spk_t=torch.randn(B,cfg.spk_dim,device=dev,generator=g)

@@ -23,7 +23,7 @@ def h16(t):  # what the kernel sees: fp16-rounded operand
 
 
 @pytest.mark.parametrize("m,k,n,act", [(1, 1024, 1024, "none"), (8, 1024, 4096, "relu"), (8, 4096, 1024, "none"),
-                                       (16, 320, 1024, "silu"), (32, 192, 80, "none"), (33, 512, 80, "none"),
+                                       (16, 320, 1024, "silu"), (32, 192, 80, "none"), (33, 512, 80, "none"), (32, 4096, 1024, "none"), (27, 2560, 512, "relu"),
                                        (300, 1024, 3072, "none"), (1000, 256, 1024, "gelu"), (5504, 1024, 256, "none"),
                                        (129, 80, 512, "mish"), (2000, 100, 18, "tanh"), (640, 512, 4097, "none")])
 def test_linear(m, k, n, act):
