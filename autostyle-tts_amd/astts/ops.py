@@ -78,6 +78,44 @@ _SIGS.update({
     "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                   c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 })
+
+
+class Weight(ctypes.Structure):
+    """astts_weight_t: packed fp16 weight image + fp32 bias."""
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("n", c_int32), ("cin", c_int32), ("cin_pad", c_int32), ("taps", c_int32)]
+
+
+class FlowResnet(ctypes.Structure):
+    _fields_ = [("c1", Weight), ("mlp", Weight), ("c2", Weight), ("res", Weight),
+                ("g1_w", c_void_p), ("g1_b", c_void_p), ("g2_w", c_void_p), ("g2_b", c_void_p)]
+
+
+class FlowTfm(ctypes.Structure):
+    _fields_ = [("n1_w", c_void_p), ("n1_b", c_void_p), ("n3_w", c_void_p), ("n3_b", c_void_p),
+                ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight)]
+
+
+class FlowBlock(ctypes.Structure):
+    _fields_ = [("res", FlowResnet), ("tfm", ctypes.POINTER(FlowTfm)), ("n_tfm", c_int32), ("resample", Weight),
+                ("resample_kind", c_int32)]
+
+
+class FlowConfig(ctypes.Structure):
+    _fields_ = [("mel", c_int32), ("channels", c_int32), ("heads", c_int32), ("groups", c_int32), ("time_in", c_int32),
+                ("time_dim", c_int32), ("n_down", c_int32), ("n_mid", c_int32), ("n_up", c_int32),
+                ("t1", Weight), ("t2", Weight), ("fin_c", Weight), ("fin_p", Weight), ("fin_g_w", c_void_p), ("fin_g_b", c_void_p)]
+
+
+FLOW_RESAMPLE_NONE, FLOW_RESAMPLE_CONV, FLOW_RESAMPLE_DOWN, FLOW_RESAMPLE_UP = range(4)
+
+_SIGS.update({
+    "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
+                                    ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
+    "astts_flow_destroy": (c_int32, [c_void_p]),
+    "astts_flow_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32]),
+    "astts_flow_solve": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                   ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float, c_void_p, c_size_t, c_void_p]),
+})
 _lib.register_signatures(_SIGS)
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "mish": 4, "elu": 5, "tanh": 6, "leaky": 7}

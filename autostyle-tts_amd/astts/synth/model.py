@@ -365,6 +365,7 @@ class FlowDecoder:
 
     def __init__(self, sd: SD, cfg: SynthConfig, device):
         self.cfg, self.device = cfg, device
+        self.use_engine = True          # False: operator-by-operator solve from Python (tests compare the two)
         self.tok_emb = _dev(sd["input_embedding.weight"], device)
         self.spk_aff = PackedWeight(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device)
         self.enc = RelPosEncoder(sd, "encoder", cfg.flow_heads, cfg.flow_layers, "swish", ("norm_mha", "norm_ff"), False,
@@ -476,6 +477,93 @@ class FlowDecoder:
         out = ops.conv1d(h, self.fin_p)
         return _mask(out, lens)
 
+    # ---- C++ solver engine (libastts astts_flow_*): the same operator sequence, issued without Python in the loop
+    def _engine(self):
+        if getattr(self, "_eng", None) is None:
+            import ctypes
+
+            from .. import _lib
+            cfg = self.cfg
+            keep = []           # ctypes arrays referenced by pointer from the block structs
+
+            def W(pw):
+                return ops.Weight(pw.data.data_ptr(), None if pw.bias is None else pw.bias.data_ptr(), pw.n, pw.cin, pw.cin_pad, pw.taps)
+
+            def R(r):
+                return ops.FlowResnet(W(r.c1), W(r.mlp), W(r.c2), W(r.res), r.g1[0].data_ptr(), r.g1[1].data_ptr(),
+                                      r.g2[0].data_ptr(), r.g2[1].data_ptr())
+
+            def TF(tfms):
+                arr = (ops.FlowTfm * len(tfms))()
+                for i, t in enumerate(tfms):
+                    arr[i] = ops.FlowTfm(t.n1[0].data_ptr(), t.n1[1].data_ptr(), t.n3[0].data_ptr(), t.n3[1].data_ptr(),
+                                         W(t.wqkv), W(t.wo), W(t.w1), W(t.w2))
+                keep.append(arr)
+                return arr
+
+            def blocks(items, kinds):
+                arr = (ops.FlowBlock * max(len(items), 1))()
+                for i, (it, kind) in enumerate(zip(items, kinds)):
+                    rs = W(it[2]) if kind != ops.FLOW_RESAMPLE_NONE else ops.Weight()
+                    arr[i] = ops.FlowBlock(R(it[0]), TF(it[1]), len(it[1]), rs, kind)
+                keep.append(arr)
+                return arr
+
+            down = blocks(self.down, [ops.FLOW_RESAMPLE_CONV if it[3] else ops.FLOW_RESAMPLE_DOWN for it in self.down])
+            mid = blocks(self.mid, [ops.FLOW_RESAMPLE_NONE] * len(self.mid))
+            up = blocks(self.up, [ops.FLOW_RESAMPLE_CONV if it[3] else ops.FLOW_RESAMPLE_UP for it in self.up])
+            c = ops.FlowConfig(cfg.mel, cfg.est_channels[0], cfg.est_heads, cfg.est_groups, cfg.est_in, cfg.est_time_dim,
+                               len(self.down), len(self.mid), len(self.up), W(self.t1), W(self.t2), W(self.fin_c), W(self.fin_p),
+                               self.fin_g[0].data_ptr(), self.fin_g[1].data_ptr())
+            h = ctypes.c_void_p()
+            _lib.check(_lib.load().astts_flow_create(ctypes.byref(c), down, mid, up, ctypes.byref(h)))
+            self._eng, self._eng_keep = h, keep
+        return self._eng
+
+    def _schedule(self):
+        n = self.cfg.cfm_steps
+        ts = 1.0 - torch.cos(torch.linspace(0, 1, n + 1) * 0.5 * math.pi)       # cosine schedule (fp32, as upstream)
+        return [float(ts[s]) for s in range(n)], [float(ts[s + 1] - ts[s]) for s in range(n)]
+
+    def solve(self, x: torch.Tensor, mu: torch.Tensor, spk_e: torch.Tensor, cond: torch.Tensor,
+              lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Euler solve with classifier-free guidance, in place on ``x`` [B, T, mel] (in: noise, out: mel).
+        ``lens`` None = fixed-length batch.  Runs in the C++ engine; ``solve_ops`` is the operator-by-operator form."""
+        import ctypes
+
+        from .. import _lib
+        lib = _lib.load()
+        eng = self._engine()
+        b, t, _ = x.shape
+        assert x.is_contiguous() and mu.is_contiguous() and cond.is_contiguous() and spk_e.is_contiguous()
+        assert x.dtype == mu.dtype == cond.dtype == spk_e.dtype == torch.float32
+        tv, dv = self._schedule()
+        n = len(tv)
+        need = int(lib.astts_flow_workspace_bytes(eng, b, t))
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.astts_flow_solve(eng, x.data_ptr(), mu.data_ptr(), spk_e.data_ptr(), cond.data_ptr(),
+                                        None if lens is None else lens.data_ptr(), b, t, n, (ctypes.c_float * n)(*tv),
+                                        (ctypes.c_float * n)(*dv), self.cfg.cfg_rate, ws.data_ptr(), need,
+                                        _lib.stream_ptr()))
+        return x
+
+    def solve_ops(self, x, mu, spk_e, cond, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same solve, one Python call per operator (the form the C++ engine is checked against, bit for bit)."""
+        b, t, _ = x.shape
+        full = lens is None
+        if full:
+            lens = torch.full((b,), t, dtype=torch.int32, device=x.device)
+        lens2 = torch.cat([lens, lens])
+        mu2 = torch.cat([mu, torch.zeros_like(mu)], 0)
+        spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
+        cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
+        tv, dv = self._schedule()
+        for s in range(len(tv)):
+            t2 = torch.full((2 * b,), tv[s], dtype=torch.float32, device=x.device)
+            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2, full=full)
+            x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=dv[s], s2=self.cfg.cfg_rate)
+        return x
+
     def decode(self, tokens, token_lens, prompt_mel, spk, z, mel_total: int) -> torch.Tensor:
         """tokens [B, Tp+Ts], prompt_mel [B, Tm_p, mel], spk [B, spk_dim], z [B, mel_total, mel]
         -> mel [B, mel_total - Tm_p, mel] (fixed-length batch)."""
@@ -486,19 +574,8 @@ class FlowDecoder:
         tmp = prompt_mel.shape[1]
         cond = torch.zeros((b, mel_total, cfg.mel), dtype=torch.float32, device=self.device)
         cond[:, :tmp] = prompt_mel
-        lens2 = torch.full((2 * b,), mel_total, dtype=torch.int32, device=self.device)
-        mu2 = torch.cat([mu, torch.zeros_like(mu)], 0)
-        spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
-        cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
-        n = cfg.cfm_steps
-        ts = 1.0 - torch.cos(torch.linspace(0, 1, n + 1) * 0.5 * math.pi)
-        x = z.clone()
-        for s in range(n):
-            t2 = torch.full((2 * b,), float(ts[s]), dtype=torch.float32, device=self.device)
-            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2, full=True)
-            x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s + 1] - ts[s]), s2=cfg.cfg_rate)
+        x = (self.solve if self.use_engine else self.solve_ops)(z.clone(), mu, spk_e, cond)
         return x[:, tmp:].contiguous()
-
 
     def decode_ragged(self, tokens: List[torch.Tensor], prompt_mels: List[torch.Tensor], spk: torch.Tensor,
                       zs: List[torch.Tensor]) -> List[torch.Tensor]:
@@ -522,16 +599,7 @@ class FlowDecoder:
         mel_lens = torch.tensor(mt, dtype=torch.int32, device=dev)
         mu = self.mu(tok, tok_lens, mmax, mel_lens)
         spk_e = ops.linear(torch.nn.functional.normalize(spk.to(dev), dim=1), self.spk_aff)
-        lens2 = torch.cat([mel_lens, mel_lens])
-        mu2 = torch.cat([mu, torch.zeros_like(mu)], 0)
-        spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
-        cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
-        n = cfg.cfm_steps
-        ts = 1.0 - torch.cos(torch.linspace(0, 1, n + 1) * 0.5 * math.pi)
-        for s_ in range(n):
-            t2 = torch.full((2 * b,), float(ts[s_]), dtype=torch.float32, device=dev)
-            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2)
-            x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=float(ts[s_ + 1] - ts[s_]), s2=cfg.cfg_rate)
+        x = (self.solve if self.use_engine else self.solve_ops)(x, mu, spk_e, cond, mel_lens)
         return [x[i, tmp[i]:mt[i]].contiguous() for i in range(b)]
 
 

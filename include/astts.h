@@ -269,6 +269,51 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
 
+/* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
+ * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
+ * CosyVoice.inference_tts_with_st, tts_with_rag.py:195).  n_steps Euler steps of the U-Net estimator with
+ * classifier-free guidance, ~520 kernel launches per step, issued from C++ with no host synchronisation
+ * (a Python host spends as long enqueueing them as the GPU spends running them). */
+typedef struct {            /* packed fp16 weight image (astts_op_pack_weight) + fp32 bias */
+    const void* w; const float* bias;
+    int32_t n, cin, cin_pad, taps;
+} astts_weight_t;
+typedef struct {            /* ResnetBlock1D: conv3 -> GN -> Mish (+ time proj) -> conv3 -> GN -> Mish, + 1x1 res conv */
+    astts_weight_t c1, mlp, c2, res;
+    const float *g1_w, *g1_b, *g2_w, *g2_b;
+} astts_flow_resnet_t;
+typedef struct {            /* BasicTransformerBlock: LN -> qkv -> attention -> out (+x) -> LN -> GELU FFN (+x) */
+    const float *n1_w, *n1_b, *n3_w, *n3_b;
+    astts_weight_t qkv, wo, w1, w2;
+} astts_flow_tfm_t;
+#define ASTTS_FLOW_RESAMPLE_NONE 0      /* mid block */
+#define ASTTS_FLOW_RESAMPLE_CONV 1      /* conv k=3 (last down / up block) */
+#define ASTTS_FLOW_RESAMPLE_DOWN 2      /* conv k=3 stride 2 */
+#define ASTTS_FLOW_RESAMPLE_UP 3        /* ConvTranspose1d k=4 stride 2 pad 1, phase-decomposed weight [2*C, 2, C] */
+typedef struct {
+    astts_flow_resnet_t res;
+    const astts_flow_tfm_t* tfm; int32_t n_tfm;
+    astts_weight_t resample; int32_t resample_kind;
+} astts_flow_block_t;
+typedef struct {
+    int32_t mel, channels, heads, groups, time_in, time_dim;
+    int32_t n_down, n_mid, n_up;
+    astts_weight_t t1, t2, fin_c, fin_p;
+    const float *fin_g_w, *fin_g_b;
+} astts_flow_config_t;
+typedef struct astts_flow astts_flow_t;
+int astts_flow_create(const astts_flow_config_t* cfg, const astts_flow_block_t* down, const astts_flow_block_t* mid,
+                      const astts_flow_block_t* up, astts_flow_t** out);
+int astts_flow_destroy(astts_flow_t* h);
+size_t astts_flow_workspace_bytes(const astts_flow_t* h, int32_t b, int32_t t);
+/* x [b, t, mel]: in = the noise z, out = the solved mel (rows beyond lens stay 0).  mu, cond [b, t, mel], spk [b, mel]
+ * (conditioning of the guided half; the unguided half of the internal 2b batch sees zeros).  lens int32 [b] or NULL
+ * (every row uses all t frames: the length masks are then not launched).  t_host / dt_host: HOST arrays [n_steps] of the
+ * step times and step sizes. */
+int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* spk, const float* cond, const int32_t* lens,
+                     int32_t b, int32_t t, int32_t n_steps, const float* t_host, const float* dt_host, float cfg_rate,
+                     void* workspace, size_t workspace_bytes, astts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
