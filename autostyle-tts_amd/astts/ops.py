@@ -109,6 +109,8 @@ class FlowConfig(ctypes.Structure):
 FLOW_RESAMPLE_NONE, FLOW_RESAMPLE_CONV, FLOW_RESAMPLE_DOWN, FLOW_RESAMPLE_UP = range(4)
 
 _SIGS.update({
+    "astts_stream_create_cu_mask": (c_int32, [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]),
+    "astts_stream_destroy": (c_int32, [c_void_p]),
     "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
                                     ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
     "astts_flow_destroy": (c_int32, [c_void_p]),
@@ -422,3 +424,15 @@ def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: floa
                                         hist_len, history.stride(0) if history is not None else 0, top_k, top_p,
                                         win_size, tau_r, eos_id, 1 if ignore_eos else 0, _st()))
     return out
+
+
+def cu_masked_stream(cu_bits, n_cus: int = 256) -> "torch.cuda.ExternalStream":
+    """A HIP stream whose kernels only run on the CUs listed in ``cu_bits`` (iterable of CU indices < n_cus),
+    wrapped for ``torch.cuda.stream()``.  The stream lives as long as the process."""
+    words = [0] * ((n_cus + 31) // 32)
+    for i in cu_bits:
+        words[i // 32] |= 1 << (i % 32)
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    out = c_void_p()
+    _lib.check(_L().astts_stream_create_cu_mask(arr, len(words), ctypes.byref(out)))
+    return torch.cuda.ExternalStream(out.value)

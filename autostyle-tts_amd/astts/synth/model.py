@@ -732,7 +732,7 @@ class PipelinedSynth:
     (None while the pipeline fills); ``drain`` enqueues what is left and returns those results.  Nothing here
     synchronises the host with the GPU."""
 
-    def __init__(self, engine: "SynthEngine", lm_depth: int = 2):
+    def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
@@ -740,8 +740,8 @@ class PipelinedSynth:
         self.depth = max(1, int(lm_depth))
         dev = engine.device
         with torch.cuda.device(dev):
-            self.s_lm = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.depth)]
-            self.s_render = torch.cuda.Stream(device=dev)
+            self.s_lm = [torch.cuda.Stream(device=dev, priority=lm_priority) for _ in range(self.depth)]
+            self.s_render = torch.cuda.Stream(device=dev, priority=render_priority)
         self._pool = ThreadPoolExecutor(max_workers=self.depth)
         self._fifo = deque()
         self._i = 0

@@ -292,7 +292,8 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
 
         for (size_t i = 0; i < h->down.size(); ++i) {
             const astts_flow::Block& blk = h->down[i];
-            RUN(k.resnet(blk.res, block_in, L, tt, cur));
+            RUN(k.resnet(blk.res, block_in, L, tt, other));     // never in place: every GEMM block reads whole input rows
+            { float* sw = cur; cur = other; other = sw; }
             for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
             RUN(k.mask(cur, L, tt, C));
             skips[n_skips] = cur;

@@ -611,6 +611,8 @@ using namespace astts;
 static int check_gemm_args(const char* who, const float* x, const void* w, float* out, int64_t m, int32_t n, int32_t cin,
                            int32_t cin_pad, int32_t taps, int32_t t_in, int32_t t_out, int32_t stride, int32_t dil, int32_t act) {
     ASTTS_REQUIRE(x && w && out, ASTTS_ERR_INVALID, "%s: null pointer", who);
+    ASTTS_REQUIRE((const void*)x != (const void*)out, ASTTS_ERR_INVALID,
+                  "%s: out aliases x (every workgroup reads whole input rows: an in-place GEMM races)", who);
     ASTTS_REQUIRE(m >= 1 && n >= 1 && cin >= 1 && taps >= 1, ASTTS_ERR_INVALID, "%s: bad shape m=%lld n=%d cin=%d taps=%d",
                   who, (long long)m, n, cin, taps);
     ASTTS_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0, ASTTS_ERR_INVALID,

@@ -6,6 +6,8 @@
 // Snake / leaky-relu of HiFT, F.interpolate of the length regulator, the CFM Euler update, ...).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace astts {
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

@@ -97,4 +97,18 @@ int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* wor
     return ASTTS_OK;
 }
 
+int astts_stream_create_cu_mask(const uint32_t* cu_mask, int32_t n_words, astts_stream_t* out) {
+    ASTTS_REQUIRE(cu_mask && n_words >= 1 && out, ASTTS_ERR_INVALID, "astts_stream_create_cu_mask: bad argument");
+    hipStream_t st = nullptr;
+    ASTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+    *out = (astts_stream_t)st;
+    return ASTTS_OK;
+}
+
+int astts_stream_destroy(astts_stream_t stream) {
+    ASTTS_REQUIRE(stream, ASTTS_ERR_INVALID, "astts_stream_destroy: null stream");
+    ASTTS_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ASTTS_OK;
+}
+
 }  // extern "C"

@@ -35,18 +35,26 @@ def render_loop(n, stream, host=None):
         if host is not None: host.append((time.perf_counter() - t0) / n)
         stream.synchronize()
 
-def run(n_lm, n_render, K=4):
-    streams = [torch.cuda.Stream(priority=-1) for _ in range(n_lm)] + [torch.cuda.Stream() for _ in range(n_render)]
+from astts import ops
+
+def run(tag, lm_streams, render_streams, K=4):
     host = []
-    th = [threading.Thread(target=lm_loop, args=(K, streams[i])) for i in range(n_lm)]
-    th += [threading.Thread(target=render_loop, args=(K, streams[n_lm + i], host)) for i in range(n_render)]
+    th = [threading.Thread(target=lm_loop, args=(K, st)) for st in lm_streams]
+    th += [threading.Thread(target=render_loop, args=(K, st, host)) for st in render_streams]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t in th: t.start()
     for t in th: t.join()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f'{n_lm} LM chains x {K} + {n_render} render loops x {K}: wall {dt*1e3:.0f} ms -> {dt*1e3/K:.1f} ms per round'
-          + (f'; render host enqueue {host[0]*1e3:.1f} ms each' if host else ''))
+    print(f'{tag}: {len(lm_streams)} LM x {K} + {len(render_streams)} render x {K}: {dt*1e3/K:.1f} ms per round', flush=True)
 
-run(1, 0); run(1, 0); run(2, 0); run(3, 0); run(4, 0)
-run(0, 1); run(0, 1); run(0, 2)
-run(1, 1); run(2, 1); run(3, 1); run(2, 2)
+def plain(n, prio=0): return [torch.cuda.Stream(priority=prio) for _ in range(n)]
+import os
+n_lm = int(os.environ.get('N_LM', '3')); prio = int(os.environ.get('LM_PRIO', '-1'))
+order = os.environ.get('ORDER', 'lm_first')
+if order == 'lm_first':
+    lm = plain(n_lm, prio); rd = plain(1)
+else:
+    rd = plain(1); lm = plain(n_lm, prio)
+run(f'n_lm={n_lm} prio={prio} {order}', lm, [])
+run(f'n_lm={n_lm} prio={prio} {order}', lm, rd)
+run(f'n_lm={n_lm} prio={prio} {order}', lm, rd, K=8)

@@ -26,34 +26,20 @@ for _ in range(K): out = eng.tts(*args)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 audio = B * ref[2].shape[1] / cfg.sample_rate
 print(f'sequential: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
-for depth in (1, 2, 3):
-    pipe = PipelinedSynth(eng, lm_depth=depth)
-    for _ in range(3): pipe.submit(*args)
-    pipe.drain(); torch.cuda.synchronize()
-    K = 12
-    t0 = time.perf_counter()
+def cmp(tag, o):
+    print(tag, 'toks', bool(torch.equal(o[0], ref[0])), 'mel', float((o[1] - ref[1]).abs().max()), 'wav', float((o[2] - ref[2]).abs().max()), flush=True)
+for i in range(3):
+    cmp(f'sequential rerun {i}', eng.tts(*args))
+eng.flow.use_engine = False
+cmp('sequential, flow ops path', eng.tts(*args))
+eng.flow.use_engine = True
+for use in (True,):
+    eng.flow.use_engine = use
+    pipe = PipelinedSynth(eng, lm_depth=2)
     outs = []
-    for _ in range(K):
+    for _ in range(6):
         r = pipe.submit(*args)
         if r is not None: outs.append(r)
     outs += pipe.drain()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    ok = all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in outs)
-    print(f'pipelined depth {depth}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}  results {len(outs)} identical {ok}')
-K = 6
-gp = GraphPipelinedSynth(eng, args)
-for _ in range(3): gp.submit()
-gp.drain(); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(K): gp.submit()
-gp.drain()
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f'graph pipelined: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
-print('identical to sequential:', all(bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0 for o in gp.out))
-# host-side enqueue cost of each stage (no sync inside)
-torch.cuda.synchronize()
-for _ in range(2):
-    t0 = time.perf_counter(); toks = eng.tts_tokens(text, tlen, spk_s, style_tok, Ts, u); t1 = time.perf_counter()
-    mel, wav = eng.tts_render(toks, timbre_tok, timbre_mel, spk_t, z, phase0, noise); t2 = time.perf_counter()
-    torch.cuda.synchronize(); t3 = time.perf_counter()
-    print(f'host enqueue: tokens {1e3 * (t1 - t0):.1f} ms, render {1e3 * (t2 - t1):.1f} ms, then wait {1e3 * (t3 - t2):.1f} ms')
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs): cmp(f'pipelined engine={use} batch {i}', o)

@@ -283,3 +283,14 @@ def test_ras_sample_matches_definition():
         out = ops.ras_sample(lg2.to(DEV), hist[:4].contiguous().to(DEV), 0, uu.to(DEV), 25, 0.8, 10, 0.1, 4096, False).cpu()
         ref = osyn.ras_sample(lg2, hist[:4, :0], uu, 25, 0.8, 10, 0.1, 4096, False)
         assert out.tolist() == ref.tolist()
+
+
+def test_gemm_rejects_in_place_output():
+    """Every GEMM workgroup reads whole input rows while others store their output tiles: out == x would race
+    (it only shows under contention), so the ABI refuses it."""
+    from astts import _lib, ops
+
+    x = torch.randn(256, 256, device=DEV)
+    pw = ops.PackedWeight(torch.randn(256, 256) / 16, None)
+    with pytest.raises(_lib.AsttsError, match="aliases"):
+        ops.gemm(x, pw, out=x)

@@ -332,3 +332,20 @@ def test_flow_solver_engine_is_bit_identical_to_operator_path(b, t, ragged):
     assert torch.equal(out, ref)
     if ragged:
         assert float((out * ~keep).abs().max()) == 0.0
+
+
+def test_no_kernel_writes_outside_its_output_tensor():
+    """scripts/oob_check.py guard-bands every tensor the operator wrappers allocate (4 KiB of pattern on both sides)
+    and runs LM prefix + decode, the flow decoder (both host paths, fixed and ragged) and the vocoder."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TINY="1", TS="12")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "oob_check.py")], capture_output=True, text=True,
+                       env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "guarded tensors" in ln]
+    assert len(lines) >= 7 and "OOB WRITE" not in r.stdout, r.stdout[-3000:]
+    assert all(ln.rstrip().endswith(" 0 with out-of-bounds writes") for ln in lines), r.stdout[-3000:]
+    assert "engine == ops: True" in r.stdout
