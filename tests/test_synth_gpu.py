@@ -8,6 +8,7 @@ Stated tolerances (fp16 weights + fp16 MFMA operands with fp32 accumulation vs a
   vocoder waveform    max |d| <= 2e-2 (full scale 0.99), SNR >= 30 dB
 """
 import math
+import os
 
 import pytest
 import torch
