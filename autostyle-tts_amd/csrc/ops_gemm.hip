@@ -23,6 +23,8 @@
 //                half of a fused QKV projection lands directly in the KV cache).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace astts {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3, ACT_MISH = 4, ACT_ELU = 5, ACT_TANH = 6, ACT_LEAKY = 7 };
@@ -66,6 +68,162 @@ struct GemmArgs {
     int x_f16, out_f16;      // activations in / out as fp16 (ld* are then in halfs)
     int out2_f16;            // skinny kernel: the split destination (KV cache) is fp16
 };
+
+#ifdef EPI_DBG_LOCAL
+#define EPI_ROW(m) ((m) - m0)   // microbenchmark only: every block stores to the first rows (no HBM traffic)
+#else
+#define EPI_ROW(m) (m)
+#endif
+// Fast epilogue for interior blocks (all BM x BN outputs valid, 16-byte aligned rows, no row scale): the activation,
+// the output type and the residual are compile-time, so the per-vector work is one ds_read_b128, the arithmetic and one
+// store, with every residual load of the slab issued before the first store.  The general epilogue below spends
+// ~1.5k VALU instructions per wave on predicates and the activation switch -- 2-3x the whole main loop of the small-K
+// projections of the flow decoder (measured: 13 of 22 us on 5504 x 1536 x 256).
+template <int TM, int TN, int ACT, bool OUT16, bool RES>
+__device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, float16v (&acc)[TM][TN], float* slab_base, int64_t m0, int n0,
+                                                   int wm, int wn, int wid, int lane) {
+    constexpr int EPI_W = 32 * TN + 4;
+    constexpr int VPR = 8 * TN;            // float4 vectors per slab row
+    constexpr int RPI = 64 / VPR;          // rows per wave-instruction
+    constexpr int NIT = 32 / RPI;
+    const int r = lane & 31, h = lane >> 5;
+    const int vq = lane % VPR, vr = lane / VPR;
+    float* slab = slab_base + wid * 32 * EPI_W;
+    const int nb = n0 + wn * TN * 32 + vq * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + nb);
+    const float alpha = a.alpha, slope = a.slope;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int64_t mrow = m0 + (wm * TM + i) * 32 + vr;
+        float4 res[NIT];
+        if constexpr (RES) {
+            const float* rp = a.residual + mrow * a.ldr + nb;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) res[it] = *reinterpret_cast<const float4*>(rp + (int64_t)it * RPI * a.ldr);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[i][j][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const float4* srow = reinterpret_cast<const float4*>(slab + vr * EPI_W + vq * 4);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float4 v = srow[it * RPI * (EPI_W / 4)];
+            v.x = apply_act(v.x + bias4.x, ACT, slope) * alpha;
+            v.y = apply_act(v.y + bias4.y, ACT, slope) * alpha;
+            v.z = apply_act(v.z + bias4.z, ACT, slope) * alpha;
+            v.w = apply_act(v.w + bias4.w, ACT, slope) * alpha;
+            if constexpr (RES) {
+                v.x += res[it].x; v.y += res[it].y; v.z += res[it].z; v.w += res[it].w;
+            }
+            const int64_t o = EPI_ROW(mrow + it * RPI) * a.ldc + nb;
+            if constexpr (OUT16) {
+                half4 h4;
+                h4[0] = (_Float16)v.x; h4[1] = (_Float16)v.y; h4[2] = (_Float16)v.z; h4[3] = (_Float16)v.w;
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(a.out) + o) = h4;
+            } else {
+                *reinterpret_cast<float4*>(a.out + o) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Epilogue shared by the tile kernels.  The accumulator layout (column on the lane, 16 rows in registers) would cost
+// 16*TM*TN four-byte stores per lane; instead each wave transposes one 32 x (32*TN) slab at a time through its own
+// LDS region (slab_base: 4 x 32 x EPI_W floats holding no live data) and stores whole 16-byte vectors
+// (store-issue bound otherwise: 2-3x the main loop).
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, float16v (&acc)[TM][TN], float* slab_base, int64_t m0, int n0,
+                                              int wm, int wn, int wid, int lane, bool interior) {
+    constexpr int EPI_W = 32 * TN + 4;
+    if (interior && !a.row_scale && (a.ldc & 3) == 0 && ((uintptr_t)a.out & 15) == 0 && ((uintptr_t)a.bias & 15) == 0 &&
+        (!a.residual || ((a.ldr & 3) == 0 && ((uintptr_t)a.residual & 15) == 0))) {
+        if (a.act == ACT_NONE && !a.residual && a.out_f16) return tile_epilogue_fast<TM, TN, ACT_NONE, true, false>(a, acc, slab_base, m0, n0, wm, wn, wid, lane);
+        if (a.act == ACT_NONE && !a.residual && !a.out_f16) return tile_epilogue_fast<TM, TN, ACT_NONE, false, false>(a, acc, slab_base, m0, n0, wm, wn, wid, lane);
+        if (a.act == ACT_NONE && a.residual && !a.out_f16) return tile_epilogue_fast<TM, TN, ACT_NONE, false, true>(a, acc, slab_base, m0, n0, wm, wn, wid, lane);
+        if (a.act == ACT_GELU && !a.residual && a.out_f16) return tile_epilogue_fast<TM, TN, ACT_GELU, true, false>(a, acc, slab_base, m0, n0, wm, wn, wid, lane);
+    }
+    const int r = lane & 31, h = lane >> 5;
+    float* slab = slab_base + wid * 32 * EPI_W;
+    constexpr int VPR = 8 * TN;            // float4 vectors per slab row
+    constexpr int RPI = 64 / VPR;          // rows per wave-instruction
+    const int vq = lane % VPR, vr = lane / VPR;
+    _Float16* out16 = reinterpret_cast<_Float16*>(a.out);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[i][j][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int nb = n0 + wn * TN * 32 + vq * 4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) {
+            bias4.x = nb < a.n ? a.bias[nb] : 0.f;
+            bias4.y = nb + 1 < a.n ? a.bias[nb + 1] : 0.f;
+            bias4.z = nb + 2 < a.n ? a.bias[nb + 2] : 0.f;
+            bias4.w = nb + 3 < a.n ? a.bias[nb + 3] : 0.f;
+        }
+#pragma unroll 1  // rolled on purpose: the activation switch must appear once, not 32 times (I-cache: 148 KB -> ~12 KB)
+        for (int rr = 0; rr < 32; rr += RPI) {
+            const int row = rr + vr;
+            const int64_t m = m0 + (wm * TM + i) * 32 + row;
+            float4 v = *reinterpret_cast<const float4*>(&slab[row * EPI_W + vq * 4]);
+            if (m < a.m && nb < a.n) {
+                v.x = apply_act(v.x + bias4.x, a.act, a.slope) * a.alpha;
+                v.y = apply_act(v.y + bias4.y, a.act, a.slope) * a.alpha;
+                v.z = apply_act(v.z + bias4.z, a.act, a.slope) * a.alpha;
+                v.w = apply_act(v.w + bias4.w, a.act, a.slope) * a.alpha;
+                if (a.row_scale) {
+                    const float rs = a.row_scale[m];
+                    v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+                }
+                const bool full = nb + 4 <= a.n;
+                if (a.residual) {
+                    const float* rp = a.residual + m * a.ldr + nb;
+                    if (full && (a.ldr & 3) == 0) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    } else {
+                        v.x += rp[0];
+                        if (nb + 1 < a.n) v.y += rp[1];
+                        if (nb + 2 < a.n) v.z += rp[2];
+                        if (nb + 3 < a.n) v.w += rp[3];
+                    }
+                }
+                if (a.out_f16) {
+                    _Float16* op = out16 + EPI_ROW(m) * a.ldc + nb;
+                    if (full && (a.ldc & 3) == 0) {
+                        half4 h4;
+                        h4[0] = (_Float16)v.x; h4[1] = (_Float16)v.y; h4[2] = (_Float16)v.z; h4[3] = (_Float16)v.w;
+                        *reinterpret_cast<half4*>(op) = h4;
+                    } else {
+                        op[0] = (_Float16)v.x;
+                        if (nb + 1 < a.n) op[1] = (_Float16)v.y;
+                        if (nb + 2 < a.n) op[2] = (_Float16)v.z;
+                        if (nb + 3 < a.n) op[3] = (_Float16)v.w;
+                    }
+                } else {
+                    float* op = a.out + EPI_ROW(m) * a.ldc + nb;
+                    if (full && (a.ldc & 3) == 0) {
+                        *reinterpret_cast<float4*>(op) = v;
+                    } else {
+                        op[0] = v.x;
+                        if (nb + 1 < a.n) op[1] = v.y;
+                        if (nb + 2 < a.n) op[2] = v.z;
+                        if (nb + 3 < a.n) op[3] = v.w;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // A16: the activations arrive as fp16 (written by a producer whose only consumers are MFMA operands:
 // LayerNorm / GroupNorm / attention / a previous GEMM), so staging is a plain 16-byte copy.
@@ -205,84 +363,140 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue.  The accumulator layout (column on the lane, 16 rows in registers) would cost 16*TM*TN
-    // four-byte stores per lane; instead each wave transposes one 32 x (32*TN) slab at a time through its own
-    // LDS region and stores whole 16-byte vectors (store-issue bound otherwise: 2-3x the main loop).
-    float* slab = reinterpret_cast<float*>(smem) + wid * 32 * EPI_W;
-    constexpr int VPR = 8 * TN;            // float4 vectors per slab row
-    constexpr int RPI = 64 / VPR;          // rows per wave-instruction
-    const int vq = lane % VPR, vr = lane / VPR;
-    _Float16* out16 = reinterpret_cast<_Float16*>(a.out);
+    tile_epilogue<TM, TN>(a, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_ring: plain GEMM (taps == 1) on fp16 activations, operands staged global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers) into a STAGES-deep ring of 64-wide K tiles.
+//
+// Why: the flow decoder's projections are small-K GEMMs (K = 256..1024 on 5.5k..11k rows) at 1-2 blocks
+// per CU; with register staging one K tile (16 KB) is in flight per block and the kernels sit at ~20 us
+// where their bytes and flops need ~5.  Here (STAGES - 1) tiles are in flight per block across the
+// barriers: a counted s_waitcnt vmcnt(N) + a raw s_barrier per K tile (a __syncthreads() would drain
+// the DMA queue), nothing else touches vmcnt inside the loop.
+//
+// LDS image of one stage: (BM + BN) rows of 128 B (64 halfs of K).  One wave-instruction writes 1 KiB =
+// 8 consecutive rows, lane l -> row l / 8, 16-byte slot l % 8: the destination is lane-linear by
+// construction, so the bank swizzle goes on the SOURCE address: slot s of row r holds K chunk
+// s ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (16 lanes = 16 rows of one chunk then
+// cover all 64 banks once).
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+template <int TM, int TN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (it cannot parse the LDS-DMA builtin)
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE_BYTES = ROWS * 128;
+    constexpr int IPW = ROWS / 32;                 // DMA instructions per wave and stage (8 rows each, 4 waves)
+    constexpr int EPI_W = 32 * TN + 4;
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    static_assert(4 * 32 * EPI_W * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the ring");
+    static_assert((STAGES - 2) * IPW <= 63, "vmcnt immediate");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int ktot = a.cin_pad;
+    const int nkt = ktot / 64;
+    const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
+
+    // per-lane source of this wave's IPW row groups at K tile 0
+    const _Float16* src[IPW];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < IPW; ++i) {
+        const int row = 8 * (wid + 4 * i) + (lane >> 3);
+        const int slot = lane & 7;
+        if (row < BM) {
+            const int c = slot ^ ((row >> 1) & 7);
+            int64_t m = m0 + row;
+            if (m >= a.m) m = a.m - 1;             // rows past the end: any valid address, never stored
+            src[i] = x16 + m * a.lda + c * 8;
+        } else {
+            const int lr = row - BM;
+            const int c = slot ^ ((lr >> 1) & 7);
+            src[i] = a.w + (int64_t)(n0 + lr) * ktot + c * 8;
+        }
+    }
+    auto issue = [&](int kt) {
+        unsigned char* dst = ring + (kt % STAGES) * STAGE_BYTES + wid * 1024;
+#ifndef RING_SKIP_LOAD
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+            __builtin_amdgcn_global_load_lds(src[i] + kt * 64, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+#endif
+    };
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[i][j][e];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int nb = n0 + wn * TN * 32 + vq * 4;
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) {
-            bias4.x = nb < a.n ? a.bias[nb] : 0.f;
-            bias4.y = nb + 1 < a.n ? a.bias[nb + 1] : 0.f;
-            bias4.z = nb + 2 < a.n ? a.bias[nb + 2] : 0.f;
-            bias4.w = nb + 3 < a.n ? a.bias[nb + 3] : 0.f;
-        }
-#pragma unroll 1  // rolled on purpose: the activation switch must appear once, not 32 times (I-cache: 148 KB -> ~12 KB)
-        for (int rr = 0; rr < 32; rr += RPI) {
-            const int row = rr + vr;
-            const int64_t m = m0 + (wm * TM + i) * 32 + row;
-            float4 v = *reinterpret_cast<const float4*>(&slab[row * EPI_W + vq * 4]);
-            if (m < a.m && nb < a.n) {
-                v.x = apply_act(v.x + bias4.x, a.act, a.slope) * a.alpha;
-                v.y = apply_act(v.y + bias4.y, a.act, a.slope) * a.alpha;
-                v.z = apply_act(v.z + bias4.z, a.act, a.slope) * a.alpha;
-                v.w = apply_act(v.w + bias4.w, a.act, a.slope) * a.alpha;
-                if (a.row_scale) {
-                    const float rs = a.row_scale[m];
-                    v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
-                }
-                const bool full = nb + 4 <= a.n;
-                if (a.residual) {
-                    const float* rp = a.residual + m * a.ldr + nb;
-                    if (full && (a.ldr & 3) == 0) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
-                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                    } else {
-                        v.x += rp[0];
-                        if (nb + 1 < a.n) v.y += rp[1];
-                        if (nb + 2 < a.n) v.z += rp[2];
-                        if (nb + 3 < a.n) v.w += rp[3];
-                    }
-                }
-                if (a.out_f16) {
-                    _Float16* op = out16 + m * a.ldc + nb;
-                    if (full && (a.ldc & 3) == 0) {
-                        half4 h4;
-                        h4[0] = (_Float16)v.x; h4[1] = (_Float16)v.y; h4[2] = (_Float16)v.z; h4[3] = (_Float16)v.w;
-                        *reinterpret_cast<half4*>(op) = h4;
-                    } else {
-                        op[0] = (_Float16)v.x;
-                        if (nb + 1 < a.n) op[1] = (_Float16)v.y;
-                        if (nb + 2 < a.n) op[2] = (_Float16)v.z;
-                        if (nb + 3 < a.n) op[3] = (_Float16)v.w;
-                    }
-                } else {
-                    float* op = a.out + m * a.ldc + nb;
-                    if (full && (a.ldc & 3) == 0) {
-                        *reinterpret_cast<float4*>(op) = v;
-                    } else {
-                        op[0] = v.x;
-                        if (nb + 1 < a.n) op[1] = v.y;
-                        if (nb + 2 < a.n) op[2] = v.z;
-                        if (nb + 3 < a.n) op[3] = v.w;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // fragment byte offsets inside a stage (row part; the K chunk is XORed in per k-step)
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int lr = (wm * TM + i) * 32 + r;
+        a_off[i] = lr * 128;
+        a_sw[i] = (lr >> 1) & 7;
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int lr = (wn * TN + j) * 32 + r;
+        b_off[j] = BM * 128 + lr * 128;
+        b_sw[j] = (lr >> 1) & 7;
+    }
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) issue(s);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        // K tile kt has landed once at most the later tiles' DMAs are outstanding
+        const int rem = nkt - kt;
+        if (rem >= STAGES - 1) wait_vmcnt<(STAGES - 2) * IPW>();
+        else if (rem == 2) wait_vmcnt<IPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // every wave's part of tile kt is in LDS; tile kt-1 is no longer read
+        if (kt + STAGES - 1 < nkt) issue(kt + STAGES - 1);
+        const unsigned char* st = ring + (kt % STAGES) * STAGE_BYTES;
+#ifndef RING_SKIP_MFMA
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 fa[TM], fb[TN];
+            const int c = ks * 2 + h;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+#endif
+    }
+    __syncthreads();                               // all fragment reads done (and no DMA outstanding): the ring becomes slab space
+#ifndef RING_SKIP_EPI
+    tile_epilogue<TM, TN>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+#else
+    if (acc[0][0][0] == 123.0f) a.out[0] = 1.0f;
+#endif
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -585,6 +799,36 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
                   "astts_op_gemm_fused: gather / LayerNorm / split output need m <= 32 and a plain (non-conv) GEMM");
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)a.m * a.n * a.cin * a.taps);
     auto blocks = [&](int bm, int bn) { return cdiv(a.m, bm) * cdiv(a.n, bn); };
+    // fp16 activations, plain GEMM, whole 64-wide K tiles: the LDS-DMA ring kernel
+    static const int ring_env = [] { const char* e = getenv("ASTTS_GEMM_RING"); return e ? atoi(e) : -1; }();
+    if (plain && a.x_f16 && a.cin == a.cin_pad && (a.lda & 7) == 0 && ((uintptr_t)a.x & 15) == 0 && a.m >= 64 && a.n > 32 &&
+        ring_env != 0) {
+        static bool ring_attr = false;
+        if (!ring_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<1, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            ring_attr = true;
+        }
+        // tile choice from scripts/micro/ring_bench.hip on the flow decoder's shapes (5.5k / 11k rows): 128x64 (two blocks
+        // per CU) for wide outputs; for n <= 256 the 128x128 tile once there are >= 160 of them, 64x64 for short K
+        int mode;
+        if (a.n >= 512) mode = blocks(128, 64) >= 160 ? 2 : 3;
+        else if (blocks(128, 128) >= 160) mode = 1;
+        else if (a.cin_pad <= 512 || blocks(128, 64) < 160) mode = 3;
+        else mode = 2;
+        if (ring_env > 0) mode = ring_env;
+        if (mode == 1 && a.n > 64) {
+            hipLaunchKernelGGL((gemm_ring<2, 2, 4>), dim3((unsigned)cdiv(a.m, 128), (unsigned)cdiv(a.n, 128)), dim3(256), 4 * 256 * 128, st, a);
+        } else if (mode == 2 || mode == 1) {
+            hipLaunchKernelGGL((gemm_ring<2, 1, 3>), dim3((unsigned)cdiv(a.m, 128), (unsigned)cdiv(a.n, 64)), dim3(256), 3 * 192 * 128, st, a);
+        } else {
+            hipLaunchKernelGGL((gemm_ring<1, 1, 4>), dim3((unsigned)cdiv(a.m, 64), (unsigned)cdiv(a.n, 64)), dim3(256), 4 * 128 * 128, st, a);
+        }
+        if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
+        ASTTS_CHECK_LAUNCH();
+        return ASTTS_OK;
+    }
     const int64_t want = 384;  // >= 1.5 blocks per CU
     // K tile: cin_pad is a multiple of 64, so 64 never straddles a tap; 128 needs cin_pad % 128 == 0
     const bool k128 = (a.cin_pad % 128) == 0 && a.taps * a.cin_pad >= 256;
