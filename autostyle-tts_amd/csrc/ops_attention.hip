@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     const int64_t qb = (int64_t)b * a.t * a.ldq + head * DH;
     const int64_t kb = (int64_t)b * a.t * a.ldk + head * DH;
 
-    // Q fragments (B operand of S^T = K Q^T): lane (c, hh) holds Q[q0+c][16s + 8hh + j] * scale
+    // Q fragments (B operand of S^T = K Q^T): lane (c, hh) holds Q[q0+c][16s + 8hh + j] * scale * log2(e)
     half8 qf[4];
     {
         const int qi = min(q0 + c, a.t - 1);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
             float x[8];
             load8<IN16>(a.q, qb + (int64_t)qi * a.ldq + 16 * s + 8 * hh, x);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qf[s][i] = (_Float16)(x[i] * a.scale);
+            for (int i = 0; i < 8; ++i) qf[s][i] = (_Float16)(x[i] * (a.scale * 1.44269504088896341f));
         }
     }
     float16v ot[2];
@@ -360,31 +360,38 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
                 const half8 kf = *reinterpret_cast<const half8*>(&ks[(sub * 32 + c) * FA_KS + 16 * s + 8 * hh]);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
             }
-            float mloc = -INFINITY;
+            // scores arrive in the log2 domain (Q carries scale * log2 e).  Keys past len only exist in the last
+            // sub-tile (block-uniform test); exp2(-inf - m) is 0 and every query sees at least one valid key here.
+            if (jb + 32 > len) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = jb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                st[e] = key < len ? st[e] : -INFINITY;
-                mloc = fmaxf(mloc, st[e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int key = jb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    st[e] = key < len ? st[e] : -INFINITY;
+                }
             }
+            float mloc = st[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, st[e]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
-            float lloc = 0.0f;
+            // rescale only when some query's running maximum moves (wave-uniform branch): after the first
+            // few tiles it rarely does, and the 32 accumulator multiplies are a third of the softmax VALU work
+            if (__builtin_amdgcn_ballot_w64(mloc > m_run) != 0) {
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first tile: exp2(-inf) = 0
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    ot[0][e] *= alpha;
+                    ot[1][e] *= alpha;
+                }
+            }
             half8 pf[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = (st[e] == -INFINITY) ? 0.0f : __expf(st[e] - m_new);
-                lloc += p;
+                const float p = __builtin_amdgcn_exp2f(st[e] - m_run);
+                l_run += p;                          // per lane half; the two halves are added once at the end
                 pf[e >> 3][e & 7] = (_Float16)p;
-            }
-            lloc += __shfl_xor(lloc, 32, 64);
-            l_run = l_run * alpha + lloc;
-            m_run = m_new;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                ot[0][e] *= alpha;
-                ot[1][e] *= alpha;
             }
             // O^T[d][query] += V^T[d][key] P^T[key][query]; key order inside a k-step follows the
             // accumulator layout: element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
         }
     }
     // O^T (dims in registers, query on the lane) -> LDS transpose -> coalesced rows
+    l_run += __shfl_xor(l_run, 32, 64);
     const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
