@@ -34,9 +34,10 @@ __device__ __forceinline__ float apply_act(float x, int act, float slope) {
         case ACT_RELU: return fmaxf(x, 0.0f);
         case ACT_SILU: return x / (1.0f + __expf(-x));
         case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        case ACT_MISH: {
-            const float sp = (x > 20.0f) ? x : log1pf(__expf(x));
-            return x * tanhf(sp);
+        case ACT_MISH: {   // n / (n + 2) form of tanh(softplus(x)), as ops_norm_elem.hip
+            const float e = __expf(fminf(x, 20.0f));
+            const float n = e * (e + 2.0f);
+            return x > 20.0f ? x : x * n * __frcp_rn(n + 2.0f);
         }
         case ACT_ELU: return x > 0.0f ? x : (__expf(x) - 1.0f);
         case ACT_TANH: return tanhf(x);

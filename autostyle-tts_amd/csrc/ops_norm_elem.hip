@@ -16,9 +16,12 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
+// mish(x) = x tanh(softplus(x)); with e = exp(x): tanh(log(1 + e)) = ((1 + e)^2 - 1) / ((1 + e)^2 + 1) = n / (n + 2),
+// n = e (e + 2) -- one exp and one reciprocal instead of exp + log1p + tanh (the GroupNorm kernels were ALU-bound on it)
 __device__ __forceinline__ float mishf(float x) {
-    const float sp = (x > 20.0f) ? x : log1pf(__expf(x));
-    return x * tanhf(sp);
+    const float e = __expf(fminf(x, 20.0f));
+    const float n = e * (e + 2.0f);
+    return x > 20.0f ? x : x * n * __frcp_rn(n + 2.0f);
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
