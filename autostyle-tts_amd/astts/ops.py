@@ -109,8 +109,7 @@ class FlowConfig(ctypes.Structure):
 FLOW_RESAMPLE_NONE, FLOW_RESAMPLE_CONV, FLOW_RESAMPLE_DOWN, FLOW_RESAMPLE_UP = range(4)
 
 _SIGS.update({
-    "astts_stream_create_cu_mask": (c_int32, [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]),
-    "astts_stream_destroy": (c_int32, [c_void_p]),
+    "astts_stream_spin": (c_int32, [c_int32, c_void_p]),
     "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
                                     ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
     "astts_flow_destroy": (c_int32, [c_void_p]),
@@ -426,13 +425,39 @@ def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: floa
     return out
 
 
-def cu_masked_stream(cu_bits, n_cus: int = 256) -> "torch.cuda.ExternalStream":
-    """A HIP stream whose kernels only run on the CUs listed in ``cu_bits`` (iterable of CU indices < n_cus),
-    wrapped for ``torch.cuda.stream()``.  The stream lives as long as the process."""
-    words = [0] * ((n_cus + 31) // 32)
-    for i in cu_bits:
-        words[i // 32] |= 1 << (i % 32)
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    out = c_void_p()
-    _lib.check(_L().astts_stream_create_cu_mask(arr, len(words), ctypes.byref(out)))
-    return torch.cuda.ExternalStream(out.value)
+def concurrent_streams(n: int, priority: int = 0, candidates: int = 16, device=None, protect: int = 2) -> list:
+    """``n`` torch streams that pairwise overlap on the device.  HIP maps its streams onto a handful of hardware queues
+    (by creation order, opaque to the caller) and two streams on one queue serialise; each candidate is probed against the
+    streams already chosen with a 300 us busy-wait kernel on both (concurrent: ~300 us wall, shared queue: ~600)."""
+    import time
+
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    lib = _L()
+
+    def overlaps(a, b) -> bool:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _lib.check(lib.astts_stream_spin(300, int(a.cuda_stream)))
+        _lib.check(lib.astts_stream_spin(300, int(b.cuda_stream)))
+        a.synchronize()
+        b.synchronize()
+        return (time.perf_counter() - t0) < 480e-6
+
+    chosen = []
+    with torch.cuda.device(dev):
+        pool = [torch.cuda.Stream(device=dev, priority=priority) for _ in range(max(candidates, n))]
+        _lib.check(lib.astts_stream_spin(10, int(pool[0].cuda_stream)))      # module load / first-launch cost out of the way
+        for s in pool:
+            if all(overlaps(s, c) for c in chosen):
+                chosen.append(s)
+                if len(chosen) == n:
+                    return chosen
+    # fewer independent queues than asked for: fill up with streams that still overlap with the first `protect` chosen
+    # ones (so only the later streams double up on a queue), then with anything
+    for strict in (True, False):
+        for s in pool:
+            if len(chosen) == n:
+                return chosen
+            if s not in chosen and (not strict or all(overlaps(s, c) for c in chosen[:protect])):
+                chosen.append(s)
+    return chosen

@@ -732,7 +732,7 @@ class PipelinedSynth:
     (None while the pipeline fills); ``drain`` enqueues what is left and returns those results.  Nothing here
     synchronises the host with the GPU."""
 
-    def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0):
+    def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
@@ -740,11 +740,62 @@ class PipelinedSynth:
         self.depth = max(1, int(lm_depth))
         dev = engine.device
         with torch.cuda.device(dev):
-            self.s_lm = [torch.cuda.Stream(device=dev, priority=lm_priority) for _ in range(self.depth)]
-            self.s_render = torch.cuda.Stream(device=dev, priority=render_priority)
+            self.front_stream = None
+            if streams is not None:
+                self.s_lm, self.s_render = list(streams[:self.depth]), streams[self.depth]
+            elif lm_priority == render_priority:
+                # streams probed to sit on distinct hardware queues (ops.concurrent_streams), in order of importance: the
+                # render stream, a front stream for the caller's own per-batch work (retrieval, input preparation: run
+                # `submit` under `torch.cuda.stream(pipe.front_stream)` -- an event recorded on a stream that shares its queue
+                # with a busy chain waits behind that chain), then the decode chains
+                st = ops.concurrent_streams(self.depth + 2, priority=lm_priority, device=dev)
+                self.s_render, self.front_stream, self.s_lm = st[0], st[1], st[2:]
+            else:
+                self.s_lm = [torch.cuda.Stream(device=dev, priority=lm_priority) for _ in range(self.depth)]
+                self.s_render = torch.cuda.Stream(device=dev, priority=render_priority)
+            if self.front_stream is None:
+                self.front_stream = torch.cuda.Stream(device=dev)
         self._pool = ThreadPoolExecutor(max_workers=self.depth)
         self._fifo = deque()
         self._i = 0
+
+    @classmethod
+    def autotune(cls, engine: "SynthEngine", sample_args, depths=(3, 2), trials: int = 3, steps: int = 4, verbose: bool = False,
+                 front=None):
+        """Build the pipeline by measurement.  How well the chains overlap depends on which hardware queues HIP hands the
+        streams (it multiplexes streams onto a few queues in an order the caller cannot see; a chain that shares a queue
+        with another busy stream, or with the stream the caller enqueues its own work on, stalls the hand-over events).
+        Each trial draws a fresh set of mutually concurrent streams (ops.concurrent_streams), runs ``steps`` batches of
+        ``sample_args`` (the positional arguments of ``submit``) and the fastest configuration is kept.  ``front``: the
+        caller's own per-batch GPU work (a callable, e.g. the style retrieval), enqueued on ``pipe.front_stream`` before
+        each submit exactly as the caller will."""
+        import time
+
+        best, best_dt = None, float("inf")
+        for depth in depths:
+            for _ in range(trials):
+                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0)
+                with torch.cuda.stream(pipe.front_stream):
+                    for _ in range(depth + 1):
+                        if front is not None:
+                            front()
+                        pipe.submit(*sample_args)
+                    pipe.drain()
+                    torch.cuda.synchronize(engine.device)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        if front is not None:
+                            front()
+                        pipe.submit(*sample_args)
+                    pipe.drain()
+                    torch.cuda.synchronize(engine.device)
+                dt = (time.perf_counter() - t0) / steps
+                if verbose:
+                    print(f"PipelinedSynth.autotune: depth {depth}: {dt * 1e3:.1f} ms/batch", flush=True)
+                if dt < best_dt:
+                    best, best_dt = pipe, dt
+        best.tuned_ms_per_batch = best_dt * 1e3
+        return best
 
     def _render(self, item):
         fut, rargs = item

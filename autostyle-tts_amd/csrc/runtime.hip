@@ -50,6 +50,14 @@ void prof_end(int kind, hipStream_t st) {
 
 using namespace astts;
 
+namespace astts {
+// wall_clock64 ticks at 100 MHz on gfx9
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace astts
+
 extern "C" {
 
 int astts_abi_version(void) { return ASTTS_ABI_VERSION; }
@@ -97,17 +105,10 @@ int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* wor
     return ASTTS_OK;
 }
 
-int astts_stream_create_cu_mask(const uint32_t* cu_mask, int32_t n_words, astts_stream_t* out) {
-    ASTTS_REQUIRE(cu_mask && n_words >= 1 && out, ASTTS_ERR_INVALID, "astts_stream_create_cu_mask: bad argument");
-    hipStream_t st = nullptr;
-    ASTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
-    *out = (astts_stream_t)st;
-    return ASTTS_OK;
-}
-
-int astts_stream_destroy(astts_stream_t stream) {
-    ASTTS_REQUIRE(stream, ASTTS_ERR_INVALID, "astts_stream_destroy: null stream");
-    ASTTS_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+int astts_stream_spin(int32_t microseconds, astts_stream_t stream) {
+    ASTTS_REQUIRE(microseconds >= 0 && microseconds <= 100000, ASTTS_ERR_INVALID, "astts_stream_spin: microseconds=%d", microseconds);
+    hipLaunchKernelGGL(astts::spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
 

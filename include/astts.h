@@ -55,11 +55,10 @@ const char* astts_last_error_string(void);
 #define ASTTS_PROF_KINDS 4
 int astts_prof_enable(int32_t kind, int32_t on, int32_t max_launches);
 int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* work_sum, int64_t* dropped);
-/* HIP stream restricted to a subset of the compute units (bit i of cu_mask = CU i enabled, n_words 32-bit words):
- * the pipelined synthesis gives the latency-bound LM decode chains and the throughput-bound flow/vocoder stage
- * disjoint CUs so that neither waits for the other's workgroups to drain. */
-int astts_stream_create_cu_mask(const uint32_t* cu_mask, int32_t n_words, astts_stream_t* out);
-int astts_stream_destroy(astts_stream_t stream);
+/* One 64-thread workgroup that busy-waits `microseconds` on `stream`.  HIP multiplexes its streams onto a few
+ * hardware queues; two streams that share one never overlap.  The pipelined synthesis uses this probe to pick streams
+ * that really run concurrently (astts/synth/model.py: PipelinedSynth). */
+int astts_stream_spin(int32_t microseconds, astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",

@@ -1,4 +1,4 @@
-import sys, time, math
+import sys, time, math, os
 sys.path[:0] = ['.', 'autostyle-tts_amd']
 import torch
 from astts.synth.config import SynthConfig
@@ -26,20 +26,27 @@ for _ in range(K): out = eng.tts(*args)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 audio = B * ref[2].shape[1] / cfg.sample_rate
 print(f'sequential: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}')
-def cmp(tag, o):
-    print(tag, 'toks', bool(torch.equal(o[0], ref[0])), 'mel', float((o[1] - ref[1]).abs().max()), 'wav', float((o[2] - ref[2]).abs().max()), flush=True)
-for i in range(3):
-    cmp(f'sequential rerun {i}', eng.tts(*args))
-eng.flow.use_engine = False
-cmp('sequential, flow ops path', eng.tts(*args))
-eng.flow.use_engine = True
-for use in (True,):
-    eng.flow.use_engine = use
-    pipe = PipelinedSynth(eng, lm_depth=2)
-    outs = []
-    for _ in range(6):
+def timed(pipe, tag, K=12):
+    t0 = time.perf_counter(); outs = []
+    for _ in range(K):
         r = pipe.submit(*args)
         if r is not None: outs.append(r)
     outs += pipe.drain()
-    torch.cuda.synchronize()
-    for i, o in enumerate(outs): cmp(f'pipelined engine={use} batch {i}', o)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', [int(s.cuda_stream) % 100000 for s in pipe.s_lm + [pipe.s_render]], flush=True)
+from astts import ops
+st = ops.concurrent_streams(4)
+import itertools
+lib = __import__('astts._lib', fromlist=['x']).load()
+default = torch.cuda.current_stream()
+def shares_default(sx):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lib.astts_stream_spin(300, int(sx.cuda_stream)); lib.astts_stream_spin(300, int(default.cuda_stream))
+    sx.synchronize(); default.synchronize()
+    return (time.perf_counter() - t0) > 480e-6
+for trial in range(6):
+    if trial: st = ops.concurrent_streams(4)
+    P = PipelinedSynth(eng, lm_depth=3, streams=st)
+    for _ in range(3): P.submit(*args)
+    P.drain(); torch.cuda.synchronize()
+    timed(P, f'trial {trial}', K=8)
