@@ -25,6 +25,9 @@ _SIGS = {
                                    c_int32, c_int32, c_float, c_float, c_void_p]),
     "astts_op_gemm_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p]),
+        "astts_op_gemm_fused_ws": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "astts_op_gemm_fused_workspace_bytes": (c_size_t, []),
     "astts_op_attn_relpos_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p] + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
@@ -236,6 +239,9 @@ def prof_read(kind: int):
     return float(ms.value), int(n.value), float(work.value), int(dropped.value)
 
 
+_SPLITK_WS: dict = {}
+
+
 def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.Tensor] = None, ln=None, ln_eps: float = 1e-5,
                act: str = "none", residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                out2: Optional[torch.Tensor] = None, n_split: int = 0, alpha: float = 1.0, slope: float = 0.1,
@@ -247,12 +253,18 @@ def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.
     if out is None:
         out = torch.empty((m, n1), dtype=torch.float32, device=x.device)
     ga, be = (ln if ln is not None else (None, None))
-    _lib.check(_L().astts_op_gemm_fused(x.data_ptr(), _p(gather), _p(ga), _p(be), ln_eps, w.data.data_ptr(), _p(w.bias),
-                                        _p(residual), out.data_ptr(), _p(out2),
-                                        1 if (out2 is not None and out2.dtype == torch.float16) else 0, m, w.n, n_split, w.cin, w.cin_pad,
-                                        lda if lda is not None else x.stride(-2), out.stride(-2),
-                                        out2.stride(-2) if out2 is not None else 0,
-                                        residual.stride(-2) if residual is not None else 0, ACT[act], alpha, slope, _st()))
+    st = _st()
+    ws = _SPLITK_WS.get((x.device.index, st))
+    if ws is None:      # zeroed once per (device, stream): the kernel leaves its arrival counters at zero
+        ws = _SPLITK_WS[(x.device.index, st)] = torch.zeros(int(_L().astts_op_gemm_fused_workspace_bytes()), dtype=torch.uint8,
+                                                            device=x.device)
+    _lib.check(_L().astts_op_gemm_fused_ws(x.data_ptr(), _p(gather), _p(ga), _p(be), ln_eps, w.data.data_ptr(), _p(w.bias),
+                                           _p(residual), out.data_ptr(), _p(out2),
+                                           1 if (out2 is not None and out2.dtype == torch.float16) else 0, m, w.n, n_split, w.cin,
+                                           w.cin_pad, lda if lda is not None else x.stride(-2), out.stride(-2),
+                                           out2.stride(-2) if out2 is not None else 0,
+                                           residual.stride(-2) if residual is not None else 0, ACT[act], alpha, slope,
+                                           ws.data_ptr(), ws.numel(), st))
     return out
 
 

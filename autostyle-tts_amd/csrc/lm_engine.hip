@@ -52,6 +52,7 @@ size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
     take(sizeof(float) * b * h->cfg.vocab_out);   // logits
     take(sizeof(int32_t) * b);                    // token
     take(sizeof(int32_t) * b);                    // lens
+    take(astts_op_gemm_fused_workspace_bytes());  // split-K counters + partial sums (FFN-out projection)
     return o;
 }
 
@@ -88,6 +89,9 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
     int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
     (void)take(sizeof(int32_t) * b);  // reserved
+    const size_t skw_bytes = astts_op_gemm_fused_workspace_bytes();
+    void* skw = take(skw_bytes);
+    ASTTS_CHECK_HIP(hipMemsetAsync(skw, 0, 1024, st));      // arrival counters start at zero (once per call; they reset themselves)
     const float scale = 0.125f;  // 1/sqrt(64)
     const int64_t kv_row = (int64_t)b * 2 * d;  // one time step of the time-major cache
 
@@ -104,8 +108,8 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
         if (s + 1 == n_steps) break;
         const int pos = pos0 + s;
         // embed: speech_embedding[tok] -> Linear -> LayerNorm -> ReLU * sqrt(d)
-        rc = astts_op_gemm_fused(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, 0, b, d, 0,
-                                 d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
+        rc = astts_op_gemm_fused_ws(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, 0, b, d, 0,
+                                 d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
         if (rc != ASTTS_OK) return rc;
         rc = astts_op_layernorm(h1, g.embed_ln_g, g.embed_ln_b, h0, b, d, d, d, c.eps, st);
         if (rc != ASTTS_OK) return rc;
@@ -119,27 +123,27 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
             char* kvc = (char*)kv_cache[l];
             const size_t esz = c.kv_f16 ? 2 : 4;
             // LN1 + QKV; K|V land in cache row `pos`
-            rc = astts_op_gemm_fused(x, nullptr, L.n1_g, L.n1_b, c.eps, L.wqkv, L.bqkv, nullptr, q,
+            rc = astts_op_gemm_fused_ws(x, nullptr, L.n1_g, L.n1_b, c.eps, L.wqkv, L.bqkv, nullptr, q,
                                      kvc + (size_t)pos * kv_row * esz, c.kv_f16, b, 3 * d, d, d, dpad, d, d, 2 * d, 0,
-                                     ASTTS_ACT_NONE, 1.f, 0.f, st);
+                                     ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
             if (rc != ASTTS_OK) return rc;
             rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * esz, c.kv_f16, L.pos, c.pos_f16, L.bias_u, L.bias_v, /*lens: every row has pos + 1 keys*/ nullptr, key_start, ao, b,
                                          c.heads, 1, pos + 1, /*ldq*/ b * d, /*ldk*/ (int32_t)kv_row, /*ldo*/ b * d, c.pos_ld,
                                          /*q_bs*/ d, /*k_bs*/ 2 * d, /*o_bs*/ d, pos, c.pos_center, 1, scale, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(ao, nullptr, nullptr, nullptr, 0.f, L.wo, L.bo, x, y, nullptr, 0, b, d, 0, d, dpad, d, d, 0, d,
-                                     ASTTS_ACT_NONE, 1.f, 0.f, st);
+            rc = astts_op_gemm_fused_ws(ao, nullptr, nullptr, nullptr, 0.f, L.wo, L.bo, x, y, nullptr, 0, b, d, 0, d, dpad, d, d, 0, d,
+                                     ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(y, nullptr, L.n2_g, L.n2_b, c.eps, L.w1, L.b1, nullptr, ff, nullptr, 0, b, c.ffn, 0, d, dpad, d,
-                                     c.ffn, 0, 0, ASTTS_ACT_RELU, 1.f, 0.f, st);
+            rc = astts_op_gemm_fused_ws(y, nullptr, L.n2_g, L.n2_b, c.eps, L.w1, L.b1, nullptr, ff, nullptr, 0, b, c.ffn, 0, d, dpad, d,
+                                     c.ffn, 0, 0, ASTTS_ACT_RELU, 1.f, 0.f, skw, skw_bytes, st);
             if (rc != ASTTS_OK) return rc;
-            rc = astts_op_gemm_fused(ff, nullptr, nullptr, nullptr, 0.f, L.w2, L.b2, y, x, nullptr, 0, b, d, 0, c.ffn, fpad, c.ffn, d,
-                                     0, d, ASTTS_ACT_NONE, 1.f, 0.f, st);
+            rc = astts_op_gemm_fused_ws(ff, nullptr, nullptr, nullptr, 0.f, L.w2, L.b2, y, x, nullptr, 0, b, d, 0, c.ffn, fpad, c.ffn, d,
+                                     0, d, ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
             if (rc != ASTTS_OK) return rc;
         }
         // after_norm + output head
-        rc = astts_op_gemm_fused(x, nullptr, g.after_g, g.after_b, c.eps, g.head_w, g.head_b, nullptr, lg, nullptr, 0, b, c.vocab_out,
-                                 0, d, dpad, d, c.vocab_out, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, st);
+        rc = astts_op_gemm_fused_ws(x, nullptr, g.after_g, g.after_b, c.eps, g.head_w, g.head_b, nullptr, lg, nullptr, 0, b, c.vocab_out,
+                                 0, d, dpad, d, c.vocab_out, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
         if (rc != ASTTS_OK) return rc;
         cur = lg;
     }

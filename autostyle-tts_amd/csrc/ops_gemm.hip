@@ -78,6 +78,10 @@ struct GemmArgs {
     int ldc2, n_split;
     int x_f16, out_f16;      // activations in / out as fp16 (ld* are then in halfs)
     int out2_f16;            // skinny kernel: the split destination (KV cache) is fp16
+    // skinny kernel split-K (ksplit > 1): partial sums [n/16][ksplit][MT*256] + one arrival counter per column block
+    float* sk_part;
+    unsigned* sk_cnt;
+    int ksplit;
 };
 
 #ifdef EPI_DBG_LOCAL
@@ -535,7 +539,10 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int ktot = a.cin_pad;
+    const int KS = a.ksplit > 1 ? a.ksplit : 1;              // split-K: block (x, y) reduces K slice y of column block x
+    const int kfull = a.cin_pad;
+    const int ktot = kfull / KS;                             // K elements of this block's slice
+    const int k_lo = (int)blockIdx.y * ktot;
     const int lines = ktot >> 6;
     const int M = (int)a.m;
     const int xs = ktot + 8;                                 // LDS row stride in halfs (16-byte skew)
@@ -556,15 +563,15 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     float4 v0[MAXV];
     if (vec_ok && wid < M) {
         const int64_t src = a.gather ? (int64_t)a.gather[wid] : (int64_t)wid;
-        const float* xr = a.x + src * a.lda;
+        const float* xr = a.x + src * a.lda + k_lo;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int k = lane * 4 + i * 256;
             v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nv && k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
+            if (i < nv && k_lo + k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
         }
     }
-    const _Float16* wrow = a.w + (int64_t)(n0 + c) * ktot + g * 16;
+    const _Float16* wrow = a.w + (int64_t)(n0 + c) * kfull + k_lo + g * 16;
     half8 fb[SK_LINES][2];
 #pragma unroll
     for (int i = 0; i < SK_LINES; ++i) {
@@ -624,13 +631,13 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     if (vec_ok && wid < M) stage_row(v0, sx + (size_t)wid * xs);   // the prefetched row
     for (int mr = vec_ok ? wid + SK_WAVES : wid; mr < M; mr += SK_WAVES) {
         const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
-        const float* xr = a.x + src * a.lda;
+        const float* xr = a.x + src * a.lda + k_lo;          // (LayerNorm / scalar paths below only run unsplit: k_lo == 0)
         _Float16* dst = sx + (size_t)mr * xs;
         if (vec_wide) {
 #pragma unroll 8  // 8 independent 16-byte loads in flight per lane (a 4096-wide row = 2 round trips)
             for (int k = lane * 4; k < ktot; k += 256) {
                 float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < a.cin) v4 = *reinterpret_cast<const float4*>(xr + k);
+                if (k_lo + k < a.cin) v4 = *reinterpret_cast<const float4*>(xr + k);
                 half4 h4;
                 h4[0] = (_Float16)v4.x; h4[1] = (_Float16)v4.y; h4[2] = (_Float16)v4.z; h4[3] = (_Float16)v4.w;
                 *reinterpret_cast<half4*>(dst + k) = h4;
@@ -640,7 +647,7 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
             for (int i = 0; i < MAXV; ++i) {
                 const int k = lane * 4 + i * 256;
                 v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < nv && k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
+                if (i < nv && k_lo + k < a.cin) v0[i] = *reinterpret_cast<const float4*>(xr + k);
             }
             stage_row(v0, dst);
         } else {
@@ -715,12 +722,39 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[((wid * MT + t) * 4 + e) * 64 + lane] = acc[t][e];
     __syncthreads();
-    if (tid < MT * 256) {   // MT*256 outputs <= 512 threads: one element each
-        const int o = tid;
-        const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
-        float v = 0.0f;
+    // MT*256 outputs <= 512 threads: one element each (threads past that only take part in the barriers)
+    const bool owner = tid < MT * 256;
+    const int o = tid;
+    const int t = o / 256, e = (o >> 6) & 3, ln = o & 63;
+    float v = 0.0f;
+    if (owner) {
 #pragma unroll
         for (int w = 0; w < SK_WAVES; ++w) v += red[((w * MT + t) * 4 + e) * 64 + ln];
+    }
+    if (KS > 1) {
+        // split-K: publish this slice's partial sums; the block that arrives LAST at the column block's counter adds the
+        // KS slices in slice order (a fixed order: the result does not depend on which block that is) and runs the
+        // epilogue.  No block ever waits for another one.
+        // The XCDs' L2 caches are not coherent with each other: partial sums and the counter are accessed with agent-scope
+        // (sc1) stores / loads / atomics, which go to the coherence point -- a __threadfence() here would write back and
+        // invalidate the whole L2 under the weight stream of 255 other blocks (measured: 2x slower than no split at all).
+        float* part = a.sk_part + (size_t)blockIdx.x * KS * (MT * 256);
+        if (owner) __hip_atomic_store(part + (size_t)blockIdx.y * (MT * 256) + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                   // waits vmcnt(0): the block's stores are acknowledged; `red` reads done
+        int* s_last = reinterpret_cast<int*>(red);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&a.sk_cnt[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_last = old == (unsigned)(KS - 1);
+            if (old == (unsigned)(KS - 1))                 // ready for the next launch
+                __hip_atomic_store(&a.sk_cnt[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!*s_last) return;
+        v = 0.0f;
+        if (owner)
+            for (int k = 0; k < KS; ++k) v += __hip_atomic_load(part + (size_t)k * (MT * 256) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (owner) {
         const int n = n0 + (ln & 15);
         const int m = t * 16 + (ln >> 4) * 4 + e;
         if (n < a.n && m < M) {
@@ -773,9 +807,15 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.m <= 32 && plain && !a.x_f16 && !a.out_f16) {
         // the block keeps its m rows of x as an fp16 image in LDS: rows are taken in chunks that fit 160 KB
         // (only m > 16 with K > 2048 needs two passes, e.g. the FFN-out projection of a 32-row decode group)
+        // split-K (a.sk_part given): deep, narrow GEMMs (the FFN-out projection: K = 4096 onto 1024 columns = 64 column
+        // blocks) are cut into 4 K slices so that 256 workgroups stream the weights instead of 64
+        const int lines_tot = a.cin_pad >> 6;
+        int ksplit = 1;
+        if (a.sk_part && !a.gather && !a.ln_gamma && lines_tot >= 32 && lines_tot % 32 == 0 && (a.n + 15) / 16 <= 128) ksplit = 4;
+        const int kslice = a.cin_pad / ksplit;
         int rows = (int)a.m;
-        while (rows > 1 && skinny_lds_bytes(rows, a.cin_pad, rows <= 16 ? 1 : 2) > 160 * 1024) rows = rows > 16 ? 16 : rows / 2;
-        if (skinny_lds_bytes(rows, a.cin_pad, 1) > 160 * 1024) {
+        while (rows > 1 && skinny_lds_bytes(rows, kslice, rows <= 16 ? 1 : 2) > 160 * 1024) rows = rows > 16 ? 16 : rows / 2;
+        if (skinny_lds_bytes(rows, kslice, 1) > 160 * 1024) {
             set_error("astts_op_gemm: cin_pad=%d does not fit the skinny kernel's LDS image", a.cin_pad);
             return ASTTS_ERR_INVALID;
         }
@@ -787,10 +827,11 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny16<2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        const dim3 grid((a.n + 15) / 16);
-        const bool small_k = a.cin_pad <= 1024;   // row of <= 4 float4 per lane: a quarter of the staging registers
+        const dim3 grid((a.n + 15) / 16, ksplit);
+        const bool small_k = kslice <= 1024;   // row of <= 4 float4 per lane: a quarter of the staging registers
         for (int r0 = 0; r0 < (int)a.m; r0 += rows) {
             GemmArgs c = a;
+            c.ksplit = ksplit;
             c.m = (int)a.m - r0 < rows ? (int)a.m - r0 : rows;
             if (c.gather) c.gather += r0; else c.x += (int64_t)r0 * a.lda;
             if (c.residual) c.residual += (int64_t)r0 * a.ldr;
@@ -798,7 +839,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
             c.out += (int64_t)r0 * a.ldc;
             if (c.out2) c.out2 = a.out2_f16 ? (float*)((_Float16*)a.out2 + (int64_t)r0 * a.ldc2) : a.out2 + (int64_t)r0 * a.ldc2;
             const int mt = c.m <= 16 ? 1 : 2;
-            const size_t lds = skinny_lds_bytes((int)c.m, a.cin_pad, mt);
+            const size_t lds = skinny_lds_bytes((int)c.m, kslice, mt);
             const bool prof = prof_begin(ASTTS_PROF_GEMM_SKINNY, st, (double)a.n * a.cin_pad * 2.0);
             if (mt == 1 && small_k)
                 hipLaunchKernelGGL((gemm_skinny16<1, 4>), grid, dim3(512), lds, st, c);
@@ -927,19 +968,35 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
     return launch_gemm(a, (hipStream_t)stream);
 }
 
-int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                        const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
-                        int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
-                        int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream) {
+size_t astts_op_gemm_fused_workspace_bytes(void) {
+    return 1024 + (size_t)128 * 4 * 512 * sizeof(float);      // arrival counters + [128 column blocks][4 slices][512] partial sums
+}
+
+int astts_op_gemm_fused_ws(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                           const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
+                           int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
+                           int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, void* workspace, size_t workspace_bytes,
+                           astts_stream_t stream) {
     const int rc = check_gemm_args("astts_op_gemm_fused", x, w_f16, out, m, n, cin, cin_pad, 1, 1, 1, 1, 1, act);
     if (rc != ASTTS_OK) return rc;
     ASTTS_REQUIRE(m <= 32, ASTTS_ERR_INVALID, "astts_op_gemm_fused: m=%d > 32", m);
     ASTTS_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), ASTTS_ERR_INVALID, "astts_op_gemm_fused: gamma/beta");
     ASTTS_REQUIRE(!out2 || (n_split > 0 && n_split < n), ASTTS_ERR_INVALID, "astts_op_gemm_fused: n_split=%d", n_split);
+    ASTTS_REQUIRE(!workspace || (workspace_bytes >= astts_op_gemm_fused_workspace_bytes() && ((uintptr_t)workspace & 255) == 0),
+                  ASTTS_ERR_WORKSPACE, "astts_op_gemm_fused: workspace too small or misaligned");
     GemmArgs a{x, (const _Float16*)w_f16, bias, residual, nullptr, out, m, n, cin, cin_pad, 1,
                lda, ldc, ldr, m, m, 1, 1, 0, act, alpha, slope,
-               gather, ln_gamma, ln_beta, ln_eps, (float*)out2, ldc2, n_split, 0, 0, out2_f16 ? 1 : 0};
+               gather, ln_gamma, ln_beta, ln_eps, (float*)out2, ldc2, n_split, 0, 0, out2_f16 ? 1 : 0,
+               workspace ? reinterpret_cast<float*>((char*)workspace + 1024) : nullptr, reinterpret_cast<unsigned*>(workspace), 0};
     return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
+                        int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
+                        int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream) {
+    return astts_op_gemm_fused_ws(x, gather, ln_gamma, ln_beta, ln_eps, w_f16, bias, residual, out, out2, out2_f16, m, n, n_split, cin,
+                                  cin_pad, lda, ldc, ldc2, ldr, act, alpha, slope, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -153,6 +153,16 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
                         const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
                         int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
                         int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, astts_stream_t stream);
+/* Same, with a workspace that enables split-K for deep, narrow shapes (K >= 2048 onto <= 2048 columns, no gather / LayerNorm:
+ * the FFN-out projection of a decode step): 4 K slices per column block, the last slice to arrive adds the partial sums in
+ * slice order, so results are reproducible.  The workspace (astts_op_gemm_fused_workspace_bytes(), 256-byte aligned) must
+ * be ZERO on first use and is left zeroed where it matters; launches sharing it must be ordered on one stream. */
+size_t astts_op_gemm_fused_workspace_bytes(void);
+int astts_op_gemm_fused_ws(const float* x, const int32_t* gather, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const void* w_f16, const float* bias, const float* residual, float* out, void* out2, int32_t out2_f16,
+                        int32_t m, int32_t n, int32_t n_split, int32_t cin, int32_t cin_pad, int32_t lda, int32_t ldc,
+                        int32_t ldc2, int32_t ldr, int32_t act, float alpha, float slope, void* workspace, size_t workspace_bytes,
+                           astts_stream_t stream);
 int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,
                        int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
 /* _ex forms: out_f16 != 0 writes fp16 (ldy in halfs) for outputs whose only consumers are MFMA operands. */

@@ -294,3 +294,54 @@ def test_gemm_rejects_in_place_output():
     pw = ops.PackedWeight(torch.randn(256, 256) / 16, None)
     with pytest.raises(_lib.AsttsError, match="aliases"):
         ops.gemm(x, pw, out=x)
+
+
+@pytest.mark.parametrize("m,k,n,act,use_res", [(8, 4096, 1024, "none", True), (24, 4096, 1024, "none", True), (32, 4096, 1024, "relu", False),
+                                               (5, 2048, 512, "relu", False), (8, 1024, 1024, "none", True), (16, 4096, 2048, "none", False)])
+def test_gemm_fused_split_k_and_plain(m, k, n, act, use_res):
+    """Decode-sized GEMM; K >= 2048 onto <= 2048 columns takes the split-K path (4 K slices per column block, the last
+    block to arrive reduces in slice order): checked against the fp16-operand reference, for run-to-run bit
+    reproducibility, and over several launches sharing the self-resetting workspace."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(m * 13 + n)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    pw = ops.PackedWeight(w, b)
+    outs = []
+    for rep in range(3):
+        x = torch.randn(m, k, generator=g)
+        res = torch.randn(m, n, generator=g) if use_res else None
+        xd = x.to(DEV)
+        rd = None if res is None else res.to(DEV)
+        y = ops.gemm_fused(xd, pw, m, act=act, residual=rd)
+        y2 = ops.gemm_fused(xd, pw, m, act=act, residual=rd)
+        assert torch.equal(y, y2)                       # same bits whichever block arrives last
+        ref = F.linear(h16(x), h16(w), b)
+        ref = F.relu(ref) if act == "relu" else ref
+        if res is not None:
+            ref = ref + res
+        assert rel_err(y, ref) < 2e-4, rep
+        outs.append(y)
+
+
+def test_gemm_fused_layernorm_gather_split_output():
+    """The fusions of the LM decode step: embedding-row gather, LayerNorm prologue, K|V half of the output written as
+    fp16 into a strided destination (a KV-cache row)."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 8, 1024, 3072
+    table = torch.randn(50, k, generator=g)
+    ids = torch.randint(0, 50, (m,), generator=g).to(torch.int32)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    ga, be = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    pw = ops.PackedWeight(w, b)
+    cache = torch.zeros(3, m, 2 * 1024, dtype=torch.float16, device=DEV)
+    q = ops.gemm_fused(table.to(DEV), pw, m, gather=ids.to(DEV), ln=(ga.to(DEV), be.to(DEV)), ln_eps=1e-5, out2=cache[1], n_split=1024)
+    xn = F.layer_norm(table[ids.long()], (k,), ga, be, 1e-5)
+    ref = F.linear(h16(xn), h16(w), b)
+    assert rel_err(q, ref[:, :1024]) < 2e-3                 # LayerNorm output rounded to fp16 before the MFMA
+    assert rel_err(cache[1].float(), ref[:, 1024:]) < 3e-3
+    assert float(cache[0].abs().max()) == 0.0 and float(cache[2].abs().max()) == 0.0
