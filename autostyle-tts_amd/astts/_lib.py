@@ -9,6 +9,11 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue never overlap.
+# The pipelined synthesis wants one queue per decode chain + render + front stream.  Read by the HIP runtime when it
+# initialises (the first HIP call), so it has to be in the environment before that; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libastts.so")
 

@@ -26,6 +26,9 @@ for _p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# one hardware queue per pipeline stream (astts/_lib.py sets the same default; it must precede the first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -114,7 +117,7 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bank-rows", type=int, default=1000)
@@ -166,7 +169,7 @@ def main():
     # overlap (PipelinedSynth.autotune) -- on this rank's own inputs.
     sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
               inp.z, inp.phase0, inp.noise)
-    pipe = PipelinedSynth.autotune(eng, sample, depths=(3, 2), trials=3, steps=4,
+    pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=max(2, min(args.steps, 8)),
                                    front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
     n_done = [0]
 

@@ -34,19 +34,6 @@ def timed(pipe, tag, K=12):
     outs += pipe.drain()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', [int(s.cuda_stream) % 100000 for s in pipe.s_lm + [pipe.s_render]], flush=True)
-from astts import ops
-st = ops.concurrent_streams(4)
-import itertools
-lib = __import__('astts._lib', fromlist=['x']).load()
-default = torch.cuda.current_stream()
-def shares_default(sx):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    lib.astts_stream_spin(300, int(sx.cuda_stream)); lib.astts_stream_spin(300, int(default.cuda_stream))
-    sx.synchronize(); default.synchronize()
-    return (time.perf_counter() - t0) > 480e-6
-for trial in range(6):
-    if trial: st = ops.concurrent_streams(4)
-    P = PipelinedSynth(eng, lm_depth=3, streams=st)
-    for _ in range(3): P.submit(*args)
-    P.drain(); torch.cuda.synchronize()
-    timed(P, f'trial {trial}', K=8)
+
+P = PipelinedSynth.autotune(eng, args, depths=(3, 2, 4), trials=2, steps=int(os.environ.get('K', '16')), verbose=True)
+print('chosen depth', P.depth, P.tuned_ms_per_batch)
