@@ -135,3 +135,74 @@ def test_search_embeddings_cli(golden_dir, tmp_path, capsys, kats):
     # error convention of the reference wrapper: print + [] (search_embeddings.py:24-27)
     from astts.compat.pymilvus import MilvusClient
     assert drv.search_milvus(MilvusClient(os.path.join(golden_dir, "milvus_demo.db")), "missing", bank[0].tolist()) == []
+
+
+def test_tts_for_dialog_driver(cosy, tmp_path):
+    """tts_for_dialog.py:145-199: 1-based JSON-lines lookups, "null" entries skipped, one file per segment named
+    {cnt}_{style_file_id}_to_{speaker}_{i}.wav under {result_dir}_{MMDDHHMM}."""
+    from astts import audio
+    from astts.cli import tts_for_dialog as drv
+
+    os.makedirs(tmp_path / "styles")
+    _tone(str(tmp_path / "styles" / "s_one.wav"), 1.2, 200.0)
+    _tone(str(tmp_path / "styles" / "s_two.wav"), 1.0, 260.0)
+    _tone(str(tmp_path / "spk_a.wav"), 1.1, 300.0)
+    _tone(str(tmp_path / "spk_b.wav"), 1.1, 340.0)
+    (tmp_path / "dialogue.jsonl").write_text("\n".join(json.dumps({"zh_text": t}) for t in ["Hello there.", "Never used.", "What now?"]) + "\n")
+    (tmp_path / "styles.jsonl").write_text("\n".join(json.dumps({"file_id": f, "zh_text": t}) for f, t in
+                                                     [("s_one", "First style."), ("s_two", "Second style.")]) + "\n")
+    (tmp_path / "map.json").write_text(json.dumps({"1": {"value": 2, "speaker": "a", "emotion": "x"}, "2": "null",
+                                                   "3": {"value": 1, "speaker": "b", "emotion": "y"}}))
+    (tmp_path / "speakers.json").write_text(json.dumps({"a": str(tmp_path / "spk_a.wav"), "b": str(tmp_path / "spk_b.wav")}))
+    argv = ["--corresponding_json", str(tmp_path / "map.json"), "--dialogue_json", str(tmp_path / "dialogue.jsonl"),
+            "--style_wav_json", str(tmp_path / "styles.jsonl"), "--style_wav_dir", str(tmp_path / "styles"),
+            "--result_dir", str(tmp_path / "out"), "--timbre_map", str(tmp_path / "speakers.json"), "--time_tag", "01020304"]
+    written = drv.tts_for_infer(drv.build_parser().parse_args(argv), cosyvoice=cosy)
+    names = sorted(os.path.basename(p) for p in written)
+    assert names == ["1_s_two_to_a_0.wav", "2_s_one_to_b_0.wav"]
+    assert all(os.path.dirname(p) == str(tmp_path / "out_01020304") for p in written)
+    for p in written:
+        w, sr = audio.read_wav(p)
+        assert sr == 22050 and w.size > 0 and np.isfinite(w).all()
+    exp = drv.tts_for_exp(drv.build_parser().parse_args(argv + ["--is_exp", "1"]), cosyvoice=cosy)
+    assert sorted(os.path.basename(p) for p in exp) == ["s_one_0_to_b_exp_0.wav", "s_one_prompt_0_0.wav", "s_two_0_to_a_exp_0.wav",
+                                                         "s_two_prompt_0_0.wav"]
+    reader = drv.JsonDataReader(str(tmp_path / "styles.jsonl"))
+    assert reader.get_zh_text_by_index(1) == "First style." and reader.get_fileid(2) == "s_two"
+
+
+def test_vc_from_dir_driver(cosy, tmp_path):
+    """vc_from_dir.py:79-220: style x timbre x line sweep, {style}_to_{timbre}_{cnt}_new.wav, meta.lst rows
+    name|style_text|timbre_path|line; vc_from_dir_seed.py's meta.lst style source."""
+    from astts.cli import vc_from_dir as drv
+
+    os.makedirs(tmp_path / "styles")
+    os.makedirs(tmp_path / "timbres")
+    for n, f in (("aa", 210.0), ("bb", 250.0), ("cc", 290.0)):
+        _tone(str(tmp_path / "styles" / f"{n}.wav"), 1.0, f)
+    for n, f in (("t1", 310.0), ("t2", 350.0)):
+        _tone(str(tmp_path / "timbres" / f"{n}.wav"), 1.0, f)
+    (tmp_path / "styles.json").write_text(json.dumps([{"file_id": f"denoise_{n}", "zh_text": f"text of {n}"} for n in ("aa", "bb", "cc")]))
+    (tmp_path / "lines.txt").write_text("One line.\nAnother line.\n")
+    argv = ["--txt_path", str(tmp_path / "lines.txt"), "--style_dir", str(tmp_path / "styles"), "--timbre_dir", str(tmp_path / "timbres"),
+            "--result_dir", str(tmp_path / "out"), "--style_num", "2", "--timbre_num", "2", "--style_json", str(tmp_path / "styles.json"),
+            "--seed", "3"]
+    rows = drv.main(argv, cosyvoice=cosy)
+    assert len(rows) == 2 * 2 * 2
+    meta = (tmp_path / "out" / "meta.lst").read_text().strip().split("\n")
+    assert len(meta) == 8
+    for row, line in zip(rows, meta):
+        name, style_text, timbre_path, text = line.split("|")
+        assert [name, style_text, timbre_path, text] == row
+        style, rest = name.split("_to_")
+        assert style in ("aa", "bb", "cc") and style_text == f"text of {style}" and rest.endswith("_new")
+        assert os.path.exists(tmp_path / "out" / (name + ".wav")) and os.path.exists(timbre_path)
+        assert text in ("One line.", "Another line.")
+    with pytest.raises(ValueError):
+        drv.get_path(str(tmp_path / "timbres"), 5)
+    # seed-tts variant: styles and their transcripts from a meta.lst
+    (tmp_path / "seed.lst").write_text(f"u1|seed text one|{tmp_path}/styles/aa.wav|x\nu2|seed text two|{tmp_path}/styles/bb.wav|y\n")
+    rows2 = drv.main(["--txt_path", str(tmp_path / "lines.txt"), "--style_dir", str(tmp_path / "styles"), "--timbre_dir",
+                      str(tmp_path / "timbres"), "--result_dir", str(tmp_path / "out2"), "--style_num", "1", "--timbre_num", "1",
+                      "--style_meta_lst", str(tmp_path / "seed.lst"), "--seed", "1"], cosyvoice=cosy)
+    assert len(rows2) == 2 and rows2[0][1] in ("seed text one", "seed text two")
