@@ -13,6 +13,8 @@
 // CosyVoice calls (tts_with_rag.py:195); third-party code, restated from the published architecture.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace astts {
 
 static constexpr int DH = 64;
@@ -434,6 +436,214 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// attn_relpos_mfma: espnet relative-position attention for full sequences (encoders, LM prefill) on the matrix cores.
+//   score[i][j] = ((q_i + u) . k_j + (q_i + v) . p_{a_i - j}) * scale,   a_i = q_pos0 + i (absolute position of query i)
+// Block = 4 waves x 32 queries, 64-key tiles staged in LDS exactly as attn_mha_flash (S^T = K (Q+u)^T: query on the
+// lane, online softmax lane-local, P^T feeds the PV MFMA from the accumulator registers).  The position term: for a
+// 32-key sub-tile a wave needs rel = a_i - j over 63 consecutive values; G^T[rel][query] = P[rel] (Q+v)^T is two 32-row
+// MFMA blocks (the window slides by 32 per sub-tile, so one block is carried over), written to a per-wave LDS tile and
+// read back skewed -- lane c takes G[c - key + 31][c], address 33 c + const: conflict-free -- and added to S^T.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ half8 ld8h(const T* p) {
+    if constexpr (sizeof(T) == 2) {
+        return *reinterpret_cast<const half8*>(p);
+    } else {
+        const float4 a0 = *reinterpret_cast<const float4*>(p);
+        const float4 a1 = *reinterpret_cast<const float4*>(p + 4);
+        half8 h;
+        h[0] = (_Float16)a0.x; h[1] = (_Float16)a0.y; h[2] = (_Float16)a0.z; h[3] = (_Float16)a0.w;
+        h[4] = (_Float16)a1.x; h[5] = (_Float16)a1.y; h[6] = (_Float16)a1.z; h[7] = (_Float16)a1.w;
+        return h;
+    }
+}
+
+template <typename KVT, typename PT>
+__global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 ks[FA_KT * FA_KS];
+    __shared__ __attribute__((aligned(16))) _Float16 vt[DH * FA_VS];
+    __shared__ float gbuf[4][64 * 33];        // per wave: G^T rows (rel) x 32 queries (+1 pad); reused for the output transpose
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0b = blockIdx.x * 128, q0 = q0b + wid * 32;
+    const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
+    const int ks0 = a.kstart ? a.kstart[b] : 0;
+    const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
+    const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH;
+    const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH;
+    const PT* posb = reinterpret_cast<const PT*>(a.pos) + head * DH;
+    const int prow_max = 2 * a.pos_center;
+    const float sc = a.scale * 1.44269504088896341f;      // scores in the log2 domain
+
+    // (Q + u), (Q + v) fragments: lane (c, hh) holds dims 16 s + 8 hh + j of query q0 + c
+    half8 quf[4], qvf[4];
+    {
+        const int qi = min(q0 + c, a.tq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int d0 = 16 * s + 8 * hh;
+            const float* qp = qb + (int64_t)qi * a.ldq + d0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float qv = qp[i];
+                quf[s][i] = (_Float16)((qv + a.bias_u[head * DH + d0 + i]) * sc);
+                qvf[s][i] = (_Float16)((qv + a.bias_v[head * DH + d0 + i]) * sc);
+            }
+        }
+    }
+    const int a0w = a.q_pos0 + q0;            // absolute position of this wave's query 0
+    float16v ot[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        ot[0][e] = 0.0f;
+        ot[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    int kmax = len;                           // keys this block needs (block-uniform)
+    if (a.causal) kmax = min(len, a.q_pos0 + q0b + 128);
+    const int jstart = (ks0 / FA_KT) * FA_KT;
+
+    const int skey = tid >> 2, sd0 = (tid & 3) * 16;
+    half8 rk[2], rv[2];
+    auto prefetch = [&](int j0) {
+        const int j = min(j0 + skey, max(len - 1, 0));
+        const int64_t off = (int64_t)j * a.ldk + sd0;
+        rk[0] = ld8h<KVT>(kb + off);
+        rk[1] = ld8h<KVT>(kb + off + 8);
+        rv[0] = ld8h<KVT>(vb + off);
+        rv[1] = ld8h<KVT>(vb + off + 8);
+    };
+    // position rows of one 32-row block: table row (rel + center) for rel = rlo + c, clamped into the table
+    auto load_p = [&](int rlo, half8 (&pf)[4]) {
+        int row = rlo + c + a.pos_center;
+        row = row < 0 ? 0 : (row > prow_max ? prow_max : row);
+        const PT* pr = posb + (int64_t)row * a.ldp + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[s] = ld8h<PT>(pr + 16 * s);
+    };
+    auto g_block = [&](const half8 (&pf)[4]) {
+        float16v g;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[s], qvf[s], g, 0, 0, 0);
+        return g;
+    };
+    float* gw = gbuf[wid];
+    if (jstart < kmax) prefetch(jstart);
+    // rel window of sub-tile jb: [a0w - jb - 31, a0w - jb + 32); hi block of the first sub-tile, then one new lo block each
+    half8 pcur[4], pnext[4];
+    float16v g_hi;
+    {
+        load_p(a0w - jstart - 31 + 32, pcur);
+        g_hi = g_block(pcur);
+        load_p(a0w - jstart - 31, pcur);
+    }
+    for (int j0 = jstart; j0 < kmax; j0 += FA_KT) {
+        __syncthreads();
+        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = rk[0];
+        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vt[(sd0 + i) * FA_VS + skey] = rv[0][i];
+            vt[(sd0 + 8 + i) * FA_VS + skey] = rv[1][i];
+        }
+        __syncthreads();
+        if (j0 + FA_KT < kmax) prefetch(j0 + FA_KT);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + sub * 32;
+            // every wave runs both sub-tiles of a staged tile (the carried G block must slide in step); pcur holds the
+            // lo block's position rows of this sub-tile, the next sub-tile's are requested now
+            load_p(a0w - (jb + 32) - 31, pnext);
+            const float16v g_lo = g_block(pcur);
+            float16v st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8 kf = *reinterpret_cast<const half8*>(&ks[(sub * 32 + c) * FA_KS + 16 * s + 8 * hh]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, quf[s], st, 0, 0, 0);
+            }
+            // G^T -> LDS (row = rel - rmin, col = query), skewed read: key row kk of query c needs rel index c - kk + 31
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                gw[rr * 33 + c] = g_lo[e];
+                gw[(32 + rr) * 33 + c] = g_hi[e];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ai = a0w + c;
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kk = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int j = jb + kk;
+                const float sv = st[e] + gw[(c - kk + 31) * 33 + c];
+                const bool valid = j >= ks0 && j < len && (!a.causal || j <= ai);
+                st[e] = valid ? sv : -INFINITY;
+                mloc = fmaxf(mloc, st[e]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            g_hi = g_lo;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pcur[s] = pnext[s];
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            if (__builtin_amdgcn_ballot_w64(mloc > m_run) != 0) {
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    ot[0][e] *= alpha;
+                    ot[1][e] *= alpha;
+                }
+            }
+            half8 pf[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = (m_run == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(st[e] - m_run);   // a query may have no valid key yet
+                l_run += p;
+                pf[e >> 3][e & 7] = (_Float16)p;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + sub * 32 + 16 * s + 4 * hh];
+                    const half4 lo = *reinterpret_cast<const half4*>(vr);
+                    const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+                    half8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    // O^T (dims in registers, query on the lane) -> LDS transpose (the wave's G tile is free now) -> coalesced rows
+    float* so = gw;                            // [32 queries][65]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            so[c * 65 + d] = ot[dt][e] * inv;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < 32; ++r) {
+        const int qi = q0 + r;
+        if (qi < a.tq) a.out[(int64_t)b * a.o_bs + (int64_t)qi * a.ldo + head * DH + lane] = so[r * 65 + lane];
+    }
+}
+
 }  // namespace astts
 
 using namespace astts;
@@ -471,6 +681,20 @@ int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_
         // the tile loader reads rel in [q_pos0+i0-(j0+63), q_pos0+i0+15-j0]; keep that inside the table
         ASTTS_REQUIRE(pos_center >= tk + RP_KB + RP_QB && pos_center >= q_pos0 + tq + RP_QB, ASTTS_ERR_INVALID,
                       "astts_op_attn_relpos: pos_center %d must exceed tk/tq by the tile margin", pos_center);
+        static const bool valu_env = getenv("ASTTS_RELPOS_VALU") != nullptr;
+        const bool al_ok = ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)pos & 15) == 0 &&
+                           (ldk & 7) == 0 && (ldp & 7) == 0 && (k_bs & 7) == 0;
+        if (!valu_env && al_ok) {
+            const dim3 gridm((tq + 127) / 128, h, b);
+            switch (variant) {
+                case 0: hipLaunchKernelGGL((attn_relpos_mfma<float, float>), gridm, dim3(256), 0, st, a); break;
+                case 1: hipLaunchKernelGGL((attn_relpos_mfma<float, _Float16>), gridm, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((attn_relpos_mfma<_Float16, float>), gridm, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((attn_relpos_mfma<_Float16, _Float16>), gridm, dim3(256), 0, st, a); break;
+            }
+            ASTTS_CHECK_LAUNCH();
+            return ASTTS_OK;
+        }
         const dim3 grid((tq + RP_QB - 1) / RP_QB, h, b);
         switch (variant) {
             case 0: hipLaunchKernelGGL((attn_relpos<float, float>), grid, dim3(256), 0, st, a); break;
