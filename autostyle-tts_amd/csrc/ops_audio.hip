@@ -173,11 +173,14 @@ struct SampleArgs {
     float top_p, tau_r;
 };
 
-__global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
+// 1024 threads per row: every pass over the 4097 logits is 4-5 elements per thread (the kernel is a chain of short
+// dependent passes; at 256 threads it took 26 us of the 575 us decode step)
+static constexpr int RS_NT = 1024;
+__global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
     extern __shared__ float prob[];  // [V]
-    __shared__ float redv[4];
-    __shared__ float sh_s[256];
-    __shared__ int sh_i[256];
+    __shared__ float redv[RS_NT / 64];
+    __shared__ float sh_s[RS_NT];
+    __shared__ int sh_i[RS_NT];
     __shared__ float s_bcast;
     __shared__ int s_tok;
     __shared__ unsigned hist[2048];
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     const float* lg = a.logits + (int64_t)bb * a.v;
     const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
     float mx = -INFINITY;
-    for (int i = tid; i < a.v; i += 256) {
+    for (int i = tid; i < a.v; i += RS_NT) {
         float x = lg[i];
         if (mask_eos && i == a.eos) x = -INFINITY;
         prob[i] = x;
@@ -196,10 +199,12 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) redv[wid] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+    mx = redv[0];
+#pragma unroll
+    for (int w = 1; w < RS_NT / 64; ++w) mx = fmaxf(mx, redv[w]);
     __syncthreads();
     float sum = 0.0f;
-    for (int i = tid; i < a.v; i += 256) {
+    for (int i = tid; i < a.v; i += RS_NT) {
         const float e = __expf(prob[i] - mx);
         prob[i] = e;
         sum += e;
@@ -208,10 +213,12 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if (lane == 0) redv[wid] = sum;
     __syncthreads();
-    const float tot = (redv[0] + redv[1]) + (redv[2] + redv[3]);
+    float tot = 0.0f;      // fixed summation order (wave partials 0..15): same bits on every run
+#pragma unroll
+    for (int w = 0; w < RS_NT / 64; ++w) tot += redv[w];
     const float inv = 1.0f / tot;
     __syncthreads();
-    for (int i = tid; i < a.v; i += 256) prob[i] *= inv;
+    for (int i = tid; i < a.v; i += RS_NT) prob[i] *= inv;
     __syncthreads();
     // top_k by (p desc, id asc).  Fast path: the exact kk-th largest probability by a 3-pass radix select on the float
     // bits (LDS histograms), then the <= 64 entries >= it are gathered and sorted by one wave.  If ties push the
@@ -226,9 +233,9 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
         for (int pass = 0; pass < 3; ++pass) {
             const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
             const int bins = pass == 2 ? 1024 : 2048;
-            for (int i = tid; i < bins; i += 256) hist[i] = 0u;
+            for (int i = tid; i < bins; i += RS_NT) hist[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < a.v; i += 256) {
+            for (int i = tid; i < a.v; i += RS_NT) {
                 const unsigned key = __float_as_uint(prob[i]);
                 if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
             }
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
         }
         if (tid == 0) s_cnt = 0;
         __syncthreads();
-        for (int i = tid; i < a.v; i += 256) {
+        for (int i = tid; i < a.v; i += RS_NT) {
             if (__float_as_uint(prob[i]) >= prefix) {
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < 64) {
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void ras_sample(SampleArgs a) {
         if (wid == 0) tl.seed(sh_s[lane], sh_i[lane], lane < s_cnt, lane);   // sort fixes the order whatever the gather order was
     } else {
         bool seeded = false;
-        for (int base = wid * 64; base < a.v; base += 256) {
+        for (int base = wid * 64; base < a.v; base += RS_NT) {
             const int i = base + lane;
             const bool valid = i < a.v;
             const float pv = valid ? prob[i] : -INFINITY;
@@ -412,7 +419,7 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
     SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, nullptr, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -427,7 +434,7 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
                   ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
     SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(256), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
