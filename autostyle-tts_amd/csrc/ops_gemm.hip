@@ -427,8 +427,21 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (1-D launch): the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
+    // its own L2.  Workgroup w becomes logical tile L = (its XCD's contiguous range) + w / 8, and L walks the N tiles of
+    // one row panel first: the blocks that share an activation panel sit on ONE XCD, so the panel is fetched into one L2
+    // instead of eight (PMC FETCH_SIZE per launch on 5504 x 1536 x 256: 39 MB -> see profiles/r01_pmc_flow.txt).
+    const int gy = (a.n + BN - 1) / BN;
+    int bx, by;
+    {
+        const int nwg = gridDim.x, w = blockIdx.x;
+        const int xcd = w & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+        bx = L / gy;
+        by = L - bx * gy;
+    }
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
     const int ktot = a.cin_pad;
     const int nkt = ktot / 64;
     const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
@@ -735,18 +748,31 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
         // split-K: publish this slice's partial sums; the block that arrives LAST at the column block's counter adds the
         // KS slices in slice order (a fixed order: the result does not depend on which block that is) and runs the
         // epilogue.  No block ever waits for another one.
-        // The XCDs' L2 caches are not coherent with each other: partial sums and the counter are accessed with agent-scope
-        // (sc1) stores / loads / atomics, which go to the coherence point -- a __threadfence() here would write back and
-        // invalidate the whole L2 under the weight stream of 255 other blocks (measured: 2x slower than no split at all).
+        // The XCDs' L2 caches are not coherent with each other, and this is ordinary (coarse-grained) device memory:
+        // an sc1 load may still hit a stale line in the reader's own L2 (seen as wrong tokens once two decode chains ran
+        // concurrently and workgroups stopped landing on the same XCD every launch).  So: partial sums are written
+        // through (sc1 stores) and acknowledged before the barrier; ONE wave per block then bumps the arrival counter,
+        // and only the last block -- one per column block -- pays an agent-scope acquire (buffer_inv: its XCD's L2 and
+        // this CU's L1) before the partials are read back.  A __threadfence() in every wave of every block (write-back +
+        // invalidate x 2048 per launch, under the weight stream) measured 2x slower than no split at all.
         float* part = a.sk_part + (size_t)blockIdx.x * KS * (MT * 256);
         if (owner) __hip_atomic_store(part + (size_t)blockIdx.y * (MT * 256) + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                   // waits vmcnt(0): the block's stores are acknowledged; `red` reads done
         int* s_last = reinterpret_cast<int*>(red);
         if (tid == 0) {
+            // Release side: the partial sums are sc1 (write-through) stores already acknowledged by every thread of the block
+            // (s_waitcnt vmcnt(0) of the barrier above) -- what an agent-scope release fence adds on top, buffer_wbl2 for
+            // dirty L2 lines, has nothing of ours to write back and costs 4 ms per 250-step decode.
+#ifdef SPLITK_RELEASE_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
             const unsigned old = __hip_atomic_fetch_add(&a.sk_cnt[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_last = old == (unsigned)(KS - 1);
-            if (old == (unsigned)(KS - 1))                 // ready for the next launch
-                __hip_atomic_store(&a.sk_cnt[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == (unsigned)(KS - 1);
+            if (last) {
+                __hip_atomic_store(&a.sk_cnt[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *s_last = last;
         }
         __syncthreads();
         if (!*s_last) return;
@@ -811,7 +837,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         // blocks) are cut into 4 K slices so that 256 workgroups stream the weights instead of 64
         const int lines_tot = a.cin_pad >> 6;
         int ksplit = 1;
-        if (a.sk_part && !a.gather && !a.ln_gamma && lines_tot >= 32 && lines_tot % 32 == 0 && (a.n + 15) / 16 <= 128) ksplit = 4;
+        static const bool nosplit_env = getenv("ASTTS_NO_SPLITK") != nullptr;
+        if (a.sk_part && !nosplit_env && !a.gather && !a.ln_gamma && lines_tot >= 32 && lines_tot % 32 == 0 && (a.n + 15) / 16 <= 128) ksplit = 4;
         const int kslice = a.cin_pad / ksplit;
         int rows = (int)a.m;
         while (rows > 1 && skinny_lds_bytes(rows, kslice, rows <= 16 ? 1 : 2) > 160 * 1024) rows = rows > 16 ? 16 : rows / 2;
@@ -878,11 +905,11 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         else mode = 2;
         if (ring_env > 0) mode = ring_env;
         if (mode == 1 && a.n > 64) {
-            hipLaunchKernelGGL((gemm_ring<2, 2, 4>), dim3((unsigned)cdiv(a.m, 128), (unsigned)cdiv(a.n, 128)), dim3(256), 4 * 256 * 128, st, a);
+            hipLaunchKernelGGL((gemm_ring<2, 2, 4>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 128))), dim3(256), 4 * 256 * 128, st, a);
         } else if (mode == 2 || mode == 1) {
-            hipLaunchKernelGGL((gemm_ring<2, 1, 3>), dim3((unsigned)cdiv(a.m, 128), (unsigned)cdiv(a.n, 64)), dim3(256), 3 * 192 * 128, st, a);
+            hipLaunchKernelGGL((gemm_ring<2, 1, 3>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 64))), dim3(256), 3 * 192 * 128, st, a);
         } else {
-            hipLaunchKernelGGL((gemm_ring<1, 1, 4>), dim3((unsigned)cdiv(a.m, 64), (unsigned)cdiv(a.n, 64)), dim3(256), 4 * 128 * 128, st, a);
+            hipLaunchKernelGGL((gemm_ring<1, 1, 4>), dim3((unsigned)(cdiv(a.m, 64) * cdiv(a.n, 64))), dim3(256), 4 * 128 * 128, st, a);
         }
         if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
         ASTTS_CHECK_LAUNCH();

@@ -35,5 +35,19 @@ def timed(pipe, tag, K=12):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', [int(s.cuda_stream) % 100000 for s in pipe.s_lm + [pipe.s_render]], flush=True)
 
-P = PipelinedSynth.autotune(eng, args, depths=(3, 2, 4), trials=2, steps=int(os.environ.get('K', '16')), verbose=True)
-print('chosen depth', P.depth, P.tuned_ms_per_batch)
+def summarize(outs):
+    return ''.join('.' if (bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0) else ('T' if not bool(torch.equal(o[0], ref[0])) else 'W') for o in outs)
+seq = [eng.tts(*args) for _ in range(10)]
+torch.cuda.synchronize()
+print('sequential reruns:', summarize(seq), flush=True)
+for trial in range(3):
+  for cob, depth in ((1, 2), (2, 2), (2, 1)):
+    pipe = PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob)
+    outs = []
+    with torch.cuda.stream(pipe.front_stream):
+        for _ in range(12):
+            r = pipe.submit(*args)
+            if r is not None: outs.append(r)
+        outs += pipe.drain()
+    torch.cuda.synchronize()
+    print(f'cobatch {cob} depth {depth}:', summarize(outs), flush=True)

@@ -350,3 +350,48 @@ def test_no_kernel_writes_outside_its_output_tensor():
     assert len(lines) >= 7 and "OOB WRITE" not in r.stdout, r.stdout[-3000:]
     assert all(ln.rstrip().endswith(" 0 with out-of-bounds writes") for ln in lines), r.stdout[-3000:]
     assert "engine == ops: True" in r.stdout
+
+
+def test_fullsize_pipeline_and_cobatching_are_bit_identical_to_sequential():
+    """Full-size model (the shapes where the decode GEMMs take the split-K path and workgroups of concurrent chains land
+    on different XCDs from launch to launch): batches pushed through the stream pipeline -- separate decode chains, and
+    two batches co-batched into one 16-row chain -- give the same tokens, mel and waveform, bit for bit, as one batch run
+    alone.  (A stale-L2 read in the split-K reduction showed up exactly here and nowhere in single-stream runs.)"""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import PipelinedSynth, SynthEngine
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig()
+    eng = SynthEngine(make_all(cfg, 0), cfg, DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    B, Tt, Tp, Ts = 8, 24, 60, 40
+    text = torch.randint(0, cfg.text_vocab, (B, Tt), device=DEV, generator=g)
+    tlen = torch.full((B,), Tt, dtype=torch.int32, device=DEV)
+    spk_s = torch.randn(B, cfg.spk_dim, device=DEV, generator=g)
+    spk_t = torch.randn(B, cfg.spk_dim, device=DEV, generator=g)
+    style_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=DEV, generator=g)
+    timbre_tok = torch.randint(0, cfg.speech_vocab, (B, Tp), device=DEV, generator=g)
+    tmp, tm = cfg.mel_frames_for_tokens(Tp), cfg.mel_frames_for_tokens(Ts)
+    timbre_mel = torch.randn(B, tmp, cfg.mel, device=DEV, generator=g)
+    u = torch.rand(Ts, B, 2, device=DEV, generator=g)
+    z = torch.randn(B, tmp + tm, cfg.mel, device=DEV, generator=g)
+    nh = cfg.nb_harmonics + 1
+    phase0 = (torch.rand(B, nh, device=DEV, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(B, tm * cfg.upsample_total, nh, device=DEV, generator=g)
+    args = (text, tlen, spk_s, style_tok, Ts, u, timbre_tok, timbre_mel, spk_t, z, phase0, noise)
+    ref = eng.tts(*args)
+    torch.cuda.synchronize()
+    for depth, cob in ((2, 1), (2, 2), (1, 3)):
+        pipe = PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob)
+        outs = []
+        with torch.cuda.stream(pipe.front_stream):
+            for _ in range(9):
+                r = pipe.submit(*args)
+                if r is not None:
+                    outs.append(r)
+            outs += pipe.drain()
+        torch.cuda.synchronize()
+        assert len(outs) == 9
+        for o in outs:
+            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, cob)
