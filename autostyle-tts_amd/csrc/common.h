@@ -51,6 +51,7 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 

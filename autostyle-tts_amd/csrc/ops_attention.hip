@@ -326,15 +326,21 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
         ot[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const int skey = tid >> 2, sd0 = (tid & 3) * 16;  // staging coordinates: key row (0..63), first of 16 dims
+    // staging coordinates.  K: key row skey (0..63), 16 dims from sd0.  V: key PAIR vkp (keys 2 vkp, 2 vkp + 1), 8 dims from
+    // vd0 -- the transposed image V^T[dim][key] is then written as whole dwords (two keys of one dim), with the key index
+    // XORed by ((dim >> 3) & 7) << 3 so that the 32 lanes of a half-wave hit 32 different banks (the 2-byte scatter of one
+    // key per thread was 8-way conflicted: SQ_LDS_BANK_CONFLICT = 49 % of the kernel's LDS cycles).
+    const int skey = tid >> 2, sd0 = (tid & 3) * 16;
+    const int vkp = tid >> 3, vd0 = (tid & 7) * 8;
     half8 rk[2], rv[2];
     auto prefetch = [&](int j0) {
         const int j = min(j0 + skey, len - 1);         // clamped; keys >= len are masked in the scores
         const int64_t off = kb + (int64_t)j * a.ldk + sd0;
         rk[0] = load8h<IN16>(a.k, off);
         rk[1] = load8h<IN16>(a.k, off + 8);
-        rv[0] = load8h<IN16>(a.v, off);
-        rv[1] = load8h<IN16>(a.v, off + 8);
+        const int jv0 = min(j0 + 2 * vkp, len - 1), jv1 = min(j0 + 2 * vkp + 1, len - 1);
+        rv[0] = load8h<IN16>(a.v, kb + (int64_t)jv0 * a.ldk + vd0);
+        rv[1] = load8h<IN16>(a.v, kb + (int64_t)jv1 * a.ldk + vd0);
     };
     if (len > 0) prefetch(0);
 
@@ -344,8 +350,10 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
         *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            vt[(sd0 + i) * FA_VS + skey] = rv[0][i];
-            vt[(sd0 + 8 + i) * FA_VS + skey] = rv[1][i];
+            half2v pr;
+            pr[0] = rv[0][i];
+            pr[1] = rv[1][i];
+            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + ((2 * vkp) ^ ((tid & 7) << 3))]) = pr;
         }
         __syncthreads();
         if (j0 + FA_KT < len) prefetch(j0 + FA_KT);
@@ -401,9 +409,11 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + sub * 32 + 16 * s + 4 * hh];
-                    const half4 lo = *reinterpret_cast<const half4*>(vr);
-                    const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+                    const int vsw = ((dt * 4 + (c >> 3)) & 7) << 3;          // the row's key swizzle ((dim >> 3) & 7) << 3
+                    const _Float16* vrow = &vt[(dt * 32 + c) * FA_VS];
+                    const int key0 = sub * 32 + 16 * s + 4 * hh;
+                    const half4 lo = *reinterpret_cast<const half4*>(vrow + (key0 ^ vsw));
+                    const half4 hi = *reinterpret_cast<const half4*>(vrow + ((key0 + 8) ^ vsw));
                     half8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -505,15 +515,17 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
     if (a.causal) kmax = min(len, a.q_pos0 + q0b + 128);
     const int jstart = (ks0 / FA_KT) * FA_KT;
 
-    const int skey = tid >> 2, sd0 = (tid & 3) * 16;
+    const int skey = tid >> 2, sd0 = (tid & 3) * 16;   // K: one key row, 16 dims; V: a key pair, 8 dims (see attn_mha_flash)
+    const int vkp = tid >> 3, vd0 = (tid & 7) * 8;
     half8 rk[2], rv[2];
     auto prefetch = [&](int j0) {
         const int j = min(j0 + skey, max(len - 1, 0));
         const int64_t off = (int64_t)j * a.ldk + sd0;
         rk[0] = ld8h<KVT>(kb + off);
         rk[1] = ld8h<KVT>(kb + off + 8);
-        rv[0] = ld8h<KVT>(vb + off);
-        rv[1] = ld8h<KVT>(vb + off + 8);
+        const int jv0 = min(j0 + 2 * vkp, max(len - 1, 0)), jv1 = min(j0 + 2 * vkp + 1, max(len - 1, 0));
+        rv[0] = ld8h<KVT>(vb + (int64_t)jv0 * a.ldk + vd0);
+        rv[1] = ld8h<KVT>(vb + (int64_t)jv1 * a.ldk + vd0);
     };
     // position rows of one 32-row block: table row (rel + center) for rel = rlo + c, clamped into the table
     auto load_p = [&](int rlo, half8 (&pf)[4]) {
@@ -547,8 +559,10 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
         *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            vt[(sd0 + i) * FA_VS + skey] = rv[0][i];
-            vt[(sd0 + 8 + i) * FA_VS + skey] = rv[1][i];
+            half2v pr;
+            pr[0] = rv[0][i];
+            pr[1] = rv[1][i];
+            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + ((2 * vkp) ^ ((tid & 7) << 3))]) = pr;
         }
         __syncthreads();
         if (j0 + FA_KT < kmax) prefetch(j0 + FA_KT);
@@ -614,9 +628,11 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const _Float16* vr = &vt[(dt * 32 + c) * FA_VS + sub * 32 + 16 * s + 4 * hh];
-                    const half4 lo = *reinterpret_cast<const half4*>(vr);
-                    const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+                    const int vsw = ((dt * 4 + (c >> 3)) & 7) << 3;          // the row's key swizzle ((dim >> 3) & 7) << 3
+                    const _Float16* vrow = &vt[(dt * 32 + c) * FA_VS];
+                    const int key0 = sub * 32 + 16 * s + 4 * hh;
+                    const half4 lo = *reinterpret_cast<const half4*>(vrow + (key0 ^ vsw));
+                    const half4 hi = *reinterpret_cast<const half4*>(vrow + ((key0 + 8) ^ vsw));
                     half8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
