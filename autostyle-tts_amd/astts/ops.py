@@ -28,6 +28,8 @@ _SIGS = {
         "astts_op_gemm_fused_ws": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "astts_op_gemm_fused_workspace_bytes": (c_size_t, []),
+    "astts_op_gemm_ln": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_attn_relpos_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p] + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_prof_enable": (c_int32, [c_int32, c_int32, c_int32]),
@@ -273,6 +275,19 @@ def linear(x: torch.Tensor, w: PackedWeight, act: str = "none", residual=None, a
     y = gemm(x.reshape(-1, x.shape[-1]), w, act=act, residual=None if residual is None else residual.reshape(-1, w.n),
              alpha=alpha, out_dtype=out_dtype)
     return y.view(*x.shape[:-1], w.n)
+
+
+def linear_ln(x: torch.Tensor, w: PackedWeight, residual: torch.Tensor, ln, eps: float = 1e-5):
+    """``out = x @ w^T + bias + residual`` (fp32) and ``LayerNorm(out) * gamma + beta`` (fp16) from one launch
+    (astts_op_gemm_ln: x fp16 ``[..., cin]``, w.n == 256).  -> (out, ln_out)"""
+    assert x.dtype == torch.float16 and x.is_contiguous() and w.n == 256 and w.taps == 1 and w.cin == w.cin_pad
+    rows = x.numel() // x.shape[-1]
+    res = _f32(residual).reshape(rows, w.n)
+    out = torch.empty((rows, w.n), dtype=torch.float32, device=x.device)
+    ln_out = torch.empty((rows, w.n), dtype=torch.float16, device=x.device)
+    _lib.check(_L().astts_op_gemm_ln(x.data_ptr(), w.data.data_ptr(), _p(w.bias), res.data_ptr(), out.data_ptr(), ln[0].data_ptr(),
+                                     ln[1].data_ptr(), eps, ln_out.data_ptr(), rows, w.n, w.cin, w.cin_pad, x.shape[-1], w.n, w.n, w.n, _st()))
+    return out.view(*x.shape[:-1], w.n), ln_out.view(*x.shape[:-1], w.n)
 
 
 def conv1d(x: torch.Tensor, w: PackedWeight, stride: int = 1, dil: int = 1, pad: int = 0, act: str = "none",

@@ -154,6 +154,90 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, float16v (
     }
 }
 
+// Epilogue of the row-complete tile (block = 32 rows x all n = 128 TN columns, 4 waves side by side in N): the new residual
+// stream value  out = acc + bias + residual  (fp32) AND LayerNorm(out) * gamma + beta (fp16, the next GEMM's operand) leave
+// in one pass -- the separate LayerNorm launch (5 us of launch floor for 8 MB of traffic, 1280 of them per flow solve) and
+// its re-read of `out` disappear.  Exact two-pass statistics: row sums, then squared deviations, each reduced over the 16
+// lanes that share a row and across the 4 waves through LDS (fixed order).
+template <int TN>
+__device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& a, float16v (&acc)[TN], float* slab_base, float* stat, int64_t m0, int wn,
+                                                 int wid, int lane) {
+    constexpr int EPI_W = 32 * TN + 4;
+    constexpr int VPR = 8 * TN, RPI = 64 / VPR, NIT = 32 / RPI;
+    const int r = lane & 31, h = lane >> 5;
+    const int vq = lane % VPR, vr = lane / VPR;
+    float* slab = slab_base + wid * 32 * EPI_W;
+    const int nb = wn * TN * 32 + vq * 4;
+    const int ncols = 4 * 32 * TN;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + nb);
+    const float4 ga = *reinterpret_cast<const float4*>(a.ln_gamma + nb);
+    const float4 be = *reinterpret_cast<const float4*>(a.ln_beta + nb);
+    float4 res[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t m = m0 + it * RPI + vr;
+        res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.residual && m < a.m) res[it] = *reinterpret_cast<const float4*>(a.residual + m * a.ldr + nb);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float4 v[NIT];
+    const float4* srow = reinterpret_cast<const float4*>(slab + vr * EPI_W + vq * 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float4 t = srow[it * RPI * (EPI_W / 4)];
+        t.x = (t.x + bias4.x) * a.alpha + res[it].x;
+        t.y = (t.y + bias4.y) * a.alpha + res[it].y;
+        t.z = (t.z + bias4.z) * a.alpha + res[it].z;
+        t.w = (t.w + bias4.w) * a.alpha + res[it].w;
+        v[it] = t;
+        const int64_t m = m0 + it * RPI + vr;
+        if (m < a.m) *reinterpret_cast<float4*>(a.out + EPI_ROW(m) * a.ldc + nb) = t;
+        float s1 = (t.x + t.y) + (t.z + t.w);
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) s1 += __shfl_xor(s1, off, 64);
+        if (vq == 0) stat[wid * 32 + it * RPI + vr] = s1;
+    }
+    __syncthreads();
+    float mean[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + vr;
+        mean[it] = ((stat[row] + stat[32 + row]) + (stat[64 + row] + stat[96 + row])) / (float)ncols;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const float dx = v[it].x - mean[it], dy = v[it].y - mean[it], dz = v[it].z - mean[it], dw = v[it].w - mean[it];
+        float s2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+        for (int off = 1; off < VPR; off <<= 1) s2 += __shfl_xor(s2, off, 64);
+        if (vq == 0) stat[wid * 32 + it * RPI + vr] = s2;
+    }
+    __syncthreads();
+    _Float16* lnout = reinterpret_cast<_Float16*>(a.out2);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + vr;
+        const float var = ((stat[row] + stat[32 + row]) + (stat[64 + row] + stat[96 + row])) / (float)ncols;
+        const float rstd = rsqrtf(var + a.ln_eps);
+        const int64_t m = m0 + row;
+        if (m < a.m) {
+            half4 h4;
+            h4[0] = (_Float16)((v[it].x - mean[it]) * rstd * ga.x + be.x);
+            h4[1] = (_Float16)((v[it].y - mean[it]) * rstd * ga.y + be.y);
+            h4[2] = (_Float16)((v[it].z - mean[it]) * rstd * ga.z + be.z);
+            h4[3] = (_Float16)((v[it].w - mean[it]) * rstd * ga.w + be.w);
+            *reinterpret_cast<half4*>(lnout + EPI_ROW(m) * a.ldc2 + nb) = h4;
+        }
+    }
+}
+
 // Epilogue shared by the tile kernels.  The accumulator layout (column on the lane, 16 rows in registers) would cost
 // 16*TM*TN four-byte stores per lane; instead each wave transposes one 32 x (32*TN) slab at a time through its own
 // LDS region (slab_base: 4 x 32 x EPI_W floats holding no live data) and stores whole 16-byte vectors
@@ -411,10 +495,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
-template <int TM, int TN, int STAGES>
+template <int TM, int TN, int STAGES, int WN = 2>      // 4 waves as (4 / WN) x WN; wave tile (32 TM) x (32 TN)
 __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (it cannot parse the LDS-DMA builtin)
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int WM = 4 / WN;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE_BYTES = ROWS * 128;
     constexpr int IPW = ROWS / 32;                 // DMA instructions per wave and stage (8 rows each, 4 waves)
@@ -425,7 +510,7 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware tile order (1-D launch): the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
     // its own L2.  Workgroup w becomes logical tile L = (its XCD's contiguous range) + w / 8, and L walks the N tiles of
@@ -527,6 +612,12 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
     }
     __syncthreads();                               // all fragment reads done (and no DMA outstanding): the ring becomes slab space
 #ifndef RING_SKIP_EPI
+    if constexpr (WN == 4 && TM == 1) {
+        if (a.ln_gamma) {      // block = whole output rows (n == BN): residual add + LayerNorm of the result fused in
+            tile_epilogue_ln<TN>(a, acc[0], reinterpret_cast<float*>(ring), reinterpret_cast<float*>(ring + 4 * 32 * EPI_W * 4), m0, wn, wid, lane);
+            return;
+        }
+    }
     tile_epilogue<TM, TN>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
 #else
     if (acc[0][0][0] == 123.0f) a.out[0] = 1.0f;
@@ -993,6 +1084,35 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
                lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
                nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
     return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_ln(const void* x_f16, const void* w_f16, const float* bias, const float* residual, float* out,
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_f16, int64_t m, int32_t n, int32_t cin,
+                     int32_t cin_pad, int32_t lda, int32_t ldc, int32_t ldr, int32_t ld_ln, astts_stream_t stream) {
+    const int rc = check_gemm_args("astts_op_gemm_ln", (const float*)x_f16, w_f16, out, m, n, cin, cin_pad, 1, (int32_t)m, (int32_t)m, 1, 1,
+                                   ASTTS_ACT_NONE);
+    if (rc != ASTTS_OK) return rc;
+    ASTTS_REQUIRE(ln_gamma && ln_beta && ln_out_f16, ASTTS_ERR_INVALID, "astts_op_gemm_ln: null pointer");
+    ASTTS_REQUIRE(n == 256 && cin == cin_pad, ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_gemm_ln: n=%d cin=%d (a workgroup owns whole output rows: n must be 256, cin a multiple of 64)", n, cin);
+    ASTTS_REQUIRE((lda & 7) == 0 && (ldc & 3) == 0 && (ld_ln & 3) == 0 && (!residual || (ldr & 3) == 0) &&
+                      (((uintptr_t)x_f16 | (uintptr_t)out | (uintptr_t)ln_out_f16 | (uintptr_t)residual | (uintptr_t)bias |
+                        (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0,
+                  ASTTS_ERR_INVALID, "astts_op_gemm_ln: operands must be 16-byte aligned with 16-byte row strides");
+    GemmArgs a{(const float*)x_f16, (const _Float16*)w_f16, bias, residual, nullptr, out, m, n, cin, cin_pad, 1,
+               lda, ldc, ldr, (int32_t)m, (int32_t)m, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f,
+               nullptr, ln_gamma, ln_beta, ln_eps, (float*)ln_out_f16, ld_ln, 0, 1, 0, 1};
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<1, 2, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 288 * 128);
+        attr = true;
+    }
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)m * n * cin);
+    hipLaunchKernelGGL((gemm_ring<1, 2, 3, 4>), dim3((unsigned)cdiv(m, 32)), dim3(256), 3 * 288 * 128, st, a);
+    if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
 }
 
 size_t astts_op_gemm_fused_workspace_bytes(void) {

@@ -372,3 +372,25 @@ def test_gemm_fused_layernorm_gather_split_output():
     assert rel_err(q, ref[:, :1024]) < 2e-3                 # LayerNorm output rounded to fp16 before the MFMA
     assert rel_err(cache[1].float(), ref[:, 1024:]) < 3e-3
     assert float(cache[0].abs().max()) == 0.0 and float(cache[2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("m,k", [(333, 512), (5504, 1024), (64, 256), (31, 64)])
+def test_linear_with_fused_residual_and_layernorm(m, k):
+    """astts_op_gemm_ln: out = x @ w^T + b + residual (fp32) and LayerNorm(out) (fp16) from one launch."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).half()
+    w = torch.randn(256, k, generator=g) / math.sqrt(k)
+    b = torch.randn(256, generator=g)
+    res = torch.randn(m, 256, generator=g) * 3.0 + 0.7
+    ga, be = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+    pw = ops.PackedWeight(w, b)
+    out, ln = ops.linear_ln(x.to(DEV), pw, res.to(DEV), (ga.to(DEV), be.to(DEV)), 1e-5)
+    ref = F.linear(x.float(), h16(w), b) + res
+    assert rel_err(out, ref) < 2e-4
+    ref_ln = F.layer_norm(out.cpu(), (256,), ga, be, 1e-5)            # LayerNorm of the kernel's own fp32 result
+    assert float((ln.float().cpu() - ref_ln).abs().max()) < 4e-3     # fp16 output rounding
+    # the unfused pair of launches gives the same fp32 result bit for bit and the same LayerNorm up to fp16 rounding
+    out2 = ops.linear(x.to(DEV), pw, residual=res.to(DEV))
+    assert rel_err(out2, out) < 1e-6

@@ -308,14 +308,22 @@ def test_ragged_flow_batch_equals_one_at_a_time():
         assert float((mels[i].cpu() - ref).abs().max()) < 3e-2 * float(ref.abs().max()), i
 
 
-@pytest.mark.parametrize("b,t,ragged", [(2, 57, False), (3, 64, True), (1, 33, True)])
-def test_flow_solver_engine_is_bit_identical_to_operator_path(b, t, ragged):
+@pytest.mark.parametrize("b,t,ragged,wide", [(2, 57, False, False), (3, 64, True, False), (1, 33, True, False), (2, 70, True, True),
+                                             (2, 64, False, True)])
+def test_flow_solver_engine_is_bit_identical_to_operator_path(b, t, ragged, wide):
     """astts_flow_solve (C++ host loop) issues the same kernels as the operator-by-operator Python solve:
     the solved mel must be identical bit for bit (odd and even T exercise the stride-2 level and its transposed
     convolution; ragged rows exercise every length mask)."""
     from astts.synth.model import FlowDecoder
 
     cfg, W = _cfg_and_weights()
+    if wide:        # 256 estimator channels: the projections with the fused residual + LayerNorm epilogue (astts_op_gemm_ln)
+        import dataclasses
+
+        from astts.synth.weights import make_flow_weights
+
+        cfg = dataclasses.replace(cfg, est_channels=(256, 256), est_heads=4, est_mid_blocks=1, est_tfm_per_block=3)
+        W = {"flow": make_flow_weights(cfg, 3)}
     fd = FlowDecoder(W["flow"], cfg, torch.device(DEV))
     g = torch.Generator().manual_seed(b * 100 + t)
     z = torch.randn(b, t, cfg.mel, generator=g).to(DEV)
