@@ -10,6 +10,8 @@ Mirrors exactly the calls the reference makes (paths under /root/reference):
                                                             milvus/search_json.py:246-252
   .create_collection(collection_name, dimension) / .insert(collection_name, data=[{...}]) /
   .drop_collection(collection_name)                          milvus/RAG.py:49-57,541-544
+  FieldSchema / CollectionSchema / DataType, .create_collection(schema=CollectionSchema(...)), .create_index(...)
+                                                            milvus/insert_embeddings.py:52-79 (auto_id pk, VARCHAR fields)
 Result shape: ``list[Q]`` of ``list[k]`` of ``{'id': pk, 'distance': cosine_similarity,
 'entity': {field: value}}`` sorted by similarity descending (``distance`` IS the similarity for
 COSINE: output_emb/search_results.json holds 0.81..0.95, larger = closer).
@@ -32,6 +34,38 @@ import numpy as np
 from ..milvus_lite import MilvusLiteFile, MilvusLiteWriter
 
 
+class DataType:
+    """The pymilvus.DataType members the reference's bank builders use (milvus/insert_embeddings.py:53-56)."""
+    BOOL, INT8, INT16, INT32, INT64 = 1, 2, 3, 4, 5
+    FLOAT, DOUBLE = 10, 11
+    VARCHAR, JSON = 21, 23
+    FLOAT_VECTOR = 101
+
+
+class FieldSchema:
+    def __init__(self, name: str, dtype: int, description: str = "", is_primary: bool = False, auto_id: bool = False,
+                 dim: Optional[int] = None, max_length: Optional[int] = None, **_kw):
+        self.name, self.dtype, self.description = name, dtype, description
+        self.is_primary, self.auto_id, self.dim, self.max_length = bool(is_primary), bool(auto_id), dim, max_length
+
+
+class CollectionSchema:
+    """Explicit schema (milvus/insert_embeddings.py:52-63).  ``metric_type`` rides on the schema there (pymilvus ignores
+    unknown keyword arguments of CollectionSchema; the collection then gets its metric from the index) -- here it selects
+    the collection's metric directly, COSINE when absent."""
+
+    def __init__(self, fields: Sequence[FieldSchema], description: str = "", enable_dynamic_field: bool = False, **kw):
+        self.fields, self.description, self.enable_dynamic_field = list(fields), description, enable_dynamic_field
+        self.metric_type = kw.get("metric_type")
+        pks = [f for f in self.fields if f.is_primary]
+        vecs = [f for f in self.fields if f.dtype == DataType.FLOAT_VECTOR]
+        if len(pks) != 1 or len(vecs) != 1 or not vecs[0].dim:
+            raise MilvusException(1, "schema needs exactly one primary key and one FLOAT_VECTOR field with a dim")
+        self.primary_field, self.vector_field = pks[0], vecs[0]
+        self.auto_id = pks[0].auto_id
+        self.dim = int(vecs[0].dim)
+
+
 class MilvusException(Exception):
     def __init__(self, code: int = 1, message: str = ""):
         super().__init__(f"<MilvusException: (code={code}, message={message})>")
@@ -48,6 +82,7 @@ class _Collection:
         self.pk_field = pk_field
         self.vector_field = vector_field
         self.index_params = dict(index_params or {})
+        self.auto_id = False
         self.vectors: List[np.ndarray] = []
         self.pks: List[int] = []
         self.metas: List[Dict[str, Any]] = []
@@ -114,7 +149,7 @@ class MilvusClient:
         c = self._get(collection_name)
         return {
             "collection_name": c.name,
-            "auto_id": False,
+            "auto_id": c.auto_id,
             "num_shards": 0,
             "description": "",
             "fields": [
@@ -131,7 +166,13 @@ class MilvusClient:
     def create_collection(self, collection_name: str, dimension: Optional[int] = None,
                           primary_field_name: str = "id", vector_field_name: str = "vector",
                           metric_type: str = "COSINE", schema=None, index_params=None, **_kw) -> None:
-        if schema is not None and dimension is None:
+        auto_id = False
+        if isinstance(schema, CollectionSchema):      # explicit schema: field names, auto id, metric from the schema object
+            dimension = schema.dim
+            primary_field_name, vector_field_name = schema.primary_field.name, schema.vector_field.name
+            metric_type = schema.metric_type or metric_type
+            auto_id = schema.auto_id
+        elif schema is not None and dimension is None:
             dimension = getattr(schema, "dim", None) or (schema.get("dim") if isinstance(schema, dict) else None)
         if not dimension:
             raise MilvusException(1, "create_collection needs a dimension")
@@ -139,9 +180,20 @@ class MilvusClient:
             return
         self._colls[collection_name] = _Collection(collection_name, int(dimension), metric_type,
                                                    primary_field_name, vector_field_name)
+        self._colls[collection_name].auto_id = auto_id
         if self._file():
             self._file().create_collection(collection_name, int(dimension), metric_type, primary_field_name,
                                            vector_field_name)
+
+    def create_index(self, collection_name: str, field_name: Optional[str] = None, index_params=None, **_kw) -> None:
+        """milvus/insert_embeddings.py:75-79.  The search here is exact brute force on the GPU, so an index request only
+        records its parameters (and a metric, if it names one, for a collection that has no rows yet)."""
+        c = self._get(collection_name)
+        params = dict(index_params) if isinstance(index_params, dict) else {}
+        mt = params.get("metric_type") or (params.get("params") or {}).get("metric_type")
+        if mt and not c.pks:
+            c.metric = str(mt).upper()
+        c.index_params.update({k: str(v) for k, v in params.items()})
 
     def drop_collection(self, collection_name: str, **_kw) -> None:
         if self._colls.pop(collection_name, None) is not None and self._file():
@@ -162,7 +214,7 @@ class MilvusClient:
                 raise MilvusException(1100, f"the dim ({vec.size}) of field data({c.vector_field}) is not "
                                             f"equal to schema dim ({c.dim})")
             c.vectors.append(vec)
-            pk = int(r.get(c.pk_field, len(c.pks)))
+            pk = (max(c.pks) + 1 if c.pks else 1) if c.auto_id else int(r.get(c.pk_field, len(c.pks)))
             c.pks.append(pk)
             ids.append(pk)
             c.metas.append({k: v for k, v in r.items() if k not in (c.vector_field, c.pk_field)})

@@ -181,3 +181,31 @@ def test_compat_install_aliases():
             if k == "pymilvus" or k.startswith("cosyvoice"):
                 sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_milvus_client_explicit_schema_variant(tmp_path):
+    """milvus/insert_embeddings.py:52-79,519: FieldSchema / CollectionSchema / DataType, create_collection(schema=),
+    create_index(...), auto-generated primary keys, VARCHAR fields returned through output_fields."""
+    from astts.compat import pymilvus as pm
+
+    db = str(tmp_path / "explicit.db")
+    client = pm.MilvusClient(db)
+    fields = [pm.FieldSchema(name="id", dtype=pm.DataType.INT64, is_primary=True, auto_id=True),
+              pm.FieldSchema(name="file_id", dtype=pm.DataType.VARCHAR, max_length=500, description="File identifier"),
+              pm.FieldSchema(name="vector", dtype=pm.DataType.FLOAT_VECTOR, dim=16, description="Combined embedding vector"),
+              pm.FieldSchema(name="text", dtype=pm.DataType.VARCHAR, max_length=1000, description="Conversation text")]
+    schema = pm.CollectionSchema(fields=fields, description="Embeddings and biographies collection", metric_type="COSINE")
+    client.create_collection(collection_name="c", schema=schema)
+    client.create_index(collection_name="c", field_name="vector", index_params={"index_type": "IVF_FLAT", "params": {"nlist": 128}})
+    rng = np.random.default_rng(0)
+    rows = [{"file_id": f"f{i}", "vector": rng.standard_normal(16).astype(np.float32).tolist(), "text": f"t{i}"} for i in range(5)]
+    r = client.insert(collection_name="c", data=rows)
+    assert r["insert_count"] == 5 and r["ids"] == [1, 2, 3, 4, 5]            # auto_id
+    info = client.describe_collection("c")
+    assert info["num_entities"] == 5 and info["fields"][1]["params"]["dim"] == 16 and info["metric_type"] == "COSINE"
+    client.close()
+    c2 = pm.MilvusClient(db)                                               # persisted: metadata comes back from the file
+    c = c2._get("c")
+    assert c.pks == [1, 2, 3, 4, 5] and c.metas[2] == {"file_id": "f2", "text": "t2"}
+    with pytest.raises(pm.MilvusException):
+        pm.CollectionSchema(fields=fields[:2])                             # no vector field
