@@ -287,13 +287,28 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 // tile are independent, so their latency overlaps); each wave then filters its quarter of the tile
 // against its current c-th best and inserts the few survivors.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_part, int ksplit,
+// Fast path: the segment (<= 8192 scores, K-split planes summed) is staged in LDS once; the c-th largest score is found by a
+// 3-pass radix select on order-preserving keys (LDS histograms), the <= 64 entries at or above it are gathered and one wave
+// sorts them by (score desc, row asc).  Ties that push the gather past 64 entries fall back to the chunked sorted-list path
+// (each wave filters its share of the segment against its current c-th best and inserts the survivors).  The insertion path
+// alone took 36 us on 1000 scores -- most of a config-2 search.
+static constexpr int kSelSeg = 8192;      // host: seg_len <= kSelSeg
+
+__device__ __forceinline__ unsigned sel_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);       // larger float <=> larger unsigned key (-0 < +0 is harmless)
+}
+
+static constexpr int kSelThreads = 1024;
+__global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restrict__ s_part, int ksplit,
                                                   int qpad, int nld, int64_t n_all, int c, int seg_len,
                                                   int* __restrict__ cand_idx,
                                                   float* __restrict__ cand_s) {
-    __shared__ float tile[kSelTile];
-    __shared__ float sh_s[256];
-    __shared__ int sh_i[256];
+    __shared__ float seg[kSelSeg];
+    __shared__ float sh_s[kSelThreads];
+    __shared__ int sh_i[kSelThreads];
+    __shared__ unsigned hist[2048];
+    __shared__ int s_sel_bin, s_sel_rem, s_cnt;
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t plane = (size_t)qpad * nld;
@@ -301,40 +316,105 @@ __global__ __launch_bounds__(256) void knn_select(const float* __restrict__ s_pa
     // this block's segment of the row: [seg0, n)
     const int64_t seg0 = (int64_t)blockIdx.y * seg_len;
     const int64_t n = (seg0 + seg_len < n_all) ? seg0 + seg_len : n_all;
+    const int nl = (int)(n - seg0);
+    for (int i = tid; i < nl; i += kSelThreads) {
+        // K-split partial planes (up to ~100 for a small bank): eight independent loads in flight per thread
+        const float* pp = base + seg0 + i;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int ks = 0;
+        for (; ks + 8 <= ksplit; ks += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(ks + u) * plane];
+        }
+        for (; ks < ksplit; ++ks) v[0] += pp[(size_t)ks * plane];
+        seg[i] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     TopList<float> tl;
     tl.init();
-    bool seeded = false;
-    for (int64_t t0 = seg0; t0 < n; t0 += kSelTile) {
-        float v[kSelTile / 256];
+    bool fast = true;
+    if (nl > 64) {
+        unsigned prefix = 0u, known = 0u;
+        int remaining = c < nl ? c : nl;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+            const int bins = pass == 2 ? 1024 : 2048;
+            for (int i = tid; i < bins; i += kSelThreads) hist[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < nl; i += kSelThreads) {
+                const unsigned key = sel_key(seg[i]);
+                if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
+            }
+            __syncthreads();
+            if (wid == 0) {
+                const int per = bins >> 6;
+                unsigned local = 0u;
+                for (int j = 0; j < per; ++j) local += hist[lane * per + j];
+                unsigned incl = local;                       // sum over lanes >= lane
 #pragma unroll
-        for (int j = 0; j < kSelTile / 256; ++j) v[j] = 0.0f;
-        for (int ks = 0; ks < ksplit; ++ks) {
-#pragma unroll
-            for (int j = 0; j < kSelTile / 256; ++j) {
-                const int64_t i = t0 + j * 256 + tid;
-                if (i < n) v[j] += base[ks * plane + i];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned tv = __shfl_down(incl, off, 64);
+                    if (lane + off < 64) incl += tv;
+                }
+                const unsigned above = incl - local;
+                if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
+                    unsigned acc = above;
+                    for (int j = per - 1; j >= 0; --j) {
+                        const unsigned hcount = hist[lane * per + j];
+                        if (acc + hcount >= (unsigned)remaining) {
+                            s_sel_bin = lane * per + j;
+                            s_sel_rem = remaining - (int)acc;
+                            break;
+                        }
+                        acc += hcount;
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_sel_bin << shift;
+            known |= (unsigned)(bins - 1) << shift;
+            remaining = s_sel_rem;
+            __syncthreads();
+        }
+        for (int i = tid; i < nl; i += kSelThreads) {
+            if (sel_key(seg[i]) >= prefix) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < 64) {
+                    sh_s[pos] = seg[i];
+                    sh_i[pos] = (int)(seg0 + i);
+                }
             }
         }
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int j = 0; j < kSelTile / 256; ++j) tile[j * 256 + tid] = v[j];
         __syncthreads();
-#pragma unroll 1
-        for (int ch = 0; ch < kSelTile / 256; ++ch) {
-            const int li = wid * (kSelTile / 4) + ch * 64 + lane;
-            const int64_t i = t0 + li;
-            if (t0 + wid * (kSelTile / 4) + ch * 64 >= n) break;  // wave-uniform
-            const bool valid = i < n;
-            const float x = tile[li];
+        fast = s_cnt <= 64;
+    } else {
+        if (tid < nl) {
+            sh_s[tid] = seg[tid];
+            sh_i[tid] = (int)(seg0 + tid);
+        }
+        if (tid == 0) s_cnt = nl;
+        __syncthreads();
+    }
+    if (fast) {
+        if (wid == 0) tl.seed(sh_s[lane], sh_i[lane], lane < s_cnt, lane);   // the sort fixes the order whatever the gather order was
+    } else {
+        __syncthreads();
+        bool seeded = false;
+        for (int b0 = wid * 64; b0 < nl; b0 += kSelThreads) {
+            const int li = b0 + lane;
+            const bool valid = li < nl;
+            const float x = valid ? seg[li] : -INFINITY;
             if (!seeded) {
-                tl.seed(x, (int)i, valid, lane);
+                tl.seed(x, (int)(seg0 + li), valid, lane);
                 seeded = true;
             } else {
-                tl.offer(x, (int)i, valid, lane, c);
+                tl.offer(x, (int)(seg0 + li), valid, lane, c);
             }
         }
+        merge_lists<float>(tl, sh_s, sh_i, c);
     }
-    merge_lists<float>(tl, sh_s, sh_i, c);
     if (tid < c) {
         const size_t o = ((size_t)q * gridDim.y + blockIdx.y) * 64 + tid;
         cand_idx[o] = (tl.idx == kNoIdx) ? -1 : tl.idx;
@@ -526,9 +606,8 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.ksplit = (int)cdiv(total_lines, p.lines_per_split);
     p.c = k <= 8 ? 16 : 64;
     // selection segments: one block per (query, 8192-score segment), at most 64 segments per query
-    p.nseg = (int)cdiv(h->n, 8192);
-    if (p.nseg > 64) p.nseg = 64;
-    if (p.nseg < 1) p.nseg = 1;
+    p.nseg = (int)cdiv(h->n, 8192);       // segments of <= kSelSeg scores (staged in LDS by knn_select)
+    if (p.nseg < 1) p.nseg = 1;           // (astts_knn_create bounds n so that nseg <= 1024)
     p.seg_len = (int)align_up((size_t)cdiv(h->n, p.nseg), 64);
     p.nseg = (int)cdiv(h->n, p.seg_len);
     size_t o = 0;
@@ -586,6 +665,8 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     ASTTS_REQUIRE(bank != nullptr, ASTTS_ERR_INVALID, "astts_knn_create: bank is null");
     ASTTS_REQUIRE(n >= 1 && n <= 0x7fffffff - 4096, ASTTS_ERR_INVALID,
                   "astts_knn_create: n=%lld out of range", (long long)n);
+    ASTTS_REQUIRE(n <= (int64_t)1024 * kSelSeg, ASTTS_ERR_UNSUPPORTED,
+                  "astts_knn_create: n=%lld rows (selection covers at most 1024 segments of %d scores)", (long long)n, kSelSeg);
     ASTTS_REQUIRE(d >= 1 && d <= (1 << 20), ASTTS_ERR_INVALID, "astts_knn_create: d=%d out of range", d);
     ASTTS_REQUIRE(dtype == ASTTS_DTYPE_F16 || dtype == ASTTS_DTYPE_F32, ASTTS_ERR_INVALID,
                   "astts_knn_create: dtype %d (want ASTTS_DTYPE_F16|F32)", dtype);
@@ -744,11 +825,11 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
             h->ev_used += 2;
         }
         if (p.nseg == 1) {
-            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(256), 0, st, spart, p.ksplit, p.qpad, h->nld,
+            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, p.ksplit, p.qpad, h->nld,
                                h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
             ASTTS_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(256), 0, st, spart, p.ksplit, p.qpad, h->nld,
+            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, p.ksplit, p.qpad, h->nld,
                                h->n, p.c, p.seg_len, sidx, ss);
             ASTTS_CHECK_LAUNCH();
             hipLaunchKernelGGL(knn_select_merge, dim3(qg), dim3(64), 0, st, sidx, ss, p.nseg, p.c,
