@@ -11,7 +11,7 @@
 //   4 knn_rescore_finalize fp64 cosine of every candidate (one wave each), order by it, emit top-k and
 //                          CERTIFY the candidate set: kth exact score > best possible score of any
 //                          non-candidate (+ error bound); otherwise queue the query for the exact path
-//   5 knn_exact            fp64 scan + exact top-k for queued queries (normally: every block exits at once)
+//     (exact path: inside knn_rescore_finalize -- a query that cannot be certified is re-scanned in fp64 by its own block)
 //
 // HBM layout: the SCAN plane is stored pre-tiled in the order the scan consumes it -- fp16
 // [N/32 row tiles][Dp/64 lines][4 k-steps][64 lanes][8 halfs]: one (row tile, line) block is a contiguous 4 KB, one
@@ -469,7 +469,8 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
         if (lane == 0) sh_cos[ci] = cs;
     }
     __syncthreads();
-    if (wid != 0) return;
+    __shared__ int s_exact;
+    if (wid == 0) {
     const bool valid = lane < c;
     const int idx = valid ? cand_idx[q * 64 + lane] : -1;
     const bool live = valid && idx >= 0;
@@ -505,49 +506,35 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
             const double tau_cos = denom > 0.0 ? (double)tau / denom : INFINITY;
             certified = isfinite(tau_cos) && (kth > tau_cos + err_bound);
         }
-        if (!certified || force_exact) {
-            const int slot = atomicAdd(nflag, 1);
+        s_exact = (!certified || force_exact) ? 1 : 0;
+        if (s_exact) {
+            const int slot = atomicAdd(nflag, 1);     // astts_knn_last_fallbacks
             flagged[slot] = q;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// 5. exact path: block f serves the f-th queued query -- fp64 cosine against every row with the
-// same wave_dot64 as the re-score (so both paths return identical scores), exact top-k.
-// Rare by construction; one block streams the whole bank.
-// ------------------------------------------------------------------------------------------
-template <typename RowT>
-__global__ __launch_bounds__(256) void knn_exact(const float* __restrict__ qf,
-                                                 const double* __restrict__ qn64,
-                                                 const RowT* __restrict__ plane,
-                                                 const double* __restrict__ norm64, int64_t n, int dp,
-                                                 int k, const int* __restrict__ nflag,
-                                                 const int* __restrict__ flagged,
-                                                 int64_t* __restrict__ out_idx,
-                                                 float* __restrict__ out_score) {
-    __shared__ double sh_s[256];
-    __shared__ int sh_i[256];
-    const int f = blockIdx.x;
-    if (f >= *nflag) return;
-    const int q = flagged[f];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    }
+    __syncthreads();
+    if (!s_exact) return;
+    // ---- exact path (rare by construction): fp64 cosine against every row with the same wave_dot64 as the re-score (both
+    // paths return identical scores), exact top-k; this query's 16 waves stream the whole bank.  (Was a fifth launch whose
+    // blocks normally exited at once: 4.5 us of launch floor on a 38 us search.)
+    __shared__ double ex_s[1024];
+    __shared__ int ex_i[1024];
     const float* qrow = qf + (int64_t)q * dp;
-    const double qn = qn64[q];
     TopList<double> tl;
     tl.init();
-    for (int64_t base = (int64_t)wid * 64; base < n; base += 4 * 64) {
+    for (int64_t base = (int64_t)wid * 64; base < n; base += 16 * 64) {
         double mine = -INFINITY;
         const int64_t lim = (n - base) < 64 ? (n - base) : 64;
         for (int j = 0; j < lim; ++j) {
             const int64_t row = base + j;
             const double dot = wave_dot64<RowT>(qrow, plane + row * (int64_t)dp, dp, lane);
-            const double cs = cos_from_parts(dot, qn, norm64[row]);
-            if (lane == j) mine = cs;
+            const double csx = cos_from_parts(dot, qn, norm64[row]);
+            if (lane == j) mine = csx;
         }
         tl.offer(mine, (int)(base + lane), lane < lim, lane, k);
     }
-    merge_lists<double>(tl, sh_s, sh_i, k);
+    merge_lists<double>(tl, ex_s, ex_i, k);
     if (tid < k) {
         const bool ok = tl.idx != kNoIdx;
         out_idx[(int64_t)q * k + tid] = ok ? tl.idx : -1;
@@ -842,16 +829,10 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
         hipLaunchKernelGGL((knn_rescore_finalize<_Float16>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
                            h->plane16, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
                            out_idx, out_score, nflag, flagged);
-        ASTTS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((knn_exact<_Float16>), dim3(nq), dim3(256), 0, st, qf, qn, h->plane16,
-                           h->norm64, h->n, h->dp, k, nflag, flagged, out_idx, out_score);
     } else {
         hipLaunchKernelGGL((knn_rescore_finalize<float>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
                            h->plane32, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
                            out_idx, out_score, nflag, flagged);
-        ASTTS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((knn_exact<float>), dim3(nq), dim3(256), 0, st, qf, qn, h->plane32,
-                           h->norm64, h->n, h->dp, k, nflag, flagged, out_idx, out_score);
     }
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
