@@ -139,9 +139,12 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
     if (row >= nq) {  // zero rows completing the last 32-query tile
         const int qt = row >> 5, r = row & 31;
         _Float16* tb = qh + (int64_t)qt * (dp >> 6) * 2048;
-        for (int k = tid; k < dp; k += 256) {
+        half8 zero8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.0f;
+        for (int k = tid * 8; k < dp; k += 2048) {
             const int line = k >> 6, kk = k & 63;
-            tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8 + (kk & 7)] = (_Float16)0.0f;
+            *reinterpret_cast<half8*>(&tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8]) = zero8;
         }
         return;
     }
@@ -149,7 +152,37 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
     float* of = qf + (int64_t)row * dp;
     float mx = 0.0f;
     double acc = 0.0;
-    for (int k = tid; k < dp; k += 256) {
+    // eight consecutive elements per thread and step: they are one 16-byte group of the tiled fp16 image, so the row is
+    // read once (kept in registers across the block-wide max) and every store is a whole vector.  dp is a multiple of 64.
+    constexpr int MAXG = 4;                        // groups per thread: covers dp <= 8192; longer rows loop again below
+    const bool vec = ((uintptr_t)s & 15) == 0 && (d & 3) == 0;
+    float vreg[MAXG][8];
+    const int ngroups = dp >> 3;
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+        const int g8 = (tid + gi * 256) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vreg[gi][j] = 0.0f;
+        if (tid + gi * 256 < ngroups) {
+            if (vec && g8 + 8 <= d) {
+                const float4 a0 = *reinterpret_cast<const float4*>(s + g8);
+                const float4 a1 = *reinterpret_cast<const float4*>(s + g8 + 4);
+                vreg[gi][0] = a0.x; vreg[gi][1] = a0.y; vreg[gi][2] = a0.z; vreg[gi][3] = a0.w;
+                vreg[gi][4] = a1.x; vreg[gi][5] = a1.y; vreg[gi][6] = a1.z; vreg[gi][7] = a1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vreg[gi][j] = (g8 + j < d) ? s[g8 + j] : 0.0f;
+            }
+            *reinterpret_cast<float4*>(of + g8) = make_float4(vreg[gi][0], vreg[gi][1], vreg[gi][2], vreg[gi][3]);
+            *reinterpret_cast<float4*>(of + g8 + 4) = make_float4(vreg[gi][4], vreg[gi][5], vreg[gi][6], vreg[gi][7]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mx = fmaxf(mx, fabsf(vreg[gi][j]));
+                acc = fma((double)vreg[gi][j], (double)vreg[gi][j], acc);
+            }
+        }
+    }
+    for (int k = MAXG * 2048 + tid; k < dp; k += 256) {      // rows longer than 8192
         float v = (k < d) ? s[k] : 0.0f;
         of[k] = v;
         mx = fmaxf(mx, fabsf(v));
@@ -176,8 +209,19 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
     {   // tiled fp16 image, same (row tile, line, k-step, lane) order as the bank's scan plane
         const int qt = row >> 5, r = row & 31;
         _Float16* tb = qh + (int64_t)qt * (dp >> 6) * 2048;
-        for (int k = tid; k < dp; k += 256) {
-            float v = (k < d) ? s[k] : 0.0f;  // second read hits L1/L2
+#pragma unroll
+        for (int gi = 0; gi < MAXG; ++gi) {
+            if (tid + gi * 256 < ngroups) {
+                const int k = (tid + gi * 256) * 8;
+                const int line = k >> 6, kk = k & 63;
+                half8 hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(vreg[gi][j] * scale);
+                *reinterpret_cast<half8*>(&tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8]) = hv;
+            }
+        }
+        for (int k = MAXG * 2048 + tid; k < dp; k += 256) {
+            float v = (k < d) ? s[k] : 0.0f;
             const int line = k >> 6, kk = k & 63;
             tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8 + (kk & 7)] = (_Float16)(v * scale);
         }
