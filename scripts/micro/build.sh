@@ -1,0 +1,18 @@
+#!/bin/sh
+# Builds the stand-alone micro-benchmarks for gfx950 (run them on the GPU box: gpurun -- 'cd scripts/micro && ./ring_bench').
+#   ring_bench          GEMM kernels on the flow decoder's projection shapes (ASTTS_GEMM_RING=0|1|2|3 selects the kernel / tile)
+#   ring_bench_<parts>  the same with parts of gemm_ring compiled out, to see where a block's time goes
+#   ring_bench_local    every block stores to the first rows: epilogue cost without HBM traffic
+#   glds_check          semantics of global_load_lds_dwordx4 (lane-linear LDS destination)
+#   coherence           reader-after-writer in one stream while a second stream keeps the GPU busy
+set -e
+cd "$(dirname "$0")"
+F="-O3 --offload-arch=gfx950"
+hipcc $F ring_bench.hip -o ring_bench
+hipcc $F -DRING_SKIP_MFMA ring_bench.hip -o ring_bench_nomfma
+hipcc $F -DRING_SKIP_EPI ring_bench.hip -o ring_bench_noepi
+hipcc $F -DRING_SKIP_LOAD ring_bench.hip -o ring_bench_noload
+hipcc $F -DRING_SKIP_MFMA -DRING_SKIP_EPI ring_bench.hip -o ring_bench_loadonly
+hipcc $F -DEPI_DBG_LOCAL ring_bench.hip -o ring_bench_local
+hipcc -O2 --offload-arch=gfx950 glds_check.hip -o glds_check
+hipcc -O2 --offload-arch=gfx950 coherence.hip -o coherence
