@@ -991,7 +991,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         // per CU) for wide outputs; for n <= 256 the 128x128 tile once there are >= 160 of them, 64x64 for short K
         int mode;
         if (a.n >= 512) mode = blocks(128, 64) >= 160 ? 2 : 3;
-        else if (blocks(128, 128) >= 160) mode = 1;
+        else if (blocks(128, 128) >= 160 && blocks(128, 128) < 512) mode = 1;     // (beyond ~2 blocks per CU the 128x64 tile wins again)
         else if (a.cin_pad <= 512 || blocks(128, 64) < 160) mode = 3;
         else mode = 2;
         if (ring_env > 0) mode = ring_env;

@@ -6,7 +6,8 @@
 #define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(r_)); exit(1); } } while (0)
 int main() {
     struct S { int m, k, n, out16, res; } shapes[] = {{5504, 256, 1536, 1, 0}, {5504, 256, 1024, 1, 0}, {5504, 512, 256, 0, 1},
-                                                     {5504, 1024, 256, 0, 1}, {11008, 256, 1536, 1, 0}, {11008, 1024, 256, 0, 1}};
+                                                     {5504, 1024, 256, 0, 1}, {11008, 256, 1536, 1, 0}, {11008, 1024, 256, 0, 1},
+                                                     {90816, 256, 1536, 1, 0}, {90816, 256, 1024, 1, 0}, {90816, 512, 256, 0, 1}, {90816, 1024, 256, 0, 1}};
     hipStream_t st; CK(hipStreamCreate(&st));
     for (auto s : shapes) {
         _Float16 *x, *w; float *out, *res, *bias;
