@@ -273,6 +273,24 @@ def main():
         sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
     torch.cuda.synchronize()
     knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
+    traffic_table = {}
+    try:   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE; cannot be collected inside this run)
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic_table = json.load(f)
+    except OSError:
+        pass
+    # retrieval kernel against ITS roofline (HBM: the bank is read once per search): HIP events around the scan launch
+    sb.profile_enable(True)
+    for _ in range(100):
+        sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
+    torch.cuda.synchronize()
+    scan_ms, scan_n = sb.profile_read()
+    sb.profile_enable(False)
+    scan_us = scan_ms * 1e3 / max(scan_n, 1)
+    knn_bytes = args.bank_rows * args.dim * 2 + args.batch * args.dim * 4 + args.batch * args.topk * 12
+    knn_roof = {"bound": "hbm", "kernel": "knn_scan", "achieved": knn_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": knn_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": scan_us, "algorithmic_bytes_per_launch": knn_bytes,
+                "traffic": traffic_table.get("knn_scan_1000_x_6144", {}).get("hbm_bytes_per_launch") if args.bank_rows == 1000 and args.dim == 6144 else None}
     from oracle import knn as oknn
 
     eidx, _ = oknn.knn_search(bank16, q_host, args.topk)
@@ -298,12 +316,7 @@ def main():
     else:
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
-    traffic = None
-    try:   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE; cannot be collected inside this run)
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        pass
+    traffic = traffic_table.get(dom, {}).get("hbm_bytes_per_launch")
     roof.update({"traffic": traffic, "traffic_source": "profiles/r01_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
                  "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
                  "launches_per_step": p["launches"],
@@ -330,6 +343,7 @@ def main():
                                    f"-> {inp.tm} mel frames -> {inp.tm * cfg.upsample_total} samples @ {cfg.sample_rate} Hz; CosyVoice-300M shapes, random-init weights",
                        "parallelism": f"dp{world} (model + bank replicated, utterances sharded, all-gather of style ids only)"},
             "knn_qps": knn_qps,
+            "knn_roofline": knn_roof,
             "ids_match_oracle": ids_ok,
             "waveform_finite_and_clamped": wav_ok,
             "pipelining": f"{pipe.depth + 1} HIP streams: the LM decode chains of {pipe.depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe.tuned_ms_per_batch:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
