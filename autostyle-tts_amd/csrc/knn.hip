@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
                                                         float* __restrict__ qf,
                                                         double* __restrict__ qn64,
                                                         float* __restrict__ qscale,
-                                                        int* __restrict__ nflag) {
+                                                        int* __restrict__ nflag,
+                                                        _Float16* __restrict__ qrow) {
     __shared__ float smax[4];
     __shared__ double ssum[4];
     const int row = blockIdx.x;
@@ -218,12 +219,14 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(vreg[gi][j] * scale);
                 *reinterpret_cast<half8*>(&tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8]) = hv;
+                if (qrow) *reinterpret_cast<half8*>(&qrow[(int64_t)row * dp + k]) = hv;      // row-major copy for the GEMM scan
             }
         }
         for (int k = MAXG * 2048 + tid; k < dp; k += 256) {
             float v = (k < d) ? s[k] : 0.0f;
             const int line = k >> 6, kk = k & 63;
             tb[((int64_t)line << 11) + ((kk & 31) >> 3) * 512 + ((kk >> 5) * 32 + r) * 8 + (kk & 7)] = (_Float16)(v * scale);
+            if (qrow) qrow[(int64_t)row * dp + k] = (_Float16)(v * scale);
         }
     }
     if (tid == 0) {
@@ -347,7 +350,8 @@ static constexpr int kSelThreads = 1024;
 __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restrict__ s_part, int ksplit,
                                                   int qpad, int nld, int64_t n_all, int c, int seg_len,
                                                   int* __restrict__ cand_idx,
-                                                  float* __restrict__ cand_s) {
+                                                  float* __restrict__ cand_s,
+                                                  const float* __restrict__ inv_norm) {
     __shared__ float seg[kSelSeg];
     __shared__ float sh_s[kSelThreads];
     __shared__ int sh_i[kSelThreads];
@@ -371,7 +375,8 @@ __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restric
             for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(ks + u) * plane];
         }
         for (; ks < ksplit; ++ks) v[0] += pp[(size_t)ks * plane];
-        seg[i] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        seg[i] = inv_norm ? sum * inv_norm[seg0 + i] : sum;      // the GEMM scan leaves raw dot products
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
@@ -614,6 +619,8 @@ namespace {
 
 struct KnnPlan {
     int qt, rt, ksplit, lines_per_split, tiles, qpad, c, nseg, seg_len;
+    bool gemm;       // query groups of >= 64: the scan is a plain GEMM on the ring kernel (MFMA-side regime)
+    size_t off_qrow;
     size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, total;
 };
 
@@ -635,6 +642,13 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     if (ks_env > 0) ks = ks_env < ks_max ? ks_env : ks_max;  // tuning override
     p.lines_per_split = (int)cdiv(total_lines, ks);
     p.ksplit = (int)cdiv(total_lines, p.lines_per_split);
+    static const bool nogemm_env = getenv("ASTTS_KNN_NO_GEMM") != nullptr;
+    // ... once the GEMM grid fills the chip; a small bank keeps the K-split scan (16 blocks x 96 K tiles would crawl)
+    p.gemm = !nogemm_env && qgroup >= 64 && cdiv(qgroup, 128) * cdiv(h->n, 64) >= 256;
+    if (p.gemm) {        // one score plane; a tail group of < 64 queries runs the register-streaming scan unsplit
+        p.ksplit = 1;
+        p.lines_per_split = total_lines;
+    }
     p.c = k <= 8 ? 16 : 64;
     // selection segments: one block per (query, 8192-score segment), at most 64 segments per query
     p.nseg = (int)cdiv(h->n, 8192);       // segments of <= kSelSeg scores (staged in LDS by knn_select)
@@ -651,6 +665,7 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.off_flagged = take(sizeof(int) * (size_t)nq);
     p.off_qh = take(sizeof(_Float16) * (align_up((size_t)nq, 32) + 256) * h->dp);  // whole 32-query tiles (+ one group's tail)
     p.off_qf = take(sizeof(float) * (size_t)nq * h->dp);
+    p.off_qrow = take(p.gemm ? sizeof(_Float16) * (size_t)nq * h->dp : 16);
     p.off_qn = take(sizeof(double) * (size_t)nq);
     p.off_qscale = take(sizeof(float) * (size_t)nq);
     p.off_spart = take(sizeof(float) * (size_t)p.ksplit * p.qpad * h->nld);
@@ -821,6 +836,7 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
     int* flagged = (int*)(ws + p.off_flagged);
     _Float16* qh = (_Float16*)(ws + p.off_qh);
     float* qf = (float*)(ws + p.off_qf);
+    _Float16* qrow = p.gemm ? (_Float16*)(ws + p.off_qrow) : nullptr;
     double* qn = (double*)(ws + p.off_qn);
     float* qscale = (float*)(ws + p.off_qscale);
     float* spart = (float*)(ws + p.off_spart);
@@ -830,7 +846,7 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
     float* ss = (float*)(ws + p.off_ss);
 
     hipLaunchKernelGGL(knn_prep_queries, dim3((unsigned)align_up((size_t)nq, 32)), dim3(256), 0, st, queries, nq, h->d, h->dp,
-                       qh, qf, qn, qscale, nflag);
+                       qh, qf, qn, qscale, nflag, qrow);
     ASTTS_CHECK_LAUNCH();
 
     for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {
@@ -839,6 +855,14 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
         int rc;
         const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
         if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
+        if (p.gemm && qg >= 64) {
+            // S[q][n] = <q, b_n> as one GEMM: activations = this group's queries (row-major fp16), "weights" = the bank's
+            // row-major fp16 plane [n][dp]; the LDS-DMA ring kernel runs it at 400+ TFLOP/s where the register-streaming scan
+            // (built for the HBM-bound small-Q regime) re-reads the query tile from L2 per bank tile.  1 / |b_n| is applied
+            // by the selection kernel.
+            rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
+                                  h->dp, h->dp, 1, h->dp, h->nld, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f, stream);
+        } else
         switch (p.qt * 10 + p.rt) {
             case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, st); break;
             case 14: rc = launch_scan<1, 4>(h, p, qh_g, qg, spart, st); break;
@@ -855,13 +879,15 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
             ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_used += 2;
         }
+        const float* sel_inv = (p.gemm && qg >= 64) ? h->inv_norm : nullptr;
+        const int sel_ks = (p.gemm && qg >= 64) ? 1 : p.ksplit;
         if (p.nseg == 1) {
-            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, p.ksplit, p.qpad, h->nld,
-                               h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
+            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
+                               h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv);
             ASTTS_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, p.ksplit, p.qpad, h->nld,
-                               h->n, p.c, p.seg_len, sidx, ss);
+            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
+                               h->n, p.c, p.seg_len, sidx, ss, sel_inv);
             ASTTS_CHECK_LAUNCH();
             hipLaunchKernelGGL(knn_select_merge, dim3(qg), dim3(64), 0, st, sidx, ss, p.nseg, p.c,
                                cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);

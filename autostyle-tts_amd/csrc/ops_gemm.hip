@@ -545,7 +545,9 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
         } else {
             const int lr = row - BM;
             const int c = slot ^ ((lr >> 1) & 7);
-            src[i] = a.w + (int64_t)(n0 + lr) * ktot + c * 8;
+            int nn = n0 + lr;                      // packed weights are padded to whole tiles; a raw [n][K] matrix (the kNN bank) is not
+            if (nn >= a.n) nn = a.n - 1;
+            src[i] = a.w + (int64_t)nn * ktot + c * 8;
         }
     }
     auto issue = [&](int kt) {
