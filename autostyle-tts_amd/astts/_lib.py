@@ -50,6 +50,10 @@ _SIGNATURES = {
     "astts_knn_last_fallbacks": (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(c_int32)]),
     "astts_knn_profile_enable": (c_int32, [c_void_p, c_int32]),
     "astts_knn_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    # frontend signal processing (astts/audio.py)
+    "astts_op_resample_poly": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_mel_spectrogram": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float,
+                                           c_void_p]),
 }
 
 

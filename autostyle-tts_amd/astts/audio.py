@@ -81,11 +81,9 @@ def write_wav(path: str, wav, sample_rate: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------ resampling
-def resample(x: torch.Tensor, sr_in: int, sr_out: int, zeros: int = 6, rolloff: float = 0.99) -> torch.Tensor:
-    """Band-limited polyphase resampling (Hann-windowed sinc, the torchaudio ``sinc_interp_hann`` recipe).
-    x: [..., n] float32."""
-    if sr_in == sr_out:
-        return x
+def _resample_kernel(sr_in: int, sr_out: int, zeros: int = 6, rolloff: float = 0.99):
+    """Hann-windowed sinc table of the polyphase resampler (the torchaudio ``sinc_interp_hann`` recipe)
+    -> (kern fp32 [up, 2 width + down], up, down, width)."""
     g = math.gcd(sr_in, sr_out)
     up, down = sr_out // g, sr_in // g
     base = min(up, down) * rolloff
@@ -96,14 +94,37 @@ def resample(x: torch.Tensor, sr_in: int, sr_out: int, zeros: int = 6, rolloff: 
     window = torch.cos(t * math.pi / zeros / 2) ** 2
     t = t * math.pi
     kern = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / down)
-    kern = kern.to(torch.float32)[:, None, :]                       # [up, 1, k]
+    return kern.to(torch.float32), up, down, width
+
+
+def resample(x: torch.Tensor, sr_in: int, sr_out: int, zeros: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """Band-limited polyphase resampling.  x: [..., n] float32.  CUDA tensors run astts_op_resample_poly (HIP); host
+    tensors run the same table through a strided convolution (file loading, tests)."""
+    if sr_in == sr_out:
+        return x
+    kern, up, down, width = _resample_kernel(sr_in, sr_out, zeros, rolloff)
     shape = x.shape
+    n_out = int(math.ceil(up * shape[-1] / down))
+    if x.is_cuda:
+        from . import _lib
+        key = (sr_in, sr_out, zeros, rolloff, x.device.index)
+        kd = _KERNEL_CACHE.get(key)
+        if kd is None:
+            kd = _KERNEL_CACHE[key] = kern.contiguous().to(x.device)
+        xx = x.reshape(-1, shape[-1]).to(torch.float32).contiguous()
+        y = torch.empty((xx.shape[0], n_out), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().astts_op_resample_poly(xx.data_ptr(), kd.data_ptr(), y.data_ptr(), xx.shape[0], xx.shape[1], n_out, up, down,
+                                                      width, _lib.stream_ptr()))
+        return y.reshape(*shape[:-1], n_out)
+    kern = kern[:, None, :]                                         # [up, 1, k]
     xx = x.reshape(-1, 1, shape[-1]).to(torch.float32)
     xx = torch.nn.functional.pad(xx, (width, width + down))
     y = torch.nn.functional.conv1d(xx, kern, stride=down)            # [N, up, frames]
     y = y.transpose(1, 2).reshape(xx.shape[0], -1)
-    n_out = int(math.ceil(up * shape[-1] / down))
     return y[:, :n_out].reshape(*shape[:-1], n_out)
+
+
+_KERNEL_CACHE: dict = {}
 
 
 def load_wav(path: str, target_sr: int) -> torch.Tensor:
@@ -144,8 +165,23 @@ def mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -
 def mel_spectrogram(wav: torch.Tensor, sr: int = 22050, n_fft: int = 1024, hop: int = 256, win: int = 1024,
                     n_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0) -> torch.Tensor:
     """matcha-style log-mel used for the timbre prompt: reflect pad (n_fft-hop)/2, magnitude STFT, Slaney mel,
-    log(clamp(., 1e-5)).  wav [1, n] -> [1, frames, n_mels]."""
+    log(clamp(., 1e-5)).  wav [B, n] -> [B, frames, n_mels].  CUDA input: HIP kernel; host input: torch.stft (tests, stand-ins)."""
     pad = (n_fft - hop) // 2
+    if wav.is_cuda:            # astts_op_mel_spectrogram (HIP): same definition, one block per frame
+        from . import _lib
+        assert win == n_fft
+        key = ("mel", sr, n_fft, n_mels, fmin, fmax, wav.device.index)
+        tabs = _KERNEL_CACHE.get(key)
+        if tabs is None:
+            tabs = _KERNEL_CACHE[key] = (torch.hann_window(win).to(wav.device),
+                                         torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).contiguous().to(wav.device))
+        w = wav.to(torch.float32).contiguous()
+        b, n = w.shape
+        frames = (n + 2 * pad - n_fft) // hop + 1
+        out = torch.empty((b, frames, n_mels), dtype=torch.float32, device=wav.device)
+        _lib.check(_lib.load().astts_op_mel_spectrogram(w.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), out.data_ptr(), b, n, n_fft, hop,
+                                                        n_mels, 1e-5, _lib.stream_ptr()))
+        return out
     y = torch.nn.functional.pad(wav[:, None, :], (pad, pad), mode="reflect")[:, 0]
     spec = torch.stft(y, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False,
                       return_complex=True)

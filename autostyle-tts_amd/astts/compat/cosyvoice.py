@@ -60,7 +60,7 @@ class CosyVoice:
             self.random_init = True
         self.engine = SynthEngine(state, config, device)          # raises without a GPU: no CPU fallback
         self.device = self.engine.device
-        self.frontend = frontend or Frontend(config)
+        self.frontend = frontend or Frontend(config, device=self.device)
         self._gen = torch.Generator().manual_seed(seed)
         self.min_token_text_ratio, self.max_token_text_ratio = 2, 20
 

@@ -108,8 +108,9 @@ class PromptFeatures:
 
 class Frontend:
     def __init__(self, cfg: SynthConfig, tokenizer=None, speech_tokenizer: Optional[Callable] = None,
-                 speaker_embedder: Optional[Callable] = None, features: Optional[Dict[str, PromptFeatures]] = None):
+                 speaker_embedder: Optional[Callable] = None, features: Optional[Dict[str, PromptFeatures]] = None, device=None):
         self.cfg = cfg
+        self.device = device            # a CUDA device: the resampler and the prompt mel run as HIP kernels (astts/audio.py)
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab)
         self.speech_tokenizer = speech_tokenizer or EnergyVQSpeechTokenizer(cfg.speech_vocab)
         self.speaker_embedder = speaker_embedder or StatsSpeakerEmbedder(cfg.spk_dim)
@@ -127,9 +128,10 @@ class Frontend:
         cfg = self.cfg
         tok = self.speech_tokenizer(wav16k)
         emb = self.speaker_embedder(wav16k)
-        wav_sr = audio.resample(wav16k, 16000, cfg.sample_rate)
+        src = wav16k.to(self.device) if self.device is not None else wav16k
+        wav_sr = audio.resample(src, 16000, cfg.sample_rate)
         mel = audio.mel_spectrogram(wav_sr, sr=cfg.sample_rate, n_fft=1024, hop=cfg.hop, win=1024, n_mels=cfg.mel,
-                                    fmin=0.0, fmax=8000.0)
+                                    fmin=0.0, fmax=8000.0).cpu()
         n_tok = min(tok.shape[1], int(mel.shape[1] * cfg.token_rate * cfg.hop / cfg.sample_rate))
         n_mel = cfg.mel_frames_for_tokens(n_tok)
         return PromptFeatures(tok[:, :n_tok].contiguous(), emb, mel[:, :n_mel].contiguous())

@@ -363,6 +363,79 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ frontend
+// Polyphase resampler of cosyvoice.utils.file_utils.load_wav / the prompt path (tts_with_rag.py:180-186 -> frontend [EXT]):
+// y[f * up + p] = sum_j kern[p][j] * xpad[f * down + j], xpad = x zero-padded by `width` on the left (the host builds the
+// Hann-windowed sinc table exactly as astts.audio.resample does).  One thread per output sample.
+__global__ __launch_bounds__(256) void resample_poly(const float* __restrict__ x, const float* __restrict__ kern, float* __restrict__ y,
+                                                     int b, int64_t n_in, int64_t n_out, int up, int down, int width, int taps) {
+    const int64_t total = (int64_t)b * n_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bb = i / n_out, o = i - bb * n_out;
+        const int64_t f = o / up;
+        const int ph = (int)(o - f * up);
+        const float* xr = x + bb * n_in;
+        const float* kr = kern + (int64_t)ph * taps;
+        const int64_t s0 = f * down - width;          // input index of tap 0
+        float acc = 0.0f;
+        for (int j = 0; j < taps; ++j) {
+            const int64_t s = s0 + j;
+            const float kv = kr[j];
+            if (kv != 0.0f && s >= 0 && s < n_in) acc = fmaf(kv, xr[s], acc);
+        }
+        y[i] = acc;
+    }
+}
+
+// Log-mel spectrogram (matcha / whisper style): reflect padding (n_fft - hop) / 2, Hann window, magnitude of the n_fft-point
+// DFT, mel filterbank, log(clamp(., floor)).  One block per frame: the windowed frame and the twiddle table sit in LDS, every
+// thread evaluates its bins by direct summation in fp32 (index k n mod n_fft into the table) -- n_fft <= 1024 and a few
+// hundred frames per prompt: 0.3 GFLOP, far below anything worth an FFT.
+__global__ __launch_bounds__(256) void mel_frames(const float* __restrict__ wav, const float* __restrict__ window,
+                                                  const float* __restrict__ fb, float* __restrict__ out, int64_t n, int frames,
+                                                  int n_fft, int hop, int n_mels, float floor_) {
+    extern __shared__ float sm[];
+    float* fr = sm;                       // [n_fft] windowed frame
+    float* twc = sm + n_fft;              // [n_fft] cos(2 pi i / n_fft)
+    float* tws = twc + n_fft;             // [n_fft] sin
+    float* mag = tws + n_fft;             // [n_fft / 2 + 1]
+    const int f = blockIdx.x, bb = blockIdx.y, tid = threadIdx.x;
+    const int pad = (n_fft - hop) / 2;
+    const float* w = wav + (int64_t)bb * n;
+    for (int i = tid; i < n_fft; i += 256) {
+        int64_t s = (int64_t)f * hop + i - pad;
+        if (s < 0) s = -s;                                     // reflect (no edge repeat)
+        if (s >= n) s = 2 * (n - 1) - s;
+        s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+        fr[i] = w[s] * window[i];
+        float sv, cv;
+        sincospif(2.0f * (float)i / (float)n_fft, &sv, &cv);
+        twc[i] = cv;
+        tws[i] = sv;
+    }
+    __syncthreads();
+    const int nb = n_fft / 2 + 1;
+    for (int k = tid; k < nb; k += 256) {
+        float re = 0.0f, im = 0.0f;
+        int idx = 0;
+        for (int i = 0; i < n_fft; ++i) {
+            re = fmaf(fr[i], twc[idx], re);
+            im = fmaf(fr[i], tws[idx], im);
+            idx += k;
+            if (idx >= n_fft) idx -= n_fft;
+        }
+        mag[k] = sqrtf(re * re + im * im + 1e-9f);
+    }
+    __syncthreads();
+    for (int m = tid; m < n_mels; m += 256) {
+        const float* fr_ = fb + (int64_t)m * nb;
+        float acc = 0.0f;
+        for (int k = 0; k < nb; ++k) acc = fmaf(fr_[k], mag[k], acc);
+        out[((int64_t)bb * frames + f) * n_mels + m] = logf(fmaxf(acc, floor_));
+    }
+}
+
 }  // namespace astts
 
 using namespace astts;
@@ -435,6 +508,35 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
     SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+
+int astts_op_resample_poly(const float* x, const float* kern, float* y, int32_t b, int64_t n_in, int64_t n_out, int32_t up, int32_t down,
+                           int32_t width, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && kern && y, ASTTS_ERR_INVALID, "astts_op_resample_poly: null pointer");
+    ASTTS_REQUIRE(b >= 1 && n_in >= 1 && n_out >= 1 && up >= 1 && down >= 1 && width >= 0, ASTTS_ERR_INVALID,
+                  "astts_op_resample_poly: bad shape");
+    hipLaunchKernelGGL(resample_poly, dim3(grid_for_a((int64_t)b * n_out)), dim3(256), 0, (hipStream_t)stream, x, kern, y, b, n_in, n_out, up,
+                       down, width, 2 * width + down);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_mel_spectrogram(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
+                             int32_t n_fft, int32_t hop, int32_t n_mels, float log_floor, astts_stream_t stream) {
+    ASTTS_REQUIRE(wav && window && mel_fb && out, ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: null pointer");
+    ASTTS_REQUIRE(b >= 1 && n_fft >= 16 && n_fft <= 2048 && hop >= 1 && hop <= n_fft && n_mels >= 1 && log_floor > 0.0f,
+                  ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: bad shape n_fft=%d hop=%d n_mels=%d", n_fft, hop, n_mels);
+    const int pad = (n_fft - hop) / 2;
+    ASTTS_REQUIRE(n_samples > pad, ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: %lld samples are shorter than the reflect padding %d",
+                  (long long)n_samples, pad);
+    const int64_t frames = (n_samples + 2 * pad - n_fft) / hop + 1;
+    ASTTS_REQUIRE(frames >= 1 && frames < (1 << 30), ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: frames=%lld", (long long)frames);
+    const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
+    hipLaunchKernelGGL(mel_frames, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
+                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -240,6 +240,16 @@ int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise
 int astts_op_stft16(const float* x, float* y, int32_t b, int64_t n_samples, astts_stream_t stream);
 int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit,
                      astts_stream_t stream);
+/* Frontend signal processing on the GPU (the reference does both on the host inside CosyVoice's frontend
+ * [EXT], reached from load_wav / inference_* at tts_with_rag.py:180-195):
+ * polyphase resampler  y[f * up + p] = sum_j kern[p][j] * x[f * down + j - width]  (kern [up][2 width + down]: the Hann-windowed
+ * sinc table of astts.audio.resample, zero outside its support; x zero beyond its ends), and the log-mel spectrogram
+ * (reflect padding (n_fft - hop) / 2, window[n_fft], magnitude DFT, mel_fb [n_mels][n_fft / 2 + 1], log(max(., log_floor)))
+ * -> out [b, frames, n_mels], frames = (n_samples + 2 pad - n_fft) / hop + 1. */
+int astts_op_resample_poly(const float* x, const float* kern, float* y, int32_t b, int64_t n_in, int64_t n_out, int32_t up, int32_t down,
+                           int32_t width, astts_stream_t stream);
+int astts_op_mel_spectrogram(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
+                             int32_t n_fft, int32_t hop, int32_t n_mels, float log_floor, astts_stream_t stream);
 int astts_op_ras_sample(const float* logits, const int32_t* history, const float* uniforms, int32_t* out_tokens,
                         int32_t b, int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p,
                         int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream);

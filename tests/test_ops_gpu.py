@@ -394,3 +394,34 @@ def test_linear_with_fused_residual_and_layernorm(m, k):
     # the unfused pair of launches gives the same fp32 result bit for bit and the same LayerNorm up to fp16 rounding
     out2 = ops.linear(x.to(DEV), pw, residual=res.to(DEV))
     assert rel_err(out2, out) < 1e-6
+
+
+@pytest.mark.parametrize("sr_in,sr_out,n", [(16000, 22050, 24000), (22050, 16000, 30001), (16000, 24000, 5000), (44100, 16000, 44100)])
+def test_resampler_kernel_matches_host_definition(sr_in, sr_out, n):
+    """astts_op_resample_poly vs the host form of the same Hann-windowed sinc table (astts.audio.resample)."""
+    from astts import audio
+
+    g = torch.Generator().manual_seed(n)
+    t = torch.arange(n) / sr_in
+    x = (0.4 * torch.sin(2 * math.pi * 440.0 * t) + 0.1 * torch.randn(n, generator=g))[None, :]
+    ref = audio.resample(x, sr_in, sr_out)
+    out = audio.resample(x.to(DEV), sr_in, sr_out)
+    assert out.shape == ref.shape and out.is_cuda
+    assert float((out.cpu() - ref).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("sr,n_fft,hop,n_mels,fmin,fmax,n", [(22050, 1024, 256, 80, 0.0, 8000.0, 66150), (16000, 400, 160, 80, 20.0, 7600.0, 24000),
+                                                            (16000, 400, 320, 128, 0.0, 8000.0, 16123), (24000, 1024, 256, 80, 0.0, 8000.0, 9000)])
+def test_mel_spectrogram_kernel_matches_host_definition(sr, n_fft, hop, n_mels, fmin, fmax, n):
+    """astts_op_mel_spectrogram (direct fp32 DFT per frame) vs torch.stft on the host: reflect padding, Hann window,
+    magnitude, Slaney mel, log floor 1e-5.  Tolerance: 2e-4 on the log-mel (fp32 summation order of 1024-point sums)."""
+    from astts import audio
+
+    g = torch.Generator().manual_seed(n)
+    t = torch.arange(n) / sr
+    x = torch.stack([0.3 * torch.sin(2 * math.pi * 220.0 * t) + 0.05 * torch.randn(n, generator=g),
+                     0.5 * torch.sin(2 * math.pi * 1760.0 * t) * torch.exp(-3.0 * t) + 0.01 * torch.randn(n, generator=g)])
+    ref = audio.mel_spectrogram(x, sr=sr, n_fft=n_fft, hop=hop, win=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
+    out = audio.mel_spectrogram(x.to(DEV), sr=sr, n_fft=n_fft, hop=hop, win=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
+    assert out.shape == ref.shape and out.is_cuda
+    assert float((out.cpu() - ref).abs().max()) < 2e-4
