@@ -984,23 +984,25 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         ring_env != 0) {
         static bool ring_attr = false;
         if (!ring_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<1, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             ring_attr = true;
         }
-        // tile choice from scripts/micro/ring_bench.hip on the flow decoder's shapes (5.5k / 11k rows): 128x64 (two blocks
-        // per CU) for wide outputs; for n <= 256 the 128x128 tile once there are >= 160 of them, 64x64 for short K
+        // Tile choice, measured IN SITU (scripts/flow_only.py; the back-to-back micro-benchmark runs on L2-hot weights and ranks
+        // the deep-K tiles differently).  Wide outputs (K = 256: four K tiles) take two-stage rings -- 48 KB of LDS puts three
+        // blocks on a CU and the overlap of one block's epilogue with its neighbours' loads beats a deeper ring (16 -> 12 us);
+        // the n <= 256 projections (K = 512 / 1024 from cold weights) keep the 4-stage 64x64 ring.
+        //   1: 128x128 x2 (once there are >= 4-8 tiles per CU)   2: 128x64 x2 (wide outputs)   3: 64x64 x4 (n <= 256)
+        const int64_t b128 = blocks(128, 128);
         int mode;
-        if (a.n >= 512) mode = blocks(128, 64) >= 160 ? 2 : 3;
-        else if (blocks(128, 128) >= 160 && blocks(128, 128) < 512) mode = 1;     // (beyond ~2 blocks per CU the 128x64 tile wins again)
-        else if (a.cin_pad <= 512 || blocks(128, 64) < 160) mode = 3;
-        else mode = 2;
+        if (b128 >= (a.n >= 512 ? 2048 : 1024)) mode = 1;
+        else if (a.n >= 512 && blocks(128, 64) >= 160) mode = 2;
+        else mode = 3;
         if (ring_env > 0) mode = ring_env;
         if (mode == 1 && a.n > 64) {
-            hipLaunchKernelGGL((gemm_ring<2, 2, 4>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 128))), dim3(256), 4 * 256 * 128, st, a);
+            hipLaunchKernelGGL((gemm_ring<2, 2, 2>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 128))), dim3(256), 2 * 256 * 128, st, a);
         } else if (mode == 2 || mode == 1) {
-            hipLaunchKernelGGL((gemm_ring<2, 1, 3>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 64))), dim3(256), 3 * 192 * 128, st, a);
+            hipLaunchKernelGGL((gemm_ring<2, 1, 2>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 64))), dim3(256), 2 * 192 * 128, st, a);
         } else {
             hipLaunchKernelGGL((gemm_ring<1, 1, 4>), dim3((unsigned)(cdiv(a.m, 64) * cdiv(a.n, 64))), dim3(256), 4 * 128 * 128, st, a);
         }
