@@ -346,7 +346,7 @@ def main():
             "knn_roofline": knn_roof,
             "ids_match_oracle": ids_ok,
             "waveform_finite_and_clamped": wav_ok,
-            "pipelining": f"{pipe.depth + 1} HIP streams: the LM decode chains of {pipe.depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe.tuned_ms_per_batch:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
+            "pipelining": f"{pipe.depth + 2} HIP streams (front: retrieval + submit, {pipe.depth} decode chains, render): the LM decode chains of {pipe.depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe.tuned_ms_per_batch:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
                                                "note": "same K steps, LM stages of 2 consecutive batches co-batched into one 16-row decode "
                                                        "chain (outputs bit-identical per batch); reported beside `value`, not as it"} if cob else None),
