@@ -48,6 +48,7 @@ _SIGS = {
     "astts_op_attn_relpos": (c_int32, [c_void_p] * 8 + [c_int32] * 8 + [c_int64] * 3 + [c_int32] * 3 + [c_float, c_void_p]),
     "astts_op_attn_mha_ex": (c_int32, [c_void_p] * 3 + [c_int32, c_void_p, c_void_p] + [c_int32] * 7 + [c_float, c_void_p]),
     "astts_op_layernorm_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_layernorm_relu": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "astts_op_groupnorm_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_int32, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p]),
     "astts_op_attn_mha": (c_int32, [c_void_p] * 5 + [c_int32] * 6 + [c_float, c_void_p]),
@@ -313,12 +314,14 @@ def conv_transpose1d(x: torch.Tensor, w: PackedWeight, padding: int) -> torch.Te
     return y[:, padding:padding + t_full, :].contiguous()
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype=torch.float32) -> torch.Tensor:
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype=torch.float32,
+              relu_scale: float = 0.0) -> torch.Tensor:
+    """``relu_scale`` > 0: ``relu_scale * max(LayerNorm(x), 0)`` in the same launch."""
     x = _f32(x)
     c = x.shape[-1]
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    _lib.check(_L().astts_op_layernorm_ex(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                          1 if out_dtype == torch.float16 else 0, x.numel() // c, c, c, c, eps, _st()))
+    _lib.check(_L().astts_op_layernorm_relu(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                            1 if out_dtype == torch.float16 else 0, x.numel() // c, c, c, c, eps, relu_scale, _st()))
     return y
 
 

@@ -77,10 +77,10 @@ class RelPosEncoder:
 
     def embed_in(self, x: torch.Tensor) -> torch.Tensor:
         h = ops.linear(x, self.embed)
-        h = ops.layernorm(h, *self.embed_ln, self.eps)
         if self.legacy_embed:
-            # relu then * sqrt(d): relu commutes with the positive scale
-            h = ops.elementwise(ops.EL_LEAKY, h, s=0.0)
+            # LayerNorm -> ReLU -> * sqrt(d) in one launch (relu commutes with the positive scale)
+            return ops.layernorm(h, *self.embed_ln, self.eps, relu_scale=math.sqrt(self.d))
+        h = ops.layernorm(h, *self.embed_ln, self.eps)
         return ops.elementwise(ops.EL_SCALE, h, s=math.sqrt(self.d))
 
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
@@ -192,8 +192,7 @@ class AcousticLM:
         body = self.body
         d, b = body.d, tok.shape[0]
         h = ops.gemm_fused(self.speech_emb, body.embed, b, gather=tok)
-        h = ops.layernorm(h, *body.embed_ln, body.eps)
-        h = ops.elementwise(ops.EL_RELU_SCALE, h, s=math.sqrt(d))
+        h = ops.layernorm(h, *body.embed_ln, body.eps, relu_scale=math.sqrt(d))
         lens = torch.full((b,), pos + 1, dtype=torch.int32, device=self.device)
         for lay, kvc in zip(body.L, cache):
             q = ops.gemm_fused(h, lay["wqkv"], b, ln=lay["n1"], ln_eps=body.eps, out2=kvc[pos], n_split=d)

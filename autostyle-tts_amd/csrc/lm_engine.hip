@@ -111,10 +111,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
         rc = astts_op_gemm_fused_ws(g.speech_emb, tok, nullptr, nullptr, 0.f, g.embed_w, g.embed_b, nullptr, h1, nullptr, 0, b, d, 0,
                                  d, dpad, d, d, 0, 0, ASTTS_ACT_NONE, 1.f, 0.f, skw, skw_bytes, st);
         if (rc != ASTTS_OK) return rc;
-        rc = astts_op_layernorm(h1, g.embed_ln_g, g.embed_ln_b, h0, b, d, d, d, c.eps, st);
-        if (rc != ASTTS_OK) return rc;
-        rc = astts_op_elementwise(ASTTS_EL_RELU_SCALE, h0, nullptr, nullptr, nullptr, h0, (int64_t)b * d, 1, d, sqrtf((float)d),
-                                  0.f, st);
+        rc = astts_op_layernorm_relu(h1, g.embed_ln_g, g.embed_ln_b, h0, 0, b, d, d, d, c.eps, sqrtf((float)d), st);
         if (rc != ASTTS_OK) return rc;
         float* x = h0;
         float* y = h1;

@@ -30,7 +30,8 @@ __device__ __forceinline__ float mishf(float x) {
 template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, OutT* __restrict__ y,
-                                                      int64_t rows, int c, int ldx, int ldy, float eps) {
+                                                      int64_t rows, int c, int ldx, int ldy, float eps, float relu_scale) {
+    // relu_scale > 0: y = relu_scale * max(LayerNorm(x), 0) (the LM's input embedding: LayerNorm -> ReLU -> * sqrt(d))
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -64,8 +65,12 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
             if (k < c) {
                 const float4 ga = *reinterpret_cast<const float4*>(gamma + k);
                 const float4 be = *reinterpret_cast<const float4*>(beta + k);
-                const float o0 = (v[i].x - mean) * rstd * ga.x + be.x, o1 = (v[i].y - mean) * rstd * ga.y + be.y;
-                const float o2 = (v[i].z - mean) * rstd * ga.z + be.z, o3 = (v[i].w - mean) * rstd * ga.w + be.w;
+                float o0 = (v[i].x - mean) * rstd * ga.x + be.x, o1 = (v[i].y - mean) * rstd * ga.y + be.y;
+                float o2 = (v[i].z - mean) * rstd * ga.z + be.z, o3 = (v[i].w - mean) * rstd * ga.w + be.w;
+                if (relu_scale > 0.0f) {
+                    o0 = relu_scale * fmaxf(o0, 0.0f); o1 = relu_scale * fmaxf(o1, 0.0f);
+                    o2 = relu_scale * fmaxf(o2, 0.0f); o3 = relu_scale * fmaxf(o3, 0.0f);
+                }
                 if constexpr (sizeof(OutT) == 2) {
                     half4 h4;
                     h4[0] = (_Float16)o0; h4[1] = (_Float16)o1; h4[2] = (_Float16)o2; h4[3] = (_Float16)o3;
@@ -86,7 +91,11 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
         v += d * d;
     }
     const float rstd = rsqrtf(wave_sum_f32(v) / (float)c + eps);
-    for (int k = lane; k < c; k += 64) yr[k] = (OutT)((xr[k] - mean) * rstd * gamma[k] + beta[k]);
+    for (int k = lane; k < c; k += 64) {
+        float o = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+        if (relu_scale > 0.0f) o = relu_scale * fmaxf(o, 0.0f);
+        yr[k] = (OutT)o;
+    }
 }
 
 // ------------------------------------------------------------------ GroupNorm on [B, T, C]
@@ -416,17 +425,22 @@ static inline int grid_for(int64_t total) {
 
 extern "C" {
 
-int astts_op_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
-                          int32_t c, int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
-    ASTTS_REQUIRE(x && gamma && beta && y && rows >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_layernorm: bad argument");
+int astts_op_layernorm_relu(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
+                            int32_t c, int32_t ldx, int32_t ldy, float eps, float relu_scale, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && gamma && beta && y && rows >= 1 && c >= 1 && relu_scale >= 0.0f, ASTTS_ERR_INVALID, "astts_op_layernorm: bad argument");
     if (out_f16)
         hipLaunchKernelGGL((layernorm_rows<_Float16>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
-                           gamma, beta, (_Float16*)y, rows, c, ldx, ldy, eps);
+                           gamma, beta, (_Float16*)y, rows, c, ldx, ldy, eps, relu_scale);
     else
         hipLaunchKernelGGL((layernorm_rows<float>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                           beta, (float*)y, rows, c, ldx, ldy, eps);
+                           beta, (float*)y, rows, c, ldx, ldy, eps, relu_scale);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
+}
+
+int astts_op_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
+                          int32_t c, int32_t ldx, int32_t ldy, float eps, astts_stream_t stream) {
+    return astts_op_layernorm_relu(x, gamma, beta, y, out_f16, rows, c, ldx, ldy, eps, 0.0f, stream);
 }
 
 int astts_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t c,

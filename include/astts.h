@@ -180,6 +180,9 @@ int astts_op_layernorm(const float* x, const float* gamma, const float* beta, fl
 /* _ex forms: out_f16 != 0 writes fp16 (ldy in halfs) for outputs whose only consumers are MFMA operands. */
 int astts_op_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
                           int32_t c, int32_t ldx, int32_t ldy, float eps, astts_stream_t stream);
+/* relu_scale > 0: y = relu_scale * max(LayerNorm(x), 0) -- the LM input embedding's LayerNorm -> ReLU -> * sqrt(d) in one launch. */
+int astts_op_layernorm_relu(const float* x, const float* gamma, const float* beta, void* y, int32_t out_f16, int64_t rows,
+                            int32_t c, int32_t ldx, int32_t ldy, float eps, float relu_scale, astts_stream_t stream);
 int astts_op_groupnorm_ex(const float* x, const int32_t* lens, const float* gamma, const float* beta,
                           const float* add_bc, void* y, int32_t out_f16, int32_t b, int32_t t, int32_t c, int32_t groups,
                           float eps, int32_t act_mish, void* workspace, size_t workspace_bytes, astts_stream_t stream);
