@@ -403,3 +403,58 @@ def test_fullsize_pipeline_and_cobatching_are_bit_identical_to_sequential():
         assert len(outs) == 9
         for o in outs:
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, cob)
+
+
+def test_fullsize_lm_logits_match_oracle():
+    """CosyVoice-300M shapes (d = 1024, 14 layers, FFN 4096): the decode step's kernels at the sizes the benchmark runs
+    -- MFMA relative-position prefill, fused LayerNorm + QKV into the fp16 KV cache, split-K FFN-out, output head --
+    against the fp32 oracle, teacher-forced over a few steps.  Tolerance as stated for the tiny model (2e-2 of the logit
+    scale: fp16 weights / operands / KV cache vs all-fp32)."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import AcousticLM
+    from astts.synth.weights import make_lm_weights
+    from oracle import synth as osyn
+
+    cfg = SynthConfig()
+    sd = make_lm_weights(cfg, 0)
+    g = torch.Generator().manual_seed(11)
+    b, tt, tp, steps = 2, 9, 14, 4
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    pre_ref = osyn.lm_prefix(sd, cfg, text, tlen, spk, prompt)
+    _, logits_ref = osyn.lm_decode(sd, cfg, pre_ref, steps, u, True, forced)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
+    assert float((pre.cpu().transpose(0, 1) - pre_ref).abs().max()) < 2e-2 * float(pre_ref.abs().max())
+    toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
+    assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * float(logits_ref.abs().max())
+
+
+def test_fullsize_flow_estimator_matches_oracle():
+    """One evaluation of the full-size U-Net estimator (256 channels, 12 mid blocks x 4 transformer blocks: the ring GEMMs,
+    flash attention, fused GroupNorm at the benchmark's widths) against the fp32 oracle on a short ragged batch."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import FlowDecoder
+    from astts.synth.weights import make_flow_weights
+    from oracle import synth as osyn
+
+    cfg = SynthConfig()
+    sd = make_flow_weights(cfg, 1)
+    g = torch.Generator().manual_seed(12)
+    b, t = 2, 70
+    x = torch.randn(b, t, cfg.mel, generator=g)
+    mu = torch.randn(b, t, cfg.mel, generator=g)
+    cond = torch.randn(b, t, cfg.mel, generator=g)
+    spk_e = torch.randn(b, cfg.mel, generator=g)
+    tt = torch.tensor([0.25, 0.7])
+    lens = torch.tensor([t, t - 9])
+    m = (torch.arange(t)[None, :] < lens[:, None]).float()[..., None]
+    ref = osyn.estimator(sd, cfg, x * m, mu * m, spk_e, cond * m, tt, lens)
+    fd = FlowDecoder(sd, cfg, torch.device(DEV))
+    out = fd.estimator((x * m).to(DEV), (mu * m).to(DEV), spk_e.to(DEV), (cond * m).to(DEV), tt.to(DEV), lens.to(DEV, torch.int32)).cpu()
+    assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
