@@ -458,3 +458,34 @@ def test_fullsize_flow_estimator_matches_oracle():
     fd = FlowDecoder(sd, cfg, torch.device(DEV))
     out = fd.estimator((x * m).to(DEV), (mu * m).to(DEV), spk_e.to(DEV), (cond * m).to(DEV), tt.to(DEV), lens.to(DEV, torch.int32)).cpu()
     assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_fullsize_hift_vocoder_matches_oracle():
+    """HiFT at its real widths (512 -> 256 -> 128 channels, x256 upsampling) on a short mel: f0, NSF source and the
+    conv-transpose / Snake-resblock stack + iSTFT against the fp32 oracle (same tolerances as the tiny model)."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import HiftVocoder
+    from astts.synth.weights import make_hift_weights
+    from oracle import synth as osyn
+
+    cfg = SynthConfig()
+    sd = make_hift_weights(cfg, 2)
+    g = torch.Generator().manual_seed(13)
+    b, tm = 1, 16
+    mel = torch.randn(b, tm, cfg.mel, generator=g)
+    nh = cfg.nb_harmonics + 1
+    phase0 = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
+    voc = HiftVocoder(sd, cfg, torch.device(DEV))
+    f0_ref = osyn.hift_f0(sd, cfg, mel)
+    f0 = voc.f0(mel.to(DEV)).cpu()
+    assert float((f0 - f0_ref).abs().max()) < 1e-2 * float(f0_ref.abs().max())
+    src_ref = osyn.hift_source(sd, cfg, f0_ref, phase0, noise)
+    src = voc.source(f0_ref.to(DEV), phase0.to(DEV), noise.to(DEV)).cpu()
+    assert float((src - src_ref).abs().max()) < 1e-4
+    wav_ref = osyn.hift_decode(sd, cfg, mel, src_ref)
+    wav = voc.decode(mel.to(DEV), src_ref.to(DEV)).cpu()
+    assert wav.shape == wav_ref.shape == (b, tm * cfg.upsample_total)
+    assert float((wav - wav_ref).abs().max()) < 2e-2
+    assert _snr_db(wav_ref, wav) > 30.0
