@@ -11,6 +11,7 @@ GPU path (frontend features are inputs of the timed region
 """
 from __future__ import annotations
 
+import functools
 import math
 import struct
 from typing import Tuple
@@ -81,6 +82,7 @@ def write_wav(path: str, wav, sample_rate: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------ resampling
+@functools.lru_cache(maxsize=16)
 def _resample_kernel(sr_in: int, sr_out: int, zeros: int = 6, rolloff: float = 0.99):
     """Hann-windowed sinc table of the polyphase resampler (the torchaudio ``sinc_interp_hann`` recipe)
     -> (kern fp32 [up, 2 width + down], up, down, width)."""

@@ -45,12 +45,14 @@ class EnergyVQSpeechTokenizer:
         g = torch.Generator().manual_seed(seed)
         self.proj = torch.randn(128, n_codes, generator=g)
         self.n_codes = n_codes
+        self.device = None          # set by Frontend: the log-mel then runs as the HIP kernel (audio.mel_spectrogram)
 
     def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
         n = wav16k.shape[-1]
         if n > 30 * 16000:
             raise ValueError("do not support extract speech token for audio longer than 30s")  # upstream assert
-        mel = audio.mel_spectrogram(wav16k, sr=16000, n_fft=400, hop=320, win=400, n_mels=128, fmin=0.0, fmax=8000.0)
+        w = wav16k.to(self.device) if self.device is not None else wav16k
+        mel = audio.mel_spectrogram(w, sr=16000, n_fft=400, hop=320, win=400, n_mels=128, fmin=0.0, fmax=8000.0).cpu()
         return torch.argmax(mel[0] @ self.proj, dim=-1).to(torch.int32)[None, :]            # [1, T] @ 50 Hz
 
 
@@ -60,9 +62,11 @@ class StatsSpeakerEmbedder:
     def __init__(self, dim: int, seed: int = 4321):
         g = torch.Generator().manual_seed(seed)
         self.proj = torch.randn(160, dim, generator=g) / np.sqrt(160.0)
+        self.device = None
 
     def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
-        mel = audio.mel_spectrogram(wav16k, sr=16000, n_fft=400, hop=160, win=400, n_mels=80, fmin=20.0, fmax=7600.0)[0]
+        w = wav16k.to(self.device) if self.device is not None else wav16k
+        mel = audio.mel_spectrogram(w, sr=16000, n_fft=400, hop=160, win=400, n_mels=80, fmin=20.0, fmax=7600.0)[0].cpu()
         mel = mel - mel.mean(dim=0, keepdim=True)
         stats = torch.cat([mel.mean(dim=0), mel.std(dim=0)])
         return (stats @ self.proj)[None, :]                                                 # [1, dim]
@@ -114,6 +118,10 @@ class Frontend:
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab)
         self.speech_tokenizer = speech_tokenizer or EnergyVQSpeechTokenizer(cfg.speech_vocab)
         self.speaker_embedder = speaker_embedder or StatsSpeakerEmbedder(cfg.spk_dim)
+        if device is not None:
+            for part in (self.speech_tokenizer, self.speaker_embedder):
+                if hasattr(part, "device") and part.device is None:
+                    part.device = device
         self.features = features or {}
 
     def text_ids(self, text: str) -> torch.Tensor:
