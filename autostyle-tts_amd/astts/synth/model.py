@@ -880,80 +880,3 @@ class PipelinedSynth:
             cur.wait_stream(st)
         cur.wait_stream(self.s_render)
         return out
-
-
-class GraphPipelinedSynth:
-    """PipelinedSynth with both stages captured into hipGraphs (torch.cuda.CUDAGraph) for FIXED shapes.
-
-    The LM stage is ~19k launches and the render stage ~6k operator calls per batch: issued eagerly they cost the
-    host ~140 ms + ~85 ms, which is what bounds the two-stream pipeline.  Captured once, a stage replays with one
-    host call.  Two instances of each graph (even / odd batches) give the two batches in flight their own KV
-    caches, token and activation buffers.  ``inputs`` are the resident tensors the graphs read (update them in place
-    between submits to change the batch); outputs of batch i live in ``self.out[i % 2]`` until batch i+2 replays."""
-
-    def __init__(self, engine: "SynthEngine", inputs):
-        self.eng = engine
-        dev = engine.device
-        (text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel, flow_spk, z,
-         phase0, noise) = inputs
-        with torch.cuda.device(dev):
-            self.s_lm = torch.cuda.Stream(device=dev, priority=-1)
-            self.s_render = torch.cuda.Stream(device=dev)
-            self.g_lm, self.g_render, self.out = [], [], []
-            self.ev_lm = [torch.cuda.Event() for _ in range(2)]
-            self.ev_render = [torch.cuda.Event() for _ in range(2)]
-            torch.cuda.synchronize(dev)
-            # warm both stages once on the capture streams (lazy one-off initialisation must not land in a capture)
-            with torch.cuda.stream(self.s_lm):
-                toks = engine.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
-                engine.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
-            torch.cuda.synchronize(dev)
-            for _p in range(2):
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, stream=self.s_lm):
-                    toks = engine.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms)
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self.s_render):
-                    mel, wav = engine.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
-                self.g_lm.append(g1)
-                self.g_render.append(g2)
-                self.out.append((toks, mel, wav))
-            torch.cuda.synchronize(dev)
-        self._i = 0
-        self._pending = None   # parity whose render stage has not been enqueued yet
-
-    def _enqueue_render(self, p):
-        with torch.cuda.stream(self.s_render):
-            self.s_render.wait_event(self.ev_lm[p])
-            self.g_render[p].replay()
-            self.ev_render[p].record(self.s_render)
-
-    def submit(self):
-        """Enqueue the LM stage of the next batch and the render stage of the previous one; returns the parity slot of
-        the batch whose render was just enqueued (or None)."""
-        p = self._i & 1
-        cur = torch.cuda.current_stream(self.eng.device)
-        self.s_lm.wait_stream(cur)
-        with torch.cuda.stream(self.s_lm):
-            if self._i >= 2:
-                self.s_lm.wait_event(self.ev_render[p])      # batch i-2 has finished reading this slot's tokens
-            self.g_lm[p].replay()
-            self.ev_lm[p].record(self.s_lm)
-        done = None
-        if self._pending is not None:
-            self._enqueue_render(self._pending)
-            done = self._pending
-        self._pending = p
-        self._i += 1
-        return done
-
-    def drain(self):
-        done = None
-        if self._pending is not None:
-            self._enqueue_render(self._pending)
-            done = self._pending
-            self._pending = None
-        cur = torch.cuda.current_stream(self.eng.device)
-        cur.wait_stream(self.s_lm)
-        cur.wait_stream(self.s_render)
-        return done
