@@ -425,3 +425,31 @@ def test_mel_spectrogram_kernel_matches_host_definition(sr, n_fft, hop, n_mels, 
     out = audio.mel_spectrogram(x.to(DEV), sr=sr, n_fft=n_fft, hop=hop, win=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
     assert out.shape == ref.shape and out.is_cuda
     assert float((out.cpu() - ref).abs().max()) < 2e-4
+
+
+def test_new_entry_points_validate_arguments():
+    """Argument errors come back as AsttsError with a message, before anything is launched."""
+    import ctypes
+
+    from astts import _lib, audio, ops
+
+    lib = _lib.load()
+    x = torch.randn(64, 128, device=DEV).half()
+    pw = ops.PackedWeight(torch.randn(128, 128) / 11, None)            # n = 128: astts_op_gemm_ln needs 256
+    res = torch.zeros(64, 128, device=DEV)
+    g = torch.ones(128, device=DEV)
+    with pytest.raises(AssertionError):
+        ops.linear_ln(x, pw, res, (g, g))
+    out = torch.empty(64, 128, device=DEV)
+    ln = torch.empty(64, 128, dtype=torch.float16, device=DEV)
+    rc = lib.astts_op_gemm_ln(x.data_ptr(), pw.data.data_ptr(), None, res.data_ptr(), out.data_ptr(), g.data_ptr(), g.data_ptr(), 1e-5,
+                              ln.data_ptr(), 64, 128, 128, 128, 128, 128, 128, 128, _lib.stream_ptr())
+    assert rc == _lib.ERR_UNSUPPORTED and b"n must be 256" in lib.astts_last_error_string()
+    with pytest.raises(_lib.AsttsError, match="astts_op_mel_spectrogram"):
+        audio.mel_spectrogram(torch.zeros(1, 100, device=DEV), n_fft=1024, hop=256, win=1024)
+    rc = lib.astts_stream_spin(-5, _lib.stream_ptr())
+    assert rc == _lib.ERR_INVALID
+    rc = lib.astts_op_gemm_fused_ws(x.data_ptr(), None, None, None, ctypes.c_float(0.0), pw.data.data_ptr(), None, None, out.data_ptr(), None, 0,
+                                    8, 128, 0, 128, 128, 128, 128, 0, 0, 0, ctypes.c_float(1.0), ctypes.c_float(0.1), ctypes.c_void_p(256), 16,
+                                    _lib.stream_ptr())
+    assert rc == _lib.ERR_WORKSPACE
