@@ -279,14 +279,45 @@ class AcousticLM:
         if use_engine and b <= 32:
             return self.decode_engine(prefix, n_steps, uniforms, ignore_eos, forced_tokens, return_logits, key_start)
         if use_engine:
-            # larger batches (BASELINE config 3: 64 long-form utterances): independent rows, decoded 32 at a time
-            outs = []
-            for b0 in range(0, b, 32):
-                sl = slice(b0, min(b0 + 32, b))
-                outs.append(self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(),
-                                               ignore_eos[sl].contiguous() if torch.is_tensor(ignore_eos) else ignore_eos,
-                                               None if forced_tokens is None else forced_tokens[sl], return_logits,
-                                               None if key_start is None else key_start[sl].contiguous()))
+            # larger batches (BASELINE config 3: 64 long-form utterances): independent rows, decoded in groups of 32.  The
+            # groups are separate launch chains, latency-bound like any decode, so two of them run concurrently on their
+            # own streams (each enqueued by its own host thread: the engine call drops the GIL); results do not depend on
+            # the grouping or on what runs beside them.
+            import threading
+
+            groups = [slice(b0, min(b0 + 32, b)) for b0 in range(0, b, 32)]
+            if getattr(self, "_group_streams", None) is None:
+                self._group_streams = ops.concurrent_streams(2, device=self.device)
+            cur = torch.cuda.current_stream(self.device)
+            outs, errs = [None] * len(groups), []
+
+            def run(gi, st):
+                try:
+                    sl = groups[gi]
+                    with torch.cuda.device(self.device), torch.cuda.stream(st):
+                        outs[gi] = self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(),
+                                                      ignore_eos[sl].contiguous() if torch.is_tensor(ignore_eos) else ignore_eos,
+                                                      None if forced_tokens is None else forced_tokens[sl], return_logits,
+                                                      None if key_start is None else key_start[sl].contiguous())
+                except BaseException as e:      # noqa: BLE001  (re-raised on the calling thread)
+                    errs.append(e)
+
+            for w0 in range(0, len(groups), 2):
+                wave = []
+                for k, gi in enumerate(range(w0, min(w0 + 2, len(groups)))):
+                    st = self._group_streams[k]
+                    st.wait_stream(cur)
+                    th = threading.Thread(target=run, args=(gi, st))
+                    th.start()
+                    wave.append((th, st))
+                for th, st in wave:
+                    th.join()
+                    cur.wait_stream(st)
+            if errs:
+                raise errs[0]
+            for o in outs:
+                for t_ in (o if isinstance(o, tuple) else (o,)):
+                    t_.record_stream(cur)
             if return_logits:
                 return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
             return torch.cat(outs, 0)
