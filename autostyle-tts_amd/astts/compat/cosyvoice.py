@@ -101,15 +101,19 @@ class CosyVoice:
         return wav.cpu()
 
     # ------------------------------------------------------------------ ragged batches (many segments in one pass)
-    def synthesize_batch(self, requests, max_batch: int = 32):
+    def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True):
         """``requests``: list of (text_ids [1, Tt] = prompt text + segment text, n_segment_text_tokens, lm_prompt,
         flow_prompt).  All segments go through ONE left-padded LM batch (per-row EOS window, tokens truncated at
         each row's EOS), one ragged flow-matching batch and the vocoder.  Returns one FloatTensor[1, n] per request,
         each what the one-at-a-time path produces for that segment up to sampling draws."""
         cfg, dev, eng = self.cfg, self.device, self.engine
         out = [None] * len(requests)
+        # length bucketing (SURVEY.md 8e): a group is padded to its longest row in every stage, so rows of similar text
+        # length go together; results return in request order
+        order = sorted(range(len(requests)), key=lambda i: -requests[i][1]) if bucket else list(range(len(requests)))
         for g0 in range(0, len(requests), max_batch):
-            grp = requests[g0:g0 + max_batch]
+            idxs = order[g0:g0 + max_batch]
+            grp = [requests[i] for i in idxs]
             b = len(grp)
             texts = [r[0].view(-1) for r in grp]
             spk_lm = torch.cat([r[2].spk_embedding for r in grp], 0)
@@ -141,7 +145,7 @@ class CosyVoice:
             mels = eng.flow.decode_ragged(all_tok, pmels, spk_flow, zs)
             for i in range(b):      # vocoder per row: its conv stack has no length masks (3 % of the time)
                 wav = eng.hift.forward(mels[i][None], draws[i][0].to(dev), draws[i][1].to(dev))
-                out[g0 + i] = wav.cpu()
+                out[idxs[i]] = wav.cpu()
         return out
 
     def inference_tts_with_st_batch(self, items, max_batch: int = 32):
