@@ -35,19 +35,23 @@ def timed(pipe, tag, K=12):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', [int(s.cuda_stream) % 100000 for s in pipe.s_lm + [pipe.s_render]], flush=True)
 
-def summarize(outs):
-    return ''.join('.' if (bool(torch.equal(o[0], ref[0])) and float((o[2] - ref[2]).abs().max()) == 0.0) else ('T' if not bool(torch.equal(o[0], ref[0])) else 'W') for o in outs)
-seq = [eng.tts(*args) for _ in range(10)]
-torch.cuda.synchronize()
-print('sequential reruns:', summarize(seq), flush=True)
-for trial in range(3):
-  for cob, depth in ((1, 2), (2, 2), (2, 1)):
-    pipe = PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob)
-    outs = []
+from astts import ops
+def timed(pipe, tag, K=16):
     with torch.cuda.stream(pipe.front_stream):
-        for _ in range(12):
+        for _ in range(3): pipe.submit(*args)
+        pipe.drain(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); outs = []
+        for _ in range(K):
             r = pipe.submit(*args)
             if r is not None: outs.append(r)
         outs += pipe.drain()
-    torch.cuda.synchronize()
-    print(f'cobatch {cob} depth {depth}:', summarize(outs), flush=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', flush=True)
+for trial in range(2):
+    timed(PipelinedSynth(eng, lm_depth=2, lm_priority=0, render_priority=0), 'all priority 0 (probed set)')
+    lm = ops.concurrent_streams(2, priority=-1); rf = ops.concurrent_streams(2, priority=0)
+    P = PipelinedSynth(eng, lm_depth=2, streams=lm + [rf[0]]); P.front_stream = rf[1]
+    timed(P, 'LM streams priority -1, render/front 0')
+    lm = ops.concurrent_streams(2, priority=0); rf = ops.concurrent_streams(2, priority=-1)
+    P = PipelinedSynth(eng, lm_depth=2, streams=lm + [rf[0]]); P.front_stream = rf[1]
+    timed(P, 'render/front priority -1, LM 0')
