@@ -108,6 +108,25 @@ def test_inexact_fp32_bank():
     _check(bank, q, 3, force_exact=True, sb=sb)
 
 
+def test_gemm_scan_path_large_query_groups():
+    """Query groups of >= 64 against a bank that fills the chip take the scan as one GEMM on the ring kernel: exact and
+    fp16-inexact banks, a tail group below 64 queries, duplicate rows (ties decided by row index), scaled queries."""
+    rng = np.random.default_rng(11)
+    bank16 = rng.standard_normal((20000, 256)).astype(np.float16)
+    bank16[777] = bank16[123]                       # exact duplicates
+    bank16[19999] = bank16[123]
+    q = rng.standard_normal((300, 256)).astype(np.float32)       # groups of 256 + 44 (tail: register-streaming scan)
+    q[5] = bank16[123].astype(np.float32) * 37.5
+    q[260] = bank16[777].astype(np.float32) * 1e-3
+    sb = _check(bank16, q, 5)
+    assert sb.last_fallbacks() <= 75
+    _check(bank16, q[:70], 3, force_exact=True, sb=sb)
+    bank32 = rng.standard_normal((12000, 384)).astype(np.float32)  # not fp16-representable: the scan plane is a rounded image
+    sb32 = _bank(bank32)
+    assert not sb32.scan_plane_exact
+    _check(bank32, rng.standard_normal((130, 384)).astype(np.float32), 3, sb=sb32)
+
+
 def test_duplicates_ties_zero_rows_and_small_banks():
     rng = np.random.default_rng(0)
     bank = rng.standard_normal((200, 128)).astype(np.float16)
