@@ -850,11 +850,14 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
         // invalidate x 2048 per launch, under the weight stream) measured 2x slower than no split at all.
         float* part = a.sk_part + (size_t)blockIdx.x * KS * (MT * 256);
         if (owner) __hip_atomic_store(part + (size_t)blockIdx.y * (MT * 256) + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();                                   // waits vmcnt(0): the block's stores are acknowledged; `red` reads done
+        // Every storing wave drains its own sc1 stores BEFORE the barrier: s_barrier alone does not wait for vmcnt, and the
+        // compiler emits no wait here (checked in the ISA: store -> s_barrier -> atomic).  Inline asm so no pass can drop it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every wave's partial sums are acknowledged; `red` reads done
         int* s_last = reinterpret_cast<int*>(red);
         if (tid == 0) {
-            // Release side: the partial sums are sc1 (write-through) stores already acknowledged by every thread of the block
-            // (s_waitcnt vmcnt(0) of the barrier above) -- what an agent-scope release fence adds on top, buffer_wbl2 for
+            // Release side: the partial sums are sc1 (write-through) stores already acknowledged by every wave of the block
+            // (the explicit s_waitcnt vmcnt(0) before the barrier above) -- what an agent-scope release fence adds on top, buffer_wbl2 for
             // dirty L2 lines, has nothing of ours to write back and costs 4 ms per 250-step decode.
 #ifdef SPLITK_RELEASE_FENCE
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -114,6 +114,94 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
                       f"oracle/ fp32 torch-CPU: lm {t1 - t0:.1f} s, flow {t2 - t1:.1f} s, vocoder {t3 - t2:.1f} s"}
 
 
+def launch_ranks(n, argv, timeout=None):
+    """Self-launcher for `python bench.py --gpus N` (no torch.distributed.run around it): one child process per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, same command line.  The parent never touches HIP (no
+    torch.cuda call before or after: children are fresh interpreters started with subprocess, nothing is exec'ed from a
+    process that has initialised the GPU).  Rank 0's stdout (the ONE JSON line) is relayed; every child's stderr passes
+    through.  Returns 0 only if every rank exited 0; a failing rank takes the others down."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # keeps rank 0's pipe drained
+    reader.start()
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    try:
+        while rc == 0 and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            rc = next((p.returncode for p in procs if p.poll() not in (None, 0)), 0)
+            if rc == 0 and t_end is not None and time.time() > t_end:
+                rc = 124
+        rc = rc or next((p.returncode for p in procs if p.returncode not in (None, 0)), 0)
+    finally:
+        for p in procs:                 # exact PIDs this function started, never a pattern
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    for line in out0.decode(errors="replace").splitlines():      # stdout carries the JSON line only; library chatter -> stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return rc
+
+
+def stub_main(args, world, rank):
+    """ASTTS_BENCH_STUB=1 (CPU tests of the launcher / timing protocol only, never a measurement): the same rendezvous,
+    barrier, max-over-ranks timing and one-JSON-line protocol as main(), over gloo, with a sleep as the step."""
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank)
+    else:
+        gathered = [0]
+    if os.environ.get("ASTTS_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world,
+                          "rccl_world_size": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "ranks_seen": gathered, "data": "stub (launcher test)"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,8 +221,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has made no HIP call and makes none)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or plainly as `python bench.py --gpus {args.gpus}` (self-launching)")
+    if os.environ.get("ASTTS_BENCH_STUB"):
+        return stub_main(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -330,6 +424,7 @@ def main():
             "value": total_audio / dt,
             "unit": "audio-s/wall-s",
             "n_gpus": world,
+            "rccl_world_size": world if dist is not None else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
