@@ -63,7 +63,7 @@ _SIGS = {
 class LmConfig(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("d", "heads", "ffn", "layers", "vocab_out", "speech_vocab", "pos_center", "pos_ld",
                                        "top_k", "ras_win")] + [(n, c_float) for n in ("top_p", "ras_tau", "eps")] + \
-               [("kv_f16", c_int32), ("pos_f16", c_int32)]
+               [("kv_f16", c_int32), ("pos_f16", c_int32), ("ln_folded", c_int32)]
 
 
 class LmGlobals(ctypes.Structure):

@@ -38,36 +38,58 @@ def rel_pos_table(d: int, max_pos: int) -> torch.Tensor:
     return pe
 
 
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Linear(LayerNorm(x; gamma, beta)) == Linear'((x - mean) * rstd) with W' = W diag(gamma), b' = b + W beta
+    (exact algebra, evaluated in fp64 at load): the decode step then normalises without reading gamma / beta --
+    eight waves of every workgroup re-read both vectors otherwise, as many bytes as the workgroup's weights."""
+    w64, g64, be64 = w.double(), gamma.double(), beta.double()
+    return (w64 * g64[None, :]).float(), (b.double() + w64 @ be64).float()
+
+
 class RelPosEncoder:
     """espnet-style pre-norm encoder with relative-position attention (text encoder, token encoder,
-    and the causal LM body).  Holds one precomputed table ``linear_pos(pe(rel))`` per layer."""
+    and the causal LM body).  Holds one precomputed table ``linear_pos(pe(rel))`` per layer.
+
+    ``fold_ln`` (the LM body): the scale / shift of norm1 / norm2 are folded into the q|k|v and FFN-in projections at
+    load (``fold_layernorm``); ``n1`` / ``n2`` / ``after`` then hold ones / zeros (``after_norm`` is folded into the
+    output head by the owner).  Prefill and decode use the same folded weights."""
 
     def __init__(self, sd: SD, prefix: str, heads: int, layers: int, act: str, norm_names: Tuple[str, str],
-                 legacy_embed: bool, causal: bool, eps: float, max_pos: int, device, pos_dtype=torch.float32):
+                 legacy_embed: bool, causal: bool, eps: float, max_pos: int, device, pos_dtype=torch.float32, fold_ln: bool = False):
         self.heads, self.layers, self.act, self.causal, self.eps = heads, layers, act, causal, eps
         self.legacy_embed = legacy_embed
         self.center = max_pos
+        self.fold_ln = fold_ln
         p = prefix
         self.d = int(sd[p + ".after_norm.weight"].shape[0])
         self.embed = PackedWeight(sd[p + ".embed.out.0.weight"], sd[p + ".embed.out.0.bias"], device)
         self.embed_ln = (_dev(sd[p + ".embed.out.1.weight"], device), _dev(sd[p + ".embed.out.1.bias"], device))
-        self.after = (_dev(sd[p + ".after_norm.weight"], device), _dev(sd[p + ".after_norm.bias"], device))
+        ident = (torch.ones(self.d, dtype=torch.float32, device=device), torch.zeros(self.d, dtype=torch.float32, device=device))
+        self.after = ident if fold_ln else (_dev(sd[p + ".after_norm.weight"], device), _dev(sd[p + ".after_norm.bias"], device))
         pe = rel_pos_table(self.d, max_pos).to(device)
         n1, n2 = norm_names
         self.L: List[dict] = []
         for i in range(layers):
             q = f"{p}.encoders.{i}"
             a = q + ".self_attn"
+            g1, b1 = sd[f"{q}.{n1}.weight"].float().cpu(), sd[f"{q}.{n1}.bias"].float().cpu()
+            g2, b2 = sd[f"{q}.{n2}.weight"].float().cpu(), sd[f"{q}.{n2}.bias"].float().cpu()
+            wq, bq = sd[a + ".linear_q.weight"].float().cpu(), sd[a + ".linear_q.bias"].float().cpu()
+            wkv = torch.cat([sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0).float().cpu()
+            bkv = torch.cat([sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0).float().cpu()
+            w1, bw1 = sd[q + ".feed_forward.w_1.weight"].float().cpu(), sd[q + ".feed_forward.w_1.bias"].float().cpu()
+            if fold_ln:
+                wq, bq = fold_layernorm(wq, bq, g1, b1)
+                wkv, bkv = fold_layernorm(wkv, bkv, g1, b1)
+                w1, bw1 = fold_layernorm(w1, bw1, g2, b2)
             lay = {
-                "n1": (_dev(sd[f"{q}.{n1}.weight"], device), _dev(sd[f"{q}.{n1}.bias"], device)),
-                "n2": (_dev(sd[f"{q}.{n2}.weight"], device), _dev(sd[f"{q}.{n2}.bias"], device)),
-                "wq": PackedWeight(sd[a + ".linear_q.weight"], sd[a + ".linear_q.bias"], device),
-                "wkv": PackedWeight(torch.cat([sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0),
-                                    torch.cat([sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0), device),
-                "wqkv": PackedWeight(torch.cat([sd[a + ".linear_q.weight"], sd[a + ".linear_k.weight"], sd[a + ".linear_v.weight"]], 0),
-                                     torch.cat([sd[a + ".linear_q.bias"], sd[a + ".linear_k.bias"], sd[a + ".linear_v.bias"]], 0), device),
+                "n1": ident if fold_ln else (_dev(g1, device), _dev(b1, device)),
+                "n2": ident if fold_ln else (_dev(g2, device), _dev(b2, device)),
+                "wq": PackedWeight(wq, bq, device),
+                "wkv": PackedWeight(wkv, bkv, device),
+                "wqkv": PackedWeight(torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0), device),
                 "wo": PackedWeight(sd[a + ".linear_out.weight"], sd[a + ".linear_out.bias"], device),
-                "w1": PackedWeight(sd[q + ".feed_forward.w_1.weight"], sd[q + ".feed_forward.w_1.bias"], device),
+                "w1": PackedWeight(w1, bw1, device),
                 "w2": PackedWeight(sd[q + ".feed_forward.w_2.weight"], sd[q + ".feed_forward.w_2.bias"], device),
                 "u": _dev(sd[a + ".pos_bias_u"].reshape(-1), device),
                 "v": _dev(sd[a + ".pos_bias_v"].reshape(-1), device),
@@ -115,8 +137,11 @@ class AcousticLM:
         self.spk_aff = PackedWeight(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device)
         # the LM body re-reads its position tables and KV cache every decode step: both live in HBM as fp16
         self.body = RelPosEncoder(sd, "llm", cfg.lm_heads, cfg.lm_layers, "relu", ("norm1", "norm2"), True, True,
-                                  cfg.ln_eps, cfg.max_positions, device, pos_dtype=torch.float16)
-        self.head = PackedWeight(sd["llm_decoder.weight"], sd["llm_decoder.bias"], device)
+                                  cfg.ln_eps, cfg.max_positions, device, pos_dtype=torch.float16, fold_ln=True)
+        # after_norm is only ever followed by the output head: folded into it (the body's `after` is the identity affine)
+        hw, hb = fold_layernorm(sd["llm_decoder.weight"].float().cpu(), sd["llm_decoder.bias"].float().cpu(),
+                                sd["llm.after_norm.weight"].float().cpu(), sd["llm.after_norm.bias"].float().cpu())
+        self.head = PackedWeight(hw, hb, device)
 
     def prefix(self, text: torch.Tensor, text_lens: torch.Tensor, spk: torch.Tensor, prompt_tokens: torch.Tensor) -> torch.Tensor:
         """-> time-major [S0, B, d]: sos | spk | text_encoder(text) | task_id | speech_emb(prompt)."""
@@ -212,7 +237,8 @@ class AcousticLM:
             from .. import _lib
             body, cfg = self.body, self.cfg
             c = ops.LmConfig(body.d, body.heads, cfg.lm_ffn, len(body.L), cfg.speech_vocab + 1, cfg.speech_vocab, body.center,
-                             body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps, 1, 1)
+                             body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps, 1, 1,
+                             1 if body.fold_ln else 0)
             g = ops.LmGlobals(self.speech_emb.data_ptr(), body.embed.data.data_ptr(), body.embed.bias.data_ptr(),
                               body.embed_ln[0].data_ptr(), body.embed_ln[1].data_ptr(), body.after[0].data_ptr(),
                               body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr())

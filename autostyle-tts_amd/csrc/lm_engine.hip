@@ -6,7 +6,10 @@
 // astts_op_attn_relpos, astts_op_ras_sample) straight from C++ with no host synchronisation:
 // sampling, repetition check, EOS masking and the token history all stay on the GPU.
 #include "common.h"
+#include "lm_step.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 struct astts_lm {
@@ -16,6 +19,104 @@ struct astts_lm {
 };
 
 using namespace astts;
+
+// ---- v2: one decode step = sampler + embed + 14 x (QKV, attention, out-proj, FFN-in, FFN-out) + head = 73 launches
+static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max, int32_t b,
+                     int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
+                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, hipStream_t st) {
+    const astts_lm_config_t& c = h->cfg;
+    const astts_lm_globals_t& g = h->g;
+    const int d = c.d;
+    char* ws = (char*)workspace;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        void* p = ws + o;
+        o = align_up(o + bytes, 256);
+        return p;
+    };
+    // carved from the same workspace as v1 (astts_lm_workspace_bytes covers both layouts)
+    float* h1 = (float*)take(sizeof(float) * b * d);                 // embedding projection (before its LayerNorm)
+    float* xa = (float*)take(sizeof(float) * b * d);                 // residual stream, ping
+    float* xb = (float*)take(sizeof(float) * b * d);                 // residual stream, pong
+    float* q = (float*)take(sizeof(float) * b * d);
+    _Float16* ff = (_Float16*)take(sizeof(float) * b * c.ffn);      // fp16 FFN hidden (half of the fp32 slot)
+    float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
+    int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
+    (void)take(sizeof(int32_t) * b);
+    float* part_o = (float*)take(astts_op_gemm_fused_workspace_bytes());   // [b][heads][2][64] + [b][heads][2][2] (v1's split-K area)
+    float* part_ml = part_o + (size_t)b * c.heads * 2 * 64;
+    const float scale = 0.125f;
+    auto gemv = [&]() {
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.m = b;
+        a.ln_eps = c.eps;
+        return a;
+    };
+    auto with_ln = [&](GemvArgs& a, const float* gam, const float* bet) {
+        if (c.ln_folded) a.ln_plain = 1;
+        else { a.ln_g = gam; a.ln_b = bet; }
+    };
+    const float* cur = logits0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (logits_out)
+            ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
+                                             cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
+                                             hipMemcpyDeviceToDevice, st));
+        int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, s < eos_min_steps ? 1 : 0, eos_min_rows, forced_tokens,
+                                        st);
+        if (rc != ASTTS_OK) return rc;
+        if (s + 1 == n_steps) break;
+        const int pos = pos0 + s;
+        // embed projection: speech_embedding[tok] -> Linear.  Its LayerNorm -> ReLU -> * sqrt(d) runs inside layer 0's QKV
+        // kernel (pre-transform of the staged rows; workgroup 0 writes the result to xa, the residual stream).
+        GemvArgs a = gemv();
+        a.x = g.speech_emb; a.gather = tok; a.ldx = d; a.w = (const _Float16*)g.embed_w; a.bias = g.embed_b; a.out = h1; a.ldo = d;
+        a.n = d; a.k = d; a.kpad = d;
+        if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+        float* x = xa;
+        float* y = xb;
+        for (int l = 0; l < c.layers; ++l) {
+            const astts_lm_layer_t& L = h->layers[l];
+            _Float16* kvc = (_Float16*)kv_cache[l];
+            a = gemv();             // LN1 + QKV: q -> `q`, K|V -> cache row `pos`
+            if (l == 0) {
+                a.x = h1; a.pre_g = g.embed_ln_g; a.pre_b = g.embed_ln_b; a.pre_scale = sqrtf((float)d); a.pre_out = x;
+            } else {
+                a.x = x;
+            }
+            a.ldx = d; with_ln(a, L.n1_g, L.n1_b);
+            a.w = (const _Float16*)L.wqkv; a.bias = L.bqkv; a.out = q; a.ldo = d; a.kv = kvc; a.n_split = d; a.ldkv = 2 * d; a.pos = pos;
+            a.n = 3 * d; a.k = d; a.kpad = d;
+            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            AttnArgs t;
+            memset(&t, 0, sizeof(t));
+            t.q = q; t.kv = kvc; t.postab = (const _Float16*)L.pos; t.bias_u = L.bias_u; t.bias_v = L.bias_v; t.kstart = key_start;
+            t.part_o = part_o; t.part_ml = part_ml; t.ksplit = 2; t.b = b; t.h = c.heads; t.ldq = d; t.ldp = c.pos_ld; t.center = c.pos_center;
+            t.d = d; t.scale = scale; t.pos = pos;
+            if ((rc = lm_attn_launch(t, st)) != ASTTS_OK) return rc;
+            a = gemv();             // out-proj on the merged attention partials + residual
+            a.x = part_o; a.x2 = part_ml; a.x_mode = 2; a.w = (const _Float16*)L.wo; a.bias = L.bo; a.res = x; a.ldr = d; a.out = y; a.ldo = d;
+            a.n = d; a.k = d; a.kpad = d;
+            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            a = gemv();             // LN2 + FFN-in + ReLU -> fp16 hidden (its only consumer is an MFMA operand)
+            a.x = y; a.ldx = d; with_ln(a, L.n2_g, L.n2_b);
+            a.w = (const _Float16*)L.w1; a.bias = L.b1; a.out16 = ff; a.ldo16 = c.ffn; a.relu = 1; a.n = c.ffn; a.k = d; a.kpad = d;
+            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            a = gemv();             // FFN-out + residual
+            a.x = ff; a.x_mode = 1; a.ldx = c.ffn; a.w = (const _Float16*)L.w2; a.bias = L.b2; a.res = y; a.ldr = d; a.out = x; a.ldo = d;
+            a.n = d; a.k = c.ffn; a.kpad = c.ffn;
+            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+        }
+        a = gemv();                 // after_norm + output head
+        a.x = x; a.ldx = d; with_ln(a, g.after_g, g.after_b);
+        a.w = (const _Float16*)g.head_w; a.bias = g.head_b; a.out = lg; a.ldo = c.vocab_out; a.n = c.vocab_out; a.k = d; a.kpad = d;
+        if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+        cur = lg;
+    }
+    return ASTTS_OK;
+}
 
 extern "C" {
 
@@ -74,6 +175,16 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     hipStream_t st = (hipStream_t)stream;
     const int d = c.d;
     const int dpad = (int)align_up((size_t)d, 64), fpad = (int)align_up((size_t)c.ffn, 64);
+    // Which step engine: "v2" = the decode-step kernels of lm_step.hip (4 launches fewer per step, one memory round trip per
+    // kernel, 8-column workgroups for 8-row batches, key-split attention merged by its consumer), "v1" = the operator chain
+    // below.  v2 is built around batches of <= 8 rows (the benchmark batch); wider batches keep v1, whose split-K FFN-out
+    // projection covers the chip at 16-32 rows.  ASTTS_LM_ENGINE=v1|v2 forces one (tests compare the two).
+    const char* env = getenv("ASTTS_LM_ENGINE");           // read per call: tests switch engines inside one process
+    const int forced = !env ? 0 : (!strcmp(env, "v1") ? 1 : (!strcmp(env, "v2") ? 2 : 0));
+    const bool v2_ok = c.kv_f16 && c.pos_f16 && (d % 64) == 0 && (c.ffn % 64) == 0 && d <= 1024;
+    if (v2_ok && (forced == 2 || (forced == 0 && b <= 8)))
+        return decode_v2(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, uniforms, forced_tokens, eos_min_steps, eos_min_rows,
+                         tokens_out, logits_out, workspace, st);
     char* ws = (char*)workspace;
     size_t o = 0;
     auto take = [&](size_t bytes) {

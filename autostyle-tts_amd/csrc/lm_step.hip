@@ -1,0 +1,708 @@
+// lm_step.hip -- decode-step kernels of the acoustic transformer (see lm_step.h for the design rules).
+//
+//   lm_gemv<MT, HALF8, XM, NL> out[m, n] = epilogue( LN?(x)[m, :] . W[n, :] ),  m <= 16*MT rows (the decode batch)
+//   lm_attn                    one new query per (row, head) against the fp16 KV cache, relative-position scores
+//
+// Arithmetic follows the operator-by-operator step (AcousticLM.step_logits / gemm_skinny16 / attn_relpos_decode): fp16
+// MFMA operands, fp32 accumulation, fp32 LayerNorm / softmax.  Only the fp32 summation ORDER of a dot product differs
+// between the variants (which K lines a wave owns), never which products are formed.
+#include "lm_step.h"
+
+#include <cstdlib>
+
+namespace astts {
+
+#ifdef LM_STAMPS
+#define LM_STAMP(a, i)                                                                                              \
+    do {                                                                                                            \
+        if ((a).stamps && threadIdx.x == 0)                                                                         \
+            (a).stamps[((size_t)(a).stamp_slot * 1024 + (blockIdx.x + blockIdx.y * gridDim.x)) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define LM_STAMP(a, i) do { } while (0)
+#endif
+
+// Kernel arguments: hipcc loads the fields of a by-value argument struct lazily, each s_load_dword right before its first
+// use and followed by its own s_waitcnt -- in a kernel with this much control flow that is ~15 SERIALISED scalar-cache
+// misses on a cold kernarg segment (measured: 1.4 us from the first instruction to the last up-front load issued, a third
+// of the kernel).  Pinning every field into SGPRs in the entry block turns them into a few wide s_loads and ONE wait.
+// (one asm statement per group: every separate statement gets its own wait)
+__device__ __forceinline__ void pin_args(const GemvArgs& a) {
+    asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.gather), "s"(a.pre_g), "s"(a.pre_b), "s"(a.pre_out), "s"(a.ln_g), "s"(a.ln_b), "s"(a.w),
+                 "s"(a.bias), "s"(a.res), "s"(a.out), "s"(a.out16), "s"(a.kv), "s"(a.st), "s"(a.m), "s"(a.n), "s"(a.k), "s"(a.kpad), "s"(a.ldx),
+                 "s"(a.ldr), "s"(a.ldo), "s"(a.ldo16), "s"(a.n_split), "s"(a.ldkv), "s"(a.x_mode), "s"(a.relu), "s"(a.pos), "s"(a.ln_plain));
+}
+__device__ __forceinline__ void pin_args(const AttnArgs& a) {
+    asm volatile("" ::"s"(a.q), "s"(a.kv), "s"(a.postab), "s"(a.bias_u), "s"(a.bias_v), "s"(a.kstart), "s"(a.out), "s"(a.part_o), "s"(a.part_ml),
+                 "s"(a.st), "s"(a.b), "s"(a.h), "s"(a.ldq), "s"(a.ldo), "s"(a.ldp), "s"(a.center), "s"(a.d), "s"(a.scale), "s"(a.ksplit), "s"(a.pos));
+}
+
+static constexpr int GV_WAVES = 8;
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// HALF8: m <= 8.  MFMA row i = r + 8h carries x[r][h*Kc + ...], MFMA column j = c + 8h' carries W[n0 + c][h'*Kc + ...]
+// (Kc = kpad / 2): the two diagonal 8x8 blocks of the 16x16 product are the two K halves of an 8-row x 8-column tile,
+// the off-diagonal blocks are never read.  The block owns 8 columns instead of 16.
+// XM: input form -- 0 fp32 rows (optional gather / embedding pre-transform / LayerNorm), 1 fp16 rows, 2 the split-key
+// partials of lm_attn (merged while staging).  NL: weight lines a wave keeps in flight (2 for K <= 1024 at 16 columns: the
+// kernel then fits two workgroups per CU, e.g. the 257 workgroups of the output head in one wave of blocks).
+template <int MT, bool HALF8, int XM, int NL>
+__global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
+    constexpr bool XF16 = XM != 0;
+    extern __shared__ __attribute__((aligned(16))) char gv_smem[];
+    pin_args(a);
+    LM_STAMP(a, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int NC = HALF8 ? 8 : 16;
+    const int n0 = blockIdx.x * NC;
+    const int M = a.m;
+    const int Kc = HALF8 ? (a.kpad >> 1) : a.kpad;          // K elements per MFMA row
+    const int lines = Kc >> 6;
+    const int xs = Kc + 8;                                    // LDS row stride in halfs (16-byte skew)
+    const int lrows = HALF8 ? 16 : M;
+    _Float16* sx = reinterpret_cast<_Float16*>(gv_smem);      // [lrows][xs]
+    float* red = reinterpret_cast<float*>(gv_smem + (((size_t)lrows * xs * 2 + 15) & ~(size_t)15));  // [8][MT][4][64]
+
+    // ---- (0) everything this block will need from memory, issued before anything waits
+    // weights: lane (c, g) owns bytes [32g, 32g + 32) of its row in every 128-byte line (two 16x16x32 k-steps)
+    const _Float16* wrow = HALF8 ? a.w + (int64_t)(n0 + (c & 7)) * a.kpad + (c >> 3) * Kc + g * 16
+                                 : a.w + (int64_t)(n0 + c) * a.kpad + g * 16;
+    // input row of this wave (fp32 path, K <= 1024: 4 float4 per lane) -- needed first, so issued first
+    constexpr int MAXV = 4;
+    const bool vec_ok = !XF16 && a.k <= 1024 && (a.k & 3) == 0 && (a.ldx & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
+    const int nv = (a.kpad + 255) >> 8;
+    float4 v0[MAXV];
+    if constexpr (!XF16) {
+        if (vec_ok && wid < M) {
+            const int64_t src = a.gather ? (int64_t)a.gather[wid] : (int64_t)wid;
+            const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int k = lane * 4 + i * 256;
+                v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nv && k < a.k) v0[i] = *reinterpret_cast<const float4*>(xr + k);
+            }
+        }
+    }
+    // fp16 input (already an MFMA operand image: FFN hidden; XM == 2: the attention partials, merged here): 16-byte
+    // pieces of 8 K positions, up to 8 per thread
+    constexpr int XP = XM == 2 ? 2 : 8;
+    half8 xh[XM == 1 ? XP : 1];
+    float4 po[XM == 2 ? XP : 1][2][2];                         // [piece][split][8 floats]
+    float2 pml[XM == 2 ? XP : 1][2];
+    const int kp8 = a.kpad >> 3;                              // 16-byte pieces per row
+    const int npieces = M * kp8;
+    if constexpr (XM == 1) {
+        const _Float16* xb = reinterpret_cast<const _Float16*>(a.x);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int q = tid + i * 512;
+            if (q < npieces) {
+                const int row = q / kp8, kk = (q - row * kp8) << 3;
+                half8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+                xh[i] = kk < a.k ? *reinterpret_cast<const half8*>(xb + (int64_t)row * a.ldx + kk) : z;
+            }
+        }
+    }
+    if constexpr (XM == 2) {
+        // x = part_o [m][heads][2][64] fp32 (unnormalised), x2 = part_ml [m][heads][2] (running max, sum)
+        const float* pob = reinterpret_cast<const float*>(a.x);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int q = tid + i * 512;
+            if (q < npieces) {
+                const int row = q / kp8, kk = (q - row * kp8) << 3;
+                const int hd = kk >> 6, dd = kk & 63;
+                const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
+                    po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
+                    pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
+                }
+            }
+        }
+    }
+    half8 fb[NL][2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int line = wid + i * GV_WAVES;
+        if (line < lines) {
+            fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
+            fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+        }
+    }
+    // LayerNorm parameters of the lanes' k positions (same positions for every row)
+    float4 lg[MAXV], lb[MAXV];
+    if constexpr (!XF16) {
+        if (vec_ok) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int k = lane * 4 + i * 256;
+                if (a.ln_g && i < nv && k < a.k) {
+                    lg[i] = *reinterpret_cast<const float4*>(a.ln_g + k);
+                    lb[i] = *reinterpret_cast<const float4*>(a.ln_b + k);
+                }
+            }
+        }
+    }
+    // epilogue operands of the thread's output element
+    constexpr int NOUT = HALF8 ? 64 : MT * 256;
+    const bool owner = tid < NOUT;
+    int on, om;                                               // output column / row of this thread
+    if constexpr (HALF8) {
+        on = n0 + (tid & 7);
+        om = (tid >> 3) & 7;
+    } else {
+        const int t = tid >> 8, e = (tid >> 6) & 3;
+        on = n0 + (lane & 15);
+        om = t * 16 + (lane >> 4) * 4 + e;
+    }
+    const bool live = owner && on < a.n && om < M;
+    float e_bias = 0.0f, e_res = 0.0f;
+    if (live) {
+        if (a.bias) e_bias = a.bias[on];
+        if (a.res) e_res = a.res[(int64_t)om * a.ldr + on];
+    }
+    int kv_pos = a.pos;
+    if (a.kv && a.st) kv_pos = a.st->pos0 + a.st->step;
+    LM_STAMP(a, 1);
+
+    // ---- (1) stage the input rows as an fp16 image in LDS
+    auto put4 = [&](int mr, int k, float4 o) {               // 4 consecutive K positions of row mr
+        half4 h4;
+        h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+        if constexpr (HALF8) {
+            const int hh = k >= Kc ? 1 : 0;
+            *reinterpret_cast<half4*>(sx + (size_t)(mr + 8 * hh) * xs + (k - hh * Kc)) = h4;
+        } else {
+            *reinterpret_cast<half4*>(sx + (size_t)mr * xs + k) = h4;
+        }
+    };
+    auto put8 = [&](int row, int kk, half8 hv) {              // 8 consecutive K positions of row `row`
+        if constexpr (HALF8) {
+            const int hh = kk >= Kc ? 1 : 0;
+            *reinterpret_cast<half8*>(sx + (size_t)(row + 8 * hh) * xs + (kk - hh * Kc)) = hv;
+        } else {
+            *reinterpret_cast<half8*>(sx + (size_t)row * xs + kk) = hv;
+        }
+    };
+    if constexpr (XM == 1) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int q = tid + i * 512;
+            if (q < npieces) {
+                const int row = q / kp8;
+                put8(row, (q - row * kp8) << 3, xh[i]);
+            }
+        }
+        for (int q = tid + XP * 512; q < npieces; q += 512) {   // rows beyond the prefetched pieces (m > 8 with K = 4096)
+            const int row = q / kp8, kk = (q - row * kp8) << 3;
+            half8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+            put8(row, kk, kk < a.k ? *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.x) + (int64_t)row * a.ldx + kk) : z);
+        }
+    } else if constexpr (XM == 2) {
+        // merge the two key-range partials of lm_attn: out = (o0 w0 + o1 w1) / (l0 w0 + l1 w1), w_s = exp(m_s - max m)
+        auto merge = [&](const float4 (&o)[2][2], const float2 (&ml)[2]) {
+            const float mx = fmaxf(ml[0].x, ml[1].x);
+            const float w0 = ml[0].x == -INFINITY ? 0.0f : __expf(ml[0].x - mx), w1 = ml[1].x == -INFINITY ? 0.0f : __expf(ml[1].x - mx);
+            const float l = ml[0].y * w0 + ml[1].y * w1;
+            const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+            half8 hv;
+            hv[0] = (_Float16)((o[0][0].x * w0 + o[1][0].x * w1) * inv); hv[1] = (_Float16)((o[0][0].y * w0 + o[1][0].y * w1) * inv);
+            hv[2] = (_Float16)((o[0][0].z * w0 + o[1][0].z * w1) * inv); hv[3] = (_Float16)((o[0][0].w * w0 + o[1][0].w * w1) * inv);
+            hv[4] = (_Float16)((o[0][1].x * w0 + o[1][1].x * w1) * inv); hv[5] = (_Float16)((o[0][1].y * w0 + o[1][1].y * w1) * inv);
+            hv[6] = (_Float16)((o[0][1].z * w0 + o[1][1].z * w1) * inv); hv[7] = (_Float16)((o[0][1].w * w0 + o[1][1].w * w1) * inv);
+            return hv;
+        };
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int q = tid + i * 512;
+            if (q < npieces) {
+                const int row = q / kp8;
+                put8(row, (q - row * kp8) << 3, merge(po[i], pml[i]));
+            }
+        }
+        for (int q = tid + XP * 512; q < npieces; q += 512) {   // m > 8 rows
+            const int row = q / kp8, kk = (q - row * kp8) << 3;
+            const int hd = kk >> 6, dd = kk & 63;
+            const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+            const float* pob = reinterpret_cast<const float*>(a.x);
+            float4 o[2][2];
+            float2 ml[2];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                o[sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
+                o[sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
+                ml[sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
+            }
+            put8(row, kk, merge(o, ml));
+        }
+    } else {
+        // register path: wave w owns rows w, w + 8, ... (the first one was prefetched above)
+        auto stage_row = [&](float4 (&v)[MAXV], int mr) {
+            const float inv_k = 1.0f / (float)a.k;
+            if (a.pre_g) {
+                // embedding stage: two-pass LayerNorm (as layernorm_rows) -> ReLU -> * pre_scale
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                const float mean = wsum64(s) * inv_k;
+                float qq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int k = lane * 4 + i * 256;
+                    if (i < nv && k < a.k) {
+                        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                        qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                    }
+                }
+                const float rstd = rsqrtf(wsum64(qq) * inv_k + a.ln_eps);
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int k = lane * 4 + i * 256;
+                    if (i < nv && k < a.k) {
+                        // (parameters loaded here, not with the up-front loads: one kernel per step takes this branch and
+                        // eight more float4 of live registers would cost every other variant its second workgroup per CU)
+                        const float4 pg = *reinterpret_cast<const float4*>(a.pre_g + k);
+                        const float4 pb = *reinterpret_cast<const float4*>(a.pre_b + k);
+                        float4 o;
+                        o.x = a.pre_scale * fmaxf((v[i].x - mean) * rstd * pg.x + pb.x, 0.0f);
+                        o.y = a.pre_scale * fmaxf((v[i].y - mean) * rstd * pg.y + pb.y, 0.0f);
+                        o.z = a.pre_scale * fmaxf((v[i].z - mean) * rstd * pg.z + pb.z, 0.0f);
+                        o.w = a.pre_scale * fmaxf((v[i].w - mean) * rstd * pg.w + pb.w, 0.0f);
+                        v[i] = o;
+                        if (a.pre_out && blockIdx.x == 0) *reinterpret_cast<float4*>(a.pre_out + (int64_t)mr * a.ldx + k) = o;
+                    }
+                }
+            }
+            float mean = 0.0f, rstd = 1.0f;
+            if (a.ln_g || a.ln_plain) {                       // single-pass statistics (as gemm_skinny16)
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                    s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                }
+                s1 = wsum64(s1);
+                s2 = wsum64(s2);
+                mean = s1 / (float)a.k;
+                const float var = fmaxf(s2 / (float)a.k - mean * mean, 0.0f);
+                rstd = rsqrtf(var + a.ln_eps);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int k = lane * 4 + i * 256;
+                if (i < nv && k < a.kpad) {
+                    float4 o = v[i];
+                    if (a.ln_g && k < a.k) {
+                        o.x = (o.x - mean) * rstd * lg[i].x + lb[i].x;
+                        o.y = (o.y - mean) * rstd * lg[i].y + lb[i].y;
+                        o.z = (o.z - mean) * rstd * lg[i].z + lb[i].z;
+                        o.w = (o.w - mean) * rstd * lg[i].w + lb[i].w;
+                    } else if (a.ln_plain && k < a.k) {      // scale and shift are folded into the weights / bias (host, at load)
+                        o.x = (o.x - mean) * rstd; o.y = (o.y - mean) * rstd;
+                        o.z = (o.z - mean) * rstd; o.w = (o.w - mean) * rstd;
+                    }
+                    put4(mr, k, o);
+                }
+            }
+        };
+        if (vec_ok) {
+            if (wid < M) stage_row(v0, wid);
+            for (int mr = wid + GV_WAVES; mr < M; mr += GV_WAVES) {
+                const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+                const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int k = lane * 4 + i * 256;
+                    v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < nv && k < a.k) v0[i] = *reinterpret_cast<const float4*>(xr + k);
+                }
+                stage_row(v0, mr);
+            }
+        } else {
+            // general path (any K / alignment; no embedding pre-transform): scalar, two-pass statistics
+            for (int mr = wid; mr < M; mr += GV_WAVES) {
+                const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+                const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+                float mean = 0.0f, rstd = 1.0f;
+                if (a.ln_g || a.ln_plain) {
+                    float s = 0.0f;
+                    for (int k = lane; k < a.k; k += 64) s += xr[k];
+                    mean = wsum64(s) / (float)a.k;
+                    float vv = 0.0f;
+                    for (int k = lane; k < a.k; k += 64) {
+                        const float d = xr[k] - mean;
+                        vv += d * d;
+                    }
+                    rstd = rsqrtf(wsum64(vv) / (float)a.k + a.ln_eps);
+                }
+                for (int k = lane; k < a.kpad; k += 64) {
+                    float v = 0.0f;
+                    if (k < a.k) {
+                        v = xr[k];
+                        if (a.ln_g) v = (v - mean) * rstd * a.ln_g[k] + a.ln_b[k];
+                        else if (a.ln_plain) v = (v - mean) * rstd;
+                    }
+                    if constexpr (HALF8) {
+                        const int hh = k >= Kc ? 1 : 0;
+                        sx[(size_t)(mr + 8 * hh) * xs + (k - hh * Kc)] = (_Float16)v;
+                    } else {
+                        sx[(size_t)mr * xs + k] = (_Float16)v;
+                    }
+                }
+            }
+        }
+    }
+    LM_STAMP(a, 2);
+    __syncthreads();
+    LM_STAMP(a, 3);
+
+    // ---- (2) MFMAs: A fragments from LDS, B fragments are the prefetched weight registers
+    float4v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.0f;
+    const _Float16* arow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int mr = t * 16 + c;
+        if constexpr (!HALF8) {
+            if (mr >= M) mr = M - 1;
+        }
+        arow[t] = sx + (size_t)mr * xs + g * 16;
+    }
+    for (int pass = 0;; ++pass) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int line = wid + (pass * NL + i) * GV_WAVES;
+            if (line < lines) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const half8 fa0 = *reinterpret_cast<const half8*>(arow[t] + line * 64);
+                    const half8 fa1 = *reinterpret_cast<const half8*>(arow[t] + line * 64 + 8);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[i][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[i][1], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (wid + (pass + 1) * NL * GV_WAVES >= lines) break;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int line = wid + ((pass + 1) * NL + i) * GV_WAVES;
+            if (line < lines) {
+                fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
+                fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+            }
+        }
+    }
+    LM_STAMP(a, 4);
+    // ---- (3) cross-wave reduction + epilogue
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[((wid * MT + t) * 4 + e) * 64 + lane] = acc[t][e];
+    __syncthreads();
+    if (live) {
+        float v = 0.0f;
+        if constexpr (HALF8) {
+            const int r = om, cc = tid & 7;
+            const int e = r & 3, la = 16 * (r >> 2) + cc, lb2 = la + 40;      // D[r][c] and D[r + 8][c + 8]
+#pragma unroll
+            for (int w = 0; w < GV_WAVES; ++w) v += red[(w * 4 + e) * 64 + la] + red[(w * 4 + e) * 64 + lb2];
+        } else {
+            const int t = tid >> 8, e = (tid >> 6) & 3;
+#pragma unroll
+            for (int w = 0; w < GV_WAVES; ++w) v += red[((w * MT + t) * 4 + e) * 64 + lane];
+        }
+        v += e_bias;
+        if (a.relu) v = fmaxf(v, 0.0f);
+        v += e_res;
+        if (a.kv && on >= a.n_split) {
+            a.kv[((int64_t)kv_pos * M + om) * a.ldkv + (on - a.n_split)] = (_Float16)v;
+        } else {
+            if (a.out) a.out[(int64_t)om * a.ldo + on] = v;
+            if (a.out16) a.out16[(int64_t)om * a.ldo16 + on] = (_Float16)v;
+        }
+    }
+    if (a.advance && a.st && blockIdx.x == 0 && tid == 0) a.st->step = a.st->step + 1;   // no other block of this kernel reads it
+    LM_STAMP(a, 5);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decode attention, one (row, head) per block.  8 lanes share a key (lane sub = tid & 7 owns dims [8 sub, 8 sub + 8):
+// one 16-byte load each of K, V and the position row), 64 keys per pass of the 512 threads, AT_U passes per chunk with
+// ALL of a chunk's K, position and V loads issued before the first score is formed: one memory round trip per 512 keys
+// (the ~400 keys of a benchmark step: one round trip for the whole kernel; K, then softmax, then V took three).
+// Chunks are combined by the usual running maximum / running sum.
+static constexpr int AT_U = 8;
+
+__device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += q[e] * (float)k[e];
+    return s;
+}
+
+__global__ __launch_bounds__(512) void lm_attn(AttnArgs a) {
+    __shared__ float s_m[8];
+    __shared__ float s_l[8];
+    __shared__ __attribute__((aligned(16))) float s_o[8][64];
+    pin_args(a);
+    LM_STAMP(a, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = tid & 7, kg = tid >> 3;                   // key group 0..63
+    const int head = blockIdx.x, bb = blockIdx.y;
+    const int qpos = a.st ? a.st->pos0 + a.st->step : a.pos;  // absolute position of the query = index of the newest key
+    const int len = qpos + 1;
+    const int ks_first = a.kstart ? min(a.kstart[bb], len - 1) : 0;
+    // key split (gridDim.z = 2): two workgroups per (row, head) take the two halves of the valid keys (a multiple of 64
+    // keys each) and write unnormalised partials; the consumer (lm_gemv XM == 2) merges them while staging its input.
+    int ks0 = ks_first, kend = len;
+    if (gridDim.z > 1) {
+        const int half = (((len - ks_first + 1) >> 1) + 63) & ~63;
+        ks0 = ks_first + (int)blockIdx.z * half;
+        kend = min(len, ks0 + half);
+    }
+    const int64_t trow = (int64_t)a.b * 2 * a.d;              // one time step of the cache
+    const _Float16* kb = a.kv + (int64_t)bb * 2 * a.d + head * 64 + sub * 8;
+    const _Float16* vb = kb + a.d;
+    const _Float16* pb = a.postab + head * 64 + sub * 8;
+    float qu[8], qv[8];
+    {
+        const float* qp = a.q + (int64_t)bb * a.ldq + head * 64 + sub * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(qp), x1 = *reinterpret_cast<const float4*>(qp + 4);
+        const float4 u0 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8), u1 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8), w1 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8 + 4);
+        const float xs_[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float us_[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        const float ws_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qu[e] = (xs_[e] + us_[e]) * a.scale;
+            qv[e] = (xs_[e] + ws_[e]) * a.scale;
+        }
+    }
+    // every wave keeps its OWN running maximum / sum / output over the keys it sees (no workgroup barrier inside the key
+    // loop); the eight waves are merged once at the end.
+    float m_run = -INFINITY, l_run = 0.0f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+    for (int j0 = ks0; j0 < kend; j0 += 64 * AT_U) {
+        half8 kk[AT_U], pp[AT_U], vv[AT_U];
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) {
+            const int j = j0 + u * 64 + kg;
+            if (j < kend) {
+                kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)j * trow);
+                pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - j + a.center) * a.ldp);
+                vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)j * trow);
+            }
+        }
+        LM_STAMP(a, 1);
+        float s[AT_U];
+        float m_new = m_run;
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) {
+            const int j = j0 + u * 64 + kg;
+            // the 8 lanes of a key group hold partial dots of the same key (an invalid key is invalid on all 8)
+            float t = j < kend ? dot8(qu, kk[u]) + dot8(qv, pp[u]) : 0.0f;
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            s[u] = j < kend ? t : -INFINITY;
+            m_new = fmaxf(m_new, s[u]);
+        }
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) m_new = fmaxf(m_new, __shfl_xor(m_new, off, 64));   // the wave's maximum
+        if (m_new > -INFINITY) {                               // wave-uniform; false only while the wave has seen no valid key
+            const float sc_old = m_run == -INFINITY ? 0.0f : __expf(m_run - m_new);
+            l_run *= sc_old;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= sc_old;
+#pragma unroll
+            for (int u = 0; u < AT_U; ++u) {
+                const int j = j0 + u * 64 + kg;
+                if (j < kend) {
+                    const float p = __expf(s[u] - m_new);
+                    l_run += p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += p * (float)vv[u][e];
+                }
+            }
+            m_run = m_new;
+        }
+    }
+    LM_STAMP(a, 2);
+    // sum over the key groups of the wave (lanes with equal `sub`); l_run is per key group and equal on its 8 lanes
+#pragma unroll
+    for (int off = 8; off <= 32; off <<= 1) {
+        l_run += __shfl_xor(l_run, off, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off, 64);
+    }
+    if (lane < 8) {
+        *reinterpret_cast<float4*>(&s_o[wid][lane * 8]) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(&s_o[wid][lane * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+        if (lane == 0) {
+            s_l[wid] = l_run;
+            s_m[wid] = m_run;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float mx = s_m[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_m[w]);
+        float tot = 0.0f, l = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {                          // fixed order: the same bits on every run
+            const float sc = s_m[w] == -INFINITY ? 0.0f : __expf(s_m[w] - mx);
+            tot += s_o[w][tid] * sc;
+            l += s_l[w] * sc;
+        }
+        const float m_run = mx;
+        if (gridDim.z > 1) {
+            const int64_t slot = ((int64_t)bb * a.h + head) * 2 + blockIdx.z;
+            a.part_o[slot * 64 + tid] = tot;
+            if (tid == 0) *reinterpret_cast<float2*>(a.part_ml + slot * 2) = make_float2(m_run, l);
+        } else {
+            a.out[(int64_t)bb * a.ldo + head * 64 + tid] = (_Float16)(l > 0.0f ? tot / l : 0.0f);
+        }
+    }
+    LM_STAMP(a, 3);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+static size_t gemv_lds_bytes(int lrows, int kc, int mt) {
+    return (((size_t)lrows * (kc + 8) * 2 + 15) & ~(size_t)15) + (size_t)GV_WAVES * mt * 4 * 64 * sizeof(float);
+}
+
+// 8-column form: twice the workgroups.  Measured (scripts/micro/decode_chain.hip, per launch incl. the 1.45 us boundary): it
+// pays where the 16-column grid leaves CUs idle (n = 1024: 64 -> 128 workgroups; the deep FFN-out projection 7.5 -> 6.0-6.4 us
+// with no split-K hand-off) and costs where the 16-column grid already covers the chip (n = 3072 / 4096: 5.7 -> 8.9 us, every
+// workgroup stages the whole input and a CU then ingests 96 KB instead of 64).
+static int half8_max_blocks() {
+    static const int v = [] { const char* e = getenv("ASTTS_LM_HALF8_MAX_BLOCKS"); return e ? atoi(e) : 256; }();
+    return v;
+}
+
+int lm_gemv_variant(const GemvArgs& a) {
+    const bool half8 = a.m <= 8 && (a.kpad % 128) == 0 && (a.n + 7) / 8 <= half8_max_blocks();
+    const int mt = a.m <= 16 ? 1 : 2;
+    return (half8 ? 1 : 0) | (mt << 1);
+}
+
+template <int MT, bool HALF8, int XM>
+static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {   // first use (never inside a capture: lm_step_set_attrs() visits every variant up front)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, HALF8, XM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, HALF8, XM, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (grid.x == 0) return;
+    if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 2>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 8>), grid, dim3(512), lds, st, a);
+}
+
+template <int MT, bool HALF8>
+static void gemv_launch_xm(const GemvArgs& a, int xm, dim3 grid, size_t lds, int lpw, hipStream_t st) {
+    if (xm == 0) gemv_launch_nl<MT, HALF8, 0>(a, grid, lds, lpw, st);
+    else if (xm == 1) gemv_launch_nl<MT, HALF8, 1>(a, grid, lds, lpw, st);
+    else gemv_launch_nl<MT, HALF8, 2>(a, grid, lds, lpw, st);
+}
+
+void lm_step_set_attrs() {
+    static bool done = false;
+    if (done) return;
+    GemvArgs z{};
+    for (int xm = 0; xm < 3; ++xm) {   // grid 0: sets the attributes, launches nothing
+        gemv_launch_xm<1, true>(z, xm, dim3(0), 0, 2, nullptr);
+        gemv_launch_xm<1, false>(z, xm, dim3(0), 0, 2, nullptr);
+        gemv_launch_xm<2, false>(z, xm, dim3(0), 0, 2, nullptr);
+    }
+    done = true;
+}
+
+int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
+    ASTTS_REQUIRE(a0.x && a0.w && (a0.out || a0.out16 || a0.kv), ASTTS_ERR_INVALID, "lm_gemv: null pointer");
+    ASTTS_REQUIRE(a0.m >= 1 && a0.m <= 32 && a0.n >= 1 && a0.k >= 1 && a0.kpad >= a0.k && (a0.kpad & 63) == 0, ASTTS_ERR_INVALID,
+                  "lm_gemv: bad shape m=%d n=%d k=%d kpad=%d", a0.m, a0.n, a0.k, a0.kpad);
+    const int xm = a0.x_mode;
+    ASTTS_REQUIRE(xm >= 0 && xm <= 2, ASTTS_ERR_INVALID, "lm_gemv: x_mode=%d", xm);
+    ASTTS_REQUIRE(xm == 0 || (!a0.gather && !a0.ln_g && !a0.pre_g && (a0.k & 7) == 0 && ((uintptr_t)a0.x & 15) == 0), ASTTS_ERR_INVALID,
+                  "lm_gemv: fp16 / partial input takes no gather / LayerNorm and needs 16-byte aligned rows");
+    ASTTS_REQUIRE(xm != 1 || (a0.ldx & 7) == 0, ASTTS_ERR_INVALID, "lm_gemv: fp16 input rows must be 16-byte aligned");
+    ASTTS_REQUIRE(xm != 2 || (a0.x2 && (a0.k & 63) == 0 && a0.k == a0.kpad), ASTTS_ERR_INVALID, "lm_gemv: attention partials need x2 and k = heads * 64");
+    ASTTS_REQUIRE(!a0.pre_g || (a0.k <= 1024 && (a0.k & 3) == 0 && (a0.ldx & 3) == 0 && ((uintptr_t)a0.x & 15) == 0), ASTTS_ERR_INVALID,
+                  "lm_gemv: the embedding pre-transform needs k <= 1024 and aligned rows");
+    lm_step_set_attrs();
+    // rows are taken in chunks whose fp16 image fits the LDS (only m > 16 with K = 4096 needs two launches)
+    int rows = a0.m;
+    for (;;) {
+        GemvArgs t = a0;
+        t.m = rows;
+        const int var = lm_gemv_variant(t);
+        const int kc = (var & 1) ? a0.kpad / 2 : a0.kpad;
+        if (gemv_lds_bytes((var & 1) ? 16 : rows, kc, var >> 1) <= 160 * 1024) break;
+        ASTTS_REQUIRE(rows > 1, ASTTS_ERR_INVALID, "lm_gemv: kpad=%d does not fit the LDS image", a0.kpad);
+        rows = rows > 16 ? 16 : rows / 2;
+    }
+    ASTTS_REQUIRE(rows == a0.m || (!a0.kv && !a0.pre_g), ASTTS_ERR_INVALID, "lm_gemv: row chunks cannot write the kv cache");
+    for (int r0 = 0; r0 < a0.m; r0 += rows) {
+        GemvArgs a = a0;
+        a.m = a0.m - r0 < rows ? a0.m - r0 : rows;
+        if (r0) {
+            if (a.gather) a.gather += r0;
+            else if (xm == 0) a.x = reinterpret_cast<const float*>(a0.x) + (int64_t)r0 * a0.ldx;
+            else if (xm == 1) a.x = reinterpret_cast<const _Float16*>(a0.x) + (int64_t)r0 * a0.ldx;
+            else {
+                a.x = reinterpret_cast<const float*>(a0.x) + (int64_t)r0 * (a0.k >> 6) * 2 * 64;
+                a.x2 = a0.x2 + (int64_t)r0 * (a0.k >> 6) * 2 * 2;
+            }
+            if (a.res) a.res += (int64_t)r0 * a0.ldr;
+            if (a.out) a.out += (int64_t)r0 * a0.ldo;
+            if (a.out16) a.out16 += (int64_t)r0 * a0.ldo16;
+        }
+        a.advance = a0.advance && r0 + rows >= a0.m;
+        const int var = lm_gemv_variant(a);
+        const bool half8 = var & 1;
+        const int mt = var >> 1;
+        const int kc = half8 ? a.kpad / 2 : a.kpad;
+        const size_t lds = gemv_lds_bytes(half8 ? 16 : a.m, kc, mt);
+        const dim3 grid((a.n + (half8 ? 7 : 15)) / (half8 ? 8 : 16));
+        const int lpw = ((kc >> 6) + GV_WAVES - 1) / GV_WAVES;
+        if (half8) gemv_launch_xm<1, true>(a, xm, grid, lds, lpw, st);
+        else if (mt == 1) gemv_launch_xm<1, false>(a, xm, grid, lds, lpw, st);
+        else gemv_launch_xm<2, false>(a, xm, grid, lds, lpw, st);
+    }
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int lm_attn_launch(const AttnArgs& a, hipStream_t st) {
+    ASTTS_REQUIRE(a.q && a.kv && a.postab && a.bias_u && a.bias_v, ASTTS_ERR_INVALID, "lm_attn: null pointer");
+    ASTTS_REQUIRE(a.b >= 1 && a.h >= 1 && a.d == a.h * 64 && (a.ldq & 3) == 0 && (a.ldp & 7) == 0, ASTTS_ERR_INVALID,
+                  "lm_attn: bad shape b=%d h=%d d=%d", a.b, a.h, a.d);
+    ASTTS_REQUIRE(a.ksplit == 1 ? a.out != nullptr : (a.ksplit == 2 && a.part_o && a.part_ml), ASTTS_ERR_INVALID,
+                  "lm_attn: ksplit=%d needs %s", a.ksplit, a.ksplit == 1 ? "out" : "the partial buffers (ksplit 1 or 2)");
+    hipLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, a);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // namespace astts

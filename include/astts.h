@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASTTS_ABI_VERSION 1
+#define ASTTS_ABI_VERSION 2
 
 #define ASTTS_OK 0
 #define ASTTS_ERR_INVALID (-1)     /* bad argument (null pointer, size, dtype, k, ...)            */
@@ -263,7 +263,9 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
 
 /* ------------------------------------------------------------------------------------------
  * Acoustic-transformer decode engine: the autoregressive loop of TransformerLM.inference (one speech
- * token per step) issued from C++ with no host synchronisation -- 5 launches per layer and step.
+ * token per step) issued from C++ with no host synchronisation -- 5 launches per layer and step.  Batches of <= 8 rows
+ * take the decode-step kernels of csrc/lm_step.hip (73 launches per step), wider ones the operator chain (74);
+ * ASTTS_LM_ENGINE=v1|v2 forces one of them.
  * All pointers are device pointers that must outlive the handle (weights packed by
  * astts_op_pack_weight; fp32 biases / norms / tables).
  * ------------------------------------------------------------------------------------------ */
@@ -275,6 +277,9 @@ typedef struct {
     int32_t top_k, ras_win;
     float top_p, ras_tau, eps;
     int32_t kv_f16, pos_f16; /* KV cache / position tables stored as fp16 */
+    int32_t ln_folded;       /* 1: the scale / shift of norm1, norm2 and after_norm are folded into wqkv, w1 and the head
+                              * (W' = W diag(gamma), b' = b + W beta, done by the host at load); the n*_g / n*_b / after_*
+                              * arrays then hold ones / zeros and the step kernels normalise without reading them */
 } astts_lm_config_t;
 typedef struct {
     const float* speech_emb;                 /* [speech_vocab, d] */
