@@ -28,6 +28,7 @@ _SIGS = {
         "astts_op_gemm_fused_ws": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p] + [c_int32] * 11 + [c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "astts_op_gemm_fused_workspace_bytes": (c_size_t, []),
+    "astts_op_gemm_set_ring_mode": (c_int32, [c_int32]),
     "astts_op_gemm_ln": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_attn_relpos_ex": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
@@ -269,6 +270,11 @@ def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.
                                            residual.stride(-2) if residual is not None else 0, ACT[act], alpha, slope,
                                            ws.data_ptr(), ws.numel(), st))
     return out
+
+
+def set_gemm_ring_mode(mode: int) -> None:
+    """-1 auto (default), 0 ring kernel off, 1 / 2 / 3 force the 128x128 / 128x64 / 64x64 ring tile (tests, tuning)."""
+    _lib.check(_L().astts_op_gemm_set_ring_mode(int(mode)))
 
 
 def linear(x: torch.Tensor, w: PackedWeight, act: str = "none", residual=None, alpha: float = 1.0,

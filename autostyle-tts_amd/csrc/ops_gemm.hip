@@ -924,6 +924,8 @@ static void launch_tile(const GemmArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((gemm_tile<WM, WN, TM, TN, false, BKT>), grid, dim3(256), 0, st, a);
 }
 
+static int g_ring_mode_override = -1;   // -1: rule below / ASTTS_GEMM_RING; 0: ring kernel off; 1..3: force that tile
+
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
     if (a.m <= 32 && plain && !a.x_f16 && !a.out_f16) {
@@ -982,7 +984,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)a.m * a.n * a.cin * a.taps);
     auto blocks = [&](int bm, int bn) { return cdiv(a.m, bm) * cdiv(a.n, bn); };
     // fp16 activations, plain GEMM, whole 64-wide K tiles: the LDS-DMA ring kernel
-    static const int ring_env = [] { const char* e = getenv("ASTTS_GEMM_RING"); return e ? atoi(e) : -1; }();
+    static const int ring_env0 = [] { const char* e = getenv("ASTTS_GEMM_RING"); return e ? atoi(e) : -1; }();
+    const int ring_env = g_ring_mode_override >= 0 ? g_ring_mode_override : ring_env0;   // astts_op_gemm_set_ring_mode (tests)
     if (plain && a.x_f16 && a.cin == a.cin_pad && (a.lda & 7) == 0 && ((uintptr_t)a.x & 15) == 0 && a.m >= 64 && a.n > 32 &&
         ring_env != 0) {
         static bool ring_attr = false;
@@ -1052,6 +1055,12 @@ static int check_gemm_args(const char* who, const float* x, const void* w, float
 }
 
 extern "C" {
+
+int astts_op_gemm_set_ring_mode(int32_t mode) {
+    ASTTS_REQUIRE(mode >= -1 && mode <= 3, ASTTS_ERR_INVALID, "astts_op_gemm_set_ring_mode: mode=%d (-1 auto, 0 off, 1..3 tile)", mode);
+    g_ring_mode_override = mode;
+    return ASTTS_OK;
+}
 
 int astts_op_pack_weight(const float* src, void* dst_f16, int32_t n, int32_t taps, int32_t cin,
                          int32_t n_pad, int32_t cin_pad, astts_stream_t stream) {

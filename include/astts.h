@@ -162,6 +162,10 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
  * LayerNorm launch -- a 32-row x 256-column workgroup streams the whole weight (0.25-0.5 MB) and only 172 of them exist, so the
  * flow engine keeps the two launches; the operator stays available for wider row counts.
  * (diffusers BasicTransformerBlock: `hidden = attn(norm1(hidden)) + hidden; hidden = ff(norm3(hidden)) + hidden`, [EXT]). */
+/* Tile choice of the LDS-DMA ring GEMM (fp16 activations): -1 = by shape (default; env ASTTS_GEMM_RING overrides), 0 = ring
+ * kernel off (register-staged tiles), 1 = 128x128 two-stage, 2 = 128x64 two-stage, 3 = 64x64 four-stage.  Process-global
+ * test / tuning switch: the parity tests run the benchmark's projection shapes through every tile. */
+int astts_op_gemm_set_ring_mode(int32_t mode);
 int astts_op_gemm_ln(const void* x_f16, const void* w_f16, const float* bias, const float* residual, float* out,
                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_f16, int64_t m, int32_t n, int32_t cin,
                      int32_t cin_pad, int32_t lda, int32_t ldc, int32_t ldr, int32_t ld_ln, astts_stream_t stream);

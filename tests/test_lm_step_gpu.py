@@ -1,8 +1,8 @@
 """The decode-step kernels of csrc/lm_step.hip (engine "v2": 8-column diagonal-MFMA GEMVs, one-round-trip attention with
 key split merged by its consumer, embedding LayerNorm inside layer 0's QKV kernel, LayerNorm scale/shift folded into
 the weights) against the fp32 oracle AND against the operator chain ("v1", the engine of round 1) under teacher
-forcing.  Stated tolerance vs the oracle: 2e-2 of the logit scale (fp16 weights / operands / KV cache vs all-fp32);
-observed values are printed.  v2 vs v1 share every operand rounding except the folded weights: 5e-3."""
+forcing.  Stated tolerance vs the oracle: 3e-3 of the logit scale (~5x the observed 5e-4) (fp16 weights / operands / KV cache vs all-fp32);
+observed values are printed.  v2 vs v1 share every operand rounding except the summation order: 1e-3."""
 import os
 
 import pytest
@@ -65,10 +65,10 @@ def test_tiny_v2_logits_match_oracle_and_v1(b):
         out[eng] = logits.cpu()
         err = float((out[eng] - ref).abs().max()) / scale
         print(f"tiny b={b} {eng}: logits rel err vs oracle {err:.2e}")
-        assert err < 2e-2
+        assert err < 3e-3
     d12 = float((out["v1"] - out["v2"]).abs().max()) / scale
     print(f"tiny b={b}: v2 vs v1 {d12:.2e}")
-    assert d12 < 5e-3
+    assert d12 < 1e-3
     # free running (sampling on the device): the two engines see logits that differ by ~1e-3 of their scale, so tokens agree
     # except at near-ties of the sampler's inverse CDF; require the first steps to agree and every token to be valid
     with _engine("v1"):
@@ -107,7 +107,7 @@ def test_tiny_v2_ragged_rows_match_oracle_one_at_a_time():
         _, lref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, i:i + 1], True, forced[i:i + 1])
         err = float((logits[i].cpu() - lref[0]).abs().max()) / float(lref.abs().max())
         print(f"ragged row {i}: {err:.2e}")
-        assert err < 2e-2, i
+        assert err < 3e-3, i
 
 
 def test_fullsize_v2_logits_match_oracle_and_v1_with_long_context():
@@ -128,10 +128,10 @@ def test_fullsize_v2_logits_match_oracle_and_v1_with_long_context():
         out[eng] = logits.cpu()
         err = float((out[eng] - ref).abs().max()) / scale
         print(f"full size b=8 {eng}: logits rel err vs oracle {err:.2e}")
-        assert err < 2e-2
+        assert err < 3e-3
     d12 = float((out["v1"] - out["v2"]).abs().max()) / scale
     print(f"full size: v2 vs v1 {d12:.2e}")
-    assert d12 < 5e-3
+    assert d12 < 1e-3
 
 
 def test_fullsize_v2_is_deterministic_and_row_independent():

@@ -2,10 +2,11 @@
 synthetic weights, same injected randomness.  PARITY UNPINNED w.r.t. the reference (its CosyVoice fork
 is not available): these tests pin the HIP kernels to this build's own fp32 CPU restatement.
 
-Stated tolerances (fp16 weights + fp16 MFMA operands with fp32 accumulation vs an all-fp32 oracle):
-  LM logits           max |d| <= 2e-2 * max|logit|   (teacher-forced, every step)
-  flow mel            max |d| <= 3e-2 * max|mel|     after 10 Euler steps x 2 (CFG) estimator passes
-  vocoder waveform    max |d| <= 2e-2 (full scale 0.99), SNR >= 30 dB
+Stated tolerances (fp16 weights + fp16 MFMA operands with fp32 accumulation vs an all-fp32 oracle), set at ~5x the error
+observed on MI355X (every check prints its observed value):
+  LM logits / encoders / estimator   max |d| <= 3e-3 * max|ref|   (teacher-forced, every step)
+  flow mel                           max |d| <= 5e-3 * max|mel|   after 10 Euler steps x 2 (CFG) estimator passes
+  vocoder waveform                   max |d| <= 5e-3 (full scale 0.99), SNR >= 40 dB
 """
 import math
 import os
@@ -24,6 +25,20 @@ def _cfg_and_weights(seed=0):
 
     cfg = SynthConfig.tiny()
     return cfg, make_all(cfg, seed)
+
+
+# Tolerances: ~5x the error OBSERVED on MI355X (printed by every check), not the loose fp16 worst case
+TOL_LOGITS = 3e-3    # LM logits / encoder outputs / estimator, relative to the tensor's scale (observed 4e-4 .. 6e-4)
+TOL_MEL = 5e-3       # mel after the full 10-step CFG solve (observed <= 1e-3)
+TOL_F0 = 2e-3        # f0 predictor (observed 2e-4)
+TOL_WAV = 5e-3       # vocoder waveform, absolute on a 0.99 full scale (observed <= 1e-3)
+
+
+def _close(got, ref, tol, scale, tag=None):
+    err = float((got - ref).abs().max()) / float(scale)
+    import inspect
+    print(f"[parity] {inspect.stack()[1].function}{'' if tag is None else ' ' + str(tag)}: rel err {err:.2e} (tol {tol:.0e})")
+    assert err < tol, (err, tol, tag)
 
 
 def _snr_db(ref, out):
@@ -46,7 +61,7 @@ def test_relpos_encoder_matches_oracle():
                         cfg.ln_eps, cfg.max_positions, torch.device(DEV))
     out = enc.forward(x.to(DEV), lens.to(DEV, torch.int32)).cpu()
     for i, L in enumerate(lens.tolist()):
-        assert float((out[i, :L] - ref[i, :L]).abs().max()) < 2e-2 * float(ref.abs().max())
+        _close(out[i, :L], ref[i, :L], TOL_LOGITS, float(ref.abs().max()))
 
 
 def test_lm_teacher_forced_logits_and_sampling():
@@ -68,11 +83,11 @@ def test_lm_teacher_forced_logits_and_sampling():
     lm = AcousticLM(sd, cfg, torch.device(DEV))
     pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
     assert pre.shape == (pre_ref.shape[1], b, cfg.lm_dim)
-    assert float((pre.cpu().transpose(0, 1) - pre_ref).abs().max()) < 2e-2 * float(pre_ref.abs().max())
+    _close(pre.cpu().transpose(0, 1), pre_ref, TOL_LOGITS, float(pre_ref.abs().max()))
     scale = float(logits_ref.abs().max())
     for use_engine in (False, True):      # Python-issued fused step, then the C++ decode engine (astts_lm_decode)
         toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True, use_engine=use_engine)
-        assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * scale
+        _close(logits.cpu(), logits_ref, TOL_LOGITS, scale)
         assert torch.equal(toks.cpu(), forced.to(torch.int32))
     # free-running: the v1 engine and the Python-issued path take identical kernels in identical order -> identical tokens
     # (the default engine for <= 8 rows is v2, csrc/lm_step.hip: tests/test_lm_step_gpu.py)
@@ -124,12 +139,12 @@ def test_flow_estimator_and_cfm_match_oracle():
     m = (torch.arange(mel_total)[None, :] < lens[:, None]).float()[..., None]
     ref = osyn.estimator(sd, cfg, x * m, mu * m, spk_e, cond * m, t, lens)
     out = fd.estimator((x * m).to(DEV), (mu * m).to(DEV), spk_e.to(DEV), (cond * m).to(DEV), t.to(DEV), lens.to(DEV, torch.int32)).cpu()
-    assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    _close(out, ref, TOL_LOGITS, float(ref.abs().max()))
     # full CFM solve
     ref_mel = osyn.flow_decode(sd, cfg, tokens, tlen, prompt_mel, spk, z, mel_total)
     mel = fd.decode(tokens.to(DEV), tlen.to(DEV, torch.int32), prompt_mel.to(DEV), spk.to(DEV), z.to(DEV), mel_total).cpu()
     assert mel.shape == ref_mel.shape == (b, mel_total - tmp, cfg.mel)
-    assert float((mel - ref_mel).abs().max()) < 3e-2 * float(ref_mel.abs().max())
+    _close(mel, ref_mel, TOL_MEL, float(ref_mel.abs().max()))
 
 
 def test_hift_vocoder_matches_oracle():
@@ -148,7 +163,7 @@ def test_hift_vocoder_matches_oracle():
     voc = HiftVocoder(sd, cfg, torch.device(DEV))
     f0_ref = osyn.hift_f0(sd, cfg, mel)
     f0 = voc.f0(mel.to(DEV)).cpu()
-    assert float((f0 - f0_ref).abs().max()) < 1e-2 * float(f0_ref.abs().max())
+    _close(f0, f0_ref, TOL_F0, float(f0_ref.abs().max()))
     # decode from the SAME source signal (the f0 -> phase map amplifies tiny f0 differences over 6k samples)
     src_ref = osyn.hift_source(sd, cfg, f0_ref, phase0, noise)
     src = voc.source(f0_ref.to(DEV), phase0.to(DEV), noise.to(DEV)).cpu()
@@ -156,8 +171,10 @@ def test_hift_vocoder_matches_oracle():
     wav_ref = osyn.hift_decode(sd, cfg, mel, src_ref)
     wav = voc.decode(mel.to(DEV), src_ref.to(DEV)).cpu()
     assert wav.shape == wav_ref.shape == (b, tm * cfg.upsample_total)
-    assert float((wav - wav_ref).abs().max()) < 2e-2
-    assert _snr_db(wav_ref, wav) > 30.0
+    _close(wav, wav_ref, TOL_WAV, 1.0)
+    snr = _snr_db(wav_ref, wav)
+    print(f"[parity] waveform SNR {snr:.1f} dB")
+    assert snr > 40.0
     assert float(wav.abs().max()) <= cfg.audio_limit + 1e-6
 
 
@@ -191,7 +208,7 @@ def test_engine_end_to_end_shapes_and_stage_parity():
     # oracle chain with the same forced tokens
     all_tok = torch.cat([timbre_tok, forced], dim=1)
     mel_ref = osyn.flow_decode(W["flow"], cfg, all_tok, torch.full((b,), tp + ts), timbre_mel, spk_t, z, tmp + tm)
-    assert float((mel.cpu() - mel_ref).abs().max()) < 3e-2 * float(mel_ref.abs().max())
+    _close(mel.cpu(), mel_ref, TOL_MEL, float(mel_ref.abs().max()))
     assert torch.isfinite(wav).all() and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
 
 
@@ -258,7 +275,7 @@ def test_large_batch_is_decoded_in_groups_of_32():
     rows = [0, 31, 32, 39]
     pre_ref = osyn.lm_prefix(sd, cfg, text[rows], tlen[rows], spk[rows], prompt[rows])
     _, logits_ref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, rows], True, forced[rows])
-    assert float((logits.cpu()[rows] - logits_ref).abs().max()) < 2e-2 * float(logits_ref.abs().max())
+    _close(logits.cpu()[rows], logits_ref, TOL_LOGITS, float(logits_ref.abs().max()))
     free = lm.decode(pre, steps, u.to(DEV), True, None)
     alone = lm.decode(pre[:, 32:].contiguous(), steps, u[:, 32:].contiguous().to(DEV), True, None)
     assert torch.equal(free[32:], alone)
@@ -289,7 +306,7 @@ def test_ragged_lm_batch_equals_one_at_a_time():
         for i in range(b):
             pre_ref = osyn.lm_prefix(sd, cfg, texts[i][None], torch.tensor([shapes[i][0]]), spk[i:i + 1], prompts[i][None])
             _, lref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, i:i + 1], True, forced[i:i + 1])
-            assert float((logits[i].cpu() - lref[0]).abs().max()) < 2e-2 * float(lref.abs().max()), (use_engine, i)
+            _close(logits[i].cpu(), lref[0], TOL_LOGITS, float(lref.abs().max()), tag=(use_engine, i))
 
 
 def test_ragged_flow_batch_equals_one_at_a_time():
@@ -314,7 +331,7 @@ def test_ragged_flow_batch_equals_one_at_a_time():
     for i, (tp, tg) in enumerate(shapes):
         ref = osyn.flow_decode(sd, cfg, toks[i][None], torch.tensor([tp + tg]), pmels[i][None], spk[i:i + 1], zs[i][None], zs[i].shape[0])[0]
         assert mels[i].shape == ref.shape
-        assert float((mels[i].cpu() - ref).abs().max()) < 3e-2 * float(ref.abs().max()), i
+        _close(mels[i].cpu(), ref, TOL_MEL, float(ref.abs().max()), tag=i)
 
 
 @pytest.mark.parametrize("b,t,ragged,wide", [(2, 57, False, False), (3, 64, True, False), (1, 33, True, False), (2, 70, True, True),
@@ -417,7 +434,7 @@ def test_fullsize_pipeline_and_cobatching_are_bit_identical_to_sequential():
 def test_fullsize_lm_logits_match_oracle():
     """CosyVoice-300M shapes (d = 1024, 14 layers, FFN 4096): the decode step's kernels at the sizes the benchmark runs
     -- MFMA relative-position prefill, fused LayerNorm + QKV into the fp16 KV cache, split-K FFN-out, output head --
-    against the fp32 oracle, teacher-forced over a few steps.  Tolerance as stated for the tiny model (2e-2 of the logit
+    against the fp32 oracle, teacher-forced over a few steps.  Tolerance as stated for the tiny model (TOL_LOGITS of the logit
     scale: fp16 weights / operands / KV cache vs all-fp32)."""
     from astts.synth.config import SynthConfig
     from astts.synth.model import AcousticLM
@@ -438,10 +455,10 @@ def test_fullsize_lm_logits_match_oracle():
     _, logits_ref = osyn.lm_decode(sd, cfg, pre_ref, steps, u, True, forced)
     lm = AcousticLM(sd, cfg, torch.device(DEV))
     pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
-    assert float((pre.cpu().transpose(0, 1) - pre_ref).abs().max()) < 2e-2 * float(pre_ref.abs().max())
+    _close(pre.cpu().transpose(0, 1), pre_ref, TOL_LOGITS, float(pre_ref.abs().max()))
     toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
     assert torch.equal(toks.cpu(), forced.to(torch.int32))
-    assert float((logits.cpu() - logits_ref).abs().max()) < 2e-2 * float(logits_ref.abs().max())
+    _close(logits.cpu(), logits_ref, TOL_LOGITS, float(logits_ref.abs().max()))
 
 
 def test_fullsize_flow_estimator_matches_oracle():
@@ -466,7 +483,7 @@ def test_fullsize_flow_estimator_matches_oracle():
     ref = osyn.estimator(sd, cfg, x * m, mu * m, spk_e, cond * m, tt, lens)
     fd = FlowDecoder(sd, cfg, torch.device(DEV))
     out = fd.estimator((x * m).to(DEV), (mu * m).to(DEV), spk_e.to(DEV), (cond * m).to(DEV), tt.to(DEV), lens.to(DEV, torch.int32)).cpu()
-    assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    _close(out, ref, TOL_LOGITS, float(ref.abs().max()))
 
 
 def test_fullsize_hift_vocoder_matches_oracle():
@@ -489,12 +506,14 @@ def test_fullsize_hift_vocoder_matches_oracle():
     voc = HiftVocoder(sd, cfg, torch.device(DEV))
     f0_ref = osyn.hift_f0(sd, cfg, mel)
     f0 = voc.f0(mel.to(DEV)).cpu()
-    assert float((f0 - f0_ref).abs().max()) < 1e-2 * float(f0_ref.abs().max())
+    _close(f0, f0_ref, TOL_F0, float(f0_ref.abs().max()))
     src_ref = osyn.hift_source(sd, cfg, f0_ref, phase0, noise)
     src = voc.source(f0_ref.to(DEV), phase0.to(DEV), noise.to(DEV)).cpu()
     assert float((src - src_ref).abs().max()) < 1e-4
     wav_ref = osyn.hift_decode(sd, cfg, mel, src_ref)
     wav = voc.decode(mel.to(DEV), src_ref.to(DEV)).cpu()
     assert wav.shape == wav_ref.shape == (b, tm * cfg.upsample_total)
-    assert float((wav - wav_ref).abs().max()) < 2e-2
-    assert _snr_db(wav_ref, wav) > 30.0
+    _close(wav, wav_ref, TOL_WAV, 1.0)
+    snr = _snr_db(wav_ref, wav)
+    print(f"[parity] waveform SNR {snr:.1f} dB")
+    assert snr > 40.0
