@@ -35,10 +35,16 @@ def main(args):
     q = np.load(args.query_npy).astype(np.float32)
     if q.shape[0] != len(rows):
         raise SystemExit(f"{args.query_npy}: {q.shape[0]} vectors for {len(rows)} input rows")
+    # rows without text are skipped, as the reference does (milvus/search_json.py:385-387) -- together with their query vector
+    keep = [i for i, r in enumerate(rows) if r.get("zh_text", "").strip()]
+    for i in sorted(set(range(len(rows))) - set(keep)):
+        print(f"Skipping empty text for speaker '{rows[i].get('speaker', 'UNKNOWN_SPEAKER')}'.")
+    rows = [rows[i] for i in keep]
+    q = q[keep]
     results = []
     try:
         hits = client.search(collection_name=args.collection_name, data=q, limit=1, filter=None,
-                             output_fields=["file_id", "text"])
+                             output_fields=["file_id", "text"]) if len(rows) else []
     except Exception as e:  # noqa: BLE001
         print(f"Error during search: {e}")
         traceback.print_exc()

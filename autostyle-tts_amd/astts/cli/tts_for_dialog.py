@@ -65,7 +65,7 @@ def tts_for_infer(args, cosyvoice=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     result_dir = args.result_dir + "_" + (args.time_tag or datetime.now().strftime("%m%d%H%M"))
     os.makedirs(result_dir, exist_ok=True)
     written = []
@@ -88,7 +88,7 @@ def tts_for_exp(args, cosyvoice=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     os.makedirs(args.result_dir, exist_ok=True)
     written = []
     cnt = 0
@@ -122,6 +122,8 @@ def build_parser():
     p.add_argument("--is_exp", type=bool, default=False, help="two-stage zero-shot -> vc experiment")
     p.add_argument("--timbre_map", required=True, help="JSON {speaker: 16 kHz-loadable wav path} (the reference hard-codes two)")
     p.add_argument("--model_dir", default=REF_MODEL_DIR, help="CosyVoice model directory (the reference hard-codes it)")
+    p.add_argument("--allow_random_init", action="store_true",
+                   help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     p.add_argument("--time_tag", default=None, help="suffix of the result directory (default: now as MMDDHHMM, as the reference)")
     return p
 

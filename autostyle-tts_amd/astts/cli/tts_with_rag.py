@@ -66,7 +66,7 @@ def tts_for_infer(args, cosyvoice=None, now=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     result_dir = args.result_dir + "_" + (now or datetime.now()).strftime("%m%d%H%M")
     os.makedirs(result_dir, exist_ok=True)
     written = []
@@ -108,6 +108,8 @@ def build_parser():
     parser.add_argument("--result_dir", required=True, help="path to save results")
     parser.add_argument("--is_exp", type=bool, default=False, help="path to save results")
     parser.add_argument("--model_dir", default=REF_MODEL_DIR)
+    parser.add_argument("--allow_random_init", action="store_true",
+                        help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     parser.add_argument("--timbre_dir", default=REF_TIMBRE_DIR)
     parser.add_argument("--whisper_timbre_wav", default=os.path.join(REF_TIMBRE_DIR, WHISPER_TIMBRE_FILE))
     parser.add_argument("--batch_size", type=int, default=1, help="rows synthesised per ragged GPU batch (1 = the reference's schedule)")

@@ -28,7 +28,7 @@ def tts_for_infer(args, cosyvoice=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     style = os.path.basename(args.style_wav_path)[:-4]
     timbre = os.path.basename(args.timbre_wav_path)[:-4]
     lines = get_text(args.txt_path)
@@ -53,7 +53,7 @@ def tts_for_exp(args, cosyvoice=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     style = os.path.basename(args.style_wav_path)[:-4]
     timbre = os.path.basename(args.timbre_wav_path)[:-4]
     style_wav = load_wav(args.style_wav_path, 16000)
@@ -82,6 +82,8 @@ def build_parser():
     parser.add_argument("--result_dir", required=True, help="path to save results")
     parser.add_argument("--is_exp", type=bool, default=False, help="path to save results")
     parser.add_argument("--model_dir", default=REF_MODEL_DIR)
+    parser.add_argument("--allow_random_init", action="store_true",
+                        help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     parser.add_argument("--keep_last_segment_only", action="store_true")
     return parser
 

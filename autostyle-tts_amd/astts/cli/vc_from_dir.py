@@ -69,7 +69,7 @@ def main(argv=None, cosyvoice=None):
 
     args = build_parser().parse_args(argv)
     rng = random.Random(args.seed) if args.seed is not None else random
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir)
+    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
     lines = get_text(args.txt_path)
     os.makedirs(args.result_dir, exist_ok=True)
     if args.style_meta_lst:
@@ -113,6 +113,8 @@ def build_parser():
     p.add_argument("--style_json", default=None, help="JSON list of {file_id, zh_text} (hard-coded path in the reference)")
     p.add_argument("--style_meta_lst", default=None, help="vc_from_dir_seed.py variant: name|text|wav|... list of style prompts")
     p.add_argument("--model_dir", default=REF_MODEL_DIR, help="CosyVoice model directory (hard-coded in the reference)")
+    p.add_argument("--allow_random_init", action="store_true",
+                   help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     p.add_argument("--seed", type=int, default=None, help="seed of the file draw (default: unseeded, as the reference)")
     p.add_argument("--keep_last_segment_only", action="store_true", help="reproduce the reference's overwrite of multi-segment lines")
     return p

@@ -40,7 +40,11 @@ def load_wav(path: str, target_sr: int) -> torch.Tensor:
 
 class CosyVoice:
     def __init__(self, model_dir: str, config: Optional[SynthConfig] = None, seed: int = 0, device=None,
-                 frontend: Optional[Frontend] = None, **_kw):
+                 frontend: Optional[Frontend] = None, allow_random_init: Optional[bool] = None, **_kw):
+        """``model_dir`` must hold ``llm.pt`` / ``flow.pt`` / ``hift.pt`` (the CosyVoice-300M state dicts), as it must for
+        the reference (tts_with_rag.py:159).  Without them the constructor RAISES -- a synthesis run on random weights
+        writes noise and must not look like a success -- unless the caller opts in: ``allow_random_init=True`` (the CLIs'
+        ``--allow_random_init``) or ``ASTTS_ALLOW_RANDOM_INIT=1`` (tests, benchmarks: no checkpoint exists offline)."""
         from ..synth.model import SynthEngine
         from ..synth.weights import load_state_dicts, make_all
 
@@ -54,8 +58,13 @@ class CosyVoice:
             state = load_state_dicts(model_dir)
             self.random_init = False
         else:
+            if allow_random_init is None:
+                allow_random_init = os.environ.get("ASTTS_ALLOW_RANDOM_INIT") == "1"
+            if not allow_random_init:
+                raise FileNotFoundError(f"CosyVoice: no llm.pt/flow.pt/hift.pt under {model_dir!r}.  Pass allow_random_init=True "
+                                        f"(--allow_random_init / ASTTS_ALLOW_RANDOM_INIT=1) to run on seeded random weights.")
             warnings.warn(f"CosyVoice: no llm.pt/flow.pt/hift.pt under {model_dir!r}; using seeded RANDOM-INIT weights "
-                          f"at the configured shapes (no checkpoint is available offline)", stacklevel=2)
+                          f"at the configured shapes (explicitly allowed)", stacklevel=2)
             state = make_all(config, seed)
             self.random_init = True
         self.engine = SynthEngine(state, config, device)          # raises without a GPU: no CPU fallback

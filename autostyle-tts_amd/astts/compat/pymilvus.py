@@ -248,6 +248,12 @@ class MilvusClient:
         if limit < 1:
             raise MilvusException(1, f"limit {limit} is invalid")
         k = min(int(limit), len(c.pks))
+        from .._lib import KNN_MAX_K
+        if k > KNN_MAX_K:
+            # pymilvus accepts limit up to 16384; the reference asks for 1 or 3 (milvus/search_json.py:411,
+            # milvus/search_embeddings.py:64).  The certified top-k kernel keeps k <= 32 candidates lists in registers.
+            raise MilvusException(1100, f"limit {limit} is not supported by this build: at most {KNN_MAX_K} hits per query "
+                                        f"(collection holds {len(c.pks)} rows)")
         idx, score = c.bank().search(q, k)
         out: List[List[Dict[str, Any]]] = []
         for qi in range(q.shape[0]):

@@ -876,9 +876,12 @@ class PipelinedSynth:
             a = [g["lm"] for g in group]
             lm_args = (torch.cat([x[0] for x in a], 0), torch.cat([x[1] for x in a], 0), torch.cat([x[2] for x in a], 0),
                        torch.cat([x[3] for x in a], 0), a[0][4], torch.cat([x[5] for x in a], 1))
-            for t in lm_args:               # built on the caller's stream, consumed on the chain's
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(stream)
+        # every input -- the caller's own tensors too -- was allocated on the caller's stream and is read on the chain's for
+        # the whole decode (~100 ms behind the host): tell the caching allocator, or a caller that builds fresh inputs per
+        # batch gets these blocks recycled under the running chain
+        for t in lm_args:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(stream)
         stream.wait_stream(cur)             # after the concatenations above were enqueued
         sizes = [int(g["lm"][0].shape[0]) for g in group]
 
@@ -897,10 +900,19 @@ class PipelinedSynth:
     def _render(self, item):
         parts, ev = item["fut"].result()
         toks = parts[item["k"]]
+        cur = torch.cuda.current_stream(self.eng.device)
         with torch.cuda.stream(self.s_render):
             self.s_render.wait_event(ev)
             toks.record_stream(self.s_render)
+            for t in item["render"]:        # the caller's tensors, read on the render stream (see _launch_group)
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self.s_render)
             mel, wav = self.eng.tts_render(toks, *item["render"])
+        # results are produced on the pipeline's streams and handed to the caller's: the caller still has to order its
+        # stream behind them (drain() does; a caller that consumes results earlier waits on `pipe.s_render` itself), but
+        # the allocator must not recycle them while the caller's stream may be using them
+        for t in (toks, mel, wav):
+            t.record_stream(cur)
         return toks, mel, wav
 
     def submit(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel,

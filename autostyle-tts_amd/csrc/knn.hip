@@ -101,7 +101,7 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
         _Float16 h = (_Float16)v;
         float back = (float)h;
         if (back != v) inexact = true;
-        if (!isfinite(back) || !isfinite(v)) overflow = true;
+        if (!isfinite(v)) overflow = true;     // (finite values beyond fp16's range make the bank inexact: rescaled per row below)
         plane16[row * (int64_t)dp + k] = h;
         if (plane32) plane32[row * (int64_t)dp + k] = v;
         {   // tiled scan image
@@ -120,6 +120,41 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
     }
     if (__any(inexact) && lane == 0) atomicOr(&flags[0], 1);
     if (__any(overflow) && lane == 0) atomicOr(&flags[1], 1);
+}
+
+// A bank that is NOT fp16-exact (an fp32 upload) gets its approximate planes re-written with a power-of-two scale per row, as
+// the queries do: max|v| of every row lands in [2^13, 2^14), so the fp16 image keeps an 11-bit significand for every element
+// that matters -- cosine is scale invariant, and rows of norm ~1e-2 (elements below fp16's normal range, 6e-5) would otherwise
+// go subnormal or flush to zero in the scan and drop out of the candidate lists while the error bound still certified the
+// query.  The scale is folded into inv_norm (exactly: a power of two); the exact plane (plane32) and the fp64 norms keep the
+// original values.  Elements more than 2^37 below their row's maximum still flush: |error| <= sqrt(dp) * 2^-38 on the cosine
+// scale, inside the 2^-20 term of the bound.
+__global__ void knn_rescale_rows(const float* __restrict__ plane32, int64_t n, int dp, _Float16* __restrict__ scan_tiled,
+                                 _Float16* __restrict__ plane16, const double* __restrict__ norm64, float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* s = plane32 + row * (int64_t)dp;
+    float mx = 0.0f;
+    for (int k = lane; k < dp; k += kWave) mx = fmaxf(mx, fabsf(s[k]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    int e = 0;
+    if (mx > 0.0f) frexpf(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
+    const int sh = mx > 0.0f ? 14 - e : 0;
+    const float scale = ldexpf(1.0f, sh);
+    for (int k = lane; k < dp; k += kWave) {
+        const _Float16 h = (_Float16)(s[k] * scale);
+        plane16[row * (int64_t)dp + k] = h;
+        const int64_t rt = row >> 5;
+        const int r = (int)(row & 31), line = k >> 6, kk = k & 63;
+        const int hh = kk >> 5, i = (kk & 31) >> 3, j = kk & 7;
+        scan_tiled[((rt * (dp >> 6) + line) << 11) + i * 512 + (hh * 32 + r) * 8 + j] = h;
+    }
+    if (lane == 0) {
+        const double nrm = norm64[row];
+        inv_norm[row] = nrm > 0.0 ? (float)ldexp(1.0 / nrm, -sh) : 0.0f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,13 +801,17 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     KNN_TRY(hipMemcpyAsync(hf, flags, sizeof(hf), hipMemcpyDeviceToHost, st));
     KNN_TRY(hipStreamSynchronize(st));
     if (hf[1]) {
-        set_error("astts_knn_create: bank holds values that are non-finite or overflow fp16");
+        set_error("astts_knn_create: bank holds non-finite values");
         return fail(ASTTS_ERR_RANGE);
     }
     h->exact16 = (hf[0] == 0);
     if (!h->exact16) {
         h->plane32 = p32;  // keep the fp32 image for exact re-scoring
         p32 = nullptr;
+        // approximate planes re-written with a per-row power-of-two scale (see knn_rescale_rows)
+        hipLaunchKernelGGL(knn_rescale_rows, grid, dim3(256), 0, st, h->plane32, n, h->dp, h->scan, h->plane16, h->norm64, h->inv_norm);
+        KNN_TRY(hipGetLastError());
+        KNN_TRY(hipStreamSynchronize(st));
     }
     (void)hipFree(flags);
     flags = nullptr;

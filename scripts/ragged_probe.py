@@ -9,7 +9,7 @@ N = int(os.environ.get('N', '64')); BS = int(os.environ.get('BS', '32'))
 sents = json.load(open('tests/golden/iemocap_test_sentences.json'))
 if isinstance(sents, dict): sents = sents.get('sentences') or list(sents.values())[0]
 texts = [s if isinstance(s, str) else s.get('text', str(s)) for s in sents][:N]
-cv = CosyVoice('/nonexistent', seed=0)
+cv = CosyVoice('/nonexistent', seed=0, allow_random_init=True)
 sr = 16000
 t = torch.arange(int(2.5 * sr)) / sr
 style = (0.3 * torch.sin(2 * math.pi * 220 * t) + 0.01 * torch.randn(t.shape))[None]

@@ -25,7 +25,7 @@ def cosy():
     from astts.synth.config import SynthConfig
 
     with pytest.warns(UserWarning, match="RANDOM-INIT"):
-        cv = CosyVoice("/nonexistent/CosyVoice-300M", config=SynthConfig.tiny(), seed=0)
+        cv = CosyVoice("/nonexistent/CosyVoice-300M", config=SynthConfig.tiny(), seed=0, allow_random_init=True)
     assert cv.random_init
     return cv
 

@@ -129,3 +129,116 @@ def test_search_json_record_format(golden_dir, tmp_path, monkeypatch):
     assert set(rows[0]) == {"zh_text", "speaker", "retrieved_file_id", "retrieved_text", "distance"}
     assert rows[1]["retrieved_file_id"] == "/data/seg_wav/" + meta["rows"][61]["file_id"]
     assert abs(rows[1]["distance"] - 1.0) < 1e-6
+
+
+def test_search_json_skips_rows_without_text(golden_dir, tmp_path, monkeypatch):
+    """milvus/search_json.py:385-387: a row whose zh_text is empty is skipped (no record), together with its query vector."""
+    from astts.cli import search_json
+    from astts.compat import pymilvus as pm
+
+    bank = np.load(os.path.join(golden_dir, "style_bank_130x6144.f16.npy")).astype(np.float32)
+    meta = json.load(open(os.path.join(golden_dir, "style_bank_meta.json")))
+    seen = {}
+
+    def fake_search(self, collection_name, data, **kw):
+        from oracle import knn as oknn
+        seen["n"] = len(data)
+        idx, sc = oknn.knn_search(bank.astype(np.float16), np.asarray(data, np.float32), 1)
+        return [[{"id": 0, "distance": float(s[0]), "entity": dict(meta["rows"][int(i[0])])}] for i, s in zip(idx, sc)]
+
+    monkeypatch.setattr(pm.MilvusClient, "search", fake_search)
+    inp = tmp_path / "in.jsonl"
+    lines = [{"zh_text": "first", "speaker": "w1"}, {"zh_text": "   ", "speaker": "m1"}, {"speaker": "m2"}, {"zh_text": "last", "speaker": "w2"}]
+    inp.write_text("\n".join(json.dumps(l) for l in lines) + "\n", encoding="utf-8")
+    np.save(tmp_path / "q.npy", bank[[5, 6, 7, 129]])
+    args = search_json.build_parser().parse_args(["--input_json", str(inp), "--query_npy", str(tmp_path / "q.npy"),
+                                                  "--db_path", os.path.join(golden_dir, "milvus_demo.db")])
+    res = search_json.main(args)
+    assert seen["n"] == 2 and [r["zh_text"] for r in res] == ["first", "last"]
+    assert res[1]["retrieved_file_id"] == meta["rows"][129]["file_id"]          # row 3's vector stayed with row 3
+
+
+def test_cosyvoice_needs_weights_or_an_explicit_opt_in(tmp_path, monkeypatch):
+    """A missing model_dir must not silently synthesise noise: the constructor raises before anything touches the
+    GPU unless random-init weights are explicitly allowed."""
+    from astts.compat.cosyvoice import CosyVoice
+
+    monkeypatch.delenv("ASTTS_ALLOW_RANDOM_INIT", raising=False)
+    with pytest.raises(FileNotFoundError, match="allow_random_init"):
+        CosyVoice(str(tmp_path / "CosyVoice-300M"))
+    for cli in ("tts_with_rag", "tts_with_style_and_timbre", "tts_for_dialog", "vc_from_dir"):
+        mod = __import__(f"astts.cli.{cli}", fromlist=["x"])
+        src = open(mod.__file__).read()
+        assert "--allow_random_init" in src
+
+
+def test_weight_norm_folding_both_checkpoint_forms():
+    """a8: real CosyVoice checkpoints store weight-normalised convolutions as (weight_g, weight_v) -- torch.nn.utils.weight_norm
+    -- or as parametrizations.weight.original0/1 -- torch.nn.utils.parametrizations.weight_norm.  Both fold to the module's
+    effective weight, for Conv1d and ConvTranspose1d (norm over dim 0's complement, torch's default)."""
+    import torch
+
+    from astts.synth.weights import _fold_weight_norm
+
+    torch.manual_seed(0)
+    for make in (lambda: torch.nn.Conv1d(6, 10, 3), lambda: torch.nn.ConvTranspose1d(6, 10, 4, 2)):
+        m_old = torch.nn.utils.weight_norm(make())
+        with torch.no_grad():
+            m_old.weight_g.mul_(1.7)
+        x = torch.randn(2, 6, 9)
+        y = m_old(x)
+        sd = {f"conv.{k}": v for k, v in m_old.state_dict().items()}
+        assert "conv.weight_g" in sd and "conv.weight_v" in sd
+        folded = _fold_weight_norm(sd)
+        assert set(folded) == {"conv.weight", "conv.bias"}
+        m_plain = make()
+        m_plain.load_state_dict({"weight": folded["conv.weight"], "bias": folded["conv.bias"]})
+        assert torch.allclose(m_plain(x), y, atol=1e-6)
+        m_new = torch.nn.utils.parametrizations.weight_norm(make())
+        with torch.no_grad():
+            m_new.parametrizations.weight.original0.mul_(0.6)
+        y2 = m_new(x)
+        sd2 = {f"conv.{k}": v for k, v in m_new.state_dict().items()}
+        assert "conv.parametrizations.weight.original0" in sd2
+        folded2 = _fold_weight_norm(sd2)
+        assert set(folded2) == {"conv.weight", "conv.bias"}
+        m_plain.load_state_dict({"weight": folded2["conv.weight"], "bias": folded2["conv.bias"]})
+        assert torch.allclose(m_plain(x), y2, atol=1e-6)
+
+
+def test_load_state_dicts_round_trip(tmp_path):
+    """a8: make_all() -> llm.pt / flow.pt / hift.pt with the vocoder's convolutions re-expressed in both weight-norm forms ->
+    load_state_dicts() returns the original tensors (the engine is then built from exactly the same state)."""
+    import torch
+
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import load_state_dicts, make_all
+
+    cfg = SynthConfig.tiny()
+    state = make_all(cfg, 3)
+    hift = dict(state["hift"])
+    n_g, n_p = 0, 0
+    for k in [k for k in hift if k.endswith(".weight") and hift[k].dim() == 3]:
+        w = hift.pop(k)
+        base = k[: -len(".weight")]
+        norm = w.flatten(1).norm(dim=1).view(-1, 1, 1)
+        if n_g <= n_p:
+            hift[base + ".weight_g"], hift[base + ".weight_v"] = norm * 1.0, w.clone()
+            n_g += 1
+        else:
+            hift[base + ".parametrizations.weight.original0"], hift[base + ".parametrizations.weight.original1"] = norm * 1.0, w / 2.0   # effective weight g v / norm(v) = w
+            n_p += 1
+    assert n_g >= 3 and n_p >= 3
+    d = tmp_path / "CosyVoice-300M"
+    d.mkdir()
+    torch.save(state["llm"], d / "llm.pt")
+    torch.save(state["flow"], d / "flow.pt")
+    torch.save(hift, d / "hift.pt")
+    got = load_state_dicts(str(d))
+    for name in ("llm", "flow", "hift"):
+        assert set(got[name]) == set(state[name]), name
+        for k, v in state[name].items():
+            assert torch.allclose(got[name][k], v.float(), atol=1e-6, rtol=1e-6), (name, k)
+    (d / "flow.pt").unlink()
+    with pytest.raises(FileNotFoundError):
+        load_state_dicts(str(d))

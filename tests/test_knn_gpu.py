@@ -108,6 +108,31 @@ def test_inexact_fp32_bank():
     _check(bank, q, 3, force_exact=True, sb=sb)
 
 
+def test_fp32_bank_rows_of_any_norm():
+    """cosine is scale invariant, but an fp32 bank row of norm ~1e-3 (elements ~1e-5, below fp16's normal
+    range) used to go subnormal / flush to zero in the fp16 scan planes and drop out of the candidate lists while the
+    query was still certified.  The approximate planes of an inexact bank now carry a power-of-two scale per row.  Rows
+    with norms from 1e-6 to 1e+7 (values beyond fp16's range included), queried at their own scale and at unit scale,
+    through the register scan (Q=9) and the GEMM scan (Q=70)."""
+    rng = np.random.default_rng(11)
+    n, d = 9000, 320
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    norms = 10.0 ** rng.uniform(-6, 7, size=n)
+    bank = (base * (norms / np.linalg.norm(base, axis=1))[:, None]).astype(np.float32)
+    sb = _bank(bank)
+    assert not sb.scan_plane_exact
+    pick = rng.integers(0, n, 70)
+    noise = 0.3 * rng.standard_normal((70, d)).astype(np.float32)
+    q_own = bank[pick] * (1.0 + noise)                                  # near its row, at the row's own (tiny or huge) scale
+    q_unit = base[pick] / np.linalg.norm(base[pick], axis=1)[:, None] * (1.0 + noise)
+    for q in (q_own, q_unit):
+        for sl in (slice(0, 9), slice(0, 70)):
+            idx, _ = sb.search(q[sl], 3)
+            assert np.array_equal(idx[:, 0], pick[sl])                  # every row is found, whatever its norm
+            _check(bank, q[sl], 3, sb=sb)
+    assert sb.last_fallbacks() <= 2                                     # ... and by the certified fast path, not the exact rescan
+
+
 def test_gemm_scan_path_large_query_groups():
     """Query groups of >= 64 against a bank that fills the chip take the scan as one GEMM on the ring kernel: exact and
     fp16-inexact banks, a tail group below 64 queries, duplicate rows (ties decided by row index), scaled queries."""
@@ -176,7 +201,7 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         sb.search(np.ones((1, 64), np.float32), _lib.KNN_MAX_K + 1)
     with pytest.raises(_lib.AsttsError):
-        StyleBank(np.full((4, 64), 1e6, np.float32))       # overflows the fp16 scan plane
+        StyleBank(np.full((4, 64), np.inf, np.float32))    # non-finite values
     with pytest.raises(_lib.AsttsError):
         StyleBank(np.ones((4, 64), np.float16), metric="L2")
 
