@@ -124,6 +124,13 @@ _SIGS.update({
     "astts_flow_solve": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                    ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float, c_void_p, c_size_t, c_void_p]),
 })
+_SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
+    "astts_op_rmsnorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_rope_llama": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
+    "astts_op_attn_causal_gqa": (c_int32, [c_void_p] * 5 + [c_int32] * 8 + [c_float, c_void_p]),
+    "astts_op_swiglu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_mean_pool": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+})
 _lib.register_signatures(_SIGS)
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "mish": 4, "elu": 5, "tanh": 6, "leaky": 7}
@@ -497,3 +504,51 @@ def concurrent_streams(n: int, priority: int = 0, candidates: int = 16, device=N
             if s not in chosen and (not strict or all(overlaps(s, c) for c in chosen[:protect])):
                 chosen.append(s)
     return chosen
+
+
+# ---------------------------------------------------------------------------------------------- query embedder (csrc/ops_llm.hip)
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype=torch.float16) -> torch.Tensor:
+    x = _f32(x)
+    c = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_L().astts_op_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 1 if out_dtype == torch.float16 else 0,
+                                     x.numel() // c, c, c, c, eps, _st()))
+    return y
+
+
+def rope_llama_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, head_dim: int, pos0: int = 0) -> torch.Tensor:
+    """In place on the first ``heads * head_dim`` columns of ``x`` fp16 ``[B, T, ld]`` (a strided view into q|k|v is fine)."""
+    assert x.dtype == torch.float16 and x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+    b, t = x.shape[0], x.shape[1]
+    assert cos.shape[0] >= pos0 + t and cos.shape[1] == head_dim // 2 and cos.is_contiguous() and sin.is_contiguous()
+    _lib.check(_L().astts_op_rope_llama(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), b, t, heads, x.stride(1), head_dim, pos0, _st()))
+    return x
+
+
+def attn_causal_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, kv_heads: int, head_dim: int,
+                    lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q ``[B, T, heads*hd]``, k / v ``[B, T, kv_heads*hd]`` fp16 strided views -> fp16 ``[B, T, heads*hd]``."""
+    b, t = q.shape[0], q.shape[1]
+    assert q.dtype == k.dtype == v.dtype == torch.float16 and q.stride(0) == t * q.stride(1) and k.stride(0) == t * k.stride(1)
+    assert k.stride(1) == v.stride(1)
+    out = torch.empty((b, t, heads * head_dim), dtype=torch.float16, device=q.device)
+    _lib.check(_L().astts_op_attn_causal_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(lens), out.data_ptr(), b, t, heads, kv_heads,
+                                             head_dim, q.stride(1), k.stride(1), heads * head_dim, 1.0 / math.sqrt(head_dim), _st()))
+    return out
+
+
+def swiglu(gate_up: torch.Tensor) -> torch.Tensor:
+    """``[..., 2f]`` fp16 (gate | up) -> ``[..., f]`` fp16 = silu(gate) * up."""
+    assert gate_up.dtype == torch.float16 and gate_up.is_contiguous()
+    f = gate_up.shape[-1] // 2
+    out = torch.empty((*gate_up.shape[:-1], f), dtype=torch.float16, device=gate_up.device)
+    _lib.check(_L().astts_op_swiglu(gate_up.data_ptr(), out.data_ptr(), gate_up.numel() // (2 * f), f, 2 * f, f, _st()))
+    return out
+
+
+def mean_pool(x: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _f32(x)
+    b, t, c = x.shape
+    out = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    _lib.check(_L().astts_op_mean_pool(x.data_ptr(), _p(lens), out.data_ptr(), b, t, c, _st()))
+    return out

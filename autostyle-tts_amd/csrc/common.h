@@ -16,6 +16,8 @@ void set_error(const char* fmt, ...);
 // bench-only launch profiler (runtime.hip); prof_begin returns true when the launch is being timed
 bool prof_begin(int kind, hipStream_t st, double work);
 void prof_end(int kind, hipStream_t st);
+// kernel-level variant: a reserved (start, stop) pair for hipExtLaunchKernelGGL; false when the kind is not being profiled
+bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1);
 
 #define ASTTS_CHECK_HIP(expr)                                                              \
     do {                                                                                   \

@@ -8,6 +8,8 @@
 // between the variants (which K lines a wave owns), never which products are formed.
 #include "lm_step.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 namespace astts {
@@ -615,6 +617,13 @@ static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_p
         attr = true;
     }
     if (grid.x == 0) return;
+    // bench-only launch profiler: algorithmic bytes of a decode GEMV = its weight image, streamed once
+    hipEvent_t e0, e1;
+    if (prof_events(ASTTS_PROF_GEMM_SKINNY, (double)a.n * a.kpad * 2.0, &e0, &e1)) {
+        if (lines_per_wave <= 2) hipExtLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 8>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
+        return;
+    }
     if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 2>), grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 8>), grid, dim3(512), lds, st, a);
 }
@@ -700,7 +709,13 @@ int lm_attn_launch(const AttnArgs& a, hipStream_t st) {
                   "lm_attn: bad shape b=%d h=%d d=%d", a.b, a.h, a.d);
     ASTTS_REQUIRE(a.ksplit == 1 ? a.out != nullptr : (a.ksplit == 2 && a.part_o && a.part_ml), ASTTS_ERR_INVALID,
                   "lm_attn: ksplit=%d needs %s", a.ksplit, a.ksplit == 1 ? "out" : "the partial buffers (ksplit 1 or 2)");
-    hipLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, a);
+    // algorithmic bytes: the fp16 K and V rows of every (row, head) + the position rows of every head, each read once
+    const double keys = (double)((a.st ? 0 : a.pos) + 1);
+    hipEvent_t e0, e1;
+    if (prof_events(ASTTS_PROF_ATTN_DECODE, keys * a.d * 2.0 * (2.0 * a.b + 1.0), &e0, &e1))
+        hipExtLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

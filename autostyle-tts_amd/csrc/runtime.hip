@@ -40,6 +40,23 @@ bool prof_begin(int kind, hipStream_t st, double work) {
     return true;
 }
 
+// Kernel-level timing (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin / end timestamps, as rocprofv3 reads
+// them, with no extra packet between dependent launches -- an hipEventRecord pair around a 4 us kernel adds ~3 us to it).
+bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_prof_any) return false;
+    ProfKind& p = g_prof[kind];
+    if (!p.on) return false;
+    if (p.used + 2 > p.ev.size()) {
+        ++p.dropped;
+        return false;
+    }
+    *e0 = p.ev[p.used];
+    *e1 = p.ev[p.used + 1];
+    p.used += 2;
+    p.work += work;
+    return true;
+}
+
 void prof_end(int kind, hipStream_t st) {
     ProfKind& p = g_prof[kind];
     (void)hipEventRecord(p.ev[p.used + 1], st);

@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--speech-tokens", type=int, default=250)
     ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,11 +369,15 @@ def main():
     torch.cuda.synchronize()
     knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
     traffic_table = {}
-    try:   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE; cannot be collected inside this run)
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic_table = json.load(f)
-    except OSError:
-        pass
+    traffic_file = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
+        try:                                                 # FETCH_SIZE, own pass; cannot be collected inside this run)
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic_table = json.load(f)
+            traffic_file = name
+            break
+        except OSError:
+            pass
     # retrieval kernel against ITS roofline (HBM: the bank is read once per search): HIP events around the scan launch
     sb.profile_enable(True)
     for _ in range(100):
@@ -390,18 +395,25 @@ def main():
     eidx, _ = oknn.knn_search(bank16, q_host, args.topk)
     ids_ok = bool(np.array_equal(out_idx.cpu().numpy(), eidx))
 
-    # ---- roofline: HIP events (on the launch stream) around every launch of the profiled kernel kinds, one step
-    kinds = {"gemm_tile": ops.PROF_GEMM_TILE, "gemm_skinny16": ops.PROF_GEMM_SKINNY, "attn_mha_flash": ops.PROF_ATTN_FLASH,
-             "attn_relpos_decode": ops.PROF_ATTN_DECODE}
-    prof = {}
-    for name, kind in kinds.items():        # one kind per pass: event records perturb neighbouring launches
+    # ---- roofline: HIP events (on each launch's own stream) around every launch of the profiled kernel kinds, ONE SEQUENTIAL
+    # step per kind (one batch at a time on one stream: the mode `sequential_ms_per_step` / `stages_ms` are measured in; the
+    # timed region above runs the same kernels pipelined on several streams, where kernels of different batches overlap and a
+    # per-kernel duration is not attributable).  One kind per pass: event records perturb neighbouring launches.
+    kinds = {"gemm_tile": ops.PROF_GEMM_TILE, "lm_gemv": ops.PROF_GEMM_SKINNY, "attn_mha_flash": ops.PROF_ATTN_FLASH,
+             "lm_attn": ops.PROF_ATTN_DECODE}
+
+    def profiled(kind, fn):
         ops.prof_enable(kind, True, 40000)
-        step_sequential()
+        fn()
         torch.cuda.synchronize()
         ms, n, work, dropped = ops.prof_read(kind)
         ops.prof_enable(kind, False)
-        prof[name] = {"ms_per_step": ms, "launches": n, "work": work, "dropped": dropped}
+        return {"ms_per_step": ms, "launches": n, "work": work, "dropped": dropped}
+
+    prof = {name: profiled(kind, step_sequential) for name, kind in kinds.items()}
     dom = max(prof, key=lambda k: prof[k]["ms_per_step"])
+    if dom == "gemm_tile":      # a family of tiles with different shapes: the single dominant KERNEL is the decode GEMV
+        dom = "lm_gemv" if prof["lm_gemv"]["ms_per_step"] > 0.5 * prof["gemm_tile"]["ms_per_step"] else dom
     p = prof[dom]
     if dom in ("gemm_tile", "attn_mha_flash"):
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e12
@@ -411,11 +423,70 @@ def main():
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     traffic = traffic_table.get(dom, {}).get("hbm_bytes_per_launch")
-    roof.update({"traffic": traffic, "traffic_source": "profiles/r01_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
+    roof.update({"traffic": traffic,
+                 "traffic_source": f"profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
                  "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
                  "launches_per_step": p["launches"],
                  "algorithmic_work_per_launch": p["work"] / max(p["launches"], 1),
-                 "all_kinds_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})
+                 "mode": "sequential step (events on the launch stream); compare with sequential_ms_per_step, not ms_per_step",
+                 "all_kinds_ms_per_sequential_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})
+
+    # ---- per-stage rooflines (sequential mode): algorithmic work of the whole stage / the stage's wall time
+    lm_w = profiled(ops.PROF_GEMM_SKINNY, lambda: eng.lm.decode(pre, inp.ts, inp.u, True))
+    lm_a = profiled(ops.PROF_ATTN_DECODE, lambda: eng.lm.decode(pre, inp.ts, inp.u, True))
+    fl_g = profiled(ops.PROF_GEMM_TILE, lambda: eng.flow.decode(all_tok, tl, inp.timbre_mel, inp.spk_timbre, inp.z, inp.tmp + inp.tm))
+    fl_a = profiled(ops.PROF_ATTN_FLASH, lambda: eng.flow.decode(all_tok, tl, inp.timbre_mel, inp.spk_timbre, inp.z, inp.tmp + inp.tm))
+    vo_g = profiled(ops.PROF_GEMM_TILE, lambda: eng.hift.forward(mel, inp.phase0, inp.noise))
+    lm_bytes = lm_w["work"] + lm_a["work"]
+    by_stage = {
+        "lm_decode": {"bound": "hbm", "achieved": lm_bytes / (stages["lm_ms"] / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": lm_bytes / (stages["lm_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes": lm_bytes, "launches": lm_w["launches"] + lm_a["launches"],
+                      "note": "weights of every decode GEMV + KV / position rows of every decode attention, each read once per step; "
+                              "the stage is a chain of dependent launches (1.45 us boundary + one memory round trip each): latency-bound"},
+        "flow": {"bound": "mfma", "achieved": (fl_g["work"] + fl_a["work"]) / (stages["flow_ms"] / 1e3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": (fl_g["work"] + fl_a["work"]) / (stages["flow_ms"] / 1e3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                 "algorithmic_flops": fl_g["work"] + fl_a["work"], "launches_gemm_attn": fl_g["launches"] + fl_a["launches"]},
+        "vocoder": {"bound": "mfma", "achieved": vo_g["work"] / (stages["vocoder_ms"] / 1e3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": vo_g["work"] / (stages["vocoder_ms"] / 1e3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                    "algorithmic_flops": vo_g["work"],
+                    "note": "conv stack as implicit GEMMs; long thin convolutions, launch- and HBM-bound rather than MFMA-bound"},
+    }
+
+    # ---- 24 kHz side measurement (the north star's rate; the reference scripts save 22 050 Hz): same pipeline, second engine
+    v24 = None
+    pipe_depth, pipe_tuned_ms = pipe.depth, pipe.tuned_ms_per_batch
+    if not args.no_24khz and args.sample_rate != 24000 and args.steps >= 2:
+        del pipe
+        cfg24 = SynthConfig(sample_rate=24000)
+        eng24 = SynthEngine(weights, cfg24, dev)
+        inp24 = SynthInputs(cfg24, args.batch, args.text_tokens, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
+        s24 = (inp24.text, inp24.tlen, inp24.spk_style, inp24.style_tok, inp24.ts, inp24.u, inp24.timbre_tok, inp24.timbre_mel,
+               inp24.spk_timbre, inp24.z, inp24.phase0, inp24.noise)
+        front24 = lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
+        pipe24 = PipelinedSynth.autotune(eng24, s24, depths=(2,), trials=2, steps=4, front=front24)
+        k24 = max(4, min(args.steps, 8))
+        with torch.cuda.stream(pipe24.front_stream):
+            for _ in range(2):
+                front24()
+                pipe24.submit(*s24)
+            pipe24.drain()
+            barrier()
+            t24 = time.perf_counter()
+            for _ in range(k24):
+                front24()
+                pipe24.submit(*s24)
+            last = pipe24.drain()
+            barrier()
+            dt24 = time.perf_counter() - t24
+        if dist is not None:
+            t = torch.tensor([dt24], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt24 = float(t.item())
+        v24 = {"value": inp24.audio_seconds * k24 * world / dt24, "unit": "audio-s/wall-s", "steps": k24, "ms_per_step": 1e3 * dt24 / k24,
+               "samples_per_utterance": inp24.tm * cfg24.upsample_total, "sample_rate": 24000,
+               "note": "same workload with SynthConfig(sample_rate=24000): 468 mel frames per 250 tokens instead of 430"}
+        del pipe24, eng24
 
     if rank == 0:
         total_audio = inp.audio_seconds * args.steps * world
@@ -431,7 +502,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 MFMA operands, f32 accumulate/activations (kNN: f16 scan + f64 re-score)",
+            "dtype": "f16",
+            "dtype_note": "fp16 weights / MFMA operands / KV cache, fp32 accumulation, residual stream, norms and softmax (kNN: fp16 scan + "
+                          "fp64 re-score).  Deviation: the reference's CosyVoice(model_dir) default runs fp32 (SURVEY.md 8d sanctions "
+                          "fp16 MFMA operands); parity tolerances vs the fp32 oracle are stated in tests/",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch={args.batch} utterances/GPU, kNN Q={args.batch} x N={args.bank_rows} x D={args.dim} k={args.topk}, "
                                    f"synthesis Tt={args.text_tokens} Tp={args.prompt_tokens} Ts={args.speech_tokens} (fixed-length decode, EOS ignored) "
@@ -441,13 +515,15 @@ def main():
             "knn_roofline": knn_roof,
             "ids_match_oracle": ids_ok,
             "waveform_finite_and_clamped": wav_ok,
-            "pipelining": f"{pipe.depth + 2} HIP streams (front: retrieval + submit, {pipe.depth} decode chains, render): the LM decode chains of {pipe.depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe.tuned_ms_per_batch:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
+            "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
                                                "note": "same K steps, LM stages of 2 consecutive batches co-batched into one 16-row decode "
                                                        "chain (outputs bit-identical per batch); reported beside `value`, not as it"} if cob else None),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "sequential_ms_per_step": round(sum(stages.values()), 3),
             "roofline": roof,
+            "roofline_by_stage": by_stage,
+            "value_24khz": v24,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)

@@ -49,9 +49,9 @@ const char* astts_last_error_string(void);
  * attention kinds, bytes for streaming kinds) is accumulated.  _read synchronises those events,
  * returns the sums since the last read and resets.  Process-global, not thread-safe, off by default. */
 #define ASTTS_PROF_GEMM_TILE 0   /* gemm_tile  (flow estimator / vocoder contractions): work = flops  */
-#define ASTTS_PROF_GEMM_SKINNY 1 /* gemm_skinny (LM decode, M <= 32): work = weight bytes streamed   */
+#define ASTTS_PROF_GEMM_SKINNY 1 /* LM decode GEMVs, M <= 32 (lm_gemv / gemm_skinny16): work = weight bytes streamed */
 #define ASTTS_PROF_ATTN_FLASH 2  /* attn_mha_flash: work = flops                                      */
-#define ASTTS_PROF_ATTN_DECODE 3 /* attn_relpos_decode: work = KV-cache bytes read                    */
+#define ASTTS_PROF_ATTN_DECODE 3 /* LM decode attention (lm_attn / attn_relpos_decode): work = KV + position bytes read */
 #define ASTTS_PROF_KINDS 4
 int astts_prof_enable(int32_t kind, int32_t on, int32_t max_launches);
 int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* work_sum, int64_t* dropped);
@@ -316,6 +316,28 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                     int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Query-embedder operators: what a Llama-3.2 decoder block needs besides the GEMM family.
+ * Replace the arithmetic of get_embedding() / generate_emotion_label() -- transformers' LlamaModel behind
+ * src/search_milvus.py:75-108 and milvus/search_json.py:154-198,214-221.  Host side: astts/llm/embedder.py.
+ * ------------------------------------------------------------------------------------------ */
+/* y = w * (x * rsqrt(mean(x^2) + eps)); x fp32 [rows, ldx], y fp32 or fp16 [rows, ldy] */
+int astts_op_rmsnorm(const float* x, const float* w, void* y, int32_t out_f16, int64_t rows, int32_t c, int32_t ldx, int32_t ldy,
+                     float eps, astts_stream_t stream);
+/* rotate-half RoPE in place on `heads` heads of head_dim columns starting at x (fp16 [b*t, ld]); cos / sin fp32
+ * [>= pos0 + t, head_dim / 2] (llama3-scaled frequencies, built by the host exactly as transformers does) */
+int astts_op_rope_llama(void* x_f16, const float* cos_tab, const float* sin_tab, int32_t b, int32_t t, int32_t heads, int32_t ld,
+                        int32_t head_dim, int32_t pos0, astts_stream_t stream);
+/* causal grouped-query attention, head_dim 128: q [b, t, heads*128], k / v [b, t, kv_heads*128] fp16 strided views
+ * (row strides ldq / ldk in halfs), lens int32 [b] valid tokens (right padding) or NULL, out fp16 [b, t, ldo] */
+int astts_op_attn_causal_gqa(const void* q_f16, const void* k_f16, const void* v_f16, const int32_t* lens, void* out_f16, int32_t b,
+                             int32_t t, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                             astts_stream_t stream);
+/* out = silu(gate) * up on a fused projection gate_up fp16 [rows, ldg] = gate[f] | up[f] */
+int astts_op_swiglu(const void* gate_up_f16, void* out_f16, int64_t rows, int32_t f, int32_t ldg, int32_t ldo, astts_stream_t stream);
+/* out[b, c] = mean over the first lens[b] (NULL: t) tokens of x fp32 [b, t, c] */
+int astts_op_mean_pool(const float* x, const int32_t* lens, float* out, int32_t b, int32_t t, int32_t c, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
