@@ -47,6 +47,8 @@ _SIGNATURES = {
     "astts_knn_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32]),
     "astts_knn_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_int32, c_void_p]),
+    "astts_knn_search_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_int32, c_void_p]),
     "astts_knn_last_fallbacks": (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(c_int32)]),
     "astts_knn_profile_enable": (c_int32, [c_void_p, c_int32]),
     "astts_knn_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

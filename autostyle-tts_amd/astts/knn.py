@@ -77,9 +77,10 @@ class StyleBank:
         return self._ws
 
     def search_device(self, queries: torch.Tensor, k: int, force_exact: bool = False,
-                      out_idx: Optional[torch.Tensor] = None, out_score: Optional[torch.Tensor] = None):
+                      out_idx: Optional[torch.Tensor] = None, out_score: Optional[torch.Tensor] = None, return_f64: bool = False):
         """queries: fp32 ``[Q, D]`` on this bank's GPU.  Returns (idx int64 [Q,k], score fp32 [Q,k])
-        on the GPU, enqueued on the current stream (no synchronisation)."""
+        on the GPU, enqueued on the current stream (no synchronisation).  ``return_f64``: a third tensor with the fp64
+        cosines (what a bank-sharded search merges on: astts.parallel.bank_sharded_search)."""
         if queries.dim() != 2 or queries.shape[1] != self.d:
             raise ValueError(f"queries must be [Q, {self.d}], got {tuple(queries.shape)}")
         if not 1 <= k <= _lib.KNN_MAX_K:
@@ -87,8 +88,8 @@ class StyleBank:
         q = queries.to(device=self.device, dtype=torch.float32).contiguous()
         nq = int(q.shape[0])
         if nq == 0:
-            return (torch.empty((0, k), dtype=torch.int64, device=self.device),
-                    torch.empty((0, k), dtype=torch.float32, device=self.device))
+            e = (torch.empty((0, k), dtype=torch.int64, device=self.device), torch.empty((0, k), dtype=torch.float32, device=self.device))
+            return e + (torch.empty((0, k), dtype=torch.float64, device=self.device),) if return_f64 else e
         with torch.cuda.device(self.device):
             ws = self._workspace(nq, k)
             base = ws.data_ptr()
@@ -97,11 +98,12 @@ class StyleBank:
                 out_idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
             if out_score is None:
                 out_score = torch.empty((nq, k), dtype=torch.float32, device=self.device)
-            _lib.check(_lib.load().astts_knn_search(
-                self._h, q.data_ptr(), nq, k, out_idx.data_ptr(), out_score.data_ptr(),
+            s64 = torch.empty((nq, k), dtype=torch.float64, device=self.device) if return_f64 else None
+            _lib.check(_lib.load().astts_knn_search_f64(
+                self._h, q.data_ptr(), nq, k, out_idx.data_ptr(), out_score.data_ptr(), None if s64 is None else s64.data_ptr(),
                 aligned, ws.numel() - (aligned - base), _lib.KNN_FORCE_EXACT if force_exact else 0,
                 _lib.stream_ptr()))
-        return out_idx, out_score
+        return (out_idx, out_score, s64) if return_f64 else (out_idx, out_score)
 
     def search(self, queries, k: int, force_exact: bool = False):
         """Host convenience: accepts numpy / lists, returns numpy (idx int64 [Q,k], score fp32 [Q,k])."""

@@ -6,6 +6,11 @@ path shards by item: rank r takes items [r*ceil(Q/W), (r+1)*ceil(Q/W)); the styl
 weights are replicated.  The ONLY collective on the data path is one all-gather of the retrieved
 style ids (int64 [ceil(Q/W), k] per rank, a few KB: latency-bound on xGMI) -- no waveform or mel
 crosses GPUs.  One process per GPU; backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in CPU tests.
+
+Stress mode (BASELINE config 5, SURVEY.md 8e "optional"): the BANK is sharded instead -- rank r holds rows
+[r*ceil(N/W), (r+1)*ceil(N/W)), every rank sees every query, returns the top-k of its rows, and one all-gather of the
+[Q, k] (fp64 score, global row) pairs is followed by a local k-way merge in the oracle's total order (score descending, row
+ascending): ``bank_sharded_search``.
 """
 from __future__ import annotations
 
@@ -63,3 +68,37 @@ def sharded_search(search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, 
     out_idx = allp[:, :k].contiguous()
     out_sc = allp[:, k:].to(torch.int32).view(torch.float32)
     return out_idx, out_sc
+
+
+def merge_topk(scores: torch.Tensor, rows: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k-way merge of per-rank candidate lists: ``scores`` fp64 ``[Q, C]``, ``rows`` int64 ``[Q, C]`` (global row indices,
+    -1 = empty slot) -> the best ``k`` per query in the oracle's total order (score descending, row ascending; the order of
+    oracle/knn.py::topk_from_scores).  Two stable sorts: by row ascending, then by score descending."""
+    big = torch.iinfo(torch.int64).max
+    r = torch.where(rows < 0, torch.full_like(rows, big), rows)
+    s = torch.where(rows < 0, torch.full_like(scores, float("-inf")), scores)
+    o1 = torch.argsort(r, dim=1, stable=True)
+    r, s = torch.gather(r, 1, o1), torch.gather(s, 1, o1)
+    o2 = torch.argsort(-s, dim=1, stable=True)
+    r, s = torch.gather(r, 1, o2)[:, :k], torch.gather(s, 1, o2)[:, :k]
+    return torch.where(r == big, torch.full_like(r, -1), r), s
+
+
+def bank_sharded_search(local_search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]], queries: torch.Tensor, k: int,
+                        row_offset: int, dist=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Bank-sharded retrieval.  ``local_search_fn(queries, k) -> (idx int64 [Q,k] LOCAL row indices (-1 = none), score fp64
+    [Q,k])`` searches this rank's rows (``StyleBank.search_device(q, k, return_f64=True)`` -> ``(idx, _, s64)`` on GPUs);
+    ``row_offset`` is the global index of this rank's first row.  Every rank passes the FULL query batch.  Returns the global
+    (idx int64 [Q,k], score fp64 [Q,k]) on every rank -- identical to an unsharded search: fp64 scores order candidates of
+    different ranks exactly as the oracle does."""
+    idx, sc = local_search_fn(queries, k)
+    gidx = torch.where(idx >= 0, idx + int(row_offset), idx)
+    if dist is None or dist.get_world_size() == 1:
+        return merge_topk(sc.to(torch.float64), gidx, k)
+    world = dist.get_world_size()
+    packed = torch.cat([gidx, sc.to(torch.float64).contiguous().view(torch.int64)], dim=1).contiguous()     # [Q, 2k] int64
+    allp = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+    dist.all_gather_into_tensor(allp.view(world * packed.shape[0], packed.shape[1]), packed)
+    rows = allp[:, :, :k].permute(1, 0, 2).reshape(packed.shape[0], world * k)
+    scores = allp[:, :, k:].contiguous().view(torch.float64).permute(1, 0, 2).reshape(packed.shape[0], world * k)
+    return merge_topk(scores, rows, k)

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
     const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
     const int* __restrict__ cand_idx, const float* __restrict__ cand_s, double err_bound,
-    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
+    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged) {
     __shared__ double sh_cos[64];
     const int q = blockIdx.x;
@@ -570,10 +570,12 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
     if (live && rank < kk) {
         out_idx[(int64_t)q * k + rank] = idx;
         out_score[(int64_t)q * k + rank] = (float)cs;
+        if (out_score64) out_score64[(int64_t)q * k + rank] = cs;
     }
     if (lane >= kk && lane < k) {  // fewer than k rows in the bank
         out_idx[(int64_t)q * k + lane] = -1;
         out_score[(int64_t)q * k + lane] = -INFINITY;
+        if (out_score64) out_score64[(int64_t)q * k + lane] = -INFINITY;
     }
     float tau = ap;  // smallest approximate score among the candidates bounds every non-candidate
 #pragma unroll
@@ -623,6 +625,7 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
         const bool ok = tl.idx != kNoIdx;
         out_idx[(int64_t)q * k + tid] = ok ? tl.idx : -1;
         out_score[(int64_t)q * k + tid] = ok ? (float)tl.s : -INFINITY;
+        if (out_score64) out_score64[(int64_t)q * k + tid] = ok ? tl.s : -INFINITY;
     }
 }
 
@@ -859,6 +862,12 @@ size_t astts_knn_workspace_bytes(const astts_knn_t* h, int32_t nq, int32_t k) {
 int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k, int64_t* out_idx,
                      float* out_score, void* workspace, size_t workspace_bytes, int32_t flags,
                      astts_stream_t stream) {
+    return astts_knn_search_f64(h, queries, nq, k, out_idx, out_score, nullptr, workspace, workspace_bytes, flags, stream);
+}
+
+int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32_t k, int64_t* out_idx,
+                         float* out_score, double* out_score64, void* workspace, size_t workspace_bytes, int32_t flags,
+                         astts_stream_t stream) {
     ASTTS_REQUIRE(h != nullptr, ASTTS_ERR_INVALID, "astts_knn_search: handle is null");
     ASTTS_REQUIRE(queries && out_idx && out_score, ASTTS_ERR_INVALID, "astts_knn_search: null pointer argument");
     ASTTS_REQUIRE(nq >= 1, ASTTS_ERR_INVALID, "astts_knn_search: nq=%d", nq);
@@ -937,11 +946,11 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
     if (h->exact16) {
         hipLaunchKernelGGL((knn_rescore_finalize<_Float16>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
                            h->plane16, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
-                           out_idx, out_score, nflag, flagged);
+                           out_idx, out_score, out_score64, nflag, flagged);
     } else {
         hipLaunchKernelGGL((knn_rescore_finalize<float>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
                            h->plane32, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
-                           out_idx, out_score, nflag, flagged);
+                           out_idx, out_score, out_score64, nflag, flagged);
     }
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

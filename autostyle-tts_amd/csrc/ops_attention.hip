@@ -262,7 +262,10 @@ struct MhaArgs {
 
 static constexpr int FA_KT = 64;  // keys per staged tile (two 32-key MFMA sub-tiles)
 static constexpr int FA_KS = 72;  // halfs per K row in LDS (64 dims + 8): conflict-free b128 reads
-static constexpr int FA_VS = 72;  // halfs per V^T row in LDS (64 keys + 8)
+static constexpr int FA_VS = 68;  // halfs per V^T row in LDS: 34 dwords, so the 32 dims (rows) a half-wave reads with ds_read_b64
+                                  // start on 32 different even banks (34 c mod 64 = 2 (17 c mod 32)): conflict-free; the half2
+                                  // scatter of the staging writes is 2-way (free on ds_write_b32).  72 + a key XOR swizzle made the
+                                  // writes conflict-free and left the reads 2-way: 43 % of the kernel's LDS cycles (r02 PMC pass)
 
 template <bool IN16>
 __device__ __forceinline__ void load8(const void* base, int64_t off, float* dst) {
@@ -327,13 +330,15 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     }
     float m_run = -INFINITY, l_run = 0.0f;
     // staging coordinates.  K: key row skey (0..63), 16 dims from sd0.  V: key PAIR vkp (keys 2 vkp, 2 vkp + 1), 8 dims from
-    // vd0 -- the transposed image V^T[dim][key] is then written as whole dwords (two keys of one dim), with the key index
-    // XORed by ((dim >> 3) & 7) << 3 so that the 32 lanes of a half-wave hit 32 different banks (the 2-byte scatter of one
-    // key per thread was 8-way conflicted: SQ_LDS_BANK_CONFLICT = 49 % of the kernel's LDS cycles).
+    // vd0 -- the transposed image V^T[dim][key] is written as whole dwords (two keys of one dim; a 2-byte scatter of one key
+    // per thread was 8-way conflicted).  Row stride FA_VS = 68 halfs: see its definition.
     const int skey = tid >> 2, sd0 = (tid & 3) * 16;
     const int vkp = tid >> 3, vd0 = (tid & 7) * 8;
-    half8 rk[2], rv[2];
-    auto prefetch = [&](int j0) {
+    // Two register sets: the loads of tile j + 2 are issued while tile j is computed, so a tile's K / V rows have two tiles of
+    // compute (and four barriers) to arrive -- one tile of compute (~0.5 us at T = 344) did not cover an L2 round trip, and
+    // the kernel ran at the pace of its global loads (18 us for 6 tiles).
+    half8 rkA[2], rvA[2], rkB[2], rvB[2];
+    auto prefetch = [&](int j0, half8 (&rk)[2], half8 (&rv)[2]) {
         const int j = min(j0 + skey, len - 1);         // clamped; keys >= len are masked in the scores
         const int64_t off = kb + (int64_t)j * a.ldk + sd0;
         rk[0] = load8h<IN16>(a.k, off);
@@ -342,10 +347,7 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
         rv[0] = load8h<IN16>(a.v, kb + (int64_t)jv0 * a.ldk + vd0);
         rv[1] = load8h<IN16>(a.v, kb + (int64_t)jv1 * a.ldk + vd0);
     };
-    if (len > 0) prefetch(0);
-
-    for (int j0 = 0; j0 < len; j0 += FA_KT) {
-        __syncthreads();
+    auto stage = [&](const half8 (&rk)[2], const half8 (&rv)[2]) {
         *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = rk[0];
         *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
 #pragma unroll
@@ -353,10 +355,10 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
             half2v pr;
             pr[0] = rv[0][i];
             pr[1] = rv[1][i];
-            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + ((2 * vkp) ^ ((tid & 7) << 3))]) = pr;
+            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + 2 * vkp]) = pr;
         }
-        __syncthreads();
-        if (j0 + FA_KT < len) prefetch(j0 + FA_KT);
+    };
+    auto compute_tile = [&](int j0) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int jb = j0 + sub * 32;
@@ -409,11 +411,10 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int vsw = ((dt * 4 + (c >> 3)) & 7) << 3;          // the row's key swizzle ((dim >> 3) & 7) << 3
                     const _Float16* vrow = &vt[(dt * 32 + c) * FA_VS];
                     const int key0 = sub * 32 + 16 * s + 4 * hh;
-                    const half4 lo = *reinterpret_cast<const half4*>(vrow + (key0 ^ vsw));
-                    const half4 hi = *reinterpret_cast<const half4*>(vrow + ((key0 + 8) ^ vsw));
+                    const half4 lo = *reinterpret_cast<const half4*>(vrow + key0);
+                    const half4 hi = *reinterpret_cast<const half4*>(vrow + key0 + 8);
                     half8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -421,6 +422,21 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
                 }
             }
         }
+    };
+    if (len > 0) prefetch(0, rkA, rvA);
+    if (len > FA_KT) prefetch(FA_KT, rkB, rvB);
+    for (int j0 = 0; j0 < len; j0 += 2 * FA_KT) {
+        __syncthreads();
+        stage(rkA, rvA);
+        __syncthreads();
+        if (j0 + 2 * FA_KT < len) prefetch(j0 + 2 * FA_KT, rkA, rvA);
+        compute_tile(j0);
+        if (j0 + FA_KT >= len) break;                  // block-uniform
+        __syncthreads();
+        stage(rkB, rvB);
+        __syncthreads();
+        if (j0 + 3 * FA_KT < len) prefetch(j0 + 3 * FA_KT, rkB, rvB);
+        compute_tile(j0 + FA_KT);
     }
     // O^T (dims in registers, query on the lane) -> LDS transpose -> coalesced rows
     l_run += __shfl_xor(l_run, 32, 64);
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
             half2v pr;
             pr[0] = rv[0][i];
             pr[1] = rv[1][i];
-            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + ((2 * vkp) ^ ((tid & 7) << 3))]) = pr;
+            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + 2 * vkp]) = pr;
         }
         __syncthreads();
         if (j0 + FA_KT < kmax) prefetch(j0 + FA_KT);
@@ -628,11 +644,10 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int vsw = ((dt * 4 + (c >> 3)) & 7) << 3;          // the row's key swizzle ((dim >> 3) & 7) << 3
                     const _Float16* vrow = &vt[(dt * 32 + c) * FA_VS];
                     const int key0 = sub * 32 + 16 * s + 4 * hh;
-                    const half4 lo = *reinterpret_cast<const half4*>(vrow + (key0 ^ vsw));
-                    const half4 hi = *reinterpret_cast<const half4*>(vrow + ((key0 + 8) ^ vsw));
+                    const half4 lo = *reinterpret_cast<const half4*>(vrow + key0);
+                    const half4 hi = *reinterpret_cast<const half4*>(vrow + key0 + 8);
                     half8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];

@@ -99,6 +99,12 @@ size_t astts_knn_workspace_bytes(const astts_knn_t* h, int32_t nq, int32_t k);
 int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k,
                      int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
                      int32_t flags, astts_stream_t stream);
+/* The same search with the fp64 cosines as well (out_score64 fp64 [nq,k], may be NULL): what a bank-SHARDED search merges
+ * on -- W ranks each return the top-k of their rows, and the k-way merge must order candidates of different ranks exactly
+ * as the oracle orders them (fp64 score descending, global row ascending); fp32-rounded scores could tie where fp64 do not. */
+int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32_t k,
+                         int64_t* out_idx, float* out_score, double* out_score64, void* workspace, size_t workspace_bytes,
+                         int32_t flags, astts_stream_t stream);
 /* Number of queries of the last search on `workspace` that took the exact-scan fallback.
  * Copies one word back and synchronises `stream` (diagnostics; not a launch-path call). */
 int astts_knn_last_fallbacks(const astts_knn_t* h, const void* workspace, astts_stream_t stream,

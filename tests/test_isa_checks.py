@@ -16,7 +16,7 @@ def _asm(src, tmp_path):
     if not (shutil.which(HIPCC) or os.path.exists(HIPCC)):
         pytest.skip("hipcc not available")
     out = tmp_path / (os.path.basename(src) + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(out)],
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", src, "-o", str(out)],
                    check=True, cwd=CSRC, timeout=600)
     return out.read_text()
 

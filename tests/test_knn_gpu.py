@@ -257,3 +257,34 @@ def test_milvus_client_search_end_to_end(golden_dir, kats):
                        anns_field="vector", metric_type="COSINE", limit=1, output_fields=["file_id"])
     assert r2[0][0]["entity"] == {"file_id": meta["rows"][5]["file_id"]}
     client.close()
+
+
+def test_bank_sharded_shards_on_one_gpu_equal_unsharded():
+    """SURVEY.md 8e stress mode, emulated on one GPU: the bank cut into 3 row shards (three StyleBank handles), every shard
+    searched with all queries (fp64 scores through astts_knn_search_f64), candidates merged by astts.parallel.merge_topk ->
+    identical to the unsharded search and to the oracle, duplicate rows across shards resolved by the lower row."""
+    from astts.knn import StyleBank
+    from astts.parallel import merge_topk, shard_bounds
+
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 4000, 256, 40, 5
+    bank = rng.standard_normal((n, d)).astype(np.float16)
+    bank[3100] = bank[17]
+    q = bank[rng.integers(0, n, nq)].astype(np.float32) + 0.4 * rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = bank[17]
+    qd = torch.from_numpy(q).cuda()
+    cand_s, cand_r = [], []
+    for r in range(3):
+        b0, b1, _ = shard_bounds(n, 3, r)
+        sb = StyleBank(bank[b0:b1])
+        idx, sc32, sc64 = sb.search_device(qd, k, return_f64=True)
+        assert sc64.dtype == torch.float64 and torch.equal(sc64.to(torch.float32), sc32)
+        cand_s.append(sc64)
+        cand_r.append(torch.where(idx >= 0, idx + b0, idx))
+    idx, sc = merge_topk(torch.cat(cand_s, 1), torch.cat(cand_r, 1), k)
+    ei, es = oknn.knn_search(bank, q, k)
+    assert np.array_equal(idx.cpu().numpy(), ei)
+    assert np.allclose(sc.cpu().numpy(), es, atol=1e-12, rtol=0)
+    assert idx[0, :2].tolist() == [17, 3100]
+    full_idx, _ = StyleBank(bank).search_device(qd, k)
+    assert torch.equal(full_idx, idx)

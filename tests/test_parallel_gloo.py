@@ -72,3 +72,62 @@ def test_shard_bounds_cover_everything():
             assert covered == list(range(n))
             assert all(e - b <= per for b, e, per in spans)
     assert shard_bounds(1623, 8, 0)[2] == 203
+
+
+def _worker_bank(rank, world, port, n, nq, k, ret):
+    """Bank-sharded mode (BASELINE config 5 stress mode): the per-rank search is the ORACLE on the rank's rows (checker only;
+    on GPUs it is StyleBank.search_device(..., return_f64=True))."""
+    for p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from astts.parallel import bank_sharded_search, shard_bounds
+    from oracle import knn as oknn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    bank = rng.standard_normal((n, 64)).astype(np.float16)
+    dup = n // 2 + 3 if n > 8 else n - 1
+    bank[dup] = bank[2]                             # an exact duplicate across the shard boundary: the lower row must win
+    q = torch.from_numpy(np.concatenate([rng.standard_normal((nq - 1, 64)), bank[2:3].astype(np.float64)]).astype(np.float32))
+    b0, b1, _ = shard_bounds(n, world, rank)
+
+    def local(qq, kk):
+        if b1 <= b0:
+            return torch.full((qq.shape[0], kk), -1, dtype=torch.int64), torch.full((qq.shape[0], kk), float("-inf"), dtype=torch.float64)
+        i, s = oknn.knn_search(bank[b0:b1], qq.numpy(), kk)
+        pad = kk - i.shape[1]                       # a shard with fewer than k rows
+        if pad:
+            i = np.concatenate([i, np.full((i.shape[0], pad), -1)], 1)
+            s = np.concatenate([s, np.full((s.shape[0], pad), -np.inf)], 1)
+        return torch.from_numpy(i), torch.from_numpy(s)
+
+    idx, sc = bank_sharded_search(local, q, k, b0, dist)
+    ei, es = oknn.knn_search(bank, q.numpy(), k)
+    ok = bool(np.array_equal(idx.numpy(), ei)) and bool(np.array_equal(sc.numpy(), es))
+    ok = ok and int(idx[-1, 0]) == 2 and int(idx[-1, 1]) == dup
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nq,k", [(301, 9, 3), (5, 4, 3)])
+def test_bank_sharded_search_world2(n, nq, k):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bank, args=(world, _free_port(), n, nq, k, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_merge_topk_total_order():
+    from astts.parallel import merge_topk
+
+    s = torch.tensor([[0.5, 0.9, 0.9, float("-inf"), 0.5, 0.7]], dtype=torch.float64)
+    r = torch.tensor([[10, 7, 3, -1, 2, 99]])
+    idx, sc = merge_topk(s, r, 4)
+    assert idx.tolist() == [[3, 7, 99, 2]] and sc.tolist() == [[0.9, 0.9, 0.7, 0.5]]
+    idx, sc = merge_topk(s[:, 3:4], r[:, 3:4], 2)           # nothing but an empty slot
+    assert idx.tolist() == [[-1]]
