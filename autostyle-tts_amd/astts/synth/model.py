@@ -795,17 +795,26 @@ class PipelinedSynth:
     waveform are bit-identical to running it alone (tested)."""
 
     def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None,
-                 cobatch: int = 1):
+                 cobatch: int = 1, render_depth: int = 1):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
         self.eng = engine
         self.depth = max(1, int(lm_depth))
+        # ``render_depth`` > 1: the flow + vocoder stages of consecutive batches alternate between that many streams.  One
+        # render chain is ~6000 dependent launches of ~10 us that each fill the chip for a few microseconds and leave it
+        # to latency (tails, boundaries) in between; a second chain runs in those gaps.
+        self.render_depth = rd = max(1, int(render_depth))
         dev = engine.device
         with torch.cuda.device(dev):
             self.front_stream = None
+            extra_render = []
             if streams is not None:
                 self.s_lm, self.s_render = list(streams[:self.depth]), streams[self.depth]
+                extra_render = list(streams[self.depth + 1:self.depth + rd])
+            elif lm_priority == render_priority and rd > 1:
+                st = ops.concurrent_streams(self.depth + 1 + rd, priority=lm_priority, device=dev)
+                self.s_render, extra_render, self.front_stream, self.s_lm = st[0], st[1:rd], st[rd], st[rd + 1:]
             elif lm_priority == render_priority:
                 # streams probed to sit on distinct hardware queues (ops.concurrent_streams), in order of importance: the
                 # render stream, a front stream for the caller's own per-batch work (retrieval, input preparation: run
@@ -818,6 +827,10 @@ class PipelinedSynth:
                 self.s_render = torch.cuda.Stream(device=dev, priority=render_priority)
             if self.front_stream is None:
                 self.front_stream = torch.cuda.Stream(device=dev)
+            while len(extra_render) < rd - 1:
+                extra_render.append(torch.cuda.Stream(device=dev, priority=render_priority))
+            self.s_renders = [self.s_render] + list(extra_render)
+            self._r = 0
         self._pool = ThreadPoolExecutor(max_workers=self.depth)
         self._fifo = deque()
         self._pending = []                  # batches waiting for their (co-batched) LM stage to be launched
@@ -838,9 +851,10 @@ class PipelinedSynth:
 
         best, best_dt = None, float("inf")
         for cfg_ in depths:
-            depth, cob = cfg_ if isinstance(cfg_, tuple) else (cfg_, 1)
+            cfg_ = cfg_ if isinstance(cfg_, tuple) else (cfg_, 1)
+            depth, cob, rdep = (tuple(cfg_) + (1,))[:3]
             for _ in range(trials):
-                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob)
+                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob, render_depth=rdep)
                 with torch.cuda.stream(pipe.front_stream):
                     for _ in range((depth + 1) * cob):
                         if front is not None:
@@ -857,7 +871,7 @@ class PipelinedSynth:
                     torch.cuda.synchronize(engine.device)
                 dt = (time.perf_counter() - t0) / steps
                 if verbose:
-                    print(f"PipelinedSynth.autotune: depth {depth} cobatch {cob}: {dt * 1e3:.1f} ms/batch", flush=True)
+                    print(f"PipelinedSynth.autotune: depth {depth} cobatch {cob} render streams {rdep}: {dt * 1e3:.1f} ms/batch", flush=True)
                 if dt < best_dt:
                     best, best_dt = pipe, dt
         best.tuned_ms_per_batch = best_dt * 1e3
@@ -901,12 +915,14 @@ class PipelinedSynth:
         parts, ev = item["fut"].result()
         toks = parts[item["k"]]
         cur = torch.cuda.current_stream(self.eng.device)
-        with torch.cuda.stream(self.s_render):
-            self.s_render.wait_event(ev)
-            toks.record_stream(self.s_render)
+        sr = self.s_renders[self._r % self.render_depth]
+        self._r += 1
+        with torch.cuda.stream(sr):
+            sr.wait_event(ev)
+            toks.record_stream(sr)
             for t in item["render"]:        # the caller's tensors, read on the render stream (see _launch_group)
                 if isinstance(t, torch.Tensor):
-                    t.record_stream(self.s_render)
+                    t.record_stream(sr)
             mel, wav = self.eng.tts_render(toks, *item["render"])
         # results are produced on the pipeline's streams and handed to the caller's: the caller still has to order its
         # stream behind them (drain() does; a caller that consumes results earlier waits on `pipe.s_render` itself), but
@@ -918,7 +934,8 @@ class PipelinedSynth:
     def submit(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, flow_prompt_tokens, flow_prompt_mel,
                flow_spk, z, phase0, noise):
         cur = torch.cuda.current_stream(self.eng.device)
-        self.s_render.wait_stream(cur)
+        for sr in self.s_renders:
+            sr.wait_stream(cur)
         item = {"lm": (text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms),
                 "render": (flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise), "fut": None, "k": 0}
         if self._pending and not self._compatible(self._pending[0]["lm"], item["lm"]):
@@ -947,5 +964,6 @@ class PipelinedSynth:
         cur = torch.cuda.current_stream(self.eng.device)
         for st in self.s_lm:
             cur.wait_stream(st)
-        cur.wait_stream(self.s_render)
+        for sr in self.s_renders:
+            cur.wait_stream(sr)
         return out

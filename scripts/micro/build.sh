@@ -16,3 +16,7 @@ hipcc $F -DRING_SKIP_MFMA -DRING_SKIP_EPI ring_bench.hip -o ring_bench_loadonly
 hipcc $F -DEPI_DBG_LOCAL ring_bench.hip -o ring_bench_local
 hipcc -O2 --offload-arch=gfx950 glds_check.hip -o glds_check
 hipcc -O2 --offload-arch=gfx950 coherence.hip -o coherence
+#   decode_chain        the LM decode step as a stand-alone launch chain (csrc/lm_step.hip): per-operator periods, eager vs
+#                       hipGraph replay, one chain vs two concurrent ones; decode_chain_stamps: in-kernel s_memrealtime stamps
+hipcc $F -std=c++17 decode_chain.hip -o decode_chain
+hipcc $F -std=c++17 -DLM_STAMPS decode_chain.hip -o decode_chain_stamps

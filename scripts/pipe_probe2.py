@@ -48,8 +48,5 @@ def timed(pipe, tag, K=16):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'{tag}: {dt / K * 1e3:.1f} ms/step RTF^-1 {audio * K / dt:.1f}', flush=True)
 for trial in range(2):
-    for depth in (2, 3, 4):
-        timed(PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0), f'depth {depth}, all priority 0 (probed set)')
-        lm = ops.concurrent_streams(depth, priority=-1); rf = ops.concurrent_streams(2, priority=0)
-        P = PipelinedSynth(eng, lm_depth=depth, streams=lm + [rf[0]]); P.front_stream = rf[1]
-        timed(P, f'depth {depth}, LM streams priority -1, render/front 0')
+    for depth, rd in ((2, 1), (2, 2), (3, 2), (2, 3), (4, 2)):
+        timed(PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, render_depth=rd), f'LM chains {depth}, render streams {rd}')
