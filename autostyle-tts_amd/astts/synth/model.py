@@ -382,9 +382,11 @@ class _Resnet1D:
         self.g2 = (_dev(sd[p + ".block2.block.1.weight"], device), _dev(sd[p + ".block2.block.1.bias"], device))
         self.res = PackedWeight.from_conv1d(sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"], device)
 
-    def forward(self, x: torch.Tensor, lens: torch.Tensor, temb_mish: torch.Tensor) -> torch.Tensor:
-        """x must already be zero beyond lens (masked)."""
-        tproj = ops.linear(temb_mish, self.mlp)                                  # [B, C]
+    def forward(self, x: torch.Tensor, lens: torch.Tensor, temb_mish: torch.Tensor, tproj: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x must already be zero beyond lens (masked).  ``tproj`` [B, C]: this block's time projection when the caller has
+        it already (the solver evaluates the time path of all Euler steps up front)."""
+        if tproj is None:
+            tproj = ops.linear(temb_mish, self.mlp)                              # [B, C]
         h = ops.conv1d(x, self.c1, pad=1)
         h = ops.groupnorm(h, *self.g1, self.groups, 1e-5, lens=lens, mish=True, add_bc=tproj, out_dtype=torch.float16)
         h = ops.conv1d(h, self.c2, pad=1)                                       # fp16 in: only consumer is the MFMA
@@ -478,24 +480,34 @@ class FlowDecoder:
         return h if mel_lens is None else ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=mel_lens)
 
     # ---- one estimator evaluation on a (2B) batch
-    def estimator(self, x, mu, spk, cond, t, lens, full: bool = False) -> torch.Tensor:
+    def time_path(self, t: torch.Tensor) -> List[torch.Tensor]:
+        """t fp32 [rows] -> the time projection of every ResnetBlock1D (down, mid, up order), each [rows, C]: sinusoidal
+        embedding -> MLP -> Mish (every block applies Mish before its own Linear).  Independent of x: the solver calls it once
+        with the rows of ALL Euler steps."""
+        temb = ops.time_embedding(t, self.cfg.est_in)
+        temb = ops.linear(ops.linear(temb, self.t1, act="silu"), self.t2)
+        temb_m = ops.elementwise(ops.EL_MISH, temb)
+        return [ops.linear(temb_m, blk[0].mlp) for grp in (self.down, self.mid, self.up) for blk in grp]
+
+    def estimator(self, x, mu, spk, cond, t, lens, full: bool = False, tprojs: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """``full``: every row uses all T frames (fixed-length batch) -- the length masks are identities and are
-        not launched."""
+        not launched.  ``tprojs``: the blocks' time projections for this call's rows (``time_path``), computed here if absent."""
         cfg = self.cfg
         b, T, _ = x.shape
         if full:
             _mask = lambda h, L: h
         else:
             _mask = lambda h, L: ops.elementwise(ops.EL_MUL_ROWMASK, h, lens=L)
-        temb = ops.time_embedding(t, cfg.est_in)
-        temb = ops.linear(ops.linear(temb, self.t1, act="silu"), self.t2)
-        temb_m = ops.elementwise(ops.EL_MISH, temb)                 # every ResnetBlock1D applies Mish first
+        if tprojs is None:
+            tprojs = self.time_path(t)
+        tp = iter(tprojs)
+        temb_m = None
         h = torch.cat([x, mu, spk[:, None, :].expand(b, T, -1), cond], dim=-1)
         hiddens, lens_stack = [], [lens]
         for res, tfms, wds, last in self.down:
             L = lens_stack[-1]
             h = _mask(h, L)
-            h = res.forward(h, L, temb_m)
+            h = res.forward(h, L, temb_m, next(tp))
             for tb in tfms:
                 h = tb.forward(h, L)
             hiddens.append(h)
@@ -509,7 +521,7 @@ class FlowDecoder:
         L = lens_stack[-1]
         h = _mask(h, L)
         for res, tfms in self.mid:
-            h = res.forward(h, L, temb_m)
+            h = res.forward(h, L, temb_m, next(tp))
             for tb in tfms:
                 h = tb.forward(h, L)
             h = _mask(h, L)
@@ -519,7 +531,7 @@ class FlowDecoder:
             skip = hiddens.pop()
             h = torch.cat([h[:, :skip.shape[1]], skip], dim=-1)
             h = _mask(h, L)
-            h = res.forward(h, L, temb_m)
+            h = res.forward(h, L, temb_m, next(tp))
             for tb in tfms:
                 h = tb.forward(h, L)
             hm = _mask(h, L)
@@ -614,9 +626,13 @@ class FlowDecoder:
         spk2 = torch.cat([spk_e, torch.zeros_like(spk_e)], 0)
         cond2 = torch.cat([cond, torch.zeros_like(cond)], 0)
         tv, dv = self._schedule()
+        b2 = 2 * b
+        t_all = torch.tensor(tv, dtype=torch.float32, device=x.device).repeat_interleave(b2)      # rows of all steps, as the engine
+        tp_all = self.time_path(t_all)
         for s in range(len(tv)):
-            t2 = torch.full((2 * b,), tv[s], dtype=torch.float32, device=x.device)
-            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2, full=full)
+            t2 = t_all[s * b2:(s + 1) * b2]
+            d = self.estimator(torch.cat([x, x], 0), mu2, spk2, cond2, t2, lens2, full=full,
+                               tprojs=[tp[s * b2:(s + 1) * b2] for tp in tp_all])
             x = ops.elementwise(ops.EL_CFG_EULER, x, z=d, s=dv[s], s2=self.cfg.cfg_rate)
         return x
 

@@ -102,8 +102,10 @@ using namespace astts;
 
 namespace {
 
+constexpr int FLOW_MAX_STEPS = 32;   // Euler steps whose time embeddings / projections are precomputed (the reference runs 10)
+
 struct Buffers {
-    float *xin, *r1, *r2, *r3, *pool[6], *temb0, *temb1, *temb2, *tproj, *tv, *d, *up;
+    float *xin, *r1, *r2, *r3, *pool[6], *temb0, *temb1, *temb2, *tproj, *tv, *d, *up;   // temb* / tproj / tv: all Euler steps at once
     _Float16 *r1h, *n16, *qkv16, *a16, *f16;
     int *lens_full, *lens_half;
     void* gn_ws;
@@ -134,11 +136,13 @@ size_t carve(const astts_flow* h, int b, int t, char* base, Buffers* B) {
     X.qkv16 = (_Float16*)take(sizeof(_Float16) * rows * 3 * hd);
     X.a16 = (_Float16*)take(sizeof(_Float16) * rows * hd);
     X.f16 = (_Float16*)take(sizeof(_Float16) * rows * 4 * C);
-    X.temb0 = (float*)take(sizeof(float) * b2 * c.time_in);
-    X.temb1 = (float*)take(sizeof(float) * b2 * c.time_dim);
-    X.temb2 = (float*)take(sizeof(float) * b2 * c.time_dim);
-    X.tproj = (float*)take(sizeof(float) * b2 * C);
-    X.tv = (float*)take(sizeof(float) * b2);
+    // the time path does not depend on x: it is evaluated for ALL Euler steps before the first one (FLOW_MAX_STEPS rows blocks)
+    const size_t n_res = h->down.size() + h->mid.size() + h->up.size();
+    X.temb0 = (float*)take(sizeof(float) * FLOW_MAX_STEPS * b2 * c.time_in);
+    X.temb1 = (float*)take(sizeof(float) * FLOW_MAX_STEPS * b2 * c.time_dim);
+    X.temb2 = (float*)take(sizeof(float) * FLOW_MAX_STEPS * b2 * c.time_dim);
+    X.tproj = (float*)take(sizeof(float) * n_res * FLOW_MAX_STEPS * b2 * C);
+    X.tv = (float*)take(sizeof(float) * FLOW_MAX_STEPS * b2);
     X.d = (float*)take(sizeof(float) * rows * c.mel);
     X.lens_full = (int*)take(sizeof(int) * b2);
     X.lens_half = (int*)take(sizeof(int) * b2);
@@ -168,12 +172,12 @@ struct Ctx {
     }
 
     // ResnetBlock1D on x [b2, t, cin] (already masked) -> out [b2, t, C]
-    int resnet(const astts_flow_resnet_t& r, const float* x, const int* lens, int t, float* out) const {
+    // `tproj` [b2, C]: this block's time projection for the current Euler step (precomputed for all steps by astts_flow_solve)
+    int resnet(const astts_flow_resnet_t& r, const float* tproj, const float* x, const int* lens, int t, float* out) const {
         const int C = h->cfg.channels, G = h->cfg.groups;
         const int64_t rows = (int64_t)b2 * t;
-        RUN(linear(B.temb2, 0, r.mlp, nullptr, B.tproj, 0, b2, ASTTS_ACT_NONE));
         RUN(gemm(x, 0, r.c1, nullptr, B.r1, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));
-        RUN(astts_op_groupnorm_ex(B.r1, lens, r.g1_w, r.g1_b, B.tproj, B.r1h, 1, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));
+        RUN(astts_op_groupnorm_ex(B.r1, lens, r.g1_w, r.g1_b, tproj, B.r1h, 1, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));
         RUN(gemm(B.r1h, 1, r.c2, nullptr, B.r2, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));
         RUN(astts_op_groupnorm_ex(B.r2, lens, r.g2_w, r.g2_b, nullptr, B.r3, 0, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));
         return gemm(x, 0, r.res, B.r3, out, 0, rows, t, t, 1, 0, ASTTS_ACT_NONE);     // res_conv(x) + h
@@ -262,15 +266,29 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
     hipLaunchKernelGGL(flow_fill_lens, dim3((b2 + 63) / 64), dim3(64), 0, st, lens, B.lens_full, B.lens_half, b, t);
     ASTTS_CHECK_LAUNCH();
 
+    // ---- the time path of every Euler step, hoisted out of the dependent chain (it depends on the schedule only): time
+    // embedding -> MLP -> Mish (every ResnetBlock1D applies Mish before its own projection) for all n_steps x 2B rows in one
+    // pass, then ONE projection GEMM per ResNet block over all steps: ~20 launches per solve instead of 21 per step.
+    ASTTS_REQUIRE(n_steps <= FLOW_MAX_STEPS, ASTTS_ERR_INVALID, "astts_flow_solve: n_steps=%d (at most %d)", n_steps, FLOW_MAX_STEPS);
+    const int64_t trows = (int64_t)n_steps * b2;
     for (int s = 0; s < n_steps; ++s) {
-        // time embedding -> MLP -> Mish (every ResnetBlock1D applies Mish before its own projection)
-        hipLaunchKernelGGL(flow_fill_time, dim3((b2 + 63) / 64), dim3(64), 0, st, B.tv, t_host[s], b2);
+        hipLaunchKernelGGL(flow_fill_time, dim3((b2 + 63) / 64), dim3(64), 0, st, B.tv + (size_t)s * b2, t_host[s], b2);
         ASTTS_CHECK_LAUNCH();
-        RUN(astts_op_time_embedding(B.tv, B.temb0, b2, c.time_in, 1000.0f, st));
-        RUN(k.linear(B.temb0, 0, c.t1, nullptr, B.temb1, 0, b2, ASTTS_ACT_SILU));
-        RUN(k.linear(B.temb1, 0, c.t2, nullptr, B.temb2, 0, b2, ASTTS_ACT_NONE));
-        RUN(astts_op_elementwise(ASTTS_EL_MISH, B.temb2, nullptr, nullptr, nullptr, B.temb2, (int64_t)b2 * c.time_dim, 1, c.time_dim,
-                                 0.0f, 0.0f, st));
+    }
+    RUN(astts_op_time_embedding(B.tv, B.temb0, (int)trows, c.time_in, 1000.0f, st));
+    RUN(k.linear(B.temb0, 0, c.t1, nullptr, B.temb1, 0, trows, ASTTS_ACT_SILU));
+    RUN(k.linear(B.temb1, 0, c.t2, nullptr, B.temb2, 0, trows, ASTTS_ACT_NONE));
+    RUN(astts_op_elementwise(ASTTS_EL_MISH, B.temb2, nullptr, nullptr, nullptr, B.temb2, trows * c.time_dim, 1, c.time_dim, 0.0f, 0.0f, st));
+    {
+        size_t ri = 0;
+        for (const std::vector<astts_flow::Block>* grp : {&h->down, &h->mid, &h->up})
+            for (const astts_flow::Block& blk : *grp)
+                RUN(k.linear(B.temb2, 0, blk.res.mlp, nullptr, B.tproj + (ri++) * (size_t)trows * C, 0, trows, ASTTS_ACT_NONE));
+    }
+
+    for (int s = 0; s < n_steps; ++s) {
+        size_t ri = 0;      // ResNet block counter of this estimator pass (down, mid, up order: the order of the table above)
+        auto tproj_of = [&]() { return B.tproj + ((ri++) * (size_t)trows + (size_t)s * b2) * C; };
         hipLaunchKernelGGL(flow_pack_input, dim3(grid_for((int64_t)b2 * t * 4 * mel)), dim3(256), 0, st, x, mu, spk, cond,
                            B.lens_full, B.xin, b, t, mel);
         ASTTS_CHECK_LAUNCH();
@@ -292,7 +310,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
 
         for (size_t i = 0; i < h->down.size(); ++i) {
             const astts_flow::Block& blk = h->down[i];
-            RUN(k.resnet(blk.res, block_in, L, tt, other));     // never in place: every GEMM block reads whole input rows
+            RUN(k.resnet(blk.res, tproj_of(), block_in, L, tt, other));     // never in place: every GEMM block reads whole input rows
             { float* sw = cur; cur = other; other = sw; }
             for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
             RUN(k.mask(cur, L, tt, C));
@@ -314,7 +332,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             block_in = cur;
         }
         for (const astts_flow::Block& blk : h->mid) {
-            RUN(k.resnet(blk.res, cur, L, tt, other));
+            RUN(k.resnet(blk.res, tproj_of(), cur, L, tt, other));
             float* sw = cur; cur = other; other = sw;
             for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
             RUN(k.mask(cur, L, tt, C));
@@ -329,7 +347,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             hipLaunchKernelGGL(flow_concat_skip, dim3(grid_for((int64_t)b2 * tt * 2 * (C / 4))), dim3(256), 0, st, up_src, up_bs,
                                skips[n_skips], L, B.xin, b2, tt, C);
             ASTTS_CHECK_LAUNCH();
-            RUN(k.resnet(blk.res, B.xin, L, tt, cur));
+            RUN(k.resnet(blk.res, tproj_of(), B.xin, L, tt, cur));
             for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
             RUN(k.mask(cur, L, tt, C));
             if (blk.kind == ASTTS_FLOW_RESAMPLE_UP) {
