@@ -26,17 +26,30 @@ struct ProfKind {
 };
 static ProfKind g_prof[ASTTS_PROF_KINDS];
 static bool g_prof_any = false;
+static std::mutex g_prof_mu;   // launches of one kind come from several host threads in the pipelined benchmark
+
+static thread_local size_t g_pair[ASTTS_PROF_KINDS];   // the event pair the calling thread's prof_begin reserved
 
 bool prof_begin(int kind, hipStream_t st, double work) {
     if (!g_prof_any) return false;
     ProfKind& p = g_prof[kind];
     if (!p.on) return false;
-    if (p.used + 2 > p.ev.size()) {
-        ++p.dropped;
+    size_t idx;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (p.used + 2 > p.ev.size()) {
+            ++p.dropped;
+            return false;
+        }
+        idx = p.used;
+        p.used += 2;
+        p.work += work;
+    }
+    g_pair[kind] = idx;
+    if (hipEventRecord(p.ev[idx], st) != hipSuccess) {
+        (void)hipEventRecord(p.ev[idx + 1], st);      // keep the pair well-formed
         return false;
     }
-    if (hipEventRecord(p.ev[p.used], st) != hipSuccess) return false;
-    p.work += work;
     return true;
 }
 
@@ -46,6 +59,7 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1) {
     if (!g_prof_any) return false;
     ProfKind& p = g_prof[kind];
     if (!p.on) return false;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (p.used + 2 > p.ev.size()) {
         ++p.dropped;
         return false;
@@ -59,8 +73,7 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1) {
 
 void prof_end(int kind, hipStream_t st) {
     ProfKind& p = g_prof[kind];
-    (void)hipEventRecord(p.ev[p.used + 1], st);
-    p.used += 2;
+    (void)hipEventRecord(p.ev[g_pair[kind] + 1], st);
 }
 
 }  // namespace astts
