@@ -124,6 +124,10 @@ _SIGS.update({
     "astts_flow_solve": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                    ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float, c_void_p, c_size_t, c_void_p]),
 })
+_SIGS.update({   # fused transformer-block front half of the flow estimator (csrc/ops_tfm_fused.hip)
+    "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
+})
 _SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
     "astts_op_rmsnorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_rope_llama": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
@@ -424,6 +428,22 @@ def attn_mha(q, k, v, heads: int, lens=None, out_dtype=torch.float32) -> torch.T
     _lib.check(_L().astts_op_attn_mha_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), 1 if q.dtype == torch.float16 else 0,
                                          _p(lens), out.data_ptr(), 1 if out_dtype == torch.float16 else 0, b, heads, t,
                                          q.stride(1), k.stride(1), heads * 64, 1.0 / math.sqrt(64.0), _st()))
+    return out
+
+
+def tfm_attn_fused_supported(c: int, heads: int, t: int) -> bool:
+    return bool(_L().astts_op_tfm_attn_fused_supported(c, heads, t))
+
+
+def tfm_attn_fused(x: torch.Tensor, wqkv: PackedWeight, heads: int, lens=None, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm (no affine: folded into ``wqkv``) + q|k|v projection + masked MHA in one launch:
+    x fp32 ``[B, T, 256]`` -> fp16 ``[B, T, heads*64]``.  Caller checks ``tfm_attn_fused_supported`` first."""
+    x = _f32(x)
+    b, t, c = x.shape
+    assert wqkv.cin == c == wqkv.cin_pad and wqkv.n == 3 * heads * 64 and wqkv.taps == 1
+    out = torch.empty((b, t, heads * 64), dtype=torch.float16, device=x.device)
+    _lib.check(_L().astts_op_tfm_attn_fused(x.data_ptr(), wqkv.data.data_ptr(), _p(wqkv.bias), _p(lens), out.data_ptr(), b, heads, t, c, eps,
+                                            1.0 / math.sqrt(64.0), _st()))
     return out
 
 

@@ -397,9 +397,14 @@ class _Resnet1D:
 class _TfmBlock:
     def __init__(self, sd: SD, p: str, heads: int, device):
         self.heads = heads
-        self.n1 = (_dev(sd[p + ".norm1.weight"], device), _dev(sd[p + ".norm1.bias"], device))
-        self.wqkv = PackedWeight(torch.cat([sd[p + ".attn1.to_q.weight"], sd[p + ".attn1.to_k.weight"],
-                                            sd[p + ".attn1.to_v.weight"]], 0), None, device)
+        # norm1's scale / shift are folded into the fused q|k|v projection (W' = W diag(gamma), b' = W beta: fold_layernorm), so
+        # that the fused LayerNorm + projection + attention kernel (ops.tfm_attn_fused) normalises without them; the unfused
+        # path (T > 352) runs the plain LayerNorm kernel with the identity affine on the same weights.
+        wqkv = torch.cat([sd[p + ".attn1.to_q.weight"], sd[p + ".attn1.to_k.weight"], sd[p + ".attn1.to_v.weight"]], 0).float().cpu()
+        wqkv, bqkv = fold_layernorm(wqkv, torch.zeros(wqkv.shape[0]), sd[p + ".norm1.weight"].float().cpu(), sd[p + ".norm1.bias"].float().cpu())
+        c = int(wqkv.shape[1])
+        self.n1 = (torch.ones(c, dtype=torch.float32, device=device), torch.zeros(c, dtype=torch.float32, device=device))
+        self.wqkv = PackedWeight(wqkv, bqkv, device)
         self.wo = PackedWeight(sd[p + ".attn1.to_out.0.weight"], sd[p + ".attn1.to_out.0.bias"], device)
         self.n3 = (_dev(sd[p + ".norm3.weight"], device), _dev(sd[p + ".norm3.bias"], device))
         self.w1 = PackedWeight(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], device)
@@ -408,9 +413,12 @@ class _TfmBlock:
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
         hd = self.heads * 64
         f16 = torch.float16   # everything between two residual adds feeds MFMA operands only: fp16 in HBM
-        n = ops.layernorm(x, *self.n1, 1e-5, out_dtype=f16)
-        qkv = ops.linear(n, self.wqkv, out_dtype=f16)
-        a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens, out_dtype=f16)
+        if ops.tfm_attn_fused_supported(x.shape[-1], self.heads, x.shape[1]):
+            a = ops.tfm_attn_fused(x, self.wqkv, self.heads, lens=lens, eps=1e-5)     # LayerNorm + q|k|v + attention: one launch
+        else:
+            n = ops.layernorm(x, *self.n1, 1e-5, out_dtype=f16)
+            qkv = ops.linear(n, self.wqkv, out_dtype=f16)
+            a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens, out_dtype=f16)
         x = ops.linear(a, self.wo, residual=x)
         n = ops.layernorm(x, *self.n3, 1e-5, out_dtype=f16)
         f = ops.linear(n, self.w1, act="gelu", out_dtype=f16)

@@ -187,10 +187,14 @@ struct Ctx {
     int tfm(const astts_flow_tfm_t& w, float* p, float* q, const int* lens, int t) const {
         const int C = h->cfg.channels, heads = h->cfg.heads, hd = heads * 64;
         const int64_t rows = (int64_t)b2 * t;
-        RUN(astts_op_layernorm_ex(p, w.n1_w, w.n1_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
-        RUN(linear(B.n16, 1, w.qkv, nullptr, B.qkv16, 1, rows, ASTTS_ACT_NONE));
-        RUN(astts_op_attn_mha_ex(B.qkv16, B.qkv16 + hd, B.qkv16 + 2 * hd, 1, lens, B.a16, 1, b2, heads, t, 3 * hd, 3 * hd, hd,
-                                 0.125f, st));
+        if (astts_op_tfm_attn_fused_supported(C, heads, t)) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
+            RUN(astts_op_tfm_attn_fused(p, w.qkv.w, w.qkv.bias, lens, B.a16, b2, heads, t, C, 1e-5f, 0.125f, st));
+        } else {
+            RUN(astts_op_layernorm_ex(p, w.n1_w, w.n1_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
+            RUN(linear(B.n16, 1, w.qkv, nullptr, B.qkv16, 1, rows, ASTTS_ACT_NONE));
+            RUN(astts_op_attn_mha_ex(B.qkv16, B.qkv16 + hd, B.qkv16 + 2 * hd, 1, lens, B.a16, 1, b2, heads, t, 3 * hd, 3 * hd, hd,
+                                     0.125f, st));
+        }
         RUN(linear(B.a16, 1, w.wo, p, q, 0, rows, ASTTS_ACT_NONE));
         RUN(astts_op_layernorm_ex(q, w.n3_w, w.n3_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
         RUN(linear(B.n16, 1, w.w1, nullptr, B.f16, 1, rows, ASTTS_ACT_GELU));

@@ -1,0 +1,358 @@
+// ops_tfm_fused.hip -- LayerNorm + q|k|v projection + masked multi-head attention of one BasicTransformerBlock of the
+// flow-matching estimator in ONE launch (the reference's hot loop #3, SURVEY.md 3.1: ConditionalDecoder's transformer
+// blocks behind cosyvoice.inference_tts_with_st, tts_with_rag.py:195; 48 of the 56 blocks of an estimator pass run at
+// T = 344 frames x 16 sequences).
+//
+// Why: as three launches (layernorm_rows 5.2 us, gemm_ring q|k|v 12.3 us, attn_mha_flash 16.4 us + 3 x 1.45 us of kernel
+// boundary) this part of a block takes 38 us for 8.2 GFLOP; each of them is bound by latency (a dependent kernel over a few MB
+// of fresh data does not finish under ~5 us on this chip) and by workgroup granularity (384 attention workgroups on 256 CUs
+// cost as much as 512), not by MFMA or HBM time.  Fused, the normalised rows, Q, K and V never leave the CU.
+//
+// Workgroup = (query half, head, sequence): 2 x 8 x 16 = 256 workgroups of 8 waves, one per CU.
+//   phase 1  for every 32-frame chunk of the sequence: 512 threads load the fp32 rows, normalise them (two-pass statistics over
+//            the 256 channels; the LayerNorm scale / shift are folded into the projection weights by the host) and stage them as
+//            fp16 in LDS (double buffered); each wave owns one 32-feature tile of this head's K | V | Q projection, its
+//            weights live in registers (64 VGPRs) for the whole phase; K goes to LDS row-major, V transposed, Q (only for the
+//            chunks of this workgroup's query half) row-major.  Both workgroups of a (head, sequence) project all keys:
+//            1.33x the projection flops, no exchange.
+//   phase 2  each wave takes one 32-query tile: S^T = K Q^T, online softmax in the log2 domain, O^T += V^T P^T exactly as
+//            attn_mha_flash (ops_attention.hip), but K and V^T are read from LDS where phase 1 left them: no staging, no
+//            barrier, no global load in the key loop.
+// LDS: K [TKP][72] + V^T [64][TKP + 4] + A [2][32][264] + Q [192][72] halfs = 154 KB at T = 344 (TKP = 352): T <= 352.
+#include "common.h"
+
+namespace astts {
+
+static constexpr int TF_C = 256;           // channels of the estimator's transformer blocks
+static constexpr int TF_DH = 64;
+static constexpr int TF_KS = 72;           // halfs per K / Q row in LDS (conflict-free ds_read_b128, as FA_KS)
+static constexpr int TF_AS = TF_C + 8;     // halfs per staged A row
+static constexpr int TF_QROWS = 192;       // queries per workgroup (6 tiles of 32)
+static constexpr int TF_MAX_T = 352;
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k + 15), result on every lane: four row rotations on the VALU.
+// (__shfl_xor compiles to ds_bpermute_b32: an LDS round trip of ~100 cycles per step, eight steps per staged chunk.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+
+struct TfmAttnArgs {
+    const float* x;          // [b, t, 256] fp32 residual stream
+    const _Float16* w;       // [3 * heads * 64 (+pad)][256] fp16: q | k | v rows, LayerNorm scale folded in
+    const float* bias;       // [3 * heads * 64] fp32 (W beta, + the projection's own bias if any) or null
+    const int* lens;         // [b] valid frames or null
+    _Float16* out;           // [b, t, heads * 64] fp16
+    int b, heads, t;
+    float eps, scale;
+};
+
+__global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    // Workgroup -> (sequence, head, query half).  Hardware deals workgroups round-robin over the 8 XCDs (id mod 8) and every XCD
+    // has its own L2: with the plain (x, y, z) order the 16 workgroups of a sequence sit on all 8 XCDs and every L2 fetches the whole
+    // activation tensor (8 x 5.6 MB of fabric traffic per launch at 16 x 344 x 256 fp32: the kernel ran at that pace).  When the
+    // batch is a multiple of 8, sequence b goes to XCD b mod 8: one L2 fetches its rows once for all 16 workgroups.
+    int qs, head, b;
+    {
+        const int units = 2 * a.heads;                  // workgroups per sequence
+        const int L = blockIdx.x;
+        if ((a.b & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            b = xcd + 8 * (slot / units);
+            const int hq = slot % units;
+            head = hq >> 1;
+            qs = hq & 1;
+        } else {
+            b = L / units;
+            const int hq = L % units;
+            head = hq >> 1;
+            qs = hq & 1;
+        }
+    }
+    const int T = a.t;
+    const int nch = (T + 31) >> 5;                   // 32-frame chunks
+    const int tkp = nch * 32;
+    const int vs = tkp + 4;                          // halfs per V^T row: (tkp / 2 + 2) dwords = 2 * odd multiple: conflict-free b64 reads
+    const int qch0 = qs == 0 ? 0 : (nch + 1) / 2;    // this workgroup's query chunks [qch0, qch1)
+    const int qch1 = qs == 0 ? (nch + 1) / 2 : nch;
+    _Float16* sK = tf_smem;                          // [tkp][72]
+    _Float16* sVt = sK + (size_t)tkp * TF_KS;        // [64][vs]
+    _Float16* sA = sVt + (size_t)TF_DH * vs;         // [2][32][264]
+    _Float16* sQ = sA + 2 * 32 * TF_AS;              // [192][72]
+    const int len = a.lens ? min(a.lens[b], T) : T;
+    const float* xb = a.x + (int64_t)b * T * TF_C;
+    const int hd = a.heads * TF_DH;
+
+    // ---- this wave's projection weights: one 32-feature tile of K (waves 0, 1), V (2, 3) or Q (4, 5), K = 256 in registers
+    // (Q is only projected for the chunks of this workgroup's query half; its two tiles alternate between waves 4, 5 and 6, 7 from
+    // chunk to chunk so that every SIMD -- waves w and w + 4 share one -- carries the same number of projection MFMAs)
+    const int role = wid < 2 ? 0 : (wid < 4 ? 1 : 2);  // 0 K, 1 V, 2 Q
+    half8 wf[16];
+    float bias_e[16];
+    if (role < 3) {
+        const int part = role == 0 ? 1 : (role == 1 ? 2 : 0);           // row block of the fused q | k | v weight
+        const int frow = part * hd + head * TF_DH + (wid & 1) * 32;
+        const _Float16* wp = a.w + (int64_t)(frow + c) * TF_C + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wf[s] = *reinterpret_cast<const half8*>(wp + 16 * s);
+        // bias of the features this lane's accumulator elements hold.  K / Q tiles: feature on the element index
+        // (f_e = (e & 3) + 8 (e >> 2) + 4 hh); V tiles: feature on the lane (c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int f = role == 1 ? c : (e & 3) + 8 * (e >> 2) + 4 * hh;
+            bias_e[e] = a.bias ? a.bias[frow + f] : 0.0f;
+        }
+    }
+
+    // ---- phase 1: normalise + project, chunk by chunk
+    const int srow = tid >> 4, sseg = (tid & 15) * 16;      // staging: 16 threads per frame, 16 channels each
+    // PF chunks of rows in flight per thread (PF x 4 float4); a workgroup reads its whole sequence (T x 1 KB of fp32 rows, shared
+    // through L2 with the 15 other workgroups of the sequence)
+    constexpr int PF = 2;
+    float4 xr[PF][4];
+    auto load_chunk = [&](int ch, float4 (&r)[4]) {
+        const int fr = min(ch * 32 + srow, T - 1);
+        const float* p = xb + (int64_t)fr * TF_C + sseg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + 4 * i);
+    };
+    auto stage_chunk = [&](int buf, const float4 (&r)[4]) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+        s = row16_sum(s);
+        const float mean = s * (1.0f / TF_C);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dx = r[i].x - mean, dy = r[i].y - mean, dz = r[i].z - mean, dw = r[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q = row16_sum(q);
+        const float rstd = rsqrtf(q * (1.0f / TF_C) + a.eps);
+        half8 h0, h1;
+        h0[0] = (_Float16)((r[0].x - mean) * rstd); h0[1] = (_Float16)((r[0].y - mean) * rstd);
+        h0[2] = (_Float16)((r[0].z - mean) * rstd); h0[3] = (_Float16)((r[0].w - mean) * rstd);
+        h0[4] = (_Float16)((r[1].x - mean) * rstd); h0[5] = (_Float16)((r[1].y - mean) * rstd);
+        h0[6] = (_Float16)((r[1].z - mean) * rstd); h0[7] = (_Float16)((r[1].w - mean) * rstd);
+        h1[0] = (_Float16)((r[2].x - mean) * rstd); h1[1] = (_Float16)((r[2].y - mean) * rstd);
+        h1[2] = (_Float16)((r[2].z - mean) * rstd); h1[3] = (_Float16)((r[2].w - mean) * rstd);
+        h1[4] = (_Float16)((r[3].x - mean) * rstd); h1[5] = (_Float16)((r[3].y - mean) * rstd);
+        h1[6] = (_Float16)((r[3].z - mean) * rstd); h1[7] = (_Float16)((r[3].w - mean) * rstd);
+        _Float16* d = sA + (size_t)buf * 32 * TF_AS + srow * TF_AS + sseg;
+        *reinterpret_cast<half8*>(d) = h0;
+        *reinterpret_cast<half8*>(d + 8) = h1;
+    };
+    auto project_chunk = [&](int ch) {
+        const int buf = ch & 1;
+        const bool q_chunk = ch >= qch0 && ch < qch1 && (((ch - qch0) & 1) == ((wid >> 1) & 1));   // waves 4, 5: even; 6, 7: odd
+        if (role < 2 || (role == 2 && q_chunk)) {
+            const _Float16* ap = sA + (size_t)buf * 32 * TF_AS + c * TF_AS + 8 * hh;
+            float16v acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = bias_e[e];
+            if (role == 1) {                            // V: frame on the element index, feature on the lane
+#pragma unroll
+                for (int s0 = 0; s0 < 16; s0 += 8) {    // eight fragment reads in flight, then their MFMAs (a read issued right
+                    half8 af[8];                        // before its MFMA exposes the LDS latency sixteen times per chunk)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const half8*>(ap + 16 * (s0 + s));
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], wf[s0 + s], acc, 0, 0, 0);
+                }
+                _Float16* vp = sVt + (size_t)((wid & 1) * 32 + c) * vs + ch * 32 + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h4;
+                    h4[0] = (_Float16)acc[4 * g]; h4[1] = (_Float16)acc[4 * g + 1]; h4[2] = (_Float16)acc[4 * g + 2]; h4[3] = (_Float16)acc[4 * g + 3];
+                    *reinterpret_cast<half4*>(vp + 8 * g) = h4;
+                }
+            } else {                                    // K / Q: feature on the element index, frame on the lane
+#pragma unroll
+                for (int s0 = 0; s0 < 16; s0 += 8) {
+                    half8 af[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const half8*>(ap + 16 * (s0 + s));
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s0 + s], af[s], acc, 0, 0, 0);
+                }
+                _Float16* kp = role == 0 ? sK + (size_t)(ch * 32 + c) * TF_KS : sQ + (size_t)((ch - qch0) * 32 + c) * TF_KS;
+                kp += (wid & 1) * 32 + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h4;
+                    h4[0] = (_Float16)acc[4 * g]; h4[1] = (_Float16)acc[4 * g + 1]; h4[2] = (_Float16)acc[4 * g + 2]; h4[3] = (_Float16)acc[4 * g + 3];
+                    *reinterpret_cast<half4*>(kp + 8 * g) = h4;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (i < nch) load_chunk(i, xr[i]);
+    stage_chunk(0, xr[0]);
+    if (PF < nch) load_chunk(PF, xr[0]);
+    __syncthreads();
+    // chunk ch is projected from buffer ch & 1 while chunk ch + 1 is normalised into the other buffer and chunk ch + 1 + PF is
+    // requested into the register set that just emptied (register set of chunk k: k mod PF; the loop is unrolled by PF so that
+    // every set index is a compile-time constant)
+    for (int ch0 = 0; ch0 < nch; ch0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int ch = ch0 + u;
+            if (ch < nch) {                             // workgroup-uniform
+                if (ch + 1 < nch) stage_chunk((ch + 1) & 1, xr[(u + 1) % PF]);
+                if (ch + 1 + PF < nch) load_chunk(ch + 1 + PF, xr[(u + 1) % PF]);
+                project_chunk(ch);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- phase 2: one 32-query tile per wave, keys and values straight from LDS
+    const int ntile = qch1 - qch0;
+    if (wid >= ntile) return;
+    const int q0 = (qch0 + wid) * 32;                   // first frame of this wave's query tile
+    _Float16* qrow = sQ + (size_t)(wid * 32) * TF_KS;  // this tile's Q rows; reused as the output transpose buffer below
+    half8 qf[4];
+    {
+        const float qscale = a.scale * 1.44269504088896341f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8 raw = *reinterpret_cast<const half8*>(qrow + c * TF_KS + 16 * s + 8 * hh);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[s][i] = (_Float16)((float)raw[i] * qscale);
+        }
+    }
+    float16v ot[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        ot[0][e] = 0.0f;
+        ot[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int jb = 0; jb < len; jb += 32) {
+        float16v st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+        half8 kf[4];
+        half4 vlo[4], vhi[4];                           // this key tile's K and V^T fragments: all requested before the first MFMA
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const half8*>(sK + (size_t)(jb + c) * TF_KS + 16 * s + 8 * hh);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const _Float16* vrow = sVt + (size_t)(dt * 32 + c) * vs + jb + 16 * s + 4 * hh;
+                vlo[dt * 2 + s] = *reinterpret_cast<const half4*>(vrow);
+                vhi[dt * 2 + s] = *reinterpret_cast<const half4*>(vrow + 8);
+            }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], st, 0, 0, 0);
+        if (jb + 32 > len) {                            // wave-uniform: only the last key tile is ragged
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = jb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                st[e] = key < len ? st[e] : -INFINITY;
+            }
+        }
+        float mloc = st[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, st[e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        if (__builtin_amdgcn_ballot_w64(mloc > m_run) != 0) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                ot[0][e] *= alpha;
+                ot[1][e] *= alpha;
+            }
+        }
+        half8 pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(st[e] - m_run);
+            l_run += p;
+            pf[e >> 3][e & 7] = (_Float16)p;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half4 lo = vlo[dt * 2 + s], hi = vhi[dt * 2 + s];
+                half8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- O^T (dims on the element index, query on the lane) -> this tile's Q rows in LDS (no longer needed) -> coalesced rows
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 h4;
+            h4[0] = (_Float16)(ot[dt][4 * g] * inv); h4[1] = (_Float16)(ot[dt][4 * g + 1] * inv);
+            h4[2] = (_Float16)(ot[dt][4 * g + 2] * inv); h4[3] = (_Float16)(ot[dt][4 * g + 3] * inv);
+            *reinterpret_cast<half4*>(qrow + c * TF_KS + dt * 32 + 8 * g + 4 * hh) = h4;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 8 + (lane >> 3), seg = (lane & 7) * 8;
+        const int fr = q0 + r;
+        if (fr < T)
+            *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + r * TF_KS + seg);
+    }
+}
+
+}  // namespace astts
+
+using namespace astts;
+
+extern "C" {
+
+/* 1 when astts_op_tfm_attn_fused serves this shape (channels 256, head dim 64, t <= 352), else 0 */
+int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t) {
+    return c == TF_C && heads >= 1 && heads <= 16 && t >= 1 && t <= TF_MAX_T ? 1 : 0;
+}
+
+int astts_op_tfm_attn_fused(const float* x, const void* wqkv_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+                            int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && wqkv_f16 && out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_attn_fused: null pointer");
+    ASTTS_REQUIRE(astts_op_tfm_attn_fused_supported(c, heads, t), ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_tfm_attn_fused: c=%d heads=%d t=%d (channels 256, t <= %d)", c, heads, t, TF_MAX_T);
+    ASTTS_REQUIRE(b >= 1 && (((uintptr_t)x | (uintptr_t)wqkv_f16 | (uintptr_t)out_f16) & 15) == 0, ASTTS_ERR_INVALID,
+                  "astts_op_tfm_attn_fused: operands must be 16-byte aligned");
+    const int nch = (t + 31) / 32, tkp = nch * 32;
+    const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_KS) * sizeof(_Float16);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    TfmAttnArgs a{x, (const _Float16*)wqkv_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale};
+    hipStream_t st = (hipStream_t)stream;
+    // profiled with the attention kind: projection + attention flops of the work actually done (K, V projected twice)
+    const double flops = (double)b * heads * (2.0 * (2.0 * 2.0 * t * 64.0 * TF_C) + 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);
+    const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, st, flops);
+    hipLaunchKernelGGL(tfm_attn_fused, dim3(2 * heads * b), dim3(512), lds, st, a);
+    if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, st);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // extern "C"

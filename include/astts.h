@@ -345,6 +345,15 @@ int astts_op_swiglu(const void* gate_up_f16, void* out_f16, int64_t rows, int32_
 /* out[b, c] = mean over the first lens[b] (NULL: t) tokens of x fp32 [b, t, c] */
 int astts_op_mean_pool(const float* x, const int32_t* lens, float* out, int32_t b, int32_t t, int32_t c, astts_stream_t stream);
 
+/* LayerNorm (scale / shift folded into the weights by the caller) + q|k|v projection + masked multi-head attention of one
+ * transformer block of the flow estimator in one launch (csrc/ops_tfm_fused.hip): x fp32 [b, t, c] -> out fp16
+ * [b, t, heads*64].  wqkv fp16 [3*heads*64 (padded rows), c] = q | k | v rows (astts_op_pack_weight), bias fp32 [3*heads*64]
+ * or NULL, lens int32 [b] or NULL.  Serves c == 256, t <= 352 (astts_op_tfm_attn_fused_supported); otherwise
+ * ASTTS_ERR_UNSUPPORTED and the caller runs astts_op_layernorm_ex + astts_op_gemm_ex + astts_op_attn_mha_ex. */
+int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);
+int astts_op_tfm_attn_fused(const float* x, const void* wqkv_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+                            int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream);
+
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
  * CosyVoice.inference_tts_with_st, tts_with_rag.py:195).  n_steps Euler steps of the U-Net estimator with

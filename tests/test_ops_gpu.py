@@ -453,3 +453,45 @@ def test_new_entry_points_validate_arguments():
                                     8, 128, 0, 128, 128, 128, 128, 0, 0, 0, ctypes.c_float(1.0), ctypes.c_float(0.1), ctypes.c_void_p(256), 16,
                                     _lib.stream_ptr())
     assert rc == _lib.ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 352, True), (1, 33, False), (2, 1, False)])
+def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
+    """astts_op_tfm_attn_fused (LayerNorm + q|k|v projection + masked MHA of a flow-estimator transformer block in one launch)
+    against the fp32 definition and against the three-launch path it replaces (layernorm -> linear -> attn_mha) on the same
+    folded weights.  Shapes: the benchmark's (16 sequences x 344 frames), the largest supported T, ragged lengths, tiny T."""
+    import torch.nn.functional as F
+
+    from astts import ops
+    from astts.synth.model import fold_layernorm
+
+    heads, c = 8, 256
+    g = torch.Generator().manual_seed(b * 1000 + t)
+    x = torch.randn(b, t, c, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w = torch.randn(3 * heads * 64, c, generator=g) / 16
+    lens = torch.tensor([t] + [max(1, t - 7 * (i + 1)) for i in range(b - 1)]) if ragged else torch.full((b,), t)
+    assert ops.tfm_attn_fused_supported(c, heads, t) and not ops.tfm_attn_fused_supported(c, heads, 353)
+    wf, bf = fold_layernorm(w, torch.zeros(w.shape[0]), gamma, beta)
+    pw = ops.PackedWeight(wf, bf)
+    ld = lens.to(DEV, torch.int32)
+    out = ops.tfm_attn_fused(x.to(DEV), pw, heads, lens=ld).float().cpu()
+    # fp32 definition
+    n = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    qkv = n @ w.T
+    q, k, v = (qkv[..., i * 512:(i + 1) * 512].view(b, t, heads, 64).transpose(1, 2) for i in range(3))
+    mask = (torch.arange(t)[None, :] >= lens[:, None])[:, None, None, :]
+    s = (q @ k.transpose(-1, -2) / 8.0).masked_fill(mask, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b, t, 512)
+    # the path it replaces
+    ident = (torch.ones(c, device=DEV), torch.zeros(c, device=DEV))
+    n16 = ops.layernorm(x.to(DEV), *ident, 1e-5, out_dtype=torch.float16)
+    qkv16 = ops.linear(n16, pw, out_dtype=torch.float16)
+    un = ops.attn_mha(qkv16[..., :512], qkv16[..., 512:1024], qkv16[..., 1024:], heads, lens=ld, out_dtype=torch.float16).float().cpu()
+    for i in range(b):
+        L = int(lens[i])
+        scale = float(ref[i, :L].abs().max())
+        e_ref = float((out[i, :L] - ref[i, :L]).abs().max()) / scale
+        e_un = float((out[i, :L] - un[i, :L]).abs().max()) / scale
+        assert e_ref < 4e-3 and e_un < 3e-3, (i, e_ref, e_un)
+    assert bool(torch.isfinite(out).all())
