@@ -97,9 +97,9 @@ class FlowResnet(ctypes.Structure):
                 ("g1_w", c_void_p), ("g1_b", c_void_p), ("g2_w", c_void_p), ("g2_b", c_void_p)]
 
 
-class FlowTfm(ctypes.Structure):
+class FlowTfm(ctypes.Structure):  # astts_flow_tfm_t
     _fields_ = [("n1_w", c_void_p), ("n1_b", c_void_p), ("n3_w", c_void_p), ("n3_b", c_void_p),
-                ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight)]
+                ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight), ("qkv_frag", c_void_p)]
 
 
 class FlowBlock(ctypes.Structure):
@@ -126,6 +126,7 @@ _SIGS.update({
 })
 _SIGS.update({   # fused transformer-block front half of the flow estimator (csrc/ops_tfm_fused.hip)
     "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "astts_op_tfm_pack_qkv": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
 })
 _SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
@@ -435,14 +436,23 @@ def tfm_attn_fused_supported(c: int, heads: int, t: int) -> bool:
     return bool(_L().astts_op_tfm_attn_fused_supported(c, heads, t))
 
 
-def tfm_attn_fused(x: torch.Tensor, wqkv: PackedWeight, heads: int, lens=None, eps: float = 1e-5) -> torch.Tensor:
+def tfm_pack_qkv(wqkv: PackedWeight) -> torch.Tensor:
+    """The fused kernel's weight image: ``wqkv.data`` (row-major fp16 [n_pad, 1, 256]) re-ordered into MFMA fragment order."""
+    assert wqkv.taps == 1 and wqkv.cin == wqkv.cin_pad == 256 and wqkv.n % 32 == 0
+    out = torch.empty((wqkv.n, 256), dtype=torch.float16, device=wqkv.data.device)
+    _lib.check(_L().astts_op_tfm_pack_qkv(wqkv.data.data_ptr(), out.data_ptr(), wqkv.n, 256, _st()))
+    return out
+
+
+def tfm_attn_fused(x: torch.Tensor, wqkv: PackedWeight, wqkv_frag: torch.Tensor, heads: int, lens=None, eps: float = 1e-5) -> torch.Tensor:
     """LayerNorm (no affine: folded into ``wqkv``) + q|k|v projection + masked MHA in one launch:
-    x fp32 ``[B, T, 256]`` -> fp16 ``[B, T, heads*64]``.  Caller checks ``tfm_attn_fused_supported`` first."""
+    x fp32 ``[B, T, 256]`` -> fp16 ``[B, T, heads*64]``.  ``wqkv_frag = tfm_pack_qkv(wqkv)``.  Caller checks
+    ``tfm_attn_fused_supported`` first."""
     x = _f32(x)
     b, t, c = x.shape
-    assert wqkv.cin == c == wqkv.cin_pad and wqkv.n == 3 * heads * 64 and wqkv.taps == 1
+    assert wqkv.cin == c == wqkv.cin_pad and wqkv.n == 3 * heads * 64 and wqkv_frag.shape == (wqkv.n, c)
     out = torch.empty((b, t, heads * 64), dtype=torch.float16, device=x.device)
-    _lib.check(_L().astts_op_tfm_attn_fused(x.data_ptr(), wqkv.data.data_ptr(), _p(wqkv.bias), _p(lens), out.data_ptr(), b, heads, t, c, eps,
+    _lib.check(_L().astts_op_tfm_attn_fused(x.data_ptr(), wqkv_frag.data_ptr(), _p(wqkv.bias), _p(lens), out.data_ptr(), b, heads, t, c, eps,
                                             1.0 / math.sqrt(64.0), _st()))
     return out
 

@@ -405,6 +405,7 @@ class _TfmBlock:
         c = int(wqkv.shape[1])
         self.n1 = (torch.ones(c, dtype=torch.float32, device=device), torch.zeros(c, dtype=torch.float32, device=device))
         self.wqkv = PackedWeight(wqkv, bqkv, device)
+        self.wqkv_frag = ops.tfm_pack_qkv(self.wqkv) if c == 256 and wqkv.shape[0] % 32 == 0 else None   # fused kernel's weight image
         self.wo = PackedWeight(sd[p + ".attn1.to_out.0.weight"], sd[p + ".attn1.to_out.0.bias"], device)
         self.n3 = (_dev(sd[p + ".norm3.weight"], device), _dev(sd[p + ".norm3.bias"], device))
         self.w1 = PackedWeight(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], device)
@@ -413,8 +414,8 @@ class _TfmBlock:
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
         hd = self.heads * 64
         f16 = torch.float16   # everything between two residual adds feeds MFMA operands only: fp16 in HBM
-        if ops.tfm_attn_fused_supported(x.shape[-1], self.heads, x.shape[1]):
-            a = ops.tfm_attn_fused(x, self.wqkv, self.heads, lens=lens, eps=1e-5)     # LayerNorm + q|k|v + attention: one launch
+        if self.wqkv_frag is not None and ops.tfm_attn_fused_supported(x.shape[-1], self.heads, x.shape[1]):
+            a = ops.tfm_attn_fused(x, self.wqkv, self.wqkv_frag, self.heads, lens=lens, eps=1e-5)     # LayerNorm + q|k|v + attention: one launch
         else:
             n = ops.layernorm(x, *self.n1, 1e-5, out_dtype=f16)
             qkv = ops.linear(n, self.wqkv, out_dtype=f16)
@@ -573,7 +574,7 @@ class FlowDecoder:
                 arr = (ops.FlowTfm * len(tfms))()
                 for i, t in enumerate(tfms):
                     arr[i] = ops.FlowTfm(t.n1[0].data_ptr(), t.n1[1].data_ptr(), t.n3[0].data_ptr(), t.n3[1].data_ptr(),
-                                         W(t.wqkv), W(t.wo), W(t.w1), W(t.w2))
+                                         W(t.wqkv), W(t.wo), W(t.w1), W(t.w2), None if t.wqkv_frag is None else t.wqkv_frag.data_ptr())
                 keep.append(arr)
                 return arr
 

@@ -187,8 +187,8 @@ struct Ctx {
     int tfm(const astts_flow_tfm_t& w, float* p, float* q, const int* lens, int t) const {
         const int C = h->cfg.channels, heads = h->cfg.heads, hd = heads * 64;
         const int64_t rows = (int64_t)b2 * t;
-        if (astts_op_tfm_attn_fused_supported(C, heads, t)) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
-            RUN(astts_op_tfm_attn_fused(p, w.qkv.w, w.qkv.bias, lens, B.a16, b2, heads, t, C, 1e-5f, 0.125f, st));
+        if (w.qkv_frag && astts_op_tfm_attn_fused_supported(C, heads, t)) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
+            RUN(astts_op_tfm_attn_fused(p, w.qkv_frag, w.qkv.bias, lens, B.a16, b2, heads, t, C, 1e-5f, 0.125f, st));
         } else {
             RUN(astts_op_layernorm_ex(p, w.n1_w, w.n1_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
             RUN(linear(B.n16, 1, w.qkv, nullptr, B.qkv16, 1, rows, ASTTS_ACT_NONE));

@@ -42,7 +42,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 struct TfmAttnArgs {
     const float* x;          // [b, t, 256] fp32 residual stream
-    const _Float16* w;       // [3 * heads * 64 (+pad)][256] fp16: q | k | v rows, LayerNorm scale folded in
+    const _Float16* w;       // q | k | v weight (LayerNorm scale folded in) in fragment order: [3 * heads * 2 tiles][16][64][8] fp16
     const float* bias;       // [3 * heads * 64] fp32 (W beta, + the projection's own bias if any) or null
     const int* lens;         // [b] valid frames or null
     _Float16* out;           // [b, t, heads * 64] fp16
@@ -90,17 +90,20 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
     const int hd = a.heads * TF_DH;
 
     // ---- this wave's projection weights: one 32-feature tile of K (waves 0, 1), V (2, 3) or Q (4, 5), K = 256 in registers
-    // (Q is only projected for the chunks of this workgroup's query half; its two tiles alternate between waves 4, 5 and 6, 7 from
-    // chunk to chunk so that every SIMD -- waves w and w + 4 share one -- carries the same number of projection MFMAs)
-    const int role = wid < 2 ? 0 : (wid < 4 ? 1 : 2);  // 0 K, 1 V, 2 Q
+    // (waves 6, 7 only take part in the staging: giving them the Q tiles of every other chunk balances the MFMAs over the SIMDs
+    // but costs two more 16 KB weight fetches per workgroup -- measured slower)
+    const int role = wid >> 1;                       // 0 K, 1 V, 2 Q, 3 none
     half8 wf[16];
     float bias_e[16];
     if (role < 3) {
         const int part = role == 0 ? 1 : (role == 1 ? 2 : 0);           // row block of the fused q | k | v weight
         const int frow = part * hd + head * TF_DH + (wid & 1) * 32;
-        const _Float16* wp = a.w + (int64_t)(frow + c) * TF_C + 8 * hh;
+        // fragment-ordered image (astts_op_tfm_pack_qkv): [32-feature tile][k-step][lane][8 halfs] -- one wave instruction reads
+        // 1 KB of consecutive bytes (the row-major image puts a lane's 16 bytes 512 bytes apart: 64 sectors per instruction, a
+        // quarter of each used; the 96 KB of weights a workgroup takes into registers cost 5.5 us that way)
+        const _Float16* wp = a.w + ((int64_t)(frow >> 5) * 16 * 64 + lane) * 8;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wf[s] = *reinterpret_cast<const half8*>(wp + 16 * s);
+        for (int s = 0; s < 16; ++s) wf[s] = *reinterpret_cast<const half8*>(wp + (int64_t)s * 64 * 8);
         // bias of the features this lane's accumulator elements hold.  K / Q tiles: feature on the element index
         // (f_e = (e & 3) + 8 (e >> 2) + 4 hh); V tiles: feature on the lane (c)
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
     };
     auto project_chunk = [&](int ch) {
         const int buf = ch & 1;
-        const bool q_chunk = ch >= qch0 && ch < qch1 && (((ch - qch0) & 1) == ((wid >> 1) & 1));   // waves 4, 5: even; 6, 7: odd
+        const bool q_chunk = ch >= qch0 && ch < qch1;
         if (role < 2 || (role == 2 && q_chunk)) {
             const _Float16* ap = sA + (size_t)buf * 32 * TF_AS + c * TF_AS + 8 * hh;
             float16v acc;
@@ -319,23 +322,42 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
     }
 }
 
+// row-major fp16 [rows][256] (astts_op_pack_weight image) -> fragment order [rows / 32][16 k-steps][64 lanes][8]:
+// lane (c = lane & 31, hh = lane >> 5) of k-step s holds W[32 tile + c][16 s + 8 hh + j]
+__global__ void tfm_pack_qkv(const _Float16* __restrict__ w, _Float16* __restrict__ out, int rows) {
+    const int64_t total = (int64_t)rows * TF_C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), ln = (int)((i >> 3) & 63), s = (int)((i >> 9) & 15);
+        const int64_t tile = i >> 13;
+        out[i] = w[(tile * 32 + (ln & 31)) * TF_C + 16 * s + 8 * (ln >> 5) + j];
+    }
+}
+
 }  // namespace astts
 
 using namespace astts;
 
 extern "C" {
 
+int astts_op_tfm_pack_qkv(const void* w_f16, void* out_f16, int32_t rows, int32_t c, astts_stream_t stream) {
+    ASTTS_REQUIRE(w_f16 && out_f16 && w_f16 != out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_pack_qkv: null / aliased pointer");
+    ASTTS_REQUIRE(c == TF_C && rows >= 32 && rows % 32 == 0, ASTTS_ERR_UNSUPPORTED, "astts_op_tfm_pack_qkv: rows=%d c=%d (c must be 256, rows a multiple of 32)", rows, c);
+    hipLaunchKernelGGL(tfm_pack_qkv, dim3(256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w_f16, (_Float16*)out_f16, rows);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
 /* 1 when astts_op_tfm_attn_fused serves this shape (channels 256, head dim 64, t <= 352), else 0 */
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t) {
     return c == TF_C && heads >= 1 && heads <= 16 && t >= 1 && t <= TF_MAX_T ? 1 : 0;
 }
 
-int astts_op_tfm_attn_fused(const float* x, const void* wqkv_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream) {
-    ASTTS_REQUIRE(x && wqkv_f16 && out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_attn_fused: null pointer");
+    ASTTS_REQUIRE(x && wqkv_frag_f16 && out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_attn_fused: null pointer");
     ASTTS_REQUIRE(astts_op_tfm_attn_fused_supported(c, heads, t), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_tfm_attn_fused: c=%d heads=%d t=%d (channels 256, t <= %d)", c, heads, t, TF_MAX_T);
-    ASTTS_REQUIRE(b >= 1 && (((uintptr_t)x | (uintptr_t)wqkv_f16 | (uintptr_t)out_f16) & 15) == 0, ASTTS_ERR_INVALID,
+    ASTTS_REQUIRE(b >= 1 && (((uintptr_t)x | (uintptr_t)wqkv_frag_f16 | (uintptr_t)out_f16) & 15) == 0, ASTTS_ERR_INVALID,
                   "astts_op_tfm_attn_fused: operands must be 16-byte aligned");
     const int nch = (t + 31) / 32, tkp = nch * 32;
     const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_KS) * sizeof(_Float16);
@@ -344,7 +366,7 @@ int astts_op_tfm_attn_fused(const float* x, const void* wqkv_f16, const float* b
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    TfmAttnArgs a{x, (const _Float16*)wqkv_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale};
+    TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale};
     hipStream_t st = (hipStream_t)stream;
     // profiled with the attention kind: projection + attention flops of the work actually done (K, V projected twice)
     const double flops = (double)b * heads * (2.0 * (2.0 * 2.0 * t * 64.0 * TF_C) + 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);

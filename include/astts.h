@@ -347,11 +347,13 @@ int astts_op_mean_pool(const float* x, const int32_t* lens, float* out, int32_t 
 
 /* LayerNorm (scale / shift folded into the weights by the caller) + q|k|v projection + masked multi-head attention of one
  * transformer block of the flow estimator in one launch (csrc/ops_tfm_fused.hip): x fp32 [b, t, c] -> out fp16
- * [b, t, heads*64].  wqkv fp16 [3*heads*64 (padded rows), c] = q | k | v rows (astts_op_pack_weight), bias fp32 [3*heads*64]
- * or NULL, lens int32 [b] or NULL.  Serves c == 256, t <= 352 (astts_op_tfm_attn_fused_supported); otherwise
- * ASTTS_ERR_UNSUPPORTED and the caller runs astts_op_layernorm_ex + astts_op_gemm_ex + astts_op_attn_mha_ex. */
+ * [b, t, heads*64].  wqkv_frag: the q | k | v weight [3*heads*64, c] re-ordered by astts_op_tfm_pack_qkv (from the row-major
+ * astts_op_pack_weight image) into MFMA fragment order; bias fp32 [3*heads*64] or NULL, lens int32 [b] or NULL.  Serves
+ * c == 256, t <= 352 (astts_op_tfm_attn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the caller runs
+ * astts_op_layernorm_ex + astts_op_gemm_ex + astts_op_attn_mha_ex on the row-major weight. */
+int astts_op_tfm_pack_qkv(const void* w_f16, void* out_f16, int32_t rows, int32_t c, astts_stream_t stream);
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);
-int astts_op_tfm_attn_fused(const float* x, const void* wqkv_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
@@ -370,6 +372,7 @@ typedef struct {            /* ResnetBlock1D: conv3 -> GN -> Mish (+ time proj) 
 typedef struct {            /* BasicTransformerBlock: LN -> qkv -> attention -> out (+x) -> LN -> GELU FFN (+x) */
     const float *n1_w, *n1_b, *n3_w, *n3_b;
     astts_weight_t qkv, wo, w1, w2;
+    const void* qkv_frag;   /* qkv.w in fragment order (astts_op_tfm_pack_qkv) for the fused attention kernel, or NULL: unfused path */
 } astts_flow_tfm_t;
 #define ASTTS_FLOW_RESAMPLE_NONE 0      /* mid block */
 #define ASTTS_FLOW_RESAMPLE_CONV 1      /* conv k=3 (last down / up block) */

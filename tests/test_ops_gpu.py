@@ -475,7 +475,7 @@ def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
     wf, bf = fold_layernorm(w, torch.zeros(w.shape[0]), gamma, beta)
     pw = ops.PackedWeight(wf, bf)
     ld = lens.to(DEV, torch.int32)
-    out = ops.tfm_attn_fused(x.to(DEV), pw, heads, lens=ld).float().cpu()
+    out = ops.tfm_attn_fused(x.to(DEV), pw, ops.tfm_pack_qkv(pw), heads, lens=ld).float().cpu()
     # fp32 definition
     n = F.layer_norm(x, (c,), gamma, beta, 1e-5)
     qkv = n @ w.T
