@@ -99,7 +99,8 @@ class FlowResnet(ctypes.Structure):
 
 class FlowTfm(ctypes.Structure):  # astts_flow_tfm_t
     _fields_ = [("n1_w", c_void_p), ("n1_b", c_void_p), ("n3_w", c_void_p), ("n3_b", c_void_p),
-                ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight), ("qkv_frag", c_void_p)]
+                ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight), ("qkv_frag", c_void_p),
+                ("w1_frag", c_void_p), ("w2_frag", c_void_p)]
 
 
 class FlowBlock(ctypes.Structure):
@@ -126,7 +127,9 @@ _SIGS.update({
 })
 _SIGS.update({   # fused transformer-block front half of the flow estimator (csrc/ops_tfm_fused.hip)
     "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
-    "astts_op_tfm_pack_qkv": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "astts_op_tfm_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "astts_op_tfm_ffn_fused_supported": (c_int32, [c_int32, c_int32]),
+    "astts_op_tfm_ffn_fused": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
     "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
 })
 _SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
@@ -436,17 +439,33 @@ def tfm_attn_fused_supported(c: int, heads: int, t: int) -> bool:
     return bool(_L().astts_op_tfm_attn_fused_supported(c, heads, t))
 
 
-def tfm_pack_qkv(wqkv: PackedWeight) -> torch.Tensor:
-    """The fused kernel's weight image: ``wqkv.data`` (row-major fp16 [n_pad, 1, 256]) re-ordered into MFMA fragment order."""
-    assert wqkv.taps == 1 and wqkv.cin == wqkv.cin_pad == 256 and wqkv.n % 32 == 0
-    out = torch.empty((wqkv.n, 256), dtype=torch.float16, device=wqkv.data.device)
-    _lib.check(_L().astts_op_tfm_pack_qkv(wqkv.data.data_ptr(), out.data_ptr(), wqkv.n, 256, _st()))
+def tfm_pack_frag(w: PackedWeight) -> torch.Tensor:
+    """``w.data`` (row-major fp16 [n, 1, cin]) re-ordered into MFMA fragment order: the weight image of the fused
+    transformer-block kernels (``tfm_attn_fused``, ``tfm_ffn_fused``)."""
+    assert w.taps == 1 and w.cin == w.cin_pad and w.cin % 16 == 0 and w.n % 32 == 0
+    out = torch.empty((w.n, w.cin), dtype=torch.float16, device=w.data.device)
+    _lib.check(_L().astts_op_tfm_pack_frag(w.data.data_ptr(), out.data_ptr(), w.n, w.cin, _st()))
+    return out
+
+
+def tfm_ffn_fused_supported(c: int, hidden: int) -> bool:
+    return bool(_L().astts_op_tfm_ffn_fused_supported(c, hidden))
+
+
+def tfm_ffn_fused(x: torch.Tensor, w1: PackedWeight, w1_frag: torch.Tensor, w2: PackedWeight, w2_frag: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """``x + W2 gelu(W1 LayerNorm(x) + b1) + b2`` in one launch (LayerNorm affine folded into ``w1``): x fp32 ``[..., 256]``."""
+    x = _f32(x)
+    c, hidden = x.shape[-1], w1.n
+    assert w1.cin == c and w2.cin == hidden and w2.n == c and w1_frag.shape == (hidden, c) and w2_frag.shape == (c, hidden)
+    out = torch.empty_like(x)
+    _lib.check(_L().astts_op_tfm_ffn_fused(x.data_ptr(), w1_frag.data_ptr(), _p(w1.bias), w2_frag.data_ptr(), _p(w2.bias), out.data_ptr(),
+                                           x.numel() // c, c, hidden, eps, _st()))
     return out
 
 
 def tfm_attn_fused(x: torch.Tensor, wqkv: PackedWeight, wqkv_frag: torch.Tensor, heads: int, lens=None, eps: float = 1e-5) -> torch.Tensor:
     """LayerNorm (no affine: folded into ``wqkv``) + q|k|v projection + masked MHA in one launch:
-    x fp32 ``[B, T, 256]`` -> fp16 ``[B, T, heads*64]``.  ``wqkv_frag = tfm_pack_qkv(wqkv)``.  Caller checks
+    x fp32 ``[B, T, 256]`` -> fp16 ``[B, T, heads*64]``.  ``wqkv_frag = tfm_pack_frag(wqkv)``.  Caller checks
     ``tfm_attn_fused_supported`` first."""
     x = _f32(x)
     b, t, c = x.shape

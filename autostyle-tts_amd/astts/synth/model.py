@@ -405,11 +405,18 @@ class _TfmBlock:
         c = int(wqkv.shape[1])
         self.n1 = (torch.ones(c, dtype=torch.float32, device=device), torch.zeros(c, dtype=torch.float32, device=device))
         self.wqkv = PackedWeight(wqkv, bqkv, device)
-        self.wqkv_frag = ops.tfm_pack_qkv(self.wqkv) if c == 256 and wqkv.shape[0] % 32 == 0 else None   # fused kernel's weight image
+        self.wqkv_frag = ops.tfm_pack_frag(self.wqkv) if c == 256 and wqkv.shape[0] % 32 == 0 else None   # fused kernel's weight image
         self.wo = PackedWeight(sd[p + ".attn1.to_out.0.weight"], sd[p + ".attn1.to_out.0.bias"], device)
-        self.n3 = (_dev(sd[p + ".norm3.weight"], device), _dev(sd[p + ".norm3.bias"], device))
-        self.w1 = PackedWeight(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], device)
+        # norm3 folded into the first feed-forward projection in the same way (ops.tfm_ffn_fused: LayerNorm + W1 + GELU + W2 +
+        # residual in one launch)
+        w1, b1 = fold_layernorm(sd[p + ".ff.net.0.proj.weight"].float().cpu(), sd[p + ".ff.net.0.proj.bias"].float().cpu(),
+                                sd[p + ".norm3.weight"].float().cpu(), sd[p + ".norm3.bias"].float().cpu())
+        self.n3 = self.n1
+        self.w1 = PackedWeight(w1, b1, device)
         self.w2 = PackedWeight(sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"], device)
+        self.ffn_fused = ops.tfm_ffn_fused_supported(c, int(w1.shape[0]))
+        self.w1_frag = ops.tfm_pack_frag(self.w1) if self.ffn_fused else None
+        self.w2_frag = ops.tfm_pack_frag(self.w2) if self.ffn_fused else None
 
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
         hd = self.heads * 64
@@ -421,6 +428,8 @@ class _TfmBlock:
             qkv = ops.linear(n, self.wqkv, out_dtype=f16)
             a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens, out_dtype=f16)
         x = ops.linear(a, self.wo, residual=x)
+        if self.ffn_fused:
+            return ops.tfm_ffn_fused(x, self.w1, self.w1_frag, self.w2, self.w2_frag, eps=1e-5)
         n = ops.layernorm(x, *self.n3, 1e-5, out_dtype=f16)
         f = ops.linear(n, self.w1, act="gelu", out_dtype=f16)
         return ops.linear(f, self.w2, residual=x)
@@ -574,7 +583,8 @@ class FlowDecoder:
                 arr = (ops.FlowTfm * len(tfms))()
                 for i, t in enumerate(tfms):
                     arr[i] = ops.FlowTfm(t.n1[0].data_ptr(), t.n1[1].data_ptr(), t.n3[0].data_ptr(), t.n3[1].data_ptr(),
-                                         W(t.wqkv), W(t.wo), W(t.w1), W(t.w2), None if t.wqkv_frag is None else t.wqkv_frag.data_ptr())
+                                         W(t.wqkv), W(t.wo), W(t.w1), W(t.w2), None if t.wqkv_frag is None else t.wqkv_frag.data_ptr(),
+                                         None if t.w1_frag is None else t.w1_frag.data_ptr(), None if t.w2_frag is None else t.w2_frag.data_ptr())
                 keep.append(arr)
                 return arr
 

@@ -196,6 +196,8 @@ struct Ctx {
                                      0.125f, st));
         }
         RUN(linear(B.a16, 1, w.wo, p, q, 0, rows, ASTTS_ACT_NONE));
+        if (w.w1_frag && w.w2_frag && astts_op_tfm_ffn_fused_supported(C, w.w1.n))      // LayerNorm + W1 + GELU + W2 + residual: one launch
+            return astts_op_tfm_ffn_fused(q, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, st);
         RUN(astts_op_layernorm_ex(q, w.n3_w, w.n3_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
         RUN(linear(B.n16, 1, w.w1, nullptr, B.f16, 1, rows, ASTTS_ACT_GELU));
         return linear(B.f16, 1, w.w2, q, p, 0, rows, ASTTS_ACT_NONE);

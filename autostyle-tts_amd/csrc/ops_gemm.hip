@@ -46,16 +46,6 @@ __device__ __forceinline__ float apply_act(float x, int act, float slope) {
     }
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one exp, one reciprocal and five FMAs instead of the
-// branchy library erff -- the exact-erf GELU of the transformer FFN is evaluated 5.6M times per projection.
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
-
 struct GemmArgs {
     const float* x;
     const _Float16* w;

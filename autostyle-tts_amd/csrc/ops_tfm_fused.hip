@@ -322,14 +322,217 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
     }
 }
 
-// row-major fp16 [rows][256] (astts_op_pack_weight image) -> fragment order [rows / 32][16 k-steps][64 lanes][8]:
-// lane (c = lane & 31, hh = lane >> 5) of k-step s holds W[32 tile + c][16 s + 8 hh + j]
-__global__ void tfm_pack_qkv(const _Float16* __restrict__ w, _Float16* __restrict__ out, int rows) {
-    const int64_t total = (int64_t)rows * TF_C;
+// row-major fp16 [rows][k] (astts_op_pack_weight image) -> fragment order [rows / 32][k / 16 k-steps][64 lanes][8]:
+// lane (c = lane & 31, hh = lane >> 5) of k-step s holds W[32 tile + c][16 s + 8 hh + j]: one wave instruction loads 1 KB of
+// consecutive bytes
+__global__ void tfm_pack_frag(const _Float16* __restrict__ w, _Float16* __restrict__ out, int rows, int k) {
+    const int64_t total = (int64_t)rows * k;
+    const int ksteps = k >> 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), ln = (int)((i >> 3) & 63), s = (int)((i >> 9) & 15);
-        const int64_t tile = i >> 13;
-        out[i] = w[(tile * 32 + (ln & 31)) * TF_C + 16 * s + 8 * (ln >> 5) + j];
+        const int j = (int)(i & 7), ln = (int)((i >> 3) & 63);
+        const int64_t q = i >> 9;
+        const int s = (int)(q % ksteps);
+        const int64_t tile = q / ksteps;
+        out[i] = w[(tile * 32 + (ln & 31)) * k + 16 * s + 8 * (ln >> 5) + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LayerNorm + Linear(256 -> hidden) + GELU + Linear(hidden -> 256) + residual of one BasicTransformerBlock in ONE launch.
+//
+// Why: as three launches (layernorm_rows 5.1 us, gemm_ring 256->1024 + GELU 11.8 us, gemm_ring 1024->256 + residual 9.4 us,
+// 3 x 1.45 us of boundary) the feed-forward part of a block takes ~31 us for 5.8 GFLOP at 16 x 344 rows: each of the three pays
+// the ~5 us a dependent kernel needs to get going on fresh data.  Fused, a workgroup owns 32 rows: it normalises them once into
+// LDS, streams the 1 MB of W1 | W2 (fragment order: every wave instruction is one 1 KB burst, 32 KB per wave in flight) through
+// registers, and the 32 x hidden intermediate never leaves the CU.
+//
+// Workgroup = 32 rows, 8 waves.  hidden is walked in chunks of 256:
+//   stage 1  wave w: H[:, 32 (8 j + w) ..+32] = gelu(A W1^T + b1): 16 MFMA 32x32x16 (weights as the A operand: hidden feature
+//            on the accumulator element, row on the lane), fp16 to LDS (double buffered), one barrier
+//   stage 2  wave w: Y[:, 32 w ..+32] += H_chunk W2^T: 16 MFMA (H as the A operand: row on the element, output feature on the
+//            lane -> 128-byte row segments in the epilogue)
+// software-pipelined: stage 1 of chunk j + 1 is issued before stage 2 of chunk j, whose MFMAs are woven with the GELU of chunk
+// j + 1 (the GELU's VALU work is the larger share of a chunk's issue cycles).  The next chunk's W1 / W2 fragments are requested
+// right after the MFMAs that consumed the current ones.
+//
+// Tried and dropped: 64 rows x half of the hidden features per workgroup (half the weight stream per CU), the two halves joined
+// through L2 with an arrival flag: 27 us against 19 -- the weight stream is ~3.4 us of this kernel, not its bound, and the hand-over
+// (with agent-scope fences: buffer_wbl2 / buffer_inv, 65 us) costs more than it saves.
+static constexpr int FF_HS = 256 + 8;      // halfs per staged H row
+
+struct TfmFfnArgs {
+    const float* x;          // [m][256] fp32 residual stream
+    const _Float16* w1;      // [hidden][256] fp16, LayerNorm scale folded in, fragment order
+    const float* b1;         // [hidden] (W1 beta + b1)
+    const _Float16* w2;      // [256][hidden] fp16, fragment order
+    const float* b2;         // [256] or null
+    float* out;              // [m][256]: x + W2 gelu(W1 LN(x) + b1) + b2
+    int64_t m;
+    int hidden;
+    float eps;
+};
+
+__global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    _Float16* sA = tf_smem;                          // [32][264] normalised rows
+    _Float16* sH = sA + 32 * TF_AS;                  // [2][32][264] one 256-wide chunk of the hidden activations
+    float* sB1 = reinterpret_cast<float*>(sH + 2 * 32 * FF_HS);   // [hidden]
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    const int nchunk = a.hidden >> 8;
+    const int ksteps2 = a.hidden >> 4;               // k-steps of a W2 tile
+
+    // ---- rows first (needed first), then the first chunk's weights.  16 threads per row; thread i of a row takes channels
+    // 4 i + 64 k (k = 0..3): every wave instruction reads 256 consecutive bytes of each of its 4 rows
+    const int srow = tid >> 4, sseg = (tid & 15) * 4;
+    float4 r[4];
+    {
+        const float* p = a.x + min(m0 + srow, a.m - 1) * TF_C + sseg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + 64 * i);
+    }
+    // The workgroups of one XCD (block ids congruent mod 8) start at different chunks and walk them cyclically: every block's
+    // weights are cold in L2 (56 blocks x 2 MB per estimator pass), and with one common order all workgroups wait for the same
+    // HBM lines chunk after chunk; rotated, the whole weight image is requested at once.  (The sum over chunks is taken in that
+    // order.)
+    const int rot = (int)((blockIdx.x >> 3) % (unsigned)nchunk);
+    auto wrap = [&](int j) { return j >= nchunk ? j - nchunk : j; };
+    half8 w1f[16], w2f[16];
+    const _Float16* w1p = a.w1 + ((int64_t)wid * 16 * 64 + lane) * 8;             // hidden tile 8 j + wid: + j * 8 tiles
+    const _Float16* w2p = a.w2 + ((int64_t)wid * ksteps2 * 64 + lane) * 8;        // output tile wid, k-step 16 j + s
+    auto load_w1 = [&](int j) {
+        const _Float16* np = w1p + (int64_t)j * 8 * 16 * 512;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w1f[s] = *reinterpret_cast<const half8*>(np + (int64_t)s * 512);
+    };
+    auto load_w2 = [&](int j) {
+        const _Float16* np = w2p + (int64_t)j * 16 * 512;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2f[s] = *reinterpret_cast<const half8*>(np + (int64_t)s * 512);
+    };
+    load_w1(rot);
+    load_w2(rot);
+    for (int i = tid; i < a.hidden; i += 512) sB1[i] = a.b1 ? a.b1[i] : 0.0f;
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+        s = row16_sum(s);
+        const float mean = s * (1.0f / TF_C);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dx = r[i].x - mean, dy = r[i].y - mean, dz = r[i].z - mean, dw = r[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q = row16_sum(q);
+        const float rstd = rsqrtf(q * (1.0f / TF_C) + a.eps);
+        _Float16* d = sA + srow * TF_AS + sseg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            half4 h4;
+            h4[0] = (_Float16)((r[i].x - mean) * rstd); h4[1] = (_Float16)((r[i].y - mean) * rstd);
+            h4[2] = (_Float16)((r[i].z - mean) * rstd); h4[3] = (_Float16)((r[i].w - mean) * rstd);
+            *reinterpret_cast<half4*>(d + 64 * i) = h4;
+        }
+    }
+    __syncthreads();
+
+    float16v acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+    const _Float16* ap = sA + c * TF_AS + 8 * hh;
+    // stage 1 of chunk j: this wave's 32 hidden features (bias in the accumulator)
+    auto stage1 = [&](int j, float16v& acc1) {
+        const float* bp = sB1 + (j * 8 + wid) * 32 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+            acc1[4 * g] = b4.x; acc1[4 * g + 1] = b4.y; acc1[4 * g + 2] = b4.z; acc1[4 * g + 3] = b4.w;
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            half8 af[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const half8*>(ap + 16 * (s0 + s));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[s0 + s], af[s], acc1, 0, 0, 0);
+        }
+    };
+    auto store_h = [&](int buf, const float (&gl)[16]) {
+        _Float16* hp = sH + (size_t)buf * 32 * FF_HS + c * FF_HS + wid * 32 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 h4;
+            h4[0] = (_Float16)gl[4 * g]; h4[1] = (_Float16)gl[4 * g + 1]; h4[2] = (_Float16)gl[4 * g + 2]; h4[3] = (_Float16)gl[4 * g + 3];
+            *reinterpret_cast<half4*>(hp + 8 * g) = h4;
+        }
+    };
+    {
+        float16v acc1;
+        stage1(rot, acc1);
+        if (nchunk > 1) load_w1(wrap(rot + 1));
+        float gl[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gl[e] = gelu_erf_fast(acc1[e]);
+        store_h(0, gl);
+    }
+    __syncthreads();
+    for (int it = 0; it + 1 < nchunk; ++it) {
+        const int jn = wrap(it + 1 + rot);
+        float16v acc1;
+        stage1(jn, acc1);
+        if (it + 2 < nchunk) load_w1(wrap(jn + 1));
+        // stage 2 of chunk `it` with the GELU of chunk it + 1 woven in by hand: every MFMA is followed by one element's GELU
+        // (~15 VALU instructions that issue while the MFMA runs).  The empty asm statements tie the MFMA's operand and the GELU's
+        // input / result to their place in the instruction stream (sched_barrier alone orders nothing before instruction
+        // selection; the MFMA reads hf[s], so it cannot sink below the second one).
+        const _Float16* hp = sH + (size_t)(it & 1) * 32 * FF_HS + c * FF_HS + 8 * hh;
+        float gl[16];
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            half8 hf[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hf[s] = *reinterpret_cast<const half8*>(hp + 16 * (s0 + s));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float gx = acc1[s0 + s];
+                asm volatile("" : "+v"(hf[s]), "+v"(gx));
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w2f[s0 + s], acc2, 0, 0, 0);
+                float gy = gelu_erf_fast(gx);
+                asm volatile("" : "+v"(gy), "+v"(hf[s]));
+                gl[s0 + s] = gy;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        load_w2(jn);
+        store_h((it + 1) & 1, gl);
+        __syncthreads();
+    }
+    // ---- last stage 2; the residual rows are requested before it.  Element e holds row (e & 3) + 8 (e >> 2) + 4 hh, the lane's
+    // output feature is 32 wid + c: 128-byte row segments
+    const int f = wid * 32 + c;
+    float xr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xr[e] = a.x[min(m0 + (e & 3) + 8 * (e >> 2) + 4 * hh, a.m - 1) * TF_C + f];
+    const float b2 = a.b2 ? a.b2[f] : 0.0f;
+    {
+        const _Float16* hp = sH + (size_t)((nchunk - 1) & 1) * 32 * FF_HS + c * FF_HS + 8 * hh;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            half8 hf[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hf[s] = *reinterpret_cast<const half8*>(hp + 16 * (s0 + s));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w2f[s0 + s], acc2, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (row < a.m) a.out[row * TF_C + f] = (xr[e] + b2) + acc2[e];
     }
 }
 
@@ -339,10 +542,39 @@ using namespace astts;
 
 extern "C" {
 
-int astts_op_tfm_pack_qkv(const void* w_f16, void* out_f16, int32_t rows, int32_t c, astts_stream_t stream) {
-    ASTTS_REQUIRE(w_f16 && out_f16 && w_f16 != out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_pack_qkv: null / aliased pointer");
-    ASTTS_REQUIRE(c == TF_C && rows >= 32 && rows % 32 == 0, ASTTS_ERR_UNSUPPORTED, "astts_op_tfm_pack_qkv: rows=%d c=%d (c must be 256, rows a multiple of 32)", rows, c);
-    hipLaunchKernelGGL(tfm_pack_qkv, dim3(256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w_f16, (_Float16*)out_f16, rows);
+int astts_op_tfm_pack_frag(const void* w_f16, void* out_f16, int32_t rows, int32_t k, astts_stream_t stream) {
+    ASTTS_REQUIRE(w_f16 && out_f16 && w_f16 != out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_pack_frag: null / aliased pointer");
+    ASTTS_REQUIRE(k >= 16 && k % 16 == 0 && rows >= 32 && rows % 32 == 0, ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_tfm_pack_frag: rows=%d k=%d (rows must be a multiple of 32, k of 16)", rows, k);
+    hipLaunchKernelGGL(tfm_pack_frag, dim3(256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w_f16, (_Float16*)out_f16, rows, k);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+/* 1 when astts_op_tfm_ffn_fused serves this shape (channels 256, hidden a multiple of 256 up to 4096), else 0 */
+int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden) {
+    return c == TF_C && hidden >= 256 && hidden % 256 == 0 && hidden <= 4096 ? 1 : 0;
+}
+
+int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
+                           int64_t m, int32_t c, int32_t hidden, float eps, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && w1_frag_f16 && w2_frag_f16 && out, ASTTS_ERR_INVALID, "astts_op_tfm_ffn_fused: null pointer");
+    ASTTS_REQUIRE(astts_op_tfm_ffn_fused_supported(c, hidden), ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_tfm_ffn_fused: c=%d hidden=%d (channels 256, hidden a multiple of 256 <= 4096)", c, hidden);
+    ASTTS_REQUIRE(m >= 1 && m <= ((int64_t)1 << 31) * 32 - 32 &&
+                      (((uintptr_t)x | (uintptr_t)w1_frag_f16 | (uintptr_t)w2_frag_f16 | (uintptr_t)out) & 15) == 0,
+                  ASTTS_ERR_INVALID, "astts_op_tfm_ffn_fused: m out of range or operands not 16-byte aligned");
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float);
+    TfmFfnArgs a{x, (const _Float16*)w1_frag_f16, b1, (const _Float16*)w2_frag_f16, b2, out, m, hidden, eps};
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden);
+    hipLaunchKernelGGL(tfm_ffn_fused, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
+    if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

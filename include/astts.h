@@ -347,14 +347,23 @@ int astts_op_mean_pool(const float* x, const int32_t* lens, float* out, int32_t 
 
 /* LayerNorm (scale / shift folded into the weights by the caller) + q|k|v projection + masked multi-head attention of one
  * transformer block of the flow estimator in one launch (csrc/ops_tfm_fused.hip): x fp32 [b, t, c] -> out fp16
- * [b, t, heads*64].  wqkv_frag: the q | k | v weight [3*heads*64, c] re-ordered by astts_op_tfm_pack_qkv (from the row-major
+ * [b, t, heads*64].  wqkv_frag: the q | k | v weight [3*heads*64, c] re-ordered by astts_op_tfm_pack_frag (from the row-major
  * astts_op_pack_weight image) into MFMA fragment order; bias fp32 [3*heads*64] or NULL, lens int32 [b] or NULL.  Serves
  * c == 256, t <= 352 (astts_op_tfm_attn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the caller runs
  * astts_op_layernorm_ex + astts_op_gemm_ex + astts_op_attn_mha_ex on the row-major weight. */
-int astts_op_tfm_pack_qkv(const void* w_f16, void* out_f16, int32_t rows, int32_t c, astts_stream_t stream);
+int astts_op_tfm_pack_frag(const void* w_f16, void* out_f16, int32_t rows, int32_t k, astts_stream_t stream);
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);
 int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream);
+
+/* The feed-forward half of the same block in one launch: out = x + W2 gelu(W1 LayerNorm(x) + b1) + b2, x / out fp32 [m, c]
+ * (out may alias x).  LayerNorm scale / shift folded into w1 / b1 by the caller; both weights in fragment order
+ * (astts_op_tfm_pack_frag of the row-major [hidden, c] and [c, hidden] images); exact-erf GELU as ASTTS_ACT_GELU.  Serves
+ * c == 256, hidden a multiple of 256 up to 4096 (astts_op_tfm_ffn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the
+ * caller runs astts_op_layernorm_ex + 2 x astts_op_gemm_ex. */
+int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden);
+int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
+                           int64_t m, int32_t c, int32_t hidden, float eps, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
@@ -372,7 +381,9 @@ typedef struct {            /* ResnetBlock1D: conv3 -> GN -> Mish (+ time proj) 
 typedef struct {            /* BasicTransformerBlock: LN -> qkv -> attention -> out (+x) -> LN -> GELU FFN (+x) */
     const float *n1_w, *n1_b, *n3_w, *n3_b;
     astts_weight_t qkv, wo, w1, w2;
-    const void* qkv_frag;   /* qkv.w in fragment order (astts_op_tfm_pack_qkv) for the fused attention kernel, or NULL: unfused path */
+    const void* qkv_frag;   /* qkv.w in fragment order (astts_op_tfm_pack_frag) for the fused attention kernel, or NULL: unfused path */
+    const void *w1_frag, *w2_frag;   /* w1.w (LayerNorm n3 folded in: n3_w / n3_b are then ones / zeros) and w2.w in fragment order for
+                                      * astts_op_tfm_ffn_fused, or NULL: unfused path */
 } astts_flow_tfm_t;
 #define ASTTS_FLOW_RESAMPLE_NONE 0      /* mid block */
 #define ASTTS_FLOW_RESAMPLE_CONV 1      /* conv k=3 (last down / up block) */

@@ -1,6 +1,5 @@
 set -x
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/tfm_probe.py
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k tfm 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_synth_gpu.py tests/test_bench_shapes_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 python scripts/flow_only.py
+timeout 300 python scripts/ffn_probe.py
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k tfm 2>&1 | tail -5
+timeout 600 bash scripts/g2.sh

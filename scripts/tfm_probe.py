@@ -8,7 +8,7 @@ x = torch.randn(b, t, c, device=dev)
 pw = ops.PackedWeight(torch.randn(1536, c) / 16, torch.randn(1536) * 0.1)
 out = torch.empty(b, t, 512, dtype=torch.float16, device=dev)
 L = _lib.load()
-wfrag = ops.tfm_pack_qkv(pw)
+wfrag = ops.tfm_pack_frag(pw)
 for sc, what in ((0.125, 'whole kernel'),):
     for _ in range(50):
         _lib.check(L.astts_op_tfm_attn_fused(x.data_ptr(), wfrag.data_ptr(), pw.bias.data_ptr(), None, out.data_ptr(), b, heads, t, c, 1e-5, sc, _lib.stream_ptr()))

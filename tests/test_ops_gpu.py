@@ -475,7 +475,7 @@ def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
     wf, bf = fold_layernorm(w, torch.zeros(w.shape[0]), gamma, beta)
     pw = ops.PackedWeight(wf, bf)
     ld = lens.to(DEV, torch.int32)
-    out = ops.tfm_attn_fused(x.to(DEV), pw, ops.tfm_pack_qkv(pw), heads, lens=ld).float().cpu()
+    out = ops.tfm_attn_fused(x.to(DEV), pw, ops.tfm_pack_frag(pw), heads, lens=ld).float().cpu()
     # fp32 definition
     n = F.layer_norm(x, (c,), gamma, beta, 1e-5)
     qkv = n @ w.T
@@ -494,4 +494,41 @@ def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
         e_ref = float((out[i, :L] - ref[i, :L]).abs().max()) / scale
         e_un = float((out[i, :L] - un[i, :L]).abs().max()) / scale
         assert e_ref < 4e-3 and e_un < 3e-3, (i, e_ref, e_un)
+    assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("m,hidden", [(5504, 1024), (37, 1024), (1, 256), (11008, 1024), (96, 512), (40000, 2048)])
+def test_tfm_ffn_fused_matches_definition_and_unfused_path(m, hidden):
+    """astts_op_tfm_ffn_fused (LayerNorm + Linear + exact-erf GELU + Linear + residual of a flow-estimator transformer block in one
+    launch) against the fp64 definition and against the three launches it replaces on the same folded weights.  Rows: the
+    benchmark's 16 x 344 and 16 x 688, a ragged last row block, a single row, several rounds of workgroups; two runs are bit-equal."""
+    import torch.nn.functional as F
+
+    from astts import ops
+    from astts.synth.model import fold_layernorm
+
+    c = 256
+    g = torch.Generator().manual_seed(m + hidden)
+    x = torch.randn(m, c, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w1, b1 = torch.randn(hidden, c, generator=g) / 16, 0.1 * torch.randn(hidden, generator=g)
+    w2, b2 = torch.randn(c, hidden, generator=g) / 32, 0.1 * torch.randn(c, generator=g)
+    assert ops.tfm_ffn_fused_supported(c, hidden) and not ops.tfm_ffn_fused_supported(c, hidden + 64) and not ops.tfm_ffn_fused_supported(320, hidden)
+    w1f, b1f = fold_layernorm(w1, b1, gamma, beta)
+    p1, p2 = ops.PackedWeight(w1f, b1f), ops.PackedWeight(w2, b2)
+    xd = x.to(DEV)
+    f1, f2 = ops.tfm_pack_frag(p1), ops.tfm_pack_frag(p2)
+    out = ops.tfm_ffn_fused(xd, p1, f1, p2, f2).cpu()
+    again = ops.tfm_ffn_fused(xd, p1, f1, p2, f2).cpu()
+    assert torch.equal(out, again)
+    xd64 = x.double()
+    n = F.layer_norm(xd64, (c,), gamma.double(), beta.double(), 1e-5)
+    ref = (xd64 + F.gelu(n @ w1.double().T + b1.double()) @ w2.double().T + b2.double()).float()
+    ident = (torch.ones(c, device=DEV), torch.zeros(c, device=DEV))
+    n16 = ops.layernorm(xd, *ident, 1e-5, out_dtype=torch.float16)
+    f16 = ops.linear(n16, p1, act="gelu", out_dtype=torch.float16)
+    un = ops.linear(f16, p2, residual=xd).cpu()
+    scale = float((ref - x).abs().max())          # the feed-forward term, without the residual that passes through in fp32
+    e_ref, e_un = float((out - ref).abs().max()) / scale, float((out - un).abs().max()) / scale
+    assert e_ref < 3e-3 and e_un < 2e-3, (e_ref, e_un)
     assert bool(torch.isfinite(out).all())
