@@ -100,7 +100,7 @@ class FlowResnet(ctypes.Structure):
 class FlowTfm(ctypes.Structure):  # astts_flow_tfm_t
     _fields_ = [("n1_w", c_void_p), ("n1_b", c_void_p), ("n3_w", c_void_p), ("n3_b", c_void_p),
                 ("qkv", Weight), ("wo", Weight), ("w1", Weight), ("w2", Weight), ("qkv_frag", c_void_p),
-                ("w1_frag", c_void_p), ("w2_frag", c_void_p)]
+                ("w1_frag", c_void_p), ("w2_frag", c_void_p), ("wo_frag", c_void_p)]
 
 
 class FlowBlock(ctypes.Structure):
@@ -129,7 +129,7 @@ _SIGS.update({   # fused transformer-block front half of the flow estimator (csr
     "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_tfm_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "astts_op_tfm_ffn_fused_supported": (c_int32, [c_int32, c_int32]),
-    "astts_op_tfm_ffn_fused": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "astts_op_tfm_ffn_fused": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
 })
 _SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
@@ -452,14 +452,23 @@ def tfm_ffn_fused_supported(c: int, hidden: int) -> bool:
     return bool(_L().astts_op_tfm_ffn_fused_supported(c, hidden))
 
 
-def tfm_ffn_fused(x: torch.Tensor, w1: PackedWeight, w1_frag: torch.Tensor, w2: PackedWeight, w2_frag: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """``x + W2 gelu(W1 LayerNorm(x) + b1) + b2`` in one launch (LayerNorm affine folded into ``w1``): x fp32 ``[..., 256]``."""
+def tfm_ffn_fused(x: torch.Tensor, w1: PackedWeight, w1_frag: torch.Tensor, w2: PackedWeight, w2_frag: torch.Tensor, eps: float = 1e-5,
+                  attn: Optional[torch.Tensor] = None, wo: Optional[PackedWeight] = None, wo_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x' + W2 gelu(W1 LayerNorm(x') + b1) + b2`` in one launch (LayerNorm affine folded into ``w1``): x fp32 ``[..., 256]``.
+    With ``attn`` (fp16 ``[..., k0]``), ``wo`` and ``wo_frag = tfm_pack_frag(wo)``: ``x' = x + attn Wo^T + bo`` (the attention's
+    output projection and residual, in the same launch); otherwise ``x' = x``."""
     x = _f32(x)
     c, hidden = x.shape[-1], w1.n
     assert w1.cin == c and w2.cin == hidden and w2.n == c and w1_frag.shape == (hidden, c) and w2_frag.shape == (c, hidden)
     out = torch.empty_like(x)
+    m = x.numel() // c
+    k0 = 0
+    if attn is not None:
+        k0 = attn.shape[-1]
+        assert attn.dtype == torch.float16 and attn.is_contiguous() and attn.numel() // k0 == m
+        assert wo is not None and wo.n == c and wo.cin == k0 and wo_frag.shape == (c, k0)
     _lib.check(_L().astts_op_tfm_ffn_fused(x.data_ptr(), w1_frag.data_ptr(), _p(w1.bias), w2_frag.data_ptr(), _p(w2.bias), out.data_ptr(),
-                                           x.numel() // c, c, hidden, eps, _st()))
+                                           m, c, hidden, eps, _p(attn), _p(wo_frag), _p(wo.bias) if wo is not None else None, k0, _st()))
     return out
 
 

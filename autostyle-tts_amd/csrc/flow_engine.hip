@@ -195,9 +195,15 @@ struct Ctx {
             RUN(astts_op_attn_mha_ex(B.qkv16, B.qkv16 + hd, B.qkv16 + 2 * hd, 1, lens, B.a16, 1, b2, heads, t, 3 * hd, 3 * hd, hd,
                                      0.125f, st));
         }
+        const bool ffn = w.w1_frag && w.w2_frag && astts_op_tfm_ffn_fused_supported(C, w.w1.n);
+        // output projection + residual + LayerNorm + W1 + GELU + W2 + residual in one launch, when its 32-row workgroups (one per
+        // CU) fit the chip in one round; in place on p
+        if (ffn && w.wo_frag && (hd == 256 || hd == 512) && rows <= 256 * 32)
+            return astts_op_tfm_ffn_fused(p, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, B.a16, w.wo_frag, w.wo.bias,
+                                          hd, st);
         RUN(linear(B.a16, 1, w.wo, p, q, 0, rows, ASTTS_ACT_NONE));
-        if (w.w1_frag && w.w2_frag && astts_op_tfm_ffn_fused_supported(C, w.w1.n))      // LayerNorm + W1 + GELU + W2 + residual: one launch
-            return astts_op_tfm_ffn_fused(q, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, st);
+        if (ffn)      // LayerNorm + W1 + GELU + W2 + residual: one launch
+            return astts_op_tfm_ffn_fused(q, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, nullptr, nullptr, nullptr, 0, st);
         RUN(astts_op_layernorm_ex(q, w.n3_w, w.n3_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
         RUN(linear(B.n16, 1, w.w1, nullptr, B.f16, 1, rows, ASTTS_ACT_GELU));
         return linear(B.f16, 1, w.w2, q, p, 0, rows, ASTTS_ACT_NONE);

@@ -366,12 +366,19 @@ struct TfmFfnArgs {
     const float* b1;         // [hidden] (W1 beta + b1)
     const _Float16* w2;      // [256][hidden] fp16, fragment order
     const float* b2;         // [256] or null
-    float* out;              // [m][256]: x + W2 gelu(W1 LN(x) + b1) + b2
+    float* out;              // [m][256]: x' + W2 gelu(W1 LN(x') + b1) + b2
+    const _Float16* attn;    // WO: [m][k0] fp16 attention output; x' = x + attn Wo^T + bo (otherwise x' = x)
+    const _Float16* wo;      // WO: [256][k0] fp16, fragment order
+    const float* bo;         // WO: [256] or null
     int64_t m;
-    int hidden;
+    int hidden, k0;
     float eps;
 };
 
+// WO: the attention's output projection + residual (the launch between tfm_attn_fused and this one: 8.5 us + boundary) runs as a
+// prologue here: x' = x + attn Wo^T + bo is formed in LDS (fp32), normalised from there, and added back in the epilogue; it is
+// never written to memory.
+template <bool WO>
 __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -411,9 +418,74 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) w2f[s] = *reinterpret_cast<const half8*>(np + (int64_t)s * 512);
     };
-    load_w1(rot);
-    load_w2(rot);
-    for (int i = tid; i < a.hidden; i += 512) sB1[i] = a.b1 ? a.b1[i] : 0.0f;
+    float* sX = sB1 + a.hidden;                      // WO: [32][260] fp32 x'
+    if constexpr (WO) {
+        // ---- x' = x + attn Wo^T + bo.  The attention rows go to LDS where the hidden chunks will live later; Wo streams through
+        // the W2 registers in halves of 256 input features while W1's first chunk is already on its way.
+        const int as0 = a.k0 + 8;                    // halfs per staged attention row
+        _Float16* sAtt = sH;                         // [32][k0 + 8] (k0 <= 512: fits the two H buffers)
+        const int nh = a.k0 >> 8;
+        const _Float16* wop = a.wo + ((int64_t)wid * (a.k0 >> 4) * 64 + lane) * 8;
+        half8 at[4];
+        {
+            const _Float16* p = a.attn + min(m0 + srow, a.m - 1) * a.k0 + (tid & 15) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i * 128 < a.k0) at[i] = *reinterpret_cast<const half8*>(p + 128 * i);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2f[s] = *reinterpret_cast<const half8*>(wop + (int64_t)s * 512);
+        load_w1(rot);
+        for (int i = tid; i < a.hidden; i += 512) sB1[i] = a.b1 ? a.b1[i] : 0.0f;
+        float16v acc0;
+        {
+            const float* bp = a.bo + wid * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = a.bo ? *reinterpret_cast<const float4*>(bp + 8 * g) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                acc0[4 * g] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sX + srow * 260 + sseg + 64 * i) = r[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 128 < a.k0) *reinterpret_cast<half8*>(sAtt + srow * as0 + (tid & 15) * 8 + 128 * i) = at[i];
+        __syncthreads();
+        const _Float16* atp = sAtt + c * as0 + 8 * hh;
+        for (int h = 0; h < nh; ++h) {
+#pragma unroll
+            for (int s0 = 0; s0 < 16; s0 += 8) {
+                half8 af[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const half8*>(atp + 16 * (16 * h + s0 + s));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[s0 + s], af[s], acc0, 0, 0, 0);
+            }
+            if (h + 1 < nh) {
+                const _Float16* np = wop + (int64_t)(h + 1) * 16 * 512;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) w2f[s] = *reinterpret_cast<const half8*>(np + (int64_t)s * 512);
+            }
+        }
+        load_w2(rot);
+        {
+            float* xp = sX + c * 260 + wid * 32 + 4 * hh;    // feature (e & 3) + 8 (e >> 2) + 4 hh of this wave's tile, row c
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = *reinterpret_cast<float4*>(xp + 8 * g);
+                v.x += acc0[4 * g]; v.y += acc0[4 * g + 1]; v.z += acc0[4 * g + 2]; v.w += acc0[4 * g + 3];
+                *reinterpret_cast<float4*>(xp + 8 * g) = v;
+            }
+        }
+        __syncthreads();                             // x' complete; the attention rows are dead (the H buffers are free)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(sX + srow * 260 + sseg + 64 * i);
+    } else {
+        load_w1(rot);
+        load_w2(rot);
+        for (int i = tid; i < a.hidden; i += 512) sB1[i] = a.b1 ? a.b1[i] : 0.0f;
+    }
     {
         float s = 0.0f;
 #pragma unroll
@@ -516,7 +588,10 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
     const int f = wid * 32 + c;
     float xr[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) xr[e] = a.x[min(m0 + (e & 3) + 8 * (e >> 2) + 4 * hh, a.m - 1) * TF_C + f];
+    for (int e = 0; e < 16; ++e) {
+        const int re = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        xr[e] = WO ? sX[re * 260 + f] : a.x[min(m0 + re, a.m - 1) * TF_C + f];
+    }
     const float b2 = a.b2 ? a.b2[f] : 0.0f;
     {
         const _Float16* hp = sH + (size_t)((nchunk - 1) & 1) * 32 * FF_HS + c * FF_HS + 8 * hh;
@@ -557,23 +632,33 @@ int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden) {
 }
 
 int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
-                           int64_t m, int32_t c, int32_t hidden, float eps, astts_stream_t stream) {
+                           int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
+                           const float* bo, int32_t k0, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w1_frag_f16 && w2_frag_f16 && out, ASTTS_ERR_INVALID, "astts_op_tfm_ffn_fused: null pointer");
     ASTTS_REQUIRE(astts_op_tfm_ffn_fused_supported(c, hidden), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_tfm_ffn_fused: c=%d hidden=%d (channels 256, hidden a multiple of 256 <= 4096)", c, hidden);
     ASTTS_REQUIRE(m >= 1 && m <= ((int64_t)1 << 31) * 32 - 32 &&
                       (((uintptr_t)x | (uintptr_t)w1_frag_f16 | (uintptr_t)w2_frag_f16 | (uintptr_t)out) & 15) == 0,
                   ASTTS_ERR_INVALID, "astts_op_tfm_ffn_fused: m out of range or operands not 16-byte aligned");
+    const bool wo = attn_f16 != nullptr;
+    if (wo) {
+        ASTTS_REQUIRE(wo_frag_f16 && (((uintptr_t)attn_f16 | (uintptr_t)wo_frag_f16 | (uintptr_t)bo) & 15) == 0, ASTTS_ERR_INVALID,
+                      "astts_op_tfm_ffn_fused: attention rows without a projection weight, or operands not 16-byte aligned");
+        ASTTS_REQUIRE(k0 == 256 || k0 == 512, ASTTS_ERR_UNSUPPORTED, "astts_op_tfm_ffn_fused: k0=%d (256 or 512)", k0);
+    }
     static bool attr = false;
     if (!attr) {
         attr = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float);
-    TfmFfnArgs a{x, (const _Float16*)w1_frag_f16, b1, (const _Float16*)w2_frag_f16, b2, out, m, hidden, eps};
-    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden);
-    hipLaunchKernelGGL(tfm_ffn_fused, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
+    const size_t lds = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float) + (wo ? 32 * 260 * sizeof(float) : 0);
+    TfmFfnArgs a{x, (const _Float16*)w1_frag_f16, b1, (const _Float16*)w2_frag_f16, b2, out, (const _Float16*)attn_f16,
+                 (const _Float16*)wo_frag_f16, bo, m, hidden, k0, eps};
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden + (wo ? 2.0 * (double)m * TF_C * k0 : 0.0));
+    if (wo) hipLaunchKernelGGL(tfm_ffn_fused<true>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(tfm_ffn_fused<false>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
@@ -600,8 +685,9 @@ int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const flo
     }
     TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale};
     hipStream_t st = (hipStream_t)stream;
-    // profiled with the attention kind: projection + attention flops of the work actually done (K, V projected twice)
-    const double flops = (double)b * heads * (2.0 * (2.0 * 2.0 * t * 64.0 * TF_C) + 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);
+    // profiled with the attention kind: ALGORITHMIC flops (q, k, v projected once + attention; the second projection of K and V by
+    // the other query half's workgroup is this kernel's overhead, not work)
+    const double flops = (double)b * heads * (3.0 * 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);
     const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, st, flops);
     hipLaunchKernelGGL(tfm_attn_fused, dim3(2 * heads * b), dim3(512), lds, st, a);
     if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, st);

@@ -356,14 +356,18 @@ int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);
 int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream);
 
-/* The feed-forward half of the same block in one launch: out = x + W2 gelu(W1 LayerNorm(x) + b1) + b2, x / out fp32 [m, c]
- * (out may alias x).  LayerNorm scale / shift folded into w1 / b1 by the caller; both weights in fragment order
- * (astts_op_tfm_pack_frag of the row-major [hidden, c] and [c, hidden] images); exact-erf GELU as ASTTS_ACT_GELU.  Serves
- * c == 256, hidden a multiple of 256 up to 4096 (astts_op_tfm_ffn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the
- * caller runs astts_op_layernorm_ex + 2 x astts_op_gemm_ex. */
+/* The feed-forward half of the same block in one launch: out = x' + W2 gelu(W1 LayerNorm(x') + b1) + b2, x / out fp32 [m, c]
+ * (out may alias x).  LayerNorm scale / shift folded into w1 / b1 by the caller; the weights in fragment order
+ * (astts_op_tfm_pack_frag of the row-major [hidden, c] and [c, hidden] images); exact-erf GELU as ASTTS_ACT_GELU.
+ * attn_f16 == NULL: x' = x.  Otherwise the attention's output projection and residual run as a prologue of the same launch:
+ * x' = x + attn Wo^T + bo with attn fp16 [m, k0] (k0 = 256 or 512), wo_frag the [c, k0] weight in fragment order, bo fp32 [c] or
+ * NULL; x' is never written to memory.  Serves c == 256, hidden a multiple of 256 up to 4096
+ * (astts_op_tfm_ffn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the caller runs astts_op_layernorm_ex +
+ * astts_op_gemm_ex. */
 int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden);
 int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
-                           int64_t m, int32_t c, int32_t hidden, float eps, astts_stream_t stream);
+                           int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
+                           const float* bo, int32_t k0, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
@@ -384,6 +388,7 @@ typedef struct {            /* BasicTransformerBlock: LN -> qkv -> attention -> 
     const void* qkv_frag;   /* qkv.w in fragment order (astts_op_tfm_pack_frag) for the fused attention kernel, or NULL: unfused path */
     const void *w1_frag, *w2_frag;   /* w1.w (LayerNorm n3 folded in: n3_w / n3_b are then ones / zeros) and w2.w in fragment order for
                                       * astts_op_tfm_ffn_fused, or NULL: unfused path */
+    const void* wo_frag;             /* wo.w in fragment order: the output projection runs inside astts_op_tfm_ffn_fused; or NULL */
 } astts_flow_tfm_t;
 #define ASTTS_FLOW_RESAMPLE_NONE 0      /* mid block */
 #define ASTTS_FLOW_RESAMPLE_CONV 1      /* conv k=3 (last down / up block) */

@@ -32,3 +32,11 @@ for m in (5504, 11008):
         return ops.linear(f16, p2, residual=x)
     tf, tu = timed(lambda: ops.tfm_ffn_fused(x, p1, f1, p2, f2)), timed(unfused)
     print(f'm={m}: fused {tf:.2f} us ({4 * m * c * hidden / tf * 1e-6:.0f} TFLOP/s), three launches {tu:.2f} us')
+
+po = ops.PackedWeight(torch.randn(c, 512) / 24, torch.randn(c) * 0.1)
+fo = ops.tfm_pack_frag(po)
+for m in (5504,):
+    x = torch.randn(m, c, device=dev); at = torch.randn(m, 512, device=dev).half()
+    t1 = timed(lambda: ops.tfm_ffn_fused(x, p1, f1, p2, f2, attn=at, wo=po, wo_frag=fo))
+    t2 = timed(lambda: ops.tfm_ffn_fused(ops.linear(at, po, residual=x), p1, f1, p2, f2))
+    print(f'm={m}: with the output projection inside {t1:.2f} us, as two launches {t2:.2f} us')

@@ -1,5 +1,4 @@
-set -x
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/ffn_probe.py
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k tfm 2>&1 | tail -5
-timeout 600 bash scripts/g2.sh
+timeout 900 python -m pytest tests/test_bench_shapes_gpu.py -x -q -m gpu -s 2>&1 | grep -E "config 3|passed|failed" | tail
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+timeout 600 python bench.py 2>&1 | tail -2

@@ -150,7 +150,11 @@ def test_config3_longform_batch_rows_are_batch_independent():
     # a 64-row batch takes other GEMM tiles than a 32-row one (tile by row count): same products, other fp32 summation order,
     # and the fp16 intermediates of 10 Euler steps x 2 x 56 transformer blocks round differently now and then.  Bar: an
     # order of magnitude inside the oracle tolerance of the flow stage (5e-3 of the mel scale).
-    assert dm < 1e-3 and dw < 5e-3
+    # The waveform: the vocoder turns a mel difference of 4e-4 into isolated sample differences of a few 1e-3 (full scale 0.99);
+    # the bar is the one the synthesis parity test puts on the vocoder against the oracle (SNR > 40 dB) plus a peak bound.
+    snr = 10.0 * math.log10(float((wav[sl].double() ** 2).sum()) / max(float(((wav2 - wav[sl]).double() ** 2).sum()), 1e-30))
+    print(f"config 3: waveform SNR of the two evaluations {snr:.1f} dB")
+    assert dm < 1e-3 and dw < 1e-2 and snr > 40.0
 
 
 def test_config5_bank_100k_x_768():

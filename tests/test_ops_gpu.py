@@ -532,3 +532,36 @@ def test_tfm_ffn_fused_matches_definition_and_unfused_path(m, hidden):
     e_ref, e_un = float((out - ref).abs().max()) / scale, float((out - un).abs().max()) / scale
     assert e_ref < 3e-3 and e_un < 2e-3, (e_ref, e_un)
     assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("m,k0", [(5504, 512), (45, 512), (1, 256), (8192, 512)])
+def test_tfm_ffn_fused_with_output_projection(m, k0):
+    """The same launch with the attention's output projection + residual as its prologue (x' = x + attn Wo^T + bo, never written
+    to memory) against the fp64 definition and against linear(residual) followed by the plain fused launch."""
+    import torch.nn.functional as F
+
+    from astts import ops
+    from astts.synth.model import fold_layernorm
+
+    c, hidden = 256, 1024
+    g = torch.Generator().manual_seed(m + k0)
+    x = torch.randn(m, c, generator=g) * 2 + 0.3
+    attn = torch.randn(m, k0, generator=g)
+    wo, bo = torch.randn(c, k0, generator=g) / 24, 0.1 * torch.randn(c, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w1, b1 = torch.randn(hidden, c, generator=g) / 16, 0.1 * torch.randn(hidden, generator=g)
+    w2, b2 = torch.randn(c, hidden, generator=g) / 32, 0.1 * torch.randn(c, generator=g)
+    w1f, b1f = fold_layernorm(w1, b1, gamma, beta)
+    p1, p2, po = ops.PackedWeight(w1f, b1f), ops.PackedWeight(w2, b2), ops.PackedWeight(wo, bo)
+    f1, f2, fo = ops.tfm_pack_frag(p1), ops.tfm_pack_frag(p2), ops.tfm_pack_frag(po)
+    xd, ad = x.to(DEV), attn.to(DEV, torch.float16)
+    out = ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu()
+    assert torch.equal(out, ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu())
+    x1 = x.double() + ad.cpu().double() @ wo.double().T + bo.double()
+    n = F.layer_norm(x1, (c,), gamma.double(), beta.double(), 1e-5)
+    ref = (x1 + F.gelu(n @ w1.double().T + b1.double()) @ w2.double().T + b2.double()).float()
+    two = ops.tfm_ffn_fused(ops.linear(ad, po, residual=xd), p1, f1, p2, f2).cpu()
+    scale = float((ref - x).abs().max())
+    e_ref, e_two = float((out - ref).abs().max()) / scale, float((out - two).abs().max()) / scale
+    assert e_ref < 3e-3 and e_two < 1e-3, (e_ref, e_two)
+    assert bool(torch.isfinite(out).all())
