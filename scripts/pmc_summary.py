@@ -11,7 +11,7 @@ for f in files:
         k = r['Kernel_Name'].split('(')[0][-48:]
         a = agg[k][r['Counter_Name']]
         a[0] += 1; a[1] += float(r['Counter_Value'])
-        m = re.search(r'(lm_gemv|lm_attn|gemm_ring|gemm_tile|gemm_skinny16|attn_mha_flash|knn_scan)', r['Kernel_Name'])
+        m = re.search(r'(lm_gemv|lm_attn|gemm_ring|gemm_tile|gemm_skinny16|attn_mha_flash|tfm_attn_fused|tfm_ffn_fused|knn_scan)', r['Kernel_Name'])
         if m:
             b = fam[m.group(1)][r['Counter_Name']]
             b[0] += 1; b[1] += float(r['Counter_Value'])
