@@ -174,20 +174,25 @@ struct SampleArgs {
 };
 
 // 1024 threads per row: every pass over the 4097 logits is 4-5 elements per thread (the kernel is a chain of short
-// dependent passes; at 256 threads it took 26 us of the 575 us decode step)
+// dependent passes; at 256 threads it took 26 us of the 575 us decode step).  A thread touches the SAME elements
+// (i = tid + 1024 n) in every pass up to the gather, so those passes need no barrier between them; the three radix-select
+// histograms and every hand-over variable have their own LDS (zeroed once, up front): 11 workgroup barriers instead of 22.
 static constexpr int RS_NT = 1024;
 __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
-    extern __shared__ float prob[];  // [V]
-    __shared__ float redv[RS_NT / 64];
+    extern __shared__ float prob[];  // [V rounded up to a multiple of 16]
+    __shared__ float red_max[RS_NT / 64], red_sum[RS_NT / 64];
     __shared__ float sh_s[RS_NT];
     __shared__ int sh_i[RS_NT];
     __shared__ float s_bcast;
     __shared__ int s_tok;
-    __shared__ unsigned hist[2048];
-    __shared__ int s_sel_bin, s_sel_rem, s_cnt;
+    __shared__ unsigned hist[3][2048];
+    __shared__ int s_sel_bin[3], s_sel_rem[3], s_cnt;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
     const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
+    for (int i = tid; i < 3 * 2048; i += RS_NT) (&hist[0][0])[i] = 0u;
+    if (tid == 0) s_cnt = 0;
+    if (tid < 16 && ((a.v + 15) & ~15) - 16 + tid >= a.v) prob[((a.v + 15) & ~15) - 16 + tid] = 0.0f;   // tail of the last 16-chunk
     float mx = -INFINITY;
     for (int i = tid; i < a.v; i += RS_NT) {
         float x = lg[i];
@@ -197,12 +202,11 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if (lane == 0) redv[wid] = mx;
+    if (lane == 0) red_max[wid] = mx;
     __syncthreads();
-    mx = redv[0];
+    mx = red_max[0];
 #pragma unroll
-    for (int w = 1; w < RS_NT / 64; ++w) mx = fmaxf(mx, redv[w]);
-    __syncthreads();
+    for (int w = 1; w < RS_NT / 64; ++w) mx = fmaxf(mx, red_max[w]);
     float sum = 0.0f;
     for (int i = tid; i < a.v; i += RS_NT) {
         const float e = __expf(prob[i] - mx);
@@ -211,39 +215,40 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0) redv[wid] = sum;
+    if (lane == 0) red_sum[wid] = sum;
     __syncthreads();
     float tot = 0.0f;      // fixed summation order (wave partials 0..15): same bits on every run
 #pragma unroll
-    for (int w = 0; w < RS_NT / 64; ++w) tot += redv[w];
+    for (int w = 0; w < RS_NT / 64; ++w) tot += red_sum[w];
     const float inv = 1.0f / tot;
-    __syncthreads();
-    for (int i = tid; i < a.v; i += RS_NT) prob[i] *= inv;
-    __syncthreads();
     // top_k by (p desc, id asc).  Fast path: the exact kk-th largest probability by a 3-pass radix select on the float
     // bits (LDS histograms), then the <= 64 entries >= it are gathered and sorted by one wave.  If ties push the
     // gather past 64 entries (e.g. fewer than kk non-zero probabilities) the general chunked path below runs instead.
     const int kk = a.top_k < 64 ? a.top_k : 64;
     TopList<float> tl;
     tl.init();
+    unsigned prefix = 0u, known = 0u;
     {
-        unsigned prefix = 0u, known = 0u;
         int remaining = kk < a.v ? kk : a.v;
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) {
             const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
             const int bins = pass == 2 ? 1024 : 2048;
-            for (int i = tid; i < bins; i += RS_NT) hist[i] = 0u;
-            __syncthreads();
+            unsigned* h = hist[pass];
             for (int i = tid; i < a.v; i += RS_NT) {
-                const unsigned key = __float_as_uint(prob[i]);
-                if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
+                float pv = prob[i];
+                if (pass == 0) {                      // the normalisation rides on the first histogram pass
+                    pv *= inv;
+                    prob[i] = pv;
+                }
+                const unsigned key = __float_as_uint(pv);
+                if ((key & known) == prefix) atomicAdd(&h[(key >> shift) & (bins - 1)], 1u);
             }
             __syncthreads();
             if (wid == 0) {
                 const int per = bins >> 6;
                 unsigned local = 0u;
-                for (int j = 0; j < per; ++j) local += hist[lane * per + j];
+                for (int j = 0; j < per; ++j) local += h[lane * per + j];
                 unsigned incl = local;                       // sum over lanes >= lane
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -254,10 +259,10 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
                 if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
                     unsigned acc = above;
                     for (int j = per - 1; j >= 0; --j) {
-                        const unsigned hcount = hist[lane * per + j];
+                        const unsigned hcount = h[lane * per + j];
                         if (acc + hcount >= (unsigned)remaining) {
-                            s_sel_bin = lane * per + j;
-                            s_sel_rem = remaining - (int)acc;
+                            s_sel_bin[pass] = lane * per + j;
+                            s_sel_rem[pass] = remaining - (int)acc;
                             break;
                         }
                         acc += hcount;
@@ -265,13 +270,10 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
                 }
             }
             __syncthreads();
-            prefix |= (unsigned)s_sel_bin << shift;
+            prefix |= (unsigned)s_sel_bin[pass] << shift;
             known |= (unsigned)(bins - 1) << shift;
-            remaining = s_sel_rem;
-            __syncthreads();
+            remaining = s_sel_rem[pass];
         }
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
         for (int i = tid; i < a.v; i += RS_NT) {
             if (__float_as_uint(prob[i]) >= prefix) {
                 const int pos = atomicAdd(&s_cnt, 1);
@@ -328,31 +330,52 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
                 found = true;
             }
         }
+        // repetition check: lane j compares the j-th token of the window (one round trip, not `win` dependent ones)
+        const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
+        int rep = 0;
+        for (int i0 = h0; i0 < a.hist_len; i0 += 64) {
+            const int i = i0 + lane;
+            const bool hit = i < a.hist_len && a.history[(int64_t)bb * a.hist_ld + i] == tok;
+            rep += __popcll(__ballot(hit));
+        }
         if (lane == 0) {
-            int rep = 0;
-            const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
-            for (int i = h0; i < a.hist_len; ++i) rep += (a.history[(int64_t)bb * a.hist_ld + i] == tok) ? 1 : 0;
             s_tok = tok;
             s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
         }
     }
     __syncthreads();
     if (s_bcast > 0.5f && tid == 0) {
-        // repetition detected: random sampling from the full distribution, id order, inverse CDF with u2
+        // repetition detected: random sampling from the full distribution, id order, inverse CDF with u2.  The running sum is
+        // the oracle's sequential fp32 accumulation (a parallel scan rounds differently), taken 16 elements per LDS round trip
+        // with ONE comparison per chunk: ~20 us worst case (an LDS read + compare + branch per element took 270 us).
         const float target = a.u[bb * 2 + 1];
         float run = 0.0f;
         int tok = -1;
-        int last = 0;
-        for (int i = 0; i < a.v; ++i) {
-            const float p = prob[i];
-            if (p > 0.0f) last = i;
-            run += p;
-            if (run > target) {
-                tok = i;
-                break;
+        const int vpad = (a.v + 15) & ~15;
+        for (int base = 0; base < vpad && tok < 0; base += 16) {
+            const float4 q0 = *reinterpret_cast<const float4*>(prob + base), q1 = *reinterpret_cast<const float4*>(prob + base + 4);
+            const float4 q2 = *reinterpret_cast<const float4*>(prob + base + 8), q3 = *reinterpret_cast<const float4*>(prob + base + 12);
+            const float pv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            float r[16];
+            r[0] = run + pv[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) r[k] = r[k - 1] + pv[k];
+            if (r[15] > target) {                    // the sums are non-decreasing: the first crossing is in this chunk
+#pragma unroll
+                for (int k = 15; k >= 0; --k)
+                    if (r[k] > target) tok = base + k;
             }
+            run = r[15];
         }
-        s_tok = tok >= 0 ? tok : last;
+        if (tok < 0 || tok >= a.v) {                 // the sum never exceeded the target: the last token with p > 0
+            tok = 0;
+            for (int i = a.v - 1; i > 0; --i)
+                if (prob[i] > 0.0f) {
+                    tok = i;
+                    break;
+                }
+        }
+        s_tok = tok;
     }
     __syncthreads();
     if (tid == 0) {
@@ -492,7 +515,7 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
     SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, nullptr, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -507,7 +530,7 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
                   ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
     SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)vocab * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -312,6 +312,36 @@ def test_ras_sample_matches_definition():
         assert out.tolist() == ref.tolist()
 
 
+def test_ras_sample_repetition_path_every_row():
+    """The repetition branch (inverse CDF over the FULL distribution in id order, sequential fp32 running sum) for every row
+    (win = 0 makes the repetition test pass trivially), with u2 across the range, u2 -> 1 (the sum may never exceed the target:
+    the last token with p > 0) and degenerate distributions; vocabulary sizes around the 16-element chunking of the scan."""
+    from astts import ops
+    from oracle import synth as osyn
+
+    g = torch.Generator().manual_seed(11)
+    for v in (4097, 4096, 1000, 17):
+        b = 12
+        logits = torch.randn(b, v, generator=g) * 3
+        logits[1] = float("-inf")
+        logits[1, [3, v - 1]] = 0.0                     # two tokens, the second one last
+        logits[2] = float("-inf")
+        logits[2, v // 2] = 1.0                         # a single token
+        logits[3, v - 5:] = float("-inf")               # zero-probability tail
+        hist = torch.randint(0, v - 1, (b, 8), generator=g, dtype=torch.int32)
+        for u2 in (None, 0.0, 0.5, 0.999999, 1.0):
+            u = torch.rand(b, 2, generator=g)
+            if u2 is not None:
+                u[:, 1] = u2
+            out = ops.ras_sample(logits.to(DEV), hist.to(DEV), 8, u.to(DEV), 25, 0.8, 0, 0.1, v - 1, False).cpu()
+            ref = osyn.ras_sample(logits, hist, u, 25, 0.8, 0, 0.1, v - 1, False)
+            # u2 == 1.0: whether a running sum of ~1.0 "exceeds" the target is decided by the last ulp of the softmax
+            # normaliser (the kernel and torch sum in different orders); only the rows whose probabilities are exact
+            # (0.5 + 0.5, 1.0: the sum never exceeds 1.0 -> last token with p > 0) are comparable there
+            rows = [1, 2] if u2 == 1.0 else list(range(b))
+            assert out[rows].tolist() == ref[rows].tolist(), (v, u2)
+
+
 def test_gemm_rejects_in_place_output():
     """Every GEMM workgroup reads whole input rows while others store their output tiles: out == x would race
     (it only shows under contention), so the ABI refuses it."""
