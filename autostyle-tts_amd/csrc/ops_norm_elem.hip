@@ -231,11 +231,27 @@ __global__ __launch_bounds__(GNF_NT) void groupnorm_fused(const float* __restric
     const int nvec = len * cv;
     const float* xb = x + (int64_t)b * t * c + g * cpg;
     float s = 0.0f;
-    for (int i = tid; i < nvec; i += GNF_NT) {
-        const int r = i / cv, q = i - r * cv;
-        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * c + q * 4);
-        *reinterpret_cast<float4*>(tile + (size_t)i * 4) = v;
-        s += (v.x + v.y) + (v.z + v.w);
+    // eight loads per thread in flight (a load -> LDS store -> add loop of runtime length is not pipelined by the compiler: the
+    // 5-6 iterations of a [344 x 32] tile were 5-6 dependent memory round trips, half of this kernel's 10 us)
+    constexpr int GU = 8;
+    for (int i0 = tid; i0 < nvec; i0 += GNF_NT * GU) {
+        float4 v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = i0 + u * GNF_NT;
+            if (i < nvec) {
+                const int r = i / cv, q = i - r * cv;
+                v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)r * c + q * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = i0 + u * GNF_NT;
+            if (i < nvec) {
+                *reinterpret_cast<float4*>(tile + (size_t)i * 4) = v[u];
+                s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            }
+        }
     }
     s = wave_sum_f32(s);
     if (lane == 0) red[wid] = s;
