@@ -8,7 +8,8 @@ Mirrors the calls the reference scripts make (paths under /root/reference):
   .inference_vc(source_wav_16k, prompt_wav_16k, stream=False)                   tts_with_rag.py:141
   load_wav(path, target_sr) -> FloatTensor[1, n]                                tts_with_rag.py:180-186
 Each method is a *generator* that yields one ``{'tts_speech': FloatTensor[1, n_samples]}`` (CPU) per text
-segment; work for segment i happens on ``next()`` (lazy, as upstream).
+segment; work for segment i happens on ``next()`` (lazy, as upstream).  With ``stream=True`` a segment is yielded as several
+consecutive chunks (2 s hops, mel / waveform cross-fades: ``astts.synth.stream``).
 
 ``inference_tts_with_st`` exists only in the authors' fork; its contract is the docstring at
 tts_with_rag.py:151-156: step 1, the LM generates speech ("style") tokens conditioned on
@@ -109,6 +110,39 @@ class CosyVoice:
         wav = eng.hift.forward(mel, phase0.to(dev), noise.to(dev))
         return wav.cpu()
 
+    def _render_stream(self, tokens: torch.Tensor, flow_prompt: PromptFeatures) -> Iterator[torch.Tensor]:
+        """``stream=True``: the segment's tokens (generated in one on-device decode pass: the chunks differ from upstream's in
+        first-chunk latency only) rendered hop by hop with upstream's overlaps and cross-fades (``astts.synth.stream``)."""
+        from ..synth.stream import StreamConsts, stream_render
+        cfg, dev, eng = self.cfg, self.device, self.engine
+        nh = cfg.nb_harmonics + 1
+        ptok = flow_prompt.speech_tokens.to(torch.int32)
+        pmel, spk = flow_prompt.mel.to(dev), flow_prompt.spk_embedding.to(dev)
+        tmp = pmel.shape[1]
+
+        def flow_mel(tok: torch.Tensor) -> torch.Tensor:
+            n_gen = cfg.mel_frames_for_tokens(int(tok.numel()))
+            z = torch.randn(1, tmp + n_gen, cfg.mel, generator=self._gen)
+            all_tok = torch.cat([ptok, tok.view(1, -1).to(torch.int32)], dim=1).to(dev)
+            tl = torch.tensor([all_tok.shape[1]], dtype=torch.int32, device=dev)
+            return eng.flow.decode(all_tok, tl, pmel, spk, z.to(dev), tmp + n_gen)
+
+        def source(f0: torch.Tensor) -> torch.Tensor:
+            phase0 = (torch.rand(1, nh, generator=self._gen) * 2 - 1) * math.pi
+            phase0[:, 0] = 0
+            noise = torch.randn(1, f0.shape[1] * cfg.upsample_total, nh, generator=self._gen)
+            return eng.hift.source(f0, phase0.to(dev), noise.to(dev))
+
+        for wav in stream_render(tokens.view(-1), StreamConsts.for_config(cfg), flow_mel, eng.hift.f0, source, eng.hift.decode):
+            yield wav.cpu()
+
+    def _emit(self, tokens: torch.Tensor, flow_prompt: PromptFeatures, stream: bool) -> Iterator[Dict[str, torch.Tensor]]:
+        if stream:
+            for wav in self._render_stream(tokens, flow_prompt):
+                yield {"tts_speech": wav}
+        else:
+            yield {"tts_speech": self._render(tokens, flow_prompt)}
+
     # ------------------------------------------------------------------ ragged batches (many segments in one pass)
     def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True):
         """``requests``: list of (text_ids [1, Tt] = prompt text + segment text, n_segment_text_tokens, lm_prompt,
@@ -187,7 +221,7 @@ class CosyVoice:
             seg_ids = fe.text_ids(seg)
             text_ids = torch.cat([style_ids, seg_ids], dim=1)
             toks = self._lm_tokens(text_ids, seg_ids.shape[1], style)       # step 1: style tokens
-            yield {"tts_speech": self._render(toks, timbre)}                 # step 2: render with the timbre
+            yield from self._emit(toks, timbre, stream)                      # step 2: render with the timbre
 
     def inference_zero_shot(self, tts_text: str, prompt_text: str, prompt_wav_16k: torch.Tensor,
                             stream: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
@@ -197,11 +231,11 @@ class CosyVoice:
         for seg in text_normalize(tts_text, fe.tokenizer, split=True):
             seg_ids = fe.text_ids(seg)
             toks = self._lm_tokens(torch.cat([prompt_ids, seg_ids], dim=1), seg_ids.shape[1], prompt)
-            yield {"tts_speech": self._render(toks, prompt)}
+            yield from self._emit(toks, prompt, stream)
 
     def inference_vc(self, source_wav_16k: torch.Tensor, prompt_wav_16k: torch.Tensor,
                      stream: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
         fe = self.frontend
         src = fe.prompt(source_wav_16k)
         prompt = fe.prompt(prompt_wav_16k)
-        yield {"tts_speech": self._render(src.speech_tokens, prompt)}          # no LM: source tokens, prompt timbre
+        yield from self._emit(src.speech_tokens, prompt, stream)               # no LM: source tokens, prompt timbre

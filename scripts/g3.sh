@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/gn_probe.py
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "groupnorm or norm" 2>&1 | tail -2
-timeout 300 python scripts/flow_only.py
+timeout 900 python -m pytest tests/test_synth_gpu.py -x -q -m gpu -k "stream" -s 2>&1 | grep -E "parity|passed|failed|Error|error" | tail -20
+timeout 900 python -m pytest tests/test_cli_gpu.py -x -q -m gpu -k "contract" 2>&1 | tail -15

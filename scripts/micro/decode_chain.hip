@@ -105,6 +105,13 @@ static Model make_model(int b) {
         y.u = rand32(m.d, s++, 0.1f); y.v = rand32(m.d, s++, 0.1f);
         m.L.push_back(y);
     }
+    if (getenv("DC_HOTW")) {   // every layer reads layer 0's weight images: what an ideal L2 prefetch of the next launch's weights would buy
+        const int nhot = atoi(getenv("DC_HOTW"));      // 1: all four projections; 2: only wo (2 MB)
+        for (int l = 1; l < m.layers; ++l) {
+            m.L[l].wo = m.L[0].wo;
+            if (nhot == 1) { m.L[l].wqkv = m.L[0].wqkv; m.L[l].w1 = m.L[0].w1; m.L[l].w2 = m.L[0].w2; }
+        }
+    }
     m.head = rand16((size_t)4224 * m.d, s++, 0.03f);
     m.head_b = rand32(4224, s++, 0.1f); m.ag = rand32(m.d, s++, 0.1f, 1.f); m.ab = rand32(m.d, s++, 0.1f);
     return m;

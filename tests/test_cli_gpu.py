@@ -59,6 +59,21 @@ def test_inference_generators_contract(cosy, tmp_path):
     assert vc[0]["tts_speech"].shape[1] == cosy.cfg.mel_frames_for_tokens(src_tok) * cosy.cfg.upsample_total
     long = "Oh my god, it was just last weekend. " * 8
     assert len(list(cosy.inference_zero_shot(long, "I do.", style))) > 1     # split into segments, one yield each
+    # stream=True: the same segment as consecutive chunks (2 s hops); a source longer than hop + overlap tokens gives several
+    _tone(str(tmp_path / "long.wav"), 5.0, 180.0)
+    src_long = load_wav(str(tmp_path / "long.wav"), 16000)
+    n_tok = cosy.frontend.prompt(src_long).speech_tokens.shape[1]
+    assert n_tok >= 240
+    st = list(cosy.inference_vc(src_long, timbre, stream=True))
+    assert len(st) == 1 + (n_tok - 120) // 100 + 1
+    for o in st:
+        c = o["tts_speech"]
+        assert c.dtype == torch.float32 and c.device.type == "cpu" and c.shape[0] == 1 and c.shape[1] > 0
+        assert torch.isfinite(c).all() and float(c.abs().max()) <= 0.99 + 1e-6
+    total = sum(o["tts_speech"].shape[1] for o in st)
+    assert abs(total / cosy.sample_rate - n_tok / cosy.cfg.token_rate) < 0.1
+    short = list(cosy.inference_vc(style, timbre, stream=True))                 # 75 tokens: one (final) chunk
+    assert len(short) == 1 and short[0]["tts_speech"].shape[1] == vc[0]["tts_speech"].shape[1]
 
 
 def test_tts_with_rag_driver_end_to_end(cosy, tmp_path, golden_dir):

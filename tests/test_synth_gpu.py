@@ -517,3 +517,95 @@ def test_fullsize_hift_vocoder_matches_oracle():
     snr = _snr_db(wav_ref, wav)
     print(f"[parity] waveform SNR {snr:.1f} dB")
     assert snr > 40.0
+
+
+def test_stream_render_stage_parity_and_chunk_shapes():
+    """stream=True (astts.synth.stream): the oracle runs the chunked schedule (3 chunks: 230 tokens = hops at 0 and 100 + 30 left
+    over) and records every stage call; each HIP stage is held to the oracle on the oracle's own inputs at every call (the
+    f0 -> phase map amplifies 1e-4 f0 differences over 50 k samples, so stages are compared on identical inputs, as in the
+    one-shot tests); then the HIP engine runs the same schedule end to end: same chunk shapes, finite, clamped."""
+    from astts.synth.model import FlowDecoder, HiftVocoder
+    from astts.synth.stream import StreamConsts, stream_render
+    from oracle import synth as osyn
+
+    cfg, W = _cfg_and_weights()
+    g = torch.Generator().manual_seed(21)
+    tp, n_tok = 16, 230
+    tmp = cfg.mel_frames_for_tokens(tp)
+    ptok = torch.randint(0, cfg.speech_vocab, (1, tp), generator=g)
+    pmel = torch.randn(1, tmp, cfg.mel, generator=g)
+    spk = torch.randn(1, cfg.spk_dim, generator=g)
+    toks = torch.randint(0, cfg.speech_vocab, (n_tok,), generator=g)
+    nh = cfg.nb_harmonics + 1
+    consts = StreamConsts.for_config(cfg)
+    draws = {"z": [], "src": []}
+    rec = {"flow": [], "f0": [], "src": [], "voc": []}
+
+    def o_flow(tok):
+        n = cfg.mel_frames_for_tokens(int(tok.numel()))
+        z = torch.randn(1, tmp + n, cfg.mel, generator=g)
+        draws["z"].append(z)
+        all_tok = torch.cat([ptok, tok.view(1, -1)], 1)
+        mel = osyn.flow_decode(W["flow"], cfg, all_tok, torch.tensor([all_tok.shape[1]]), pmel, spk, z, tmp + n)
+        rec["flow"].append((tok.clone(), mel))
+        return mel
+
+    def o_f0(mel):
+        f = osyn.hift_f0(W["hift"], cfg, mel)
+        rec["f0"].append((mel.clone(), f))
+        return f
+
+    def o_src(f):
+        ph = (torch.rand(1, nh, generator=g) * 2 - 1) * math.pi
+        ph[:, 0] = 0
+        nz = torch.randn(1, f.shape[1] * cfg.upsample_total, nh, generator=g)
+        draws["src"].append((ph, nz))
+        s = osyn.hift_source(W["hift"], cfg, f, ph, nz)
+        rec["src"].append((f.clone(), s))
+        return s
+
+    def o_voc(mel, s):
+        w = osyn.hift_decode(W["hift"], cfg, mel, s)
+        rec["voc"].append((mel.clone(), s.clone(), w))
+        return w
+
+    ref_chunks = list(stream_render(toks, consts, o_flow, o_f0, o_src, o_voc))
+    assert len(ref_chunks) == 3 and [int(t.numel()) for t, _ in rec["flow"]] == [120, 120, 30]
+
+    dev = torch.device(DEV)
+    fd, voc = FlowDecoder(W["flow"], cfg, dev), HiftVocoder(W["hift"], cfg, dev)
+    # stage parity on the oracle's inputs, call by call
+    for i, (tok, mel_ref) in enumerate(rec["flow"]):
+        all_tok = torch.cat([ptok, tok.view(1, -1)], 1).to(dev, torch.int32)
+        mel = fd.decode(all_tok, torch.tensor([all_tok.shape[1]], dtype=torch.int32, device=dev), pmel.to(dev), spk.to(dev),
+                        draws["z"][i].to(dev), tmp + mel_ref.shape[1]).cpu()
+        _close(mel, mel_ref, TOL_MEL, float(mel_ref.abs().max()), f"flow chunk {i}")
+    for i, (mel_in, f_ref) in enumerate(rec["f0"]):
+        _close(voc.f0(mel_in.to(dev)).cpu(), f_ref, TOL_F0, float(f_ref.abs().max()), f"f0 chunk {i}")
+    for i, (f_in, s_ref) in enumerate(rec["src"]):
+        ph, nz = draws["src"][i]
+        assert float((voc.source(f_in.to(dev), ph.to(dev), nz.to(dev)).cpu() - s_ref).abs().max()) < 1e-4
+    for i, (mel_in, s_in, w_ref) in enumerate(rec["voc"]):
+        w = voc.decode(mel_in.to(dev), s_in.to(dev)).cpu()
+        _close(w, w_ref, TOL_WAV, 1.0, f"vocoder chunk {i}")
+        assert _snr_db(w_ref, w) > 40.0
+    # the product schedule end to end on the HIP stages (same draws)
+    it = {"z": iter(draws["z"]), "src": iter(draws["src"])}
+
+    def h_flow(tok):
+        z = next(it["z"])
+        all_tok = torch.cat([ptok, tok.view(1, -1)], 1).to(dev, torch.int32)
+        return fd.decode(all_tok, torch.tensor([all_tok.shape[1]], dtype=torch.int32, device=dev), pmel.to(dev), spk.to(dev), z.to(dev),
+                         z.shape[1])
+
+    def h_src(f):
+        ph, nz = next(it["src"])
+        return voc.source(f, ph.to(dev), nz.to(dev))
+
+    chunks = [c.cpu() for c in stream_render(toks, consts, h_flow, voc.f0, h_src, voc.decode)]
+    assert [tuple(c.shape) for c in chunks] == [tuple(c.shape) for c in ref_chunks]
+    for c in chunks:
+        assert bool(torch.isfinite(c).all()) and float(c.abs().max()) <= cfg.audio_limit + 1e-6
+    total = sum(int(c.shape[1]) for c in chunks)
+    print(f"[parity] stream: {len(chunks)} chunks, {total} samples for {n_tok} tokens ({n_tok / cfg.token_rate:.2f} s -> {total / cfg.sample_rate:.2f} s)")
+    assert abs(total / cfg.sample_rate - n_tok / cfg.token_rate) < 0.1
