@@ -382,22 +382,21 @@ __device__ __forceinline__ unsigned sel_key(float f) {
 }
 
 static constexpr int kSelThreads = 1024;
-__global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restrict__ s_part, int ksplit,
-                                                  int qpad, int nld, int64_t n_all, int c, int seg_len,
-                                                  int* __restrict__ cand_idx,
-                                                  float* __restrict__ cand_s,
-                                                  const float* __restrict__ inv_norm) {
+// body of the selection for query q, segment segy; the c candidates go to cand_idx / cand_s [0, c) (global memory: the
+// stand-alone kernel; LDS: the fused select + re-score kernel)
+__device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all, int c,
+                                                int seg_len, int q, int segy, int* cand_idx, float* cand_s,
+                                                const float* __restrict__ inv_norm) {
     __shared__ float seg[kSelSeg];
     __shared__ float sh_s[kSelThreads];
     __shared__ int sh_i[kSelThreads];
     __shared__ unsigned hist[2048];
     __shared__ int s_sel_bin, s_sel_rem, s_cnt;
-    const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t plane = (size_t)qpad * nld;
     const float* base = s_part + (size_t)q * nld;
     // this block's segment of the row: [seg0, n)
-    const int64_t seg0 = (int64_t)blockIdx.y * seg_len;
+    const int64_t seg0 = (int64_t)segy * seg_len;
     const int64_t n = (seg0 + seg_len < n_all) ? seg0 + seg_len : n_all;
     const int nl = (int)(n - seg0);
     for (int i = tid; i < nl; i += kSelThreads) {
@@ -500,10 +499,16 @@ __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restric
         merge_lists<float>(tl, sh_s, sh_i, c);
     }
     if (tid < c) {
-        const size_t o = ((size_t)q * gridDim.y + blockIdx.y) * 64 + tid;
-        cand_idx[o] = (tl.idx == kNoIdx) ? -1 : tl.idx;
-        cand_s[o] = tl.s;
+        cand_idx[tid] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        cand_s[tid] = tl.s;
     }
+}
+
+__global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all,
+                                                          int c, int seg_len, int* __restrict__ cand_idx, float* __restrict__ cand_s,
+                                                          const float* __restrict__ inv_norm) {
+    const size_t o = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64;
+    knn_select_body(s_part, ksplit, qpad, nld, n_all, c, seg_len, blockIdx.x, blockIdx.y, cand_idx + o, cand_s + o, inv_norm);
 }
 
 // merge the per-segment candidate lists of one query (one wave) into the final top-C
@@ -532,19 +537,19 @@ __global__ __launch_bounds__(64) void knn_select_merge(const int* __restrict__ s
 // 4. fp64 re-score of the candidates (16 waves, one candidate each per round), then wave 0 orders
 // them by the exact score, emits the top-k and certifies the candidate set.
 // ------------------------------------------------------------------------------------------
+// body for query q; cand_idx / cand_s: this query's candidates [0, c) (global memory or LDS)
 template <typename RowT>
-__global__ __launch_bounds__(1024) void knn_rescore_finalize(
-    const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
+__device__ __forceinline__ void knn_rescore_body(
+    const int q, const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
-    const int* __restrict__ cand_idx, const float* __restrict__ cand_s, double err_bound,
+    const int* cand_idx, const float* cand_s, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged) {
     __shared__ double sh_cos[64];
-    const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const double qn = qn64[q];
     for (int ci = wid; ci < c; ci += 16) {
-        const int idx = cand_idx[q * 64 + ci];
+        const int idx = cand_idx[ci];
         double cs = -INFINITY;
         if (idx >= 0) {
             const double dot = wave_dot64<RowT>(qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
@@ -556,10 +561,10 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
     __shared__ int s_exact;
     if (wid == 0) {
     const bool valid = lane < c;
-    const int idx = valid ? cand_idx[q * 64 + lane] : -1;
+    const int idx = valid ? cand_idx[lane] : -1;
     const bool live = valid && idx >= 0;
     const double cs = live ? sh_cos[lane] : -INFINITY;
-    const float ap = live ? cand_s[q * 64 + lane] : INFINITY;
+    const float ap = live ? cand_s[lane] : INFINITY;
     int rank = 0;
     for (int j = 0; j < c; ++j) {
         const double sj = __shfl(cs, j, 64);
@@ -627,6 +632,36 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
         out_score[(int64_t)q * k + tid] = ok ? (float)tl.s : -INFINITY;
         if (out_score64) out_score64[(int64_t)q * k + tid] = ok ? tl.s : -INFINITY;
     }
+}
+
+template <typename RowT>
+__global__ __launch_bounds__(1024) void knn_rescore_finalize(
+    const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
+    const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
+    const int* __restrict__ cand_idx, const float* __restrict__ cand_s, double err_bound,
+    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
+    int* __restrict__ nflag, int* __restrict__ flagged) {
+    const int q = blockIdx.x;
+    knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, cand_idx + q * 64, cand_s + q * 64, err_bound, force_exact,
+                           out_idx, out_score, out_score64, nflag, flagged);
+}
+
+// Selection + re-score in one launch when a query's score row is one segment (N <= 8192) and all queries fit one pass: the
+// candidates stay in LDS (a config-2 search is four dependent launches of 5-9 us each, mostly launch floor: one less).
+template <typename RowT>
+__global__ __launch_bounds__(1024) void knn_select_rescore(
+    const float* __restrict__ s_part, int ksplit, int qpad, int nld, int seg_len, const float* __restrict__ inv_norm,
+    const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
+    const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k, double err_bound,
+    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
+    int* __restrict__ nflag, int* __restrict__ flagged) {
+    __shared__ int f_ci[64];
+    __shared__ float f_cs[64];
+    const int q = blockIdx.x;
+    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm);
+    __syncthreads();
+    knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
+                           out_score64, nflag, flagged);
 }
 
 }  // namespace astts
@@ -929,6 +964,19 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
         }
         const float* sel_inv = (p.gemm && qg >= 64) ? h->inv_norm : nullptr;
         const int sel_ks = (p.gemm && qg >= 64) ? 1 : p.ksplit;
+        if (p.nseg == 1 && nq <= kMaxQPerPass) {      // one segment, one query group: selection + re-score in one launch
+            const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
+            if (h->exact16)
+                hipLaunchKernelGGL((knn_select_rescore<_Float16>), dim3(nq), dim3(1024), 0, st, spart, sel_ks, p.qpad, h->nld, p.seg_len,
+                                   sel_inv, qf, qn, qscale, h->plane16, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force, out_idx,
+                                   out_score, out_score64, nflag, flagged);
+            else
+                hipLaunchKernelGGL((knn_select_rescore<float>), dim3(nq), dim3(1024), 0, st, spart, sel_ks, p.qpad, h->nld, p.seg_len,
+                                   sel_inv, qf, qn, qscale, h->plane32, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force, out_idx,
+                                   out_score, out_score64, nflag, flagged);
+            ASTTS_CHECK_LAUNCH();
+            return ASTTS_OK;
+        }
         if (p.nseg == 1) {
             hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
                                h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv);

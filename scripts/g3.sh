@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_synth_gpu.py -x -q -m gpu -k "stream" -s 2>&1 | grep -E "parity|passed|failed|Error|error" | tail -20
-timeout 900 python -m pytest tests/test_cli_gpu.py -x -q -m gpu -k "contract" 2>&1 | tail -15
+timeout 300 python scripts/knn_small.py 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_knn_gpu.py -x -q -m gpu 2>&1 | tail -3

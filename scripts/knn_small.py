@@ -10,3 +10,10 @@ qs = bank[torch.randint(0, n, (q,), generator=g, device='cuda')].float() + 0.5 *
 oi = torch.empty((q, k), dtype=torch.int64, device='cuda'); os_ = torch.empty((q, k), dtype=torch.float32, device='cuda')
 for _ in range(200): sb.search_device(qs, k, out_idx=oi, out_score=os_)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+N = 2000
+for _ in range(N): sb.search_device(qs, k, out_idx=oi, out_score=os_)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / N
+print(f'config 2 search (N={n}, D={d}, Q={q}, k={k}): {us:.2f} us per search = {q / us * 1e6:.0f} QPS')
