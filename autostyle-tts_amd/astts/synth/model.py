@@ -417,8 +417,7 @@ class _TfmBlock:
         self.ffn_fused = ops.tfm_ffn_fused_supported(c, int(w1.shape[0]))
         self.w1_frag = ops.tfm_pack_frag(self.w1) if self.ffn_fused else None
         self.w2_frag = ops.tfm_pack_frag(self.w2) if self.ffn_fused else None
-        # ... and the attention's output projection + residual as that launch's prologue when the 32-row workgroups fit the chip
-        # in one round (it needs twice the LDS: one workgroup per CU)
+        # ... and the attention's output projection + residual as that launch's prologue
         self.wo_frag = ops.tfm_pack_frag(self.wo) if self.ffn_fused and self.wo.cin in (256, 512) else None
 
     def forward(self, x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
@@ -430,7 +429,7 @@ class _TfmBlock:
             n = ops.layernorm(x, *self.n1, 1e-5, out_dtype=f16)
             qkv = ops.linear(n, self.wqkv, out_dtype=f16)
             a = ops.attn_mha(qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:], self.heads, lens=lens, out_dtype=f16)
-        if self.wo_frag is not None and x.numel() // x.shape[-1] <= 256 * 32:
+        if self.wo_frag is not None:
             return ops.tfm_ffn_fused(x, self.w1, self.w1_frag, self.w2, self.w2_frag, eps=1e-5, attn=a.contiguous(), wo=self.wo, wo_frag=self.wo_frag)
         x = ops.linear(a, self.wo, residual=x)
         if self.ffn_fused:

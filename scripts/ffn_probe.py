@@ -35,7 +35,7 @@ for m in (5504, 11008):
 
 po = ops.PackedWeight(torch.randn(c, 512) / 24, torch.randn(c) * 0.1)
 fo = ops.tfm_pack_frag(po)
-for m in (5504,):
+for m in (5504, 11008, 44032):
     x = torch.randn(m, c, device=dev); at = torch.randn(m, 512, device=dev).half()
     t1 = timed(lambda: ops.tfm_ffn_fused(x, p1, f1, p2, f2, attn=at, wo=po, wo_frag=fo))
     t2 = timed(lambda: ops.tfm_ffn_fused(ops.linear(at, po, residual=x), p1, f1, p2, f2))

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/knn_small.py 2>&1 | tail -3
-timeout 1200 python -m pytest tests/test_knn_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_synth_gpu.py tests/test_bench_shapes_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 300 python scripts/flow_only.py
