@@ -118,6 +118,7 @@ FLOW_RESAMPLE_NONE, FLOW_RESAMPLE_CONV, FLOW_RESAMPLE_DOWN, FLOW_RESAMPLE_UP = r
 
 _SIGS.update({
     "astts_stream_spin": (c_int32, [c_int32, c_void_p]),
+    "astts_stream_chain": (c_int32, [c_int32, c_int32, c_int32, c_void_p]),
     "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
                                     ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
     "astts_flow_destroy": (c_int32, [c_void_p]),
@@ -562,6 +563,59 @@ def concurrent_streams(n: int, priority: int = 0, candidates: int = 16, device=N
             if s not in chosen and (not strict or all(overlaps(s, c) for c in chosen[:protect])):
                 chosen.append(s)
     return chosen
+
+
+def stream_pipe_classes(candidates: int = 12, priority: int = 0, device=None, verbose: bool = False) -> list:
+    """Torch streams grouped by the command-processor pipe their hardware queue sits on: ``[[s, ...], [s, ...], ...]``.
+
+    Two streams on different hardware queues overlap LONG kernels (what ``concurrent_streams`` probes), but queues that share a
+    pipe take turns at every kernel boundary: two LAUNCH CHAINS on such a pair run 2.4x slower EACH (11 us per launch instead of
+    4.6; MI355X / ROCm 7.2: four pipes, streams i and i + 4 of the pool collide).  A decode chain next to the render chain on
+    one pipe is what made three-chain pipelines 152-220 ms per batch.  Probe: two chains of 300 dependent 3-us kernels, one per
+    stream, enqueued from two host threads; a pair is in one class when it takes > 1.6x the slower stream's own time."""
+    import threading
+    import time
+
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    lib = _L()
+    count, us, blocks = 300, 3, 64
+
+    def run(group) -> float:
+        torch.cuda.synchronize(dev)
+
+        def one(st):
+            _lib.check(lib.astts_stream_chain(count, us, blocks, int(st.cuda_stream)))
+            st.synchronize()
+        th = [threading.Thread(target=one, args=(st,)) for st in group]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return (time.perf_counter() - t0) / count
+
+    with torch.cuda.device(dev):
+        pool = [torch.cuda.Stream(device=dev, priority=priority) for _ in range(candidates)]
+        alone = []
+        for st in pool:
+            run([st])                       # first use of a stream creates its queue: out of the way
+            alone.append(min(run([st]), run([st])))
+        classes, reps = [], []
+        for i, st in enumerate(pool):
+            home = None
+            for ci, r in enumerate(reps):
+                if run([pool[r], st]) > 1.6 * max(alone[r], alone[i]):
+                    home = ci
+                    break
+            if home is None:
+                classes.append([st])
+                reps.append(i)
+            else:
+                classes[home].append(st)
+    if verbose:
+        print(f"stream_pipe_classes: {len(pool)} streams on {len(classes)} pipes ({[len(c) for c in classes]} per pipe); "
+              f"a chain alone {min(alone) * 1e6:.1f} us per launch", flush=True)
+    return classes
 
 
 # ---------------------------------------------------------------------------------------------- query embedder (csrc/ops_llm.hip)

@@ -835,7 +835,7 @@ class PipelinedSynth:
     waveform are bit-identical to running it alone (tested)."""
 
     def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None,
-                 cobatch: int = 1, render_depth: int = 1):
+                 cobatch: int = 1, render_depth: int = 1, pipe_classes=None):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
@@ -856,12 +856,26 @@ class PipelinedSynth:
                 st = ops.concurrent_streams(self.depth + 1 + rd, priority=lm_priority, device=dev)
                 self.s_render, extra_render, self.front_stream, self.s_lm = st[0], st[1:rd], st[rd], st[rd + 1:]
             elif lm_priority == render_priority:
-                # streams probed to sit on distinct hardware queues (ops.concurrent_streams), in order of importance: the
-                # render stream, a front stream for the caller's own per-batch work (retrieval, input preparation: run
-                # `submit` under `torch.cuda.stream(pipe.front_stream)` -- an event recorded on a stream that shares its queue
-                # with a busy chain waits behind that chain), then the decode chains
-                st = ops.concurrent_streams(self.depth + 2, priority=lm_priority, device=dev)
-                self.s_render, self.front_stream, self.s_lm = st[0], st[1], st[2:]
+                # One stream per command-processor pipe (ops.stream_pipe_classes: launch chains whose queues share a pipe take
+                # turns at every kernel boundary and run 2.4x slower each), in order of importance: the render stream, the
+                # decode chains, then a front stream for the caller's own per-batch work (retrieval, input preparation: run
+                # `submit` under `torch.cuda.stream(pipe.front_stream)`).  With more streams than pipes the front stream (a
+                # few launches per batch) doubles up with the render stream's pipe, then decode chains double up among
+                # themselves -- never with the render stream.
+                classes = pipe_classes if pipe_classes is not None else ops.stream_pipe_classes(priority=lm_priority, device=dev)
+                firsts = [c[0] for c in classes]
+                need = self.depth + 1
+                if len(firsts) >= need + 1:
+                    self.s_render, self.s_lm, self.front_stream = firsts[0], firsts[1:need], firsts[need]
+                else:
+                    self.s_render = firsts[0]
+                    self.front_stream = classes[0][1] if len(classes[0]) > 1 else None
+                    lm_classes = classes[1:] if len(classes) > 1 else classes
+                    self.s_lm = []
+                    for i in range(self.depth):
+                        cl = lm_classes[i % len(lm_classes)]
+                        j = i // len(lm_classes) + (0 if len(classes) > 1 else 2)
+                        self.s_lm.append(cl[j] if j < len(cl) else torch.cuda.Stream(device=dev, priority=lm_priority))
             else:
                 self.s_lm = [torch.cuda.Stream(device=dev, priority=lm_priority) for _ in range(self.depth)]
                 self.s_render = torch.cuda.Stream(device=dev, priority=render_priority)
@@ -890,11 +904,14 @@ class PipelinedSynth:
         import time
 
         best, best_dt = None, float("inf")
+        with torch.cuda.device(engine.device):
+            classes = ops.stream_pipe_classes(device=engine.device, verbose=verbose)      # one probe for all trials
         for cfg_ in depths:
             cfg_ = cfg_ if isinstance(cfg_, tuple) else (cfg_, 1)
             depth, cob, rdep = (tuple(cfg_) + (1,))[:3]
             for _ in range(trials):
-                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob, render_depth=rdep)
+                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob, render_depth=rdep,
+                           pipe_classes=classes if rdep == 1 else None)
                 with torch.cuda.stream(pipe.front_stream):
                     for _ in range((depth + 1) * cob):
                         if front is not None:

@@ -142,4 +142,15 @@ int astts_stream_spin(int32_t microseconds, astts_stream_t stream) {
     return ASTTS_OK;
 }
 
+/* `count` dependent busy-wait kernels of `microseconds` each on `stream`, one workgroup of `threads` threads per launch x `blocks`
+ * workgroups: a stand-in for a launch chain (LM decode) when probing which streams really run side by side -- two streams
+ * whose hardware queues sit on one command-processor pipe overlap long kernels but take turns at every kernel boundary. */
+int astts_stream_chain(int32_t count, int32_t microseconds, int32_t blocks, astts_stream_t stream) {
+    ASTTS_REQUIRE(count >= 1 && count <= 100000 && microseconds >= 0 && microseconds <= 100000 && blocks >= 1 && blocks <= 65536,
+                  ASTTS_ERR_INVALID, "astts_stream_chain: count=%d microseconds=%d blocks=%d", count, microseconds, blocks);
+    for (int i = 0; i < count; ++i) hipLaunchKernelGGL(astts::spin_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
 }  // extern "C"

@@ -264,7 +264,7 @@ def main():
     # overlap (PipelinedSynth.autotune) -- on this rank's own inputs.
     sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
               inp.z, inp.phase0, inp.noise)
-    pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=max(2, min(args.steps, 8)),
+    pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=max(2, min(args.steps, 8)), verbose=rank == 0 and bool(os.environ.get("ASTTS_BENCH_VERBOSE")),
                                    front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
     n_done = [0]
 
@@ -485,7 +485,7 @@ def main():
         s24 = (inp24.text, inp24.tlen, inp24.spk_style, inp24.style_tok, inp24.ts, inp24.u, inp24.timbre_tok, inp24.timbre_mel,
                inp24.spk_timbre, inp24.z, inp24.phase0, inp24.noise)
         front24 = lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
-        pipe24 = PipelinedSynth.autotune(eng24, s24, depths=(2,), trials=2, steps=4, front=front24)
+        pipe24 = PipelinedSynth.autotune(eng24, s24, depths=(main_pipe.depth,), trials=2, steps=4, front=front24)
         k24 = max(4, min(args.steps, 8))
         with torch.cuda.stream(pipe24.front_stream):
             for _ in range(2):

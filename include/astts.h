@@ -59,6 +59,8 @@ int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* wor
  * hardware queues; two streams that share one never overlap.  The pipelined synthesis uses this probe to pick streams
  * that really run concurrently (astts/synth/model.py: PipelinedSynth). */
 int astts_stream_spin(int32_t microseconds, astts_stream_t stream);
+/* `count` dependent busy-wait launches (`blocks` workgroups, `microseconds` each): a launch-chain stand-in for stream probing */
+int astts_stream_chain(int32_t count, int32_t microseconds, int32_t blocks, astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",

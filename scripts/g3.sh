@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_synth_gpu.py tests/test_bench_shapes_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 python scripts/flow_only.py
+timeout 600 python scripts/phase_probe.py 2>&1 | tail -8

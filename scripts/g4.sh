@@ -1,5 +1,2 @@
-cd /root/repo/scripts/micro
-echo "== cold"; timeout 120 ./decode_chain 8 200 2>&1 | tail -6
-echo "== DC_HOTW=1"; DC_HOTW=1 timeout 120 ./decode_chain 8 200 2>&1 | tail -6
-echo "== DC_KSPLIT=2 cold"; DC_KSPLIT=2 timeout 120 ./decode_chain 8 200 2>&1 | tail -4
-echo "== DC_KSPLIT=2 hot"; DC_KSPLIT=2 DC_HOTW=1 timeout 120 ./decode_chain 8 200 2>&1 | tail -4
+cd $GRAFT_REPO_ROOT
+timeout 300 python scripts/queue_probe.py

@@ -331,6 +331,26 @@ int main(int argc, char** argv) {
             w1 = std::chrono::steady_clock::now();
             printf("B=%d eager, TWO concurrent chains:      %.1f us per step of each chain (wall)\n", b,
                    std::chrono::duration<double, std::micro>(w1 - w0).count() / steps);
+            // N chains (3, 4, 6), each on its own stream and host thread: how far does chain-level concurrency scale?
+            std::vector<Ctx> cs;
+            std::vector<hipStream_t> ss(8);
+            for (int i = 0; i < 8; ++i) {
+                cs.push_back(make_ctx(m, b, 300 + 100 * i));
+                CK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+            }
+            for (int rep = 0; rep < 2; ++rep)
+            for (int nc : {2, 3, 4, 5, 6, 8}) {
+                for (int i = 0; i < nc; ++i) reset(cs[i], ss[i]);
+                CK(hipDeviceSynchronize());
+                w0 = std::chrono::steady_clock::now();
+                std::vector<std::thread> th;
+                for (int i = 0; i < nc; ++i)
+                    th.emplace_back([&, i] { for (int k = 0; k < steps; ++k) enqueue_step(m, cs[i], ss[i], 0); CK(hipStreamSynchronize(ss[i])); });
+                for (auto& t : th) t.join();
+                w1 = std::chrono::steady_clock::now();
+                const double us = std::chrono::duration<double, std::micro>(w1 - w0).count() / steps;
+                printf("B=%d eager, %d concurrent chains: %.1f us per step of each chain (wall) = %.1f us per chain-step\n", b, nc, us, us / nc);
+            }
         }
     }
     return 0;
