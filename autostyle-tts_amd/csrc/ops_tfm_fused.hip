@@ -48,6 +48,7 @@ struct TfmAttnArgs {
     _Float16* out;           // [b, t, heads * 64] fp16
     int b, heads, t;
     float eps, scale;
+    int balance;             // split the key range of the tiles owned by waves 4 / 5 with the otherwise idle waves
 };
 
 __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
@@ -218,11 +219,28 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
         }
     }
 
-    // ---- phase 2: one 32-query tile per wave, keys and values straight from LDS
+    // ---- phase 2: 32-query tiles, keys and values straight from LDS.  Waves 0..3 own tiles 0..3.  Waves w and w + 4 share a
+    // SIMD, so a fifth / sixth tile given whole to waves 4 / 5 would load SIMDs 0 / 1 with 22 key tiles against 11 on SIMDs
+    // 2 / 3: instead the key range of tile 4 (5) is split between waves 4 and 6 (5 and 7) -- four ways over waves 4..7 when there
+    // are five tiles -- and the owner merges the helpers' unnormalised partials through LDS (the staging buffers are free now):
+    // 16.5 tile-units per SIMD.
     const int ntile = qch1 - qch0;
-    if (wid >= ntile) return;
-    const int q0 = (qch0 + wid) * 32;                   // first frame of this wave's query tile
-    _Float16* qrow = sQ + (size_t)(wid * 32) * TF_KS;  // this tile's Q rows; reused as the output transpose buffer below
+    int tile = -1, part = 0, parts = 1;
+    if (wid < 4) {
+        if (wid < ntile) tile = wid;
+    } else if (!a.balance) {
+        if (wid < ntile) tile = wid;
+    } else if (ntile == 5) {
+        tile = 4; part = wid - 4; parts = 4;
+    } else if (ntile == 6) {
+        tile = 4 + (wid & 1); part = (wid - 4) >> 1; parts = 2;
+    }
+    const int nkt = (len + 31) >> 5;                    // key tiles with at least one valid key
+    const int jb0 = tile >= 0 ? (nkt * part / parts) * 32 : 0;
+    const int jb1 = tile >= 0 ? min((nkt * (part + 1) / parts) * 32, len) : 0;
+    const int tsafe = tile >= 0 ? tile : 0;
+    const int q0 = (qch0 + tsafe) * 32;                 // first frame of this wave's query tile
+    _Float16* qrow = sQ + (size_t)(tsafe * 32) * TF_KS;   // this tile's Q rows; reused by its owner as the output transpose buffer
     half8 qf[4];
     {
         const float qscale = a.scale * 1.44269504088896341f;
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
         ot[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    for (int jb = 0; jb < len; jb += 32) {
+    for (int jb = jb0; jb < jb1; jb += 32) {
         float16v st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.0f;
@@ -297,6 +315,35 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
                 ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], ot[dt], 0, 0, 0);
             }
+        }
+    }
+    // ---- helpers hand their partial (O^T, running maximum, running sum) to the tile's owner
+    float* sM = reinterpret_cast<float*>(sA);            // [3 slots][34][64] fp32 in the (now idle) staging buffers
+    if (part > 0) {
+        float* mp = sM + (size_t)(ntile == 5 ? part - 1 : wid - 6) * 34 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            mp[e * 64] = ot[0][e];
+            mp[(16 + e) * 64] = ot[1][e];
+        }
+        mp[32 * 64] = m_run;
+        mp[33 * 64] = l_run;
+    }
+    __syncthreads();
+    if (tile < 0 || part > 0) return;
+    for (int hp = 1; hp < parts; ++hp) {
+        const float* mp = sM + (size_t)(ntile == 5 ? hp - 1 : wid - 4) * 34 * 64 + lane;
+        const float m_p = mp[32 * 64], l_p = mp[33 * 64];
+        const float m_new = fmaxf(m_run, m_p);
+        if (m_new > -INFINITY) {                         // lane-local: a lane's maximum belongs to its query
+            const float sa = __builtin_amdgcn_exp2f(m_run - m_new), sb = __builtin_amdgcn_exp2f(m_p - m_new);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                ot[0][e] = ot[0][e] * sa + mp[e * 64] * sb;
+                ot[1][e] = ot[1][e] * sa + mp[(16 + e) * 64] * sb;
+            }
+            l_run = l_run * sa + l_p * sb;
+            m_run = m_new;
         }
     }
     // ---- O^T (dims on the element index, query on the lane) -> this tile's Q rows in LDS (no longer needed) -> coalesced rows
@@ -683,7 +730,7 @@ int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale};
+    TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale, getenv("ASTTS_TFM_BALANCE") ? atoi(getenv("ASTTS_TFM_BALANCE")) : 1};
     hipStream_t st = (hipStream_t)stream;
     // profiled with the attention kind: ALGORITHMIC flops (q, k, v projected once + attention; the second projection of K and V by
     // the other query half's workgroup is this kernel's overhead, not work)

@@ -1,2 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/phase_probe.py 2>&1 | tail -8
+for i in 1 2; do
+ASTTS_TFM_BALANCE=0 timeout 300 python scripts/tfm_probe.py
+ASTTS_TFM_BALANCE=1 timeout 300 python scripts/tfm_probe.py
+done
+for i in 1 2; do
+ASTTS_TFM_BALANCE=0 timeout 300 python scripts/flow_only.py
+ASTTS_TFM_BALANCE=1 timeout 300 python scripts/flow_only.py
+done
