@@ -246,9 +246,13 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
             }
             __syncthreads();
             if (wid == 0) {
-                const int per = bins >> 6;
+                const int per = bins >> 6;                   // 32 or 16 bins per lane, kept in registers for both walks
+                unsigned hv[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) hv[j] = j < per ? h[lane * per + j] : 0u;
                 unsigned local = 0u;
-                for (int j = 0; j < per; ++j) local += h[lane * per + j];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) local += hv[j];
                 unsigned incl = local;                       // sum over lanes >= lane
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -258,14 +262,18 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
                 const unsigned above = incl - local;
                 if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
                     unsigned acc = above;
-                    for (int j = per - 1; j >= 0; --j) {
-                        const unsigned hcount = h[lane * per + j];
-                        if (acc + hcount >= (unsigned)remaining) {
-                            s_sel_bin[pass] = lane * per + j;
-                            s_sel_rem[pass] = remaining - (int)acc;
-                            break;
+                    bool done = false;
+#pragma unroll
+                    for (int j = 31; j >= 0; --j) {
+                        if (j < per && !done) {
+                            if (acc + hv[j] >= (unsigned)remaining) {
+                                s_sel_bin[pass] = lane * per + j;
+                                s_sel_rem[pass] = remaining - (int)acc;
+                                done = true;
+                            } else {
+                                acc += hv[j];
+                            }
                         }
-                        acc += hcount;
                     }
                 }
             }
@@ -305,29 +313,40 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
         merge_lists<float>(tl, sh_s, sh_i, kk);
     }
     if (wid == 0) {
-        // nucleus: sequential float accumulation in rank order (matches the oracle's definition bit for bit)
+        // nucleus: sequential float accumulation in rank order (matches the oracle's definition bit for bit).  The sorted list
+        // goes through LDS so that the <= 64 loads are independent of the running sum (as __shfl of rank r inside a loop with
+        // `break` every rank cost a dependent ds_bpermute round trip: ~50 of them, 2.5 us of this kernel)
+        sh_s[lane] = tl.s;
+        sh_i[lane] = tl.idx;
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0), then the wave re-converges: the list is visible to every lane
+        __builtin_amdgcn_wave_barrier();
         float cum = 0.0f;
         int cnt = 0;
+        bool open = true;
+#pragma unroll 8
         for (int r = 0; r < kk; ++r) {
-            const float pr = __shfl(tl.s, r, 64);
-            const int ir = __shfl(tl.idx, r, 64);
-            if (ir == kNoIdx) break;
-            if (cum < a.top_p && cnt < a.top_k) {
+            const float pr = sh_s[r];
+            const int ir = sh_i[r];
+            open = open && ir != kNoIdx && cum < a.top_p && cnt < a.top_k;
+            if (open) {
                 cum += pr;
                 ++cnt;
-            } else {
-                break;
             }
         }
         const float target = a.u[bb * 2] * cum;
         float run = 0.0f;
-        int tok = __shfl(tl.idx, cnt > 0 ? cnt - 1 : 0, 64);
+        int tok = sh_i[cnt > 0 ? cnt - 1 : 0];
         bool found = false;
-        for (int r = 0; r < cnt; ++r) {
-            run += __shfl(tl.s, r, 64);
-            if (!found && run > target) {
-                tok = __shfl(tl.idx, r, 64);
-                found = true;
+#pragma unroll 8
+        for (int r = 0; r < kk; ++r) {
+            const float pr = sh_s[r];
+            const int ir = sh_i[r];
+            if (r < cnt) {
+                run += pr;
+                if (!found && run > target) {
+                    tok = ir;
+                    found = true;
+                }
             }
         }
         // repetition check: lane j compares the j-th token of the window (one round trip, not `win` dependent ones)
