@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/sampler_probe.py
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "ras" 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_synth_gpu.py tests/test_lm_step_gpu.py -x -q -m gpu 2>&1 | tail -2
+ASTTS_BENCH_VERBOSE=1 timeout 900 python bench.py --no-24khz --no-cpu-baseline 2>&1 | grep -E "autotune|stream_pipe|Error|error|^\{" | cut -c1-300
