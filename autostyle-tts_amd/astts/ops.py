@@ -129,6 +129,10 @@ _SIGS.update({
 _SIGS.update({   # fused transformer-block front half of the flow estimator (csrc/ops_tfm_fused.hip)
     "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_tfm_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "astts_op_conv_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_conv1d_snake_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "astts_op_conv1d_snake": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
+                                        c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_tfm_ffn_fused_supported": (c_int32, [c_int32, c_int32]),
     "astts_op_tfm_ffn_fused": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
@@ -438,6 +442,38 @@ def attn_mha(q, k, v, heads: int, lens=None, out_dtype=torch.float32) -> torch.T
 
 def tfm_attn_fused_supported(c: int, heads: int, t: int) -> bool:
     return bool(_L().astts_op_tfm_attn_fused_supported(c, heads, t))
+
+
+def conv_pack_frag(w: PackedWeight) -> torch.Tensor:
+    """Conv1d weight image ``[n, taps, cin]`` (``PackedWeight.from_conv1d``) in per-tap MFMA fragment order for ``conv1d_snake``."""
+    assert w.cin == w.cin_pad and w.cin % 16 == 0 and w.n % 32 == 0
+    out = torch.empty((w.taps, w.n, w.cin), dtype=torch.float16, device=w.data.device)
+    _lib.check(_L().astts_op_conv_pack_frag(w.data.data_ptr(), out.data_ptr(), w.n, w.taps, w.cin, _st()))
+    return out
+
+
+def conv1d_snake_supported(c: int, taps: int, dil: int) -> bool:
+    return bool(_L().astts_op_conv1d_snake_supported(c, taps, dil))
+
+
+def conv1d_snake(x: torch.Tensor, w: PackedWeight, w_frag: torch.Tensor, dil: int = 1, alpha: Optional[torch.Tensor] = None,
+                 residual: Optional[torch.Tensor] = None, out_dtype=torch.float32, want_y: bool = True,
+                 acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False):
+    """``conv1d_same(snake_alpha(x)) + bias + residual`` on channels-last ``[B, L, C]`` (C -> C, LDS-staged kernel).  Returns ``y``
+    (``out_dtype``) unless ``want_y`` is False; ``acc`` (fp32, same shape) receives ``(acc if acc_add else 0) + acc_scale * y``."""
+    assert x.dtype in (torch.float32, torch.float16) and x.is_contiguous() and x.dim() == 3
+    b, l, c = x.shape
+    assert w.n == c and w.cin == c and w_frag.shape == (w.taps, c, c)
+    y = torch.empty((b, l, c), dtype=out_dtype, device=x.device) if want_y else None
+    if residual is not None:
+        residual = _f32(residual)
+        assert residual.shape == x.shape
+    if acc is not None:
+        assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.shape == x.shape
+    _lib.check(_L().astts_op_conv1d_snake(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, _p(alpha), w_frag.data_ptr(), _p(w.bias),
+                                          _p(residual), _p(y), 1 if out_dtype == torch.float16 else 0, _p(acc), acc_scale,
+                                          1 if acc_add else 0, b, l, c, w.taps, dil, _st()))
+    return y
 
 
 def tfm_pack_frag(w: PackedWeight) -> torch.Tensor:

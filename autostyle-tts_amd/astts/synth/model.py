@@ -706,16 +706,40 @@ class _ResBlock:
         self.c2 = [PackedWeight.from_conv1d(sd[f"{p}.convs2.{j}.weight"], sd[f"{p}.convs2.{j}.bias"], device) for j in range(len(dils))]
         self.a1 = [_dev(sd[f"{p}.activations1.{j}.alpha"], device) for j in range(len(dils))]
         self.a2 = [_dev(sd[f"{p}.activations2.{j}.alpha"], device) for j in range(len(dils))]
+        # LDS-staged form (ops.conv1d_snake: Snake applied while the input tile is staged, taps as shifted LDS reads, bias /
+        # residual / resblock mean in the epilogue) for the production widths (128 / 256 channels)
+        c = self.c1[0].n
+        self.lds = all(w.n == c and w.cin == c and w.cin == w.cin_pad for w in self.c1 + self.c2) and \
+            all(ops.conv1d_snake_supported(c, k, d) for d in dils)
+        self.f1 = [ops.conv_pack_frag(w) for w in self.c1] if self.lds else None
+        self.f2 = [ops.conv_pack_frag(w) for w in self.c2] if self.lds else None
 
-    def forward(self, x: torch.Tensor, final_alpha: float = 1.0, accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x + sum of branches; the last conv can fold the 1/3 averaging and the running sum of the
-        parallel resblocks into its epilogue: out = (conv + x) ... handled by the caller via alpha."""
+    def forward(self, x: torch.Tensor, acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False) -> Optional[torch.Tensor]:
+        """x + the branches, iteration by iteration: x <- x + conv2(snake(conv1(snake(x)))).  With ``acc`` the last iteration writes
+        ``acc = (acc if acc_add else 0) + acc_scale * x_final`` instead of returning ``x_final`` (the mean over the parallel
+        resblocks / the sum with the up-sampled stream without a launch of their own)."""
         k = self.k
+        n = len(self.dils)
         for j, d in enumerate(self.dils):
-            xt = ops.elementwise(ops.EL_SNAKE, x, p0=self.a1[j])
-            xt = ops.conv1d(xt, self.c1[j], dil=d, pad=d * (k - 1) // 2)
-            xt = ops.elementwise(ops.EL_SNAKE, xt, p0=self.a2[j])
-            x = ops.conv1d(xt, self.c2[j], pad=(k - 1) // 2, residual=x)
+            last = j == n - 1
+            if self.lds:
+                h = ops.conv1d_snake(x.contiguous(), self.c1[j], self.f1[j], dil=d, alpha=self.a1[j], out_dtype=torch.float16)
+                if last and acc is not None:
+                    ops.conv1d_snake(h, self.c2[j], self.f2[j], dil=1, alpha=self.a2[j], residual=x, want_y=False, acc=acc,
+                                     acc_scale=acc_scale, acc_add=acc_add)
+                    return None
+                x = ops.conv1d_snake(h, self.c2[j], self.f2[j], dil=1, alpha=self.a2[j], residual=x)
+            else:
+                xt = ops.elementwise(ops.EL_SNAKE, x, p0=self.a1[j])
+                xt = ops.conv1d(xt, self.c1[j], dil=d, pad=d * (k - 1) // 2)
+                xt = ops.elementwise(ops.EL_SNAKE, xt, p0=self.a2[j])
+                x = ops.conv1d(xt, self.c2[j], pad=(k - 1) // 2, residual=x)
+        if acc is not None:
+            if acc_add:
+                acc.copy_(ops.elementwise(ops.EL_ADD, acc, z=x, s=acc_scale))
+            else:
+                acc.copy_(ops.elementwise(ops.EL_SCALE, x, s=acc_scale))
+            return None
         return x
 
 
@@ -764,12 +788,11 @@ class HiftVocoder:
                 x = torch.cat([x[:, 1:2], x], dim=1)                           # ReflectionPad1d((1, 0)): plumbing
             wd, kd = self.sdowns[i]
             si = ops.conv1d(s_stft, wd, stride=kd // 2, pad=kd // 4) if kd > 1 else ops.conv1d(s_stft, wd)
-            si = self.sres[i].forward(si)
-            x = ops.elementwise(ops.EL_ADD, x, z=si, s=1.0)
-            xs = None
-            for rb in self.res[i]:
-                y = rb.forward(x)
-                xs = ops.elementwise(ops.EL_SCALE, y, s=1.0 / nk) if xs is None else ops.elementwise(ops.EL_ADD, xs, z=y, s=1.0 / nk)
+            x = x.contiguous()
+            self.sres[i].forward(si, acc=x, acc_scale=1.0, acc_add=True)      # x += source resblock(si): the last conv's epilogue
+            xs = torch.empty_like(x)
+            for kk, rb in enumerate(self.res[i]):                            # mean of the parallel resblocks, same way
+                rb.forward(x, acc=xs, acc_scale=1.0 / nk, acc_add=kk > 0)
             x = xs
         x = ops.elementwise(ops.EL_LEAKY, x, s=0.01)
         x = ops.conv1d(x, self.conv_post, pad=3)

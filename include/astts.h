@@ -371,6 +371,19 @@ int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float*
                            int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
                            const float* bo, int32_t k0, astts_stream_t stream);
 
+/* ---- HiFT resblock convolution, LDS-staged (csrc/ops_conv_lds.hip): y = conv1d_same(snake_alpha(x)) + bias + res on
+ * channels-last [b, l, c] activations, c -> c channels (128 or 256), odd taps, dilation dil, zero padding dil*(taps-1)/2 on
+ * both sides.  x fp32 or fp16 (x_f16); alpha fp32 [c] or NULL (no activation: snake(x) = x + sin^2(alpha x) / (alpha + 1e-9));
+ * w_frag: the Conv1d weight re-ordered by astts_op_conv_pack_frag from the astts_op_pack_weight image [c, taps, c]; bias /
+ * res (fp32 [b, l, c]) optional.  Outputs, either or both: y (fp32 or fp16) and acc (fp32): acc = (acc_add ? acc : 0) +
+ * acc_scale * y -- the mean over the parallel resblocks.  Outputs may not alias x (workgroups read halo rows of their
+ * neighbours); res may alias y.  astts_op_conv1d_snake_supported tells whether a shape is served. */
+int astts_op_conv_pack_frag(const void* w_f16, void* out_f16, int32_t rows, int32_t taps, int32_t k, astts_stream_t stream);
+int astts_op_conv1d_snake_supported(int32_t c, int32_t taps, int32_t dil);
+int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, const void* w_frag_f16, const float* bias, const float* res,
+                          void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
+                          int32_t taps, int32_t dil, astts_stream_t stream);
+
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
  * CosyVoice.inference_tts_with_st, tts_with_rag.py:195).  n_steps Euler steps of the U-Net estimator with

@@ -595,3 +595,46 @@ def test_tfm_ffn_fused_with_output_projection(m, k0):
     e_ref, e_two = float((out - ref).abs().max()) / scale, float((out - two).abs().max()) / scale
     assert e_ref < 3e-3 and e_two < 1e-3, (e_ref, e_two)
     assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("c,l,taps,dil", [(128, 700, 3, 1), (128, 700, 7, 3), (128, 515, 11, 5), (128, 40, 11, 5), (256, 300, 3, 1),
+                                          (256, 300, 7, 5), (256, 129, 11, 3), (128, 1, 7, 1)])
+def test_conv1d_snake_matches_definition(c, l, taps, dil):
+    """astts_op_conv1d_snake (LDS-staged Snake + Conv1d + bias + residual + resblock-mean accumulation of the HiFT resblocks) against
+    the fp64 definition: torch conv1d on the Snake-activated input, zero padding, dilation; fp32 and fp16 inputs / outputs; tiles
+    with ragged tails, sequences shorter than the halo, the accumulate form."""
+    import torch.nn.functional as F
+
+    from astts import ops
+
+    g = torch.Generator().manual_seed(c + l + taps + dil)
+    b = 2
+    x = torch.randn(b, l, c, generator=g)
+    alpha = torch.rand(c, generator=g) * 2 + 0.1
+    w = torch.randn(c, c, taps, generator=g) / math.sqrt(c * taps)
+    bias = 0.1 * torch.randn(c, generator=g)
+    res = torch.randn(b, l, c, generator=g)
+    assert ops.conv1d_snake_supported(c, taps, dil) and not ops.conv1d_snake_supported(192, taps, dil) and not ops.conv1d_snake_supported(c, 4, 1)
+    pw = ops.PackedWeight.from_conv1d(w, bias)
+    wf = ops.conv_pack_frag(pw)
+    xs = x.double() + torch.sin(alpha.double() * x.double()) ** 2 / (alpha.double() + 1e-9)
+    ref = F.conv1d(xs.transpose(1, 2), w.double(), bias.double(), dilation=dil, padding=dil * (taps - 1) // 2).transpose(1, 2)
+    scale = float(ref.abs().max())
+    xd, rd = x.to(DEV), res.to(DEV)
+    # snake + conv + bias + residual, fp32 in / out
+    y = ops.conv1d_snake(xd, pw, wf, dil=dil, alpha=alpha.to(DEV), residual=rd).cpu()
+    e = float((y - (ref + res.double()).float()).abs().max()) / scale
+    assert e < 3e-3, e
+    # fp16 input, fp16 output, no activation; accumulate form on top of an existing tensor
+    x16 = xd.half()
+    ref2 = F.conv1d(x16.cpu().double().transpose(1, 2), w.double(), bias.double(), dilation=dil, padding=dil * (taps - 1) // 2).transpose(1, 2)
+    acc0 = torch.randn(b, l, c, generator=g)
+    acc = acc0.to(DEV)
+    y16 = ops.conv1d_snake(x16, pw, wf, dil=dil, out_dtype=torch.float16, acc=acc, acc_scale=1.0 / 3.0, acc_add=True)
+    e2 = float((y16.float().cpu() - ref2.float()).abs().max()) / float(ref2.abs().max())
+    e3 = float((acc.cpu() - (acc0.double() + ref2 / 3.0).float()).abs().max()) / float(ref2.abs().max())
+    assert e2 < 3e-3 and e3 < 3e-3, (e2, e3)
+    # accumulator only (no y), initialising form
+    acc2 = torch.full((b, l, c), 7.0, device=DEV)
+    assert ops.conv1d_snake(x16, pw, wf, dil=dil, want_y=False, acc=acc2, acc_scale=0.5) is None
+    assert float((acc2.cpu() - (0.5 * ref2).float()).abs().max()) / float(ref2.abs().max()) < 3e-3

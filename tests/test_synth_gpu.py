@@ -609,3 +609,34 @@ def test_stream_render_stage_parity_and_chunk_shapes():
     total = sum(int(c.shape[1]) for c in chunks)
     print(f"[parity] stream: {len(chunks)} chunks, {total} samples for {n_tok} tokens ({n_tok / cfg.token_rate:.2f} s -> {total / cfg.sample_rate:.2f} s)")
     assert abs(total / cfg.sample_rate - n_tok / cfg.token_rate) < 0.1
+
+
+def test_hift_vocoder_production_widths_match_oracle():
+    """The vocoder at the PRODUCTION channel widths (hift_base 512: 256- and 128-channel resblocks -> the LDS-staged Snake
+    convolution ops.conv1d_snake, resblock mean and source sum folded into conv epilogues) on a short mel against the oracle, same
+    source signal as in test_hift_vocoder_matches_oracle."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import HiftVocoder
+    from astts.synth.weights import make_hift_weights
+    from oracle import synth as osyn
+
+    cfg = SynthConfig()
+    sd = make_hift_weights(cfg, 3)
+    g = torch.Generator().manual_seed(33)
+    b, tm = 2, 9
+    mel = torch.randn(b, tm, cfg.mel, generator=g)
+    nh = cfg.nb_harmonics + 1
+    phase0 = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    phase0[:, 0] = 0
+    noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
+    voc = HiftVocoder(sd, cfg, torch.device(DEV))
+    assert all(rb.lds for grp in voc.res for rb in grp) and all(rb.lds for rb in voc.sres)
+    f0_ref = osyn.hift_f0(sd, cfg, mel)
+    src_ref = osyn.hift_source(sd, cfg, f0_ref, phase0, noise)
+    wav_ref = osyn.hift_decode(sd, cfg, mel, src_ref)
+    wav = voc.decode(mel.to(DEV), src_ref.to(DEV)).cpu()
+    assert wav.shape == wav_ref.shape == (b, tm * cfg.upsample_total)
+    _close(wav, wav_ref, TOL_WAV, 1.0)
+    snr = _snr_db(wav_ref, wav)
+    print(f"[parity] waveform SNR {snr:.1f} dB")
+    assert snr > 40.0 and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
