@@ -9,10 +9,15 @@
 // astts_op_conv_pack_frag) stream from L2 through registers one (tap, 128-channel slice) ahead.  Epilogue: bias, residual,
 // and the resblock mean (acc_out = [acc_out +] scale * y) in the same pass.
 //
-// Workgroup = BM output frames of one sequence x all C output channels: 8 waves = (BM / 64) x (C / 64), wave tile 64 x 64
+// Workgroup = BM output frames of one sequence x all C output channels: (BM / 64) x (C / 64) waves, wave tile 64 x 64
 // (2 x 2 MFMA 32x32x16 tiles: every A fragment read from LDS feeds two MFMAs, half an LDS fragment per MFMA).
-//   C = 128: BM = 256, tile 306 x 136 halfs = 83 KB;  C = 256: BM = 128, tile 178 x 264 halfs = 94 KB.
+//   C = 128: BM = 128, 4 waves, tile 178 x 136 halfs = 48 KB: TWO workgroups per CU (212 VGPRs), one stages while the other
+//            computes -- with BM = 256 / 8 waves / one workgroup per CU a stage-2 convolution spent ~70 of its 89-140 us in
+//            staging and epilogue with the MFMAs idle;
+//   C = 256: BM = 128, 8 waves, tile 178 x 264 halfs = 94 KB (stage 1: 28 MB tensors, MFMA-heavier).
 #include "common.h"
+
+#include <algorithm>
 
 namespace astts {
 
@@ -35,13 +40,14 @@ __device__ __forceinline__ float snakef(float x, float al, float inv) {
 }
 
 template <int C, int BM>
-__global__ __launch_bounds__(512, 1) void conv_lds(ConvLdsArgs a) {
+__global__ __launch_bounds__((BM / 64) * (C / 64) * 64, (BM / 64) * (C / 64) == 4 ? 2 : 1) void conv_lds(ConvLdsArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 cl_smem[];
     constexpr int RS = C + 8;                         // halfs per staged row
     constexpr int WN = C / 64;                        // waves along the output channels
     constexpr int KC = C / 128;                       // 128-channel slices per tap
+    constexpr int NT = (BM / 64) * (C / 64) * 64;     // threads: one wave per 64 x 64 output tile
     constexpr int CV = C / 4;                         // float4 columns per row
-    constexpr int RPP = 512 / CV;                     // rows staged per pass of the 512 threads
+    constexpr int RPP = NT / CV;                      // rows staged per pass of the workgroup
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const int wn = wid % WN, wm = wid / WN;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(512, 1) void conv_lds(ConvLdsArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) inv[j] = 1.0f / (al[j] + 1e-9f);
         }
-        constexpr int SU = 8;                         // rows per thread in flight
+        constexpr int SU = 12;                        // rows per thread in flight (a 178-row tile in two trips)
         for (int rb = r0; rb < sr; rb += RPP * SU) {
             float4 v[SU];
 #pragma unroll
@@ -144,41 +150,54 @@ __global__ __launch_bounds__(512, 1) void conv_lds(ConvLdsArgs a) {
     }
 
     // ---- epilogue: element e of tile (mt, nt) holds frame wm 64 + mt 32 + (e & 3) + 8 (e >> 2) + 4 hh, the lane's channel is
-    // wn 64 + nt 32 + c: 128-byte row segments
+    // wn 64 + nt 32 + c.  Stored from there a wave instruction writes two 64-byte (fp16) pieces -- 37 of the 78 us of a 3-tap
+    // convolution; instead each wave transposes its tile through its own 8.7 KB of LDS (the input tile is dead) 32 frames at a
+    // time and moves whole rows: 16-byte loads of the residual / accumulator, 16- or 8-byte stores.
+    __syncthreads();                                  // every wave is done reading the staged input
+    float* tr = reinterpret_cast<float*>(cl_smem) + (size_t)wid * 32 * 68;       // [32 frames][64 + 4] fp32, this wave's
+    const int er = lane >> 4, ec = (lane & 15) * 4;   // read-back: 16 lanes per frame, 4 frames per instruction
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + wn * 64 + ec);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int f = wn * 64 + nt * 32 + c;
-        const float bias = a.bias ? a.bias[f] : 0.0f;
+    for (int mt = 0; mt < 2; ++mt) {
+        const int tb = t0 + wm * 64 + mt * 32;        // first frame of this 32-frame slab
+        float4 rv[8], pv[8];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float rv[16];
+        for (int i = 0; i < 8; ++i) {                 // residual / accumulator rows requested before the transpose
+            const int t = tb + er + 4 * i;
+            const int64_t o = (seq + min(t, a.l - 1)) * C + wn * 64 + ec;
+            rv[i] = a.res ? *reinterpret_cast<const float4*>(a.res + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[i] = (a.acc && a.acc_add) ? *reinterpret_cast<const float4*>(a.acc + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int t = t0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const int64_t o = (seq + min(t, a.l - 1)) * C + f;
-                rv[e] = a.res ? a.res[o] : 0.0f;
-            }
-            float pv[16];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int t = t0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const int64_t o = (seq + min(t, a.l - 1)) * C + f;
-                pv[e] = (a.acc && a.acc_add) ? a.acc[o] : 0.0f;
-            }
+            for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * hh) * 68 + nt * 32 + c] = acc[mt][nt][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int t = t0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (t < a.l) {
-                    const int64_t o = (seq + t) * C + f;
-                    const float v = acc[mt][nt][e] + bias + rv[e];
-                    if (a.y) {
-                        if (a.y_f16) ((_Float16*)a.y)[o] = (_Float16)v;
-                        else ((float*)a.y)[o] = v;
+        for (int i = 0; i < 8; ++i) {
+            const int t = tb + er + 4 * i;
+            const float4 v4 = *reinterpret_cast<const float4*>(tr + (er + 4 * i) * 68 + ec);
+            if (t < a.l) {
+                const int64_t o = (seq + t) * C + wn * 64 + ec;
+                const float4 v = make_float4(v4.x + bias4.x + rv[i].x, v4.y + bias4.y + rv[i].y, v4.z + bias4.z + rv[i].z, v4.w + bias4.w + rv[i].w);
+                if (a.y) {
+                    if (a.y_f16) {
+                        half4 h4;
+                        h4[0] = (_Float16)v.x; h4[1] = (_Float16)v.y; h4[2] = (_Float16)v.z; h4[3] = (_Float16)v.w;
+                        *reinterpret_cast<half4*>((_Float16*)a.y + o) = h4;
+                    } else {
+                        *reinterpret_cast<float4*>((float*)a.y + o) = v;
                     }
-                    if (a.acc) a.acc[o] = pv[e] + a.acc_scale * v;
                 }
+                if (a.acc)
+                    *reinterpret_cast<float4*>(a.acc + o) = make_float4(pv[i].x + a.acc_scale * v.x, pv[i].y + a.acc_scale * v.y,
+                                                                        pv[i].z + a.acc_scale * v.z, pv[i].w + a.acc_scale * v.w);
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // the read-back is complete before the next slab overwrites the buffer
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -225,13 +244,14 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
     ASTTS_REQUIRE(x && w_frag_f16 && (y || acc), ASTTS_ERR_INVALID, "astts_op_conv1d_snake: null pointer");
     ASTTS_REQUIRE(astts_op_conv1d_snake_supported(c, taps, dil), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_conv1d_snake: c=%d taps=%d dil=%d (c 128 or 256, odd taps, halo <= 25)", c, taps, dil);
-    ASTTS_REQUIRE(b >= 1 && l >= 1 && (((uintptr_t)x | (uintptr_t)w_frag_f16 | (uintptr_t)alpha) & 15) == 0, ASTTS_ERR_INVALID,
+    ASTTS_REQUIRE(b >= 1 && l >= 1 && (((uintptr_t)x | (uintptr_t)w_frag_f16 | (uintptr_t)alpha | (uintptr_t)bias | (uintptr_t)res |
+                                        (uintptr_t)y | (uintptr_t)acc) & 15) == 0, ASTTS_ERR_INVALID,
                   "astts_op_conv1d_snake: bad shape b=%d l=%d or operands not 16-byte aligned", b, l);
     ASTTS_REQUIRE(x != y && x != (const void*)acc, ASTTS_ERR_INVALID, "astts_op_conv1d_snake: the output may not alias the input (halo rows)");
     static bool attr = false;
     if (!attr) {
         attr = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     }
     ConvLdsArgs a{x, alpha, (const _Float16*)w_frag_f16, bias, res, y, acc, l, taps, dil, x_f16, y_f16, acc_add, acc_scale};
@@ -239,10 +259,10 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
     const int halo = dil * (taps - 1) / 2;
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * l * c * c * taps);
     if (c == 128) {
-        const size_t lds = (size_t)(256 + 2 * halo) * (128 + 8) * sizeof(_Float16);
-        hipLaunchKernelGGL((conv_lds<128, 256>), dim3((unsigned)((l + 255) / 256), b), dim3(512), lds, st, a);
+        const size_t lds = std::max((size_t)(128 + 2 * halo) * (128 + 8) * sizeof(_Float16), (size_t)4 * 32 * 68 * sizeof(float));   // input tile | 4 waves' transpose buffers
+        hipLaunchKernelGGL((conv_lds<128, 128>), dim3((unsigned)((l + 127) / 128), b), dim3(256), lds, st, a);
     } else {
-        const size_t lds = (size_t)(128 + 2 * halo) * (256 + 8) * sizeof(_Float16);
+        const size_t lds = std::max((size_t)(128 + 2 * halo) * (256 + 8) * sizeof(_Float16), (size_t)8 * 32 * 68 * sizeof(float));
         hipLaunchKernelGGL((conv_lds<256, 128>), dim3((unsigned)((l + 127) / 128), b), dim3(512), lds, st, a);
     }
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
