@@ -184,11 +184,18 @@ struct Ctx {
     }
 
     // BasicTransformerBlock: x (in p) -> result back in p, q is scratch of the same size
-    int tfm(const astts_flow_tfm_t& w, float* p, float* q, const int* lens, int t) const {
+    // `next_w` / `next_bytes`: the weight image the launch AFTER this block reads first (the next block's q|k|v image, or the next
+    // ResNet's first convolution): prefetched into L2 by the feed-forward launch
+    int tfm(const astts_flow_tfm_t& w, float* p, float* q, const int* lens, int t, const void* next_w = nullptr, uint32_t next_bytes = 0) const {
         const int C = h->cfg.channels, heads = h->cfg.heads, hd = heads * 64;
         const int64_t rows = (int64_t)b2 * t;
         if (w.qkv_frag && astts_op_tfm_attn_fused_supported(C, heads, t)) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
-            RUN(astts_op_tfm_attn_fused(p, w.qkv_frag, w.qkv.bias, lens, B.a16, b2, heads, t, C, 1e-5f, 0.125f, st));
+            // the feed-forward launch that follows streams 1.25 MB of weights no launch has touched since the last Euler step:
+            // requested into L2 from here
+            const void* pf[3] = {w.wo_frag, w.w1_frag, w.w2_frag};
+            const uint32_t pfb[3] = {(uint32_t)((size_t)C * hd * 2), (uint32_t)((size_t)w.w1.n * C * 2), (uint32_t)((size_t)C * w.w1.n * 2)};
+            RUN(astts_op_tfm_attn_fused_pf(p, w.qkv_frag, w.qkv.bias, lens, B.a16, b2, heads, t, C, 1e-5f, 0.125f, pf, pfb,
+                                           (w.wo_frag && w.w1_frag && w.w2_frag) ? 3 : 0, st));
         } else {
             RUN(astts_op_layernorm_ex(p, w.n1_w, w.n1_b, B.n16, 1, rows, C, C, C, 1e-5f, st));
             RUN(linear(B.n16, 1, w.qkv, nullptr, B.qkv16, 1, rows, ASTTS_ACT_NONE));
@@ -199,8 +206,8 @@ struct Ctx {
         // output projection + residual + LayerNorm + W1 + GELU + W2 + residual in one launch (in place on p); faster than the
         // separate projection at every row count measured (5 504: 20.2 vs 26.8 us, 11 008: 36.6 vs 45.0, 44 032: 116 vs 128)
         if (ffn && w.wo_frag && (hd == 256 || hd == 512))
-            return astts_op_tfm_ffn_fused(p, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, B.a16, w.wo_frag, w.wo.bias,
-                                          hd, st);
+            return astts_op_tfm_ffn_fused_pf(p, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, B.a16, w.wo_frag,
+                                             w.wo.bias, hd, next_w, next_bytes, st);
         RUN(linear(B.a16, 1, w.wo, p, q, 0, rows, ASTTS_ACT_NONE));
         if (ffn)      // LayerNorm + W1 + GELU + W2 + residual: one launch
             return astts_op_tfm_ffn_fused(q, w.w1_frag, w.w1.bias, w.w2_frag, w.w2.bias, p, rows, C, w.w1.n, 1e-5f, nullptr, nullptr, nullptr, 0, st);
@@ -324,7 +331,11 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             const astts_flow::Block& blk = h->down[i];
             RUN(k.resnet(blk.res, tproj_of(), block_in, L, tt, other));     // never in place: every GEMM block reads whole input rows
             { float* sw = cur; cur = other; other = sw; }
-            for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
+            for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
+                const bool more = ti + 1 < blk.tfm.size();
+                RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : nullptr,
+                          more ? (uint32_t)(3u * (uint32_t)c.heads * 64u * (uint32_t)C * 2u) : 0u));
+            }
             RUN(k.mask(cur, L, tt, C));
             skips[n_skips] = cur;
             skip_t[n_skips] = tt;
@@ -343,10 +354,18 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             RUN(k.mask(cur, L, tt, C));
             block_in = cur;
         }
-        for (const astts_flow::Block& blk : h->mid) {
+        for (size_t mi = 0; mi < h->mid.size(); ++mi) {
+            const astts_flow::Block& blk = h->mid[mi];
             RUN(k.resnet(blk.res, tproj_of(), cur, L, tt, other));
             float* sw = cur; cur = other; other = sw;
-            for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
+            for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
+                const bool more = ti + 1 < blk.tfm.size();
+                // after the last transformer block of a mid block comes the next mid block's first convolution
+                const astts_weight_t* nc = (!more && mi + 1 < h->mid.size()) ? &h->mid[mi + 1].res.c1 : nullptr;
+                RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : (nc ? nc->w : nullptr),
+                          more ? (uint32_t)(3u * (uint32_t)c.heads * 64u * (uint32_t)C * 2u)
+                               : (nc ? (uint32_t)((size_t)nc->n * nc->taps * nc->cin_pad * 2) : 0u)));
+            }
             RUN(k.mask(cur, L, tt, C));
         }
         const float* up_src = cur;          // [b2, up_t >= skip t, C] with batch stride up_bs
@@ -360,7 +379,11 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
                                skips[n_skips], L, B.xin, b2, tt, C);
             ASTTS_CHECK_LAUNCH();
             RUN(k.resnet(blk.res, tproj_of(), B.xin, L, tt, cur));
-            for (const astts_flow_tfm_t& w : blk.tfm) RUN(k.tfm(w, cur, other, L, tt));
+            for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
+                const bool more = ti + 1 < blk.tfm.size();
+                RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : nullptr,
+                          more ? (uint32_t)(3u * (uint32_t)c.heads * 64u * (uint32_t)C * 2u) : 0u));
+            }
             RUN(k.mask(cur, L, tt, C));
             if (blk.kind == ASTTS_FLOW_RESAMPLE_UP) {
                 // phase-decomposed ConvTranspose1d: [b2 * (tt + 1), 2C] == [b2, 2 (tt + 1), C]; output step j is row 1 + j

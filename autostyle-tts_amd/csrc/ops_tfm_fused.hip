@@ -49,6 +49,8 @@ struct TfmAttnArgs {
     int b, heads, t;
     float eps, scale;
     int balance;             // split the key range of the tiles owned by waves 4 / 5 with the otherwise idle waves
+    const char* pf[3];       // L2 prefetch of the NEXT launch's weights (cold otherwise: every block has its own): up to three ranges,
+    unsigned pf_bytes[3];    // touched one 128-byte line per thread by the workgroups of each XCD at the start of phase 2
 };
 
 __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
@@ -235,6 +237,20 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
     } else if (ntile == 6) {
         tile = 4 + (wid & 1); part = (wid - 4) >> 1; parts = 2;
     }
+    unsigned pf_sink = 0;
+    {   // the workgroups of one XCD (ids congruent mod 8) split each range between them; the loaded words are only "used" by a
+        // never-true test at the very end (so that the wait lands there)
+        const unsigned slot = blockIdx.x >> 3, nslots = max(gridDim.x >> 3, 1u);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned lines = (a.pf_bytes[r] + 127) >> 7;
+            const unsigned per = (lines + nslots - 1) / nslots;
+            for (unsigned i = tid; i < per; i += 512) {
+                const unsigned ln = slot * per + i;
+                if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf[r] + ((size_t)ln << 7));
+            }
+        }
+    }
     const int nkt = (len + 31) >> 5;                    // key tiles with at least one valid key
     const int jb0 = tile >= 0 ? (nkt * part / parts) * 32 : 0;
     const int jb1 = tile >= 0 ? min((nkt * (part + 1) / parts) * 32, len) : 0;
@@ -367,6 +383,7 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
         if (fr < T)
             *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + r * TF_KS + seg);
     }
+    if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = (_Float16)0.0f;     // never true: keeps the prefetch loads alive
 }
 
 // row-major fp16 [rows][k] (astts_op_pack_weight image) -> fragment order [rows / 32][k / 16 k-steps][64 lanes][8]:
@@ -420,6 +437,8 @@ struct TfmFfnArgs {
     int64_t m;
     int hidden, k0;
     float eps;
+    const char* pf;          // L2 prefetch of the next launch's weights (one range), touched one 128-byte line per thread
+    unsigned pf_bytes;
 };
 
 // WO: the attention's output projection + residual (the launch between tfm_attn_fused and this one: 8.5 us + boundary) runs as a
@@ -558,6 +577,16 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
     }
     __syncthreads();
 
+    unsigned pf_sink = 0;
+    {   // workgroups of one XCD (ids congruent mod 8) split the range; see tfm_attn_fused
+        const unsigned slot = blockIdx.x >> 3, nslots = max((gridDim.x + 7) >> 3, 1u);
+        const unsigned lines = (a.pf_bytes + 127) >> 7;
+        const unsigned per = (lines + nslots - 1) / nslots;
+        for (unsigned i = tid; i < per; i += 512) {
+            const unsigned ln = slot * per + i;
+            if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf + ((size_t)ln << 7));
+        }
+    }
     float16v acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
@@ -656,6 +685,7 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
         const int64_t row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (row < a.m) a.out[row * TF_C + f] = (xr[e] + b2) + acc2[e];
     }
+    if (pf_sink == 0x9e3779b9u && a.m < 0) a.out[0] = 0.0f;               // never true: keeps the prefetch loads alive
 }
 
 }  // namespace astts
@@ -681,6 +711,13 @@ int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden) {
 int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
                            int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
                            const float* bo, int32_t k0, astts_stream_t stream) {
+    return astts_op_tfm_ffn_fused_pf(x, w1_frag_f16, b1, w2_frag_f16, b2, out, m, c, hidden, eps, attn_f16, wo_frag_f16, bo, k0, nullptr, 0,
+                                     stream);
+}
+
+int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
+                              int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
+                              const float* bo, int32_t k0, const void* pf_ptr, uint32_t pf_bytes, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w1_frag_f16 && w2_frag_f16 && out, ASTTS_ERR_INVALID, "astts_op_tfm_ffn_fused: null pointer");
     ASTTS_REQUIRE(astts_op_tfm_ffn_fused_supported(c, hidden), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_tfm_ffn_fused: c=%d hidden=%d (channels 256, hidden a multiple of 256 <= 4096)", c, hidden);
@@ -702,7 +739,12 @@ int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float) + (wo ? 32 * 260 * sizeof(float) : 0);
     TfmFfnArgs a{x, (const _Float16*)w1_frag_f16, b1, (const _Float16*)w2_frag_f16, b2, out, (const _Float16*)attn_f16,
-                 (const _Float16*)wo_frag_f16, bo, m, hidden, k0, eps};
+                 (const _Float16*)wo_frag_f16, bo, m, hidden, k0, eps, nullptr, 0u};
+    static const bool pf_on = !(getenv("ASTTS_TFM_PREFETCH") && atoi(getenv("ASTTS_TFM_PREFETCH")) == 0);
+    if (pf_ptr && pf_on) {
+        a.pf = (const char*)pf_ptr;
+        a.pf_bytes = pf_bytes;
+    }
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden + (wo ? 2.0 * (double)m * TF_C * k0 : 0.0));
     if (wo) hipLaunchKernelGGL(tfm_ffn_fused<true>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(tfm_ffn_fused<false>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
@@ -718,6 +760,13 @@ int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t) {
 
 int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream) {
+    return astts_op_tfm_attn_fused_pf(x, wqkv_frag_f16, bias, lens, out_f16, b, heads, t, c, eps, scale, nullptr, nullptr, 0, stream);
+}
+
+int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+                               int32_t heads, int32_t t, int32_t c, float eps, float scale, const void* const* pf_ptrs,
+                               const uint32_t* pf_bytes, int32_t n_pf, astts_stream_t stream) {
+    ASTTS_REQUIRE(n_pf >= 0 && n_pf <= 3 && (n_pf == 0 || (pf_ptrs && pf_bytes)), ASTTS_ERR_INVALID, "astts_op_tfm_attn_fused_pf: n_pf=%d", n_pf);
     ASTTS_REQUIRE(x && wqkv_frag_f16 && out_f16, ASTTS_ERR_INVALID, "astts_op_tfm_attn_fused: null pointer");
     ASTTS_REQUIRE(astts_op_tfm_attn_fused_supported(c, heads, t), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_tfm_attn_fused: c=%d heads=%d t=%d (channels 256, t <= %d)", c, heads, t, TF_MAX_T);
@@ -730,7 +779,13 @@ int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale, getenv("ASTTS_TFM_BALANCE") ? atoi(getenv("ASTTS_TFM_BALANCE")) : 1};
+    TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale, getenv("ASTTS_TFM_BALANCE") ? atoi(getenv("ASTTS_TFM_BALANCE")) : 1,
+                  {nullptr, nullptr, nullptr}, {0u, 0u, 0u}};
+    static const bool pf_on = !(getenv("ASTTS_TFM_PREFETCH") && atoi(getenv("ASTTS_TFM_PREFETCH")) == 0);
+    for (int i = 0; i < n_pf && pf_on; ++i) {
+        a.pf[i] = (const char*)pf_ptrs[i];
+        a.pf_bytes[i] = pf_ptrs[i] ? pf_bytes[i] : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     // profiled with the attention kind: ALGORITHMIC flops (q, k, v projected once + attention; the second projection of K and V by
     // the other query half's workgroup is this kernel's overhead, not work)

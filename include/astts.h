@@ -357,6 +357,11 @@ int astts_op_tfm_pack_frag(const void* w_f16, void* out_f16, int32_t rows, int32
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);
 int astts_op_tfm_attn_fused(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
                             int32_t heads, int32_t t, int32_t c, float eps, float scale, astts_stream_t stream);
+/* Same, plus an L2 prefetch of up to three ranges (the NEXT launch's weights -- every block has its own, cold in L2): touched one
+ * 128-byte line per thread while the attention phase runs. */
+int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const float* bias, const int32_t* lens, void* out_f16, int32_t b,
+                               int32_t heads, int32_t t, int32_t c, float eps, float scale, const void* const* pf_ptrs,
+                               const uint32_t* pf_bytes, int32_t n_pf, astts_stream_t stream);
 
 /* The feed-forward half of the same block in one launch: out = x' + W2 gelu(W1 LayerNorm(x') + b1) + b2, x / out fp32 [m, c]
  * (out may alias x).  LayerNorm scale / shift folded into w1 / b1 by the caller; the weights in fragment order
@@ -370,6 +375,10 @@ int astts_op_tfm_ffn_fused_supported(int32_t c, int32_t hidden);
 int astts_op_tfm_ffn_fused(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
                            int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
                            const float* bo, int32_t k0, astts_stream_t stream);
+/* Same, plus an L2 prefetch of one range (the next launch's weights). */
+int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const float* b1, const void* w2_frag_f16, const float* b2, float* out,
+                              int64_t m, int32_t c, int32_t hidden, float eps, const void* attn_f16, const void* wo_frag_f16,
+                              const float* bo, int32_t k0, const void* pf_ptr, uint32_t pf_bytes, astts_stream_t stream);
 
 /* ---- HiFT resblock convolution, LDS-staged (csrc/ops_conv_lds.hip): y = conv1d_same(snake_alpha(x)) + bias + res on
  * channels-last [b, l, c] activations, c -> c channels (128 or 256), odd taps, dilation dil, zero padding dil*(taps-1)/2 on

@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/conv_probe.py 2>&1 | tail -6
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_synth_gpu.py -x -q -m gpu -k "tfm or flow" 2>&1 | tail -2
+for i in 1 2; do
+ASTTS_TFM_PREFETCH=0 timeout 300 python scripts/flow_only.py
+ASTTS_TFM_PREFETCH=1 timeout 300 python scripts/flow_only.py
+done
