@@ -129,6 +129,10 @@ _SIGS.update({
 _SIGS.update({   # fused transformer-block front half of the flow estimator (csrc/ops_tfm_fused.hip)
     "astts_op_tfm_attn_fused_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_tfm_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    # the flow engine's forms (L2 prefetch of the next launch's weights): called from C++, declared here for the ABI table
+    "astts_op_tfm_attn_fused_pf": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p, c_void_p, c_int32, c_void_p]),
+    "astts_op_tfm_ffn_fused_pf": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_void_p, ctypes.c_uint32, c_void_p]),
     "astts_op_conv_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_conv1d_snake_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_conv1d_snake": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
