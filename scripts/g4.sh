@@ -1,4 +1,2 @@
-cd /root/repo; export TMPDIR=/tmp
-rm -rf /tmp/trh && HIFT_N=2 rocprofv3 --kernel-trace -d /tmp/trh -o tr --output-format csv -- python3 scripts/hift_only.py > gpurun_out/hift_trace.log 2>&1
-tail -1 gpurun_out/hift_trace.log
-python scripts/trace_summary.py /tmp/trh 45 | grep -v "pack_weight\|pack_frag\|copyBuffer"
+cd /root/repo/scripts/micro
+for pf in 0 1 0 1; do echo "== DC_PF=$pf"; DC_PF=$pf DC_KSPLIT=2 GPU_MAX_HW_QUEUES=8 timeout 200 ./decode_chain 8 200 2>&1 | grep -E "eager:|eager, TWO|eager, 2 conc" | head -3; done
