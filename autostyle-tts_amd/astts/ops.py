@@ -94,7 +94,8 @@ class Weight(ctypes.Structure):
 
 class FlowResnet(ctypes.Structure):
     _fields_ = [("c1", Weight), ("mlp", Weight), ("c2", Weight), ("res", Weight),
-                ("g1_w", c_void_p), ("g1_b", c_void_p), ("g2_w", c_void_p), ("g2_b", c_void_p)]
+                ("g1_w", c_void_p), ("g1_b", c_void_p), ("g2_w", c_void_p), ("g2_b", c_void_p),
+                ("c1_frag", c_void_p), ("c2_frag", c_void_p), ("res_frag", c_void_p)]
 
 
 class FlowTfm(ctypes.Structure):  # astts_flow_tfm_t
@@ -134,6 +135,9 @@ _SIGS.update({   # fused transformer-block front half of the flow estimator (csr
     "astts_op_tfm_ffn_fused_pf": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
                                             c_void_p, ctypes.c_uint32, c_void_p]),
     "astts_op_conv_pack_frag": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_resnet_conv_stats_floats": (c_size_t, [c_int32, c_int32]),
+    "astts_op_resnet_conv_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "astts_op_resnet_conv": (c_int32, [c_void_p] * 14 + [c_int32] * 4 + [c_float, c_void_p]),
     "astts_op_conv1d_snake_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_conv1d_snake": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
                                         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -454,6 +458,27 @@ def conv_pack_frag(w: PackedWeight) -> torch.Tensor:
     out = torch.empty((w.taps, w.n, w.cin), dtype=torch.float16, device=w.data.device)
     _lib.check(_L().astts_op_conv_pack_frag(w.data.data_ptr(), out.data_ptr(), w.n, w.taps, w.cin, _st()))
     return out
+
+
+def resnet_conv_supported(cin: int, cout: int, groups: int, taps: int) -> bool:
+    return bool(_L().astts_op_resnet_conv_supported(cin, cout, groups, taps))
+
+
+def resnet_conv(x: torch.Tensor, w: PackedWeight, w_frag: torch.Tensor, lens=None, in_gn=None, in_add=None, res_gn=None,
+                want_stats: bool = False, eps: float = 1e-5):
+    """One convolution of a ResnetBlock1D with the neighbouring GroupNorm + Mish folded in (csrc/ops_resnet_conv.hip).
+    ``in_gn`` = (stats, gamma, beta): the input is GroupNorm -> Mish (+ ``in_add`` [B, C]) -> mask of ``x`` (applied while staging);
+    ``res_gn`` = (h, stats, gamma, beta): ``mask * mish(GroupNorm(h))`` is added to the output.  Returns ``out`` or ``(out, stats)``."""
+    x = _f32(x)
+    b, t, c = x.shape
+    assert w.n == c and w.cin == c and w_frag.shape == (w.taps, c, c)
+    out = torch.empty_like(x)
+    stats = torch.empty(int(_L().astts_op_resnet_conv_stats_floats(b, t)), dtype=torch.float32, device=x.device) if want_stats else None
+    i_s, i_g, i_b = in_gn if in_gn is not None else (None, None, None)
+    r_h, r_s, r_g, r_b = res_gn if res_gn is not None else (None, None, None, None)
+    _lib.check(_L().astts_op_resnet_conv(x.data_ptr(), w_frag.data_ptr(), _p(w.bias), out.data_ptr(), _p(i_s), _p(i_g), _p(i_b), _p(in_add),
+                                         _p(r_h), _p(r_s), _p(r_g), _p(r_b), _p(stats), _p(lens), b, t, c, w.taps, eps, _st()))
+    return (out, stats) if want_stats else out
 
 
 def conv1d_snake_supported(c: int, taps: int, dil: int) -> bool:

@@ -381,12 +381,25 @@ class _Resnet1D:
         self.c2 = PackedWeight.from_conv1d(sd[p + ".block2.block.0.weight"], sd[p + ".block2.block.0.bias"], device)
         self.g2 = (_dev(sd[p + ".block2.block.1.weight"], device), _dev(sd[p + ".block2.block.1.bias"], device))
         self.res = PackedWeight.from_conv1d(sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"], device)
+        # 256 -> 256 blocks (all mid blocks): three launches with the GroupNorm + Mish passes folded into the convolutions
+        # (ops.resnet_conv) instead of five
+        self.fused = all(w.cin == w.cin_pad for w in (self.c1, self.c2, self.res)) and \
+            ops.resnet_conv_supported(self.c1.cin, self.c1.n, groups, self.c1.taps) and \
+            ops.resnet_conv_supported(self.c2.cin, self.c2.n, groups, self.c2.taps) and \
+            ops.resnet_conv_supported(self.res.cin, self.res.n, groups, self.res.taps)
+        self.c1_frag, self.c2_frag, self.res_frag = ((ops.conv_pack_frag(self.c1), ops.conv_pack_frag(self.c2), ops.conv_pack_frag(self.res))
+                                                     if self.fused else (None, None, None))
 
     def forward(self, x: torch.Tensor, lens: torch.Tensor, temb_mish: torch.Tensor, tproj: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x must already be zero beyond lens (masked).  ``tproj`` [B, C]: this block's time projection when the caller has
         it already (the solver evaluates the time path of all Euler steps up front)."""
         if tproj is None:
             tproj = ops.linear(temb_mish, self.mlp)                              # [B, C]
+        if self.fused:
+            x = x.contiguous()
+            h1, s1 = ops.resnet_conv(x, self.c1, self.c1_frag, lens=lens, want_stats=True)
+            h2, s2 = ops.resnet_conv(h1, self.c2, self.c2_frag, lens=lens, in_gn=(s1, *self.g1), in_add=tproj.contiguous(), want_stats=True)
+            return ops.resnet_conv(x, self.res, self.res_frag, lens=lens, res_gn=(h2, s2, *self.g2))
         h = ops.conv1d(x, self.c1, pad=1)
         h = ops.groupnorm(h, *self.g1, self.groups, 1e-5, lens=lens, mish=True, add_bc=tproj, out_dtype=torch.float16)
         h = ops.conv1d(h, self.c2, pad=1)                                       # fp16 in: only consumer is the MFMA
@@ -580,8 +593,9 @@ class FlowDecoder:
                 return ops.Weight(pw.data.data_ptr(), None if pw.bias is None else pw.bias.data_ptr(), pw.n, pw.cin, pw.cin_pad, pw.taps)
 
             def R(r):
+                fp = [None if f is None else f.data_ptr() for f in (r.c1_frag, r.c2_frag, r.res_frag)]
                 return ops.FlowResnet(W(r.c1), W(r.mlp), W(r.c2), W(r.res), r.g1[0].data_ptr(), r.g1[1].data_ptr(),
-                                      r.g2[0].data_ptr(), r.g2[1].data_ptr())
+                                      r.g2[0].data_ptr(), r.g2[1].data_ptr(), *fp)
 
             def TF(tfms):
                 arr = (ops.FlowTfm * len(tfms))()

@@ -110,6 +110,7 @@ struct Buffers {
     int *lens_full, *lens_half;
     void* gn_ws;
     size_t gn_ws_bytes;
+    float *rstat1, *rstat2;   // astts_op_resnet_conv: per-tile GroupNorm statistics of conv 1 / conv 2
 };
 
 // one carve-up serves astts_flow_workspace_bytes (base == nullptr) and astts_flow_solve
@@ -148,6 +149,8 @@ size_t carve(const astts_flow* h, int b, int t, char* base, Buffers* B) {
     X.lens_half = (int*)take(sizeof(int) * b2);
     X.gn_ws_bytes = astts_op_groupnorm_workspace_bytes((int)b2, t, c.groups);
     X.gn_ws = take(X.gn_ws_bytes > 16 ? X.gn_ws_bytes : 16);
+    X.rstat1 = (float*)take(sizeof(float) * astts_op_resnet_conv_stats_floats((int32_t)b2, t));
+    X.rstat2 = (float*)take(sizeof(float) * astts_op_resnet_conv_stats_floats((int32_t)b2, t));
     return o;
 }
 
@@ -176,6 +179,16 @@ struct Ctx {
     int resnet(const astts_flow_resnet_t& r, const float* tproj, const float* x, const int* lens, int t, float* out) const {
         const int C = h->cfg.channels, G = h->cfg.groups;
         const int64_t rows = (int64_t)b2 * t;
+        if (r.c1_frag && r.c2_frag && r.res_frag && astts_op_resnet_conv_supported(r.c1.cin, r.c1.n, G, r.c1.taps) &&
+            astts_op_resnet_conv_supported(r.c2.cin, r.c2.n, G, r.c2.taps) && astts_op_resnet_conv_supported(r.res.cin, r.res.n, G, r.res.taps)) {
+            // three launches, GroupNorm + Mish folded into the convolutions (ops_resnet_conv.hip)
+            RUN(astts_op_resnet_conv(x, r.c1_frag, r.c1.bias, B.r1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     B.rstat1, lens, b2, t, C, r.c1.taps, 1e-5f, st));
+            RUN(astts_op_resnet_conv(B.r1, r.c2_frag, r.c2.bias, B.r2, B.rstat1, r.g1_w, r.g1_b, tproj, nullptr, nullptr, nullptr, nullptr,
+                                     B.rstat2, lens, b2, t, C, r.c2.taps, 1e-5f, st));
+            return astts_op_resnet_conv(x, r.res_frag, r.res.bias, out, nullptr, nullptr, nullptr, nullptr, B.r2, B.rstat2, r.g2_w, r.g2_b,
+                                        nullptr, lens, b2, t, C, r.res.taps, 1e-5f, st);
+        }
         RUN(gemm(x, 0, r.c1, nullptr, B.r1, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));
         RUN(astts_op_groupnorm_ex(B.r1, lens, r.g1_w, r.g1_b, tproj, B.r1h, 1, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));
         RUN(gemm(B.r1h, 1, r.c2, nullptr, B.r2, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));

@@ -1,0 +1,256 @@
+// ops_resnet_conv.hip -- the three convolutions of a ResnetBlock1D of the flow-matching estimator (the reference's hot loop #3,
+// ConditionalDecoder's ResnetBlock1D = Block1D(conv3 -> GroupNorm -> Mish) x 2 + 1x1 residual conv, behind
+// cosyvoice.inference_tts_with_st, tts_with_rag.py:195) with the two GroupNorm + Mish passes folded INTO them.
+//
+// Why: a ResNet block was five dependent launches -- conv (12.6 us), GroupNorm + Mish (8.7), conv (13.2), GroupNorm + Mish (8.7),
+// 1x1 conv + residual (12.6) -- and a GroupNorm launch is nothing but launch floor (4 us) + one pass over 5.6 MB.  GroupNorm needs
+// whole-sequence statistics, so it cannot simply ride on a GEMM's operand load; split in two it can:
+//   * statistics: the convolution that PRODUCES the tensor reduces its own output tile (exact two-pass mean / M2 in registers:
+//     a wave's 32 x 32 tile is exactly one group's channels) and leaves one (count, mean, M2) triple per (sequence, tile, group);
+//   * normalise + Mish (+ time-embedding add, + length mask): done by the CONSUMER -- while it stages its input tile (conv 2: once
+//     per element, the staged tile serves all output channels) or in its epilogue on the residual operand (1x1 conv) -- after
+//     merging the <= 22 triples of its sequence in a fixed order (Chan's update: deterministic, no atomics).
+// Three launches per block instead of five; nothing else changes (same masks, same statistics over the valid frames only).
+//
+// Kernel: C = 256 -> 256 channels, 1 or 3 taps.  Workgroup = 32 frames of one sequence x all 256 output channels, 8 waves, wave w =
+// output channels 32 w .. 32 w + 31 (= group w).  The (32 + halo) x 256 input tile is staged once in LDS as fp16; every wave
+// streams its own 32-column weight slice (fragment order, astts_op_conv_pack_frag) through registers one tap ahead: no weight
+// byte is fetched twice by a workgroup.  Grid = ceil(T / 32) x sequences (176 workgroups at 16 x 344).
+#include "common.h"
+
+namespace astts {
+
+static constexpr int RC_C = 256;
+static constexpr int RC_RS = RC_C + 8;     // halfs per staged row
+
+__device__ __forceinline__ float rc_mish(float x) {      // as ops_norm_elem.hip: x n / (n + 2), n = e^x (e^x + 2)
+    const float e = __expf(fminf(x, 20.0f));
+    const float n = e * (e + 2.0f);
+    return x > 20.0f ? x : x * n * __frcp_rn(n + 2.0f);
+}
+
+__device__ __forceinline__ float rc_wsum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct RconvArgs {
+    const float* x;           // [b][t][256] fp32 input (conv 1 / 1x1: the block input, already masked; conv 2: conv 1's raw output)
+    const _Float16* w;        // [taps][8][16][64][8] fp16 fragment order
+    const float* bias;        // [256]
+    float* out;               // [b][t][256] fp32
+    // staging transform (conv 2): x <- mask * (mish(GroupNorm(x; in_stats, in_gamma, in_beta)) + in_add[b])
+    const float* in_stats;    // [b][ntile][8][3] (count, mean, M2) triples of x, or null: x is used as it is
+    const float* in_gamma;
+    const float* in_beta;
+    const float* in_add;      // [b][256] or null
+    // epilogue residual (1x1 conv): out += mask * mish(GroupNorm(res; res_stats, res_gamma, res_beta))
+    const float* res;         // [b][t][256] fp32 or null
+    const float* res_stats;
+    const float* res_gamma;
+    const float* res_beta;
+    float* out_stats;         // [b][ntile][8][3]: triples of THIS convolution's output over the valid frames, or null
+    const int* lens;          // [b] valid frames or null (all)
+    int t, taps;
+    float eps;
+};
+
+// merge the per-tile triples of sequence bb, group g, in tile order -> (mean, rstd)
+__device__ __forceinline__ void rc_merge(const float* stats, int bb, int ntile, int g, float eps, float* mean_out, float* rstd_out) {
+    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+    const float* p = stats + ((int64_t)bb * ntile * 8 + g) * 3;
+    for (int i = 0; i < ntile; ++i) {
+        const float nb = p[(int64_t)i * 24], mb = p[(int64_t)i * 24 + 1], qb = p[(int64_t)i * 24 + 2];
+        if (nb > 0.0f) {
+            const float nn = n + nb, d = mb - mean;
+            mean += d * (nb / nn);
+            m2 += qb + d * d * (n * nb / nn);
+            n = nn;
+        }
+    }
+    *mean_out = mean;
+    *rstd_out = rsqrtf((n > 0.0f ? m2 / n : 0.0f) + eps);
+}
+
+__global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 rc_smem[];
+    __shared__ float s_in[8][2], s_res[8][2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int bb = blockIdx.y, t0 = blockIdx.x * 32;
+    const int ntile = gridDim.x;
+    const int halo = (a.taps - 1) / 2;
+    const int sr = 32 + 2 * halo;
+    const int len = a.lens ? min(a.lens[bb], a.t) : a.t;
+    const int64_t seq = (int64_t)bb * a.t;
+
+    // ---- weights of tap 0 first, then the rows
+    half8 wf[2][16];
+    const _Float16* wbase = a.w + ((int64_t)wid * 16 * 64 + lane) * 8;
+    auto load_tap = [&](int tap, half8 (&dst)[16]) {
+        const _Float16* p = wbase + (int64_t)tap * 8 * 16 * 512;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) dst[ks] = *reinterpret_cast<const half8*>(p + (int64_t)ks * 512);
+    };
+    load_tap(0, wf[0]);
+    // 64 threads per row (one float4 each), 8 rows per pass; a thread keeps one column group (4 channels of group col / 32)
+    const int col = (tid & 63) * 4, r0 = tid >> 6;
+    float4 v[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int r = r0 + 8 * u;
+        const int t = t0 - halo + r;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < sr && t >= 0 && t < a.t) v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * RC_C + col);
+    }
+    if (a.taps > 1) load_tap(1, wf[1]);
+    if (a.in_stats && tid < 8) rc_merge(a.in_stats, bb, ntile, tid, a.eps, &s_in[tid][0], &s_in[tid][1]);
+    if (a.res_stats && tid >= 64 && tid < 72) rc_merge(a.res_stats, bb, ntile, tid - 64, a.eps, &s_res[tid - 64][0], &s_res[tid - 64][1]);
+    float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f), ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.in_stats) {
+        ga = *reinterpret_cast<const float4*>(a.in_gamma + col);
+        be = *reinterpret_cast<const float4*>(a.in_beta + col);
+        if (a.in_add) ad = *reinterpret_cast<const float4*>(a.in_add + (int64_t)bb * RC_C + col);
+        __syncthreads();                              // the merged statistics are in LDS
+    }
+    {
+        const float mean = a.in_stats ? s_in[col >> 5][0] : 0.0f, rstd = a.in_stats ? s_in[col >> 5][1] : 1.0f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int r = r0 + 8 * u;
+            const int t = t0 - halo + r;
+            if (r < sr) {
+                float4 o = v[u];
+                if (a.in_stats) {
+                    if (t >= 0 && t < len)
+                        o = make_float4(rc_mish((o.x - mean) * rstd * ga.x + be.x) + ad.x, rc_mish((o.y - mean) * rstd * ga.y + be.y) + ad.y,
+                                        rc_mish((o.z - mean) * rstd * ga.z + be.z) + ad.z, rc_mish((o.w - mean) * rstd * ga.w + be.w) + ad.w);
+                    else
+                        o = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                half4 h4;
+                h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
+                *reinterpret_cast<half4*>(rc_smem + (size_t)r * RC_RS + col) = h4;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- taps: A fragments from LDS (row-shifted), B fragments from registers, next tap's weights on their way
+    float16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const _Float16* arow = rc_smem + (size_t)c * RC_RS + 8 * hh;
+    auto compute_tap = [&](int tap, const half8 (&w)[16]) {
+        const _Float16* ap = arow + (size_t)tap * RC_RS;
+#pragma unroll
+        for (int ks0 = 0; ks0 < 16; ks0 += 8) {
+            half8 af[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const half8*>(ap + 16 * (ks0 + ks));
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], w[ks0 + ks], acc, 0, 0, 0);
+        }
+    };
+    for (int tap = 0; tap < a.taps; tap += 2) {
+        compute_tap(tap, wf[0]);
+        if (tap + 2 < a.taps) load_tap(tap + 2, wf[0]);
+        if (tap + 1 < a.taps) {
+            compute_tap(tap + 1, wf[1]);
+            if (tap + 3 < a.taps) load_tap(tap + 3, wf[1]);
+        }
+    }
+
+    // ---- epilogue: element e = frame t0 + (e & 3) + 8 (e >> 2) + 4 hh, the lane's channel is 32 wid + c (group wid)
+    const int f = wid * 32 + c;
+    const float bias = a.bias ? a.bias[f] : 0.0f;
+    float rmean = 0.0f, rrstd = 1.0f, rg = 1.0f, rb = 0.0f;
+    if (a.res) {
+        rmean = s_res[wid][0]; rrstd = s_res[wid][1];
+        rg = a.res_gamma[f]; rb = a.res_beta[f];
+    }
+    float rv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        rv[e] = (a.res && t < len) ? a.res[(seq + t) * RC_C + f] : 0.0f;
+    }
+    float val[16];
+    float s = 0.0f;
+    int nval = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        val[e] = acc[e] + bias;
+        if (t < len) {
+            s += val[e];
+            ++nval;
+        }
+    }
+    if (a.out_stats) {                                // this tile's (count, mean, M2) over the valid frames: exact two-pass
+        const float cnt = rc_wsum((float)nval);
+        s = rc_wsum(s);
+        const float mean = cnt > 0.0f ? s / cnt : 0.0f;
+        float q = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (t < len) {
+                const float d = val[e] - mean;
+                q += d * d;
+            }
+        }
+        q = rc_wsum(q);
+        if (lane == 0) {
+            float* p = a.out_stats + (((int64_t)bb * ntile + blockIdx.x) * 8 + wid) * 3;
+            p[0] = cnt; p[1] = mean; p[2] = q;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (t < a.t) {
+            float o = val[e];
+            if (a.res && t < len) o += rc_mish((rv[e] - rmean) * rrstd * rg + rb);
+            a.out[(seq + t) * RC_C + f] = o;
+        }
+    }
+}
+
+}  // namespace astts
+
+using namespace astts;
+
+extern "C" {
+
+/* floats of one statistics buffer of astts_op_resnet_conv for b sequences of t frames */
+size_t astts_op_resnet_conv_stats_floats(int32_t b, int32_t t) { return (size_t)b * ((t + 31) / 32) * 8 * 3; }
+
+/* 1 when astts_op_resnet_conv serves this shape: 256 -> 256 channels in 8 groups of 32, 1 or 3 taps */
+int astts_op_resnet_conv_supported(int32_t cin, int32_t cout, int32_t groups, int32_t taps) {
+    return cin == RC_C && cout == RC_C && groups == 8 && (taps == 1 || taps == 3) ? 1 : 0;
+}
+
+int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
+                         const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
+                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t c, int32_t taps,
+                         float eps, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && w_frag_f16 && out && x != out, ASTTS_ERR_INVALID, "astts_op_resnet_conv: null / aliased pointer");
+    ASTTS_REQUIRE(astts_op_resnet_conv_supported(c, c, 8, taps), ASTTS_ERR_UNSUPPORTED, "astts_op_resnet_conv: c=%d taps=%d (256 channels, 1 or 3 taps)", c, taps);
+    ASTTS_REQUIRE(b >= 1 && t >= 1 && (!in_stats || (in_gamma && in_beta)) && (!res || (res_stats && res_gamma && res_beta)),
+                  ASTTS_ERR_INVALID, "astts_op_resnet_conv: b=%d t=%d or a GroupNorm operand without its statistics / scale / shift", b, t);
+    ASTTS_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_f16 | (uintptr_t)out | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)in_add) & 15) == 0,
+                  ASTTS_ERR_INVALID, "astts_op_resnet_conv: operands must be 16-byte aligned");
+    RconvArgs a{x, (const _Float16*)w_frag_f16, bias, out, in_stats, in_gamma, in_beta, in_add, res, res_stats, res_gamma, res_beta, out_stats,
+                lens, t, taps, eps};
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(32 + 2) * RC_RS * sizeof(_Float16);
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * c * c * taps);
+    hipLaunchKernelGGL(rconv_lds, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
+    if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+}  // extern "C"

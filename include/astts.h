@@ -393,6 +393,21 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
                           void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
                           int32_t taps, int32_t dil, astts_stream_t stream);
 
+/* ---- ResnetBlock1D convolutions with the GroupNorm + Mish passes folded in (csrc/ops_resnet_conv.hip): out = conv1d_same(x') +
+ * bias [+ res'] on channels-last fp32 [b, t, 256], 1 or 3 taps, 256 -> 256 channels in 8 groups.
+ *   x'   = x, or (in_stats given) mask * (mish(GroupNorm(x; in_gamma, in_beta)) + in_add[b]) applied while the input tile is staged;
+ *   res' = (res given) mask * mish(GroupNorm(res; res_gamma, res_beta)) added in the epilogue;
+ *   out_stats (optional): (count, mean, M2) of THIS convolution's output per (sequence, 32-frame tile, group) over the valid frames
+ *   -- what a later call takes as in_stats / res_stats (astts_op_resnet_conv_stats_floats(b, t) floats).
+ * mask = (frame < lens[b]); lens NULL = all frames.  A ResNet block is three calls: conv 1 (out_stats), conv 2 (in_stats = those,
+ * out_stats), 1x1 conv (res = conv 2's output, res_stats).  w_frag: astts_op_conv_pack_frag image. */
+size_t astts_op_resnet_conv_stats_floats(int32_t b, int32_t t);
+int astts_op_resnet_conv_supported(int32_t cin, int32_t cout, int32_t groups, int32_t taps);
+int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
+                         const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
+                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t c, int32_t taps,
+                         float eps, astts_stream_t stream);
+
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
  * CosyVoice.inference_tts_with_st, tts_with_rag.py:195).  n_steps Euler steps of the U-Net estimator with
@@ -405,6 +420,8 @@ typedef struct {            /* packed fp16 weight image (astts_op_pack_weight) +
 typedef struct {            /* ResnetBlock1D: conv3 -> GN -> Mish (+ time proj) -> conv3 -> GN -> Mish, + 1x1 res conv */
     astts_weight_t c1, mlp, c2, res;
     const float *g1_w, *g1_b, *g2_w, *g2_b;
+    const void *c1_frag, *c2_frag, *res_frag;   /* astts_op_conv_pack_frag images of c1 / c2 / res for astts_op_resnet_conv (256 -> 256
+                                                 * blocks), or NULL: the five-launch path */
 } astts_flow_resnet_t;
 typedef struct {            /* BasicTransformerBlock: LN -> qkv -> attention -> out (+x) -> LN -> GELU FFN (+x) */
     const float *n1_w, *n1_b, *n3_w, *n3_b;

@@ -638,3 +638,59 @@ def test_conv1d_snake_matches_definition(c, l, taps, dil):
     acc2 = torch.full((b, l, c), 7.0, device=DEV)
     assert ops.conv1d_snake(x16, pw, wf, dil=dil, want_y=False, acc=acc2, acc_scale=0.5) is None
     assert float((acc2.cpu() - (0.5 * ref2).float()).abs().max()) / float(ref2.abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 33, True), (1, 1, False), (2, 688, True)])
+def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged):
+    """A ResnetBlock1D as three astts_op_resnet_conv launches (GroupNorm statistics taken by the producing convolution's epilogue,
+    normalise + Mish + time-embedding add + mask applied by the consumer) against the fp64 definition (oracle semantics: statistics
+    over the valid frames of each sequence) and against the five launches it replaces (conv, groupnorm, conv, groupnorm, conv)."""
+    import torch.nn.functional as F
+
+    from astts import ops
+
+    c, groups = 256, 8
+    g = torch.Generator().manual_seed(b * 100 + t)
+    lens = torch.tensor([t] + [max(1, t - 9 * (i + 1)) for i in range(b - 1)]) if ragged else torch.full((b,), t)
+    m = (torch.arange(t)[None, :] < lens[:, None]).float()[..., None]
+    x = torch.randn(b, t, c, generator=g) * m
+    w1, w2, wr = (torch.randn(c, c, k, generator=g) / math.sqrt(c * k) for k in (3, 3, 1))
+    b1, b2_, br = (0.1 * torch.randn(c, generator=g) for _ in range(3))
+    g1, be1, g2, be2 = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g), 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    tproj = torch.randn(b, c, generator=g)
+
+    def block(h, w, bias, gam, bet):     # conv3 -> GroupNorm over the valid frames -> Mish, masked
+        h = F.conv1d(h.transpose(1, 2), w.double(), bias.double(), padding=w.shape[-1] // 2).transpose(1, 2)
+        out = torch.zeros_like(h)
+        for i in range(b):
+            L = int(lens[i])
+            out[i, :L] = F.mish(F.group_norm(h[i:i + 1, :L].transpose(1, 2), groups, gam.double(), bet.double(), 1e-5)).transpose(1, 2)[0]
+        return out
+
+    xd = x.double()
+    h = block(xd, w1, b1, g1, be1) + tproj.double()[:, None, :] * m.double()
+    h = block(h, w2, b2_, g2, be2)
+    ref = (F.conv1d(xd.transpose(1, 2), wr.double(), br.double()).transpose(1, 2) + h).float()
+
+    dev = torch.device(DEV)
+    p1, p2, pr = ops.PackedWeight.from_conv1d(w1, b1), ops.PackedWeight.from_conv1d(w2, b2_), ops.PackedWeight.from_conv1d(wr, br)
+    f1, f2, fr = ops.conv_pack_frag(p1), ops.conv_pack_frag(p2), ops.conv_pack_frag(pr)
+    xg, lg = x.to(dev), lens.to(dev, torch.int32)
+    gd = [v.to(dev) for v in (g1, be1, g2, be2)]
+    h1, s1 = ops.resnet_conv(xg, p1, f1, lens=lg, want_stats=True)
+    h2, s2 = ops.resnet_conv(h1, p2, f2, lens=lg, in_gn=(s1, gd[0], gd[1]), in_add=tproj.to(dev), want_stats=True)
+    out = ops.resnet_conv(xg, pr, fr, lens=lg, res_gn=(h2, s2, gd[2], gd[3])).cpu()
+    # the five launches it replaces
+    o1 = ops.conv1d(xg, p1, pad=1)
+    o1 = ops.groupnorm(o1, gd[0], gd[1], groups, 1e-5, lens=lg, mish=True, add_bc=tproj.to(dev), out_dtype=torch.float16)
+    o2 = ops.conv1d(o1, p2, pad=1)
+    o2 = ops.groupnorm(o2, gd[2], gd[3], groups, 1e-5, lens=lg, mish=True)
+    five = ops.conv1d(xg, pr, residual=o2).cpu()
+    scale = float(ref.abs().max())
+    for i in range(b):
+        L = int(lens[i])
+        e_ref = float((out[i, :L] - ref[i, :L]).abs().max()) / scale
+        e_five = float((out[i, :L] - five[i, :L]).abs().max()) / scale
+        assert e_ref < 4e-3 and e_five < 4e-3, (i, e_ref, e_five)
+    assert torch.equal(out, ops.resnet_conv(xg, pr, fr, lens=lg, res_gn=(h2, s2, gd[2], gd[3])).cpu())
+    assert bool(torch.isfinite(out).all())
