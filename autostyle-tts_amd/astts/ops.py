@@ -471,8 +471,8 @@ def resnet_conv(x: torch.Tensor, w: PackedWeight, w_frag: torch.Tensor, lens=Non
     ``res_gn`` = (h, stats, gamma, beta): ``mask * mish(GroupNorm(h))`` is added to the output.  Returns ``out`` or ``(out, stats)``."""
     x = _f32(x)
     b, t, c = x.shape
-    assert w.n == c and w.cin == c and w_frag.shape == (w.taps, c, c)
-    out = torch.empty_like(x)
+    assert w.cin == c and w.n == 256 and w_frag.shape == (w.taps, w.n, c)
+    out = torch.empty((b, t, w.n), dtype=torch.float32, device=x.device)
     stats = torch.empty(int(_L().astts_op_resnet_conv_stats_floats(b, t)), dtype=torch.float32, device=x.device) if want_stats else None
     i_s, i_g, i_b = in_gn if in_gn is not None else (None, None, None)
     r_h, r_s, r_g, r_b = res_gn if res_gn is not None else (None, None, None, None)

@@ -183,11 +183,11 @@ struct Ctx {
             astts_op_resnet_conv_supported(r.c2.cin, r.c2.n, G, r.c2.taps) && astts_op_resnet_conv_supported(r.res.cin, r.res.n, G, r.res.taps)) {
             // three launches, GroupNorm + Mish folded into the convolutions (ops_resnet_conv.hip)
             RUN(astts_op_resnet_conv(x, r.c1_frag, r.c1.bias, B.r1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     B.rstat1, lens, b2, t, C, r.c1.taps, 1e-5f, st));
+                                     B.rstat1, lens, b2, t, r.c1.cin, r.c1.taps, 1e-5f, st));
             RUN(astts_op_resnet_conv(B.r1, r.c2_frag, r.c2.bias, B.r2, B.rstat1, r.g1_w, r.g1_b, tproj, nullptr, nullptr, nullptr, nullptr,
-                                     B.rstat2, lens, b2, t, C, r.c2.taps, 1e-5f, st));
+                                     B.rstat2, lens, b2, t, r.c2.cin, r.c2.taps, 1e-5f, st));
             return astts_op_resnet_conv(x, r.res_frag, r.res.bias, out, nullptr, nullptr, nullptr, nullptr, B.r2, B.rstat2, r.g2_w, r.g2_b,
-                                        nullptr, lens, b2, t, C, r.res.taps, 1e-5f, st);
+                                        nullptr, lens, b2, t, r.res.cin, r.res.taps, 1e-5f, st);
         }
         RUN(gemm(x, 0, r.c1, nullptr, B.r1, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));
         RUN(astts_op_groupnorm_ex(B.r1, lens, r.g1_w, r.g1_b, tproj, B.r1h, 1, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));

@@ -20,8 +20,7 @@
 
 namespace astts {
 
-static constexpr int RC_C = 256;
-static constexpr int RC_RS = RC_C + 8;     // halfs per staged row
+static constexpr int RC_C = 256;           // output channels (8 groups of 32); input channels CIN = 256 or 512 (the up blocks' concat)
 
 __device__ __forceinline__ float rc_mish(float x) {      // as ops_norm_elem.hip: x n / (n + 2), n = e^x (e^x + 2)
     const float e = __expf(fminf(x, 20.0f));
@@ -36,8 +35,8 @@ __device__ __forceinline__ float rc_wsum(float v) {
 }
 
 struct RconvArgs {
-    const float* x;           // [b][t][256] fp32 input (conv 1 / 1x1: the block input, already masked; conv 2: conv 1's raw output)
-    const _Float16* w;        // [taps][8][16][64][8] fp16 fragment order
+    const float* x;           // [b][t][cin] fp32 input (conv 1 / 1x1: the block input, already masked; conv 2: conv 1's raw output)
+    const _Float16* w;        // [taps][8][cin / 16][64][8] fp16 fragment order
     const float* bias;        // [256]
     float* out;               // [b][t][256] fp32
     // staging transform (conv 2): x <- mask * (mish(GroupNorm(x; in_stats, in_gamma, in_beta)) + in_add[b])
@@ -73,9 +72,15 @@ __device__ __forceinline__ void rc_merge(const float* stats, int bb, int ntile, 
     *rstd_out = rsqrtf((n > 0.0f ? m2 / n : 0.0f) + eps);
 }
 
+template <int CIN>
 __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 rc_smem[];
     __shared__ float s_in[8][2], s_res[8][2];
+    constexpr int RS = CIN + 8;                       // halfs per staged row
+    constexpr int KC = CIN / 256;                     // 256-channel slices per tap
+    constexpr int TPR = CIN / 4;                      // threads per staged row (one float4 each)
+    constexpr int RPP = 512 / TPR;                    // rows per pass
+    constexpr int NPASS = (34 + RPP - 1) / RPP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const int bb = blockIdx.y, t0 = blockIdx.x * 32;
@@ -85,44 +90,47 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
     const int len = a.lens ? min(a.lens[bb], a.t) : a.t;
     const int64_t seq = (int64_t)bb * a.t;
 
-    // ---- weights of tap 0 first, then the rows
+    // ---- weights of the first unit (tap 0, slice 0) first, then the rows
     half8 wf[2][16];
-    const _Float16* wbase = a.w + ((int64_t)wid * 16 * 64 + lane) * 8;
-    auto load_tap = [&](int tap, half8 (&dst)[16]) {
-        const _Float16* p = wbase + (int64_t)tap * 8 * 16 * 512;
+    const _Float16* wbase = a.w + ((int64_t)wid * (CIN / 16) * 64 + lane) * 8;
+    auto load_unit = [&](int u, half8 (&dst)[16]) {   // unit = tap * KC + slice
+        const int tap = u / KC, kc = u - tap * KC;
+        const _Float16* p = wbase + ((int64_t)tap * 8 * (CIN / 16) + kc * 16) * 512;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) dst[ks] = *reinterpret_cast<const half8*>(p + (int64_t)ks * 512);
     };
-    load_tap(0, wf[0]);
-    // 64 threads per row (one float4 each), 8 rows per pass; a thread keeps one column group (4 channels of group col / 32)
-    const int col = (tid & 63) * 4, r0 = tid >> 6;
-    float4 v[5];
+    const int nunits = a.taps * KC;
+    load_unit(0, wf[0]);
+    // TPR threads per row (one float4 each), RPP rows per pass; a thread keeps one column group (4 channels)
+    const int col = (tid % TPR) * 4, r0 = tid / TPR;
+    float4 v[NPASS];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int r = r0 + 8 * u;
+    for (int u = 0; u < NPASS; ++u) {
+        const int r = r0 + RPP * u;
         const int t = t0 - halo + r;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < sr && t >= 0 && t < a.t) v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * RC_C + col);
+        if (r < sr && t >= 0 && t < a.t) v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * CIN + col);
     }
-    if (a.taps > 1) load_tap(1, wf[1]);
+    if (nunits > 1) load_unit(1, wf[1]);
     if (a.in_stats && tid < 8) rc_merge(a.in_stats, bb, ntile, tid, a.eps, &s_in[tid][0], &s_in[tid][1]);
     if (a.res_stats && tid >= 64 && tid < 72) rc_merge(a.res_stats, bb, ntile, tid - 64, a.eps, &s_res[tid - 64][0], &s_res[tid - 64][1]);
     float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f), ad = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.in_stats) {
+    const bool in_gn = CIN == RC_C && a.in_stats != nullptr;      // the staging transform exists for 256-channel inputs only
+    if (in_gn) {
         ga = *reinterpret_cast<const float4*>(a.in_gamma + col);
         be = *reinterpret_cast<const float4*>(a.in_beta + col);
         if (a.in_add) ad = *reinterpret_cast<const float4*>(a.in_add + (int64_t)bb * RC_C + col);
         __syncthreads();                              // the merged statistics are in LDS
     }
     {
-        const float mean = a.in_stats ? s_in[col >> 5][0] : 0.0f, rstd = a.in_stats ? s_in[col >> 5][1] : 1.0f;
+        const float mean = in_gn ? s_in[(col >> 5) & 7][0] : 0.0f, rstd = in_gn ? s_in[(col >> 5) & 7][1] : 1.0f;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int r = r0 + 8 * u;
+        for (int u = 0; u < NPASS; ++u) {
+            const int r = r0 + RPP * u;
             const int t = t0 - halo + r;
             if (r < sr) {
                 float4 o = v[u];
-                if (a.in_stats) {
+                if (in_gn) {
                     if (t >= 0 && t < len)
                         o = make_float4(rc_mish((o.x - mean) * rstd * ga.x + be.x) + ad.x, rc_mish((o.y - mean) * rstd * ga.y + be.y) + ad.y,
                                         rc_mish((o.z - mean) * rstd * ga.z + be.z) + ad.z, rc_mish((o.w - mean) * rstd * ga.w + be.w) + ad.w);
@@ -131,19 +139,20 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
                 }
                 half4 h4;
                 h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
-                *reinterpret_cast<half4*>(rc_smem + (size_t)r * RC_RS + col) = h4;
+                *reinterpret_cast<half4*>(rc_smem + (size_t)r * RS + col) = h4;
             }
         }
     }
     __syncthreads();
 
-    // ---- taps: A fragments from LDS (row-shifted), B fragments from registers, next tap's weights on their way
+    // ---- (tap, slice) units: A fragments from LDS (row-shifted), B fragments from registers, next unit's weights on their way
     float16v acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    const _Float16* arow = rc_smem + (size_t)c * RC_RS + 8 * hh;
-    auto compute_tap = [&](int tap, const half8 (&w)[16]) {
-        const _Float16* ap = arow + (size_t)tap * RC_RS;
+    const _Float16* arow = rc_smem + (size_t)c * RS + 8 * hh;
+    auto compute_unit = [&](int u, const half8 (&w)[16]) {
+        const int tap = u / KC, kc = u - tap * KC;
+        const _Float16* ap = arow + (size_t)tap * RS + kc * 256;
 #pragma unroll
         for (int ks0 = 0; ks0 < 16; ks0 += 8) {
             half8 af[8];
@@ -153,12 +162,12 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
             for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], w[ks0 + ks], acc, 0, 0, 0);
         }
     };
-    for (int tap = 0; tap < a.taps; tap += 2) {
-        compute_tap(tap, wf[0]);
-        if (tap + 2 < a.taps) load_tap(tap + 2, wf[0]);
-        if (tap + 1 < a.taps) {
-            compute_tap(tap + 1, wf[1]);
-            if (tap + 3 < a.taps) load_tap(tap + 3, wf[1]);
+    for (int u = 0; u < nunits; u += 2) {
+        compute_unit(u, wf[0]);
+        if (u + 2 < nunits) load_unit(u + 2, wf[0]);
+        if (u + 1 < nunits) {
+            compute_unit(u + 1, wf[1]);
+            if (u + 3 < nunits) load_unit(u + 3, wf[1]);
         }
     }
 
@@ -227,17 +236,19 @@ extern "C" {
 /* floats of one statistics buffer of astts_op_resnet_conv for b sequences of t frames */
 size_t astts_op_resnet_conv_stats_floats(int32_t b, int32_t t) { return (size_t)b * ((t + 31) / 32) * 8 * 3; }
 
-/* 1 when astts_op_resnet_conv serves this shape: 256 -> 256 channels in 8 groups of 32, 1 or 3 taps */
+/* 1 when astts_op_resnet_conv serves this shape: 256 or 512 -> 256 channels in 8 groups of 32, 1 or 3 taps */
 int astts_op_resnet_conv_supported(int32_t cin, int32_t cout, int32_t groups, int32_t taps) {
-    return cin == RC_C && cout == RC_C && groups == 8 && (taps == 1 || taps == 3) ? 1 : 0;
+    return (cin == RC_C || cin == 2 * RC_C) && cout == RC_C && groups == 8 && (taps == 1 || taps == 3) ? 1 : 0;
 }
 
 int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
                          const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
-                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t c, int32_t taps,
+                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
                          float eps, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w_frag_f16 && out && x != out, ASTTS_ERR_INVALID, "astts_op_resnet_conv: null / aliased pointer");
-    ASTTS_REQUIRE(astts_op_resnet_conv_supported(c, c, 8, taps), ASTTS_ERR_UNSUPPORTED, "astts_op_resnet_conv: c=%d taps=%d (256 channels, 1 or 3 taps)", c, taps);
+    ASTTS_REQUIRE(astts_op_resnet_conv_supported(cin, RC_C, 8, taps), ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_resnet_conv: cin=%d taps=%d (256 or 512 input channels, 1 or 3 taps)", cin, taps);
+    ASTTS_REQUIRE(!(in_stats && cin != RC_C), ASTTS_ERR_UNSUPPORTED, "astts_op_resnet_conv: the GroupNorm staging transform needs 256 input channels");
     ASTTS_REQUIRE(b >= 1 && t >= 1 && (!in_stats || (in_gamma && in_beta)) && (!res || (res_stats && res_gamma && res_beta)),
                   ASTTS_ERR_INVALID, "astts_op_resnet_conv: b=%d t=%d or a GroupNorm operand without its statistics / scale / shift", b, t);
     ASTTS_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_f16 | (uintptr_t)out | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)in_add) & 15) == 0,
@@ -245,9 +256,10 @@ int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bi
     RconvArgs a{x, (const _Float16*)w_frag_f16, bias, out, in_stats, in_gamma, in_beta, in_add, res, res_stats, res_gamma, res_beta, out_stats,
                 lens, t, taps, eps};
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(32 + 2) * RC_RS * sizeof(_Float16);
-    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * c * c * taps);
-    hipLaunchKernelGGL(rconv_lds, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
+    const size_t lds = (size_t)(32 + 2) * (cin + 8) * sizeof(_Float16);
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * cin * RC_C * taps);
+    if (cin == RC_C) hipLaunchKernelGGL(rconv_lds<256>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(rconv_lds<512>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

@@ -394,7 +394,7 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
                           int32_t taps, int32_t dil, astts_stream_t stream);
 
 /* ---- ResnetBlock1D convolutions with the GroupNorm + Mish passes folded in (csrc/ops_resnet_conv.hip): out = conv1d_same(x') +
- * bias [+ res'] on channels-last fp32 [b, t, 256], 1 or 3 taps, 256 -> 256 channels in 8 groups.
+ * bias [+ res'] on channels-last fp32 x [b, t, cin] -> out [b, t, 256], 1 or 3 taps, cin = 256 or 512 (the staging transform: 256 only).
  *   x'   = x, or (in_stats given) mask * (mish(GroupNorm(x; in_gamma, in_beta)) + in_add[b]) applied while the input tile is staged;
  *   res' = (res given) mask * mish(GroupNorm(res; res_gamma, res_beta)) added in the epilogue;
  *   out_stats (optional): (count, mean, M2) of THIS convolution's output per (sequence, 32-frame tile, group) over the valid frames
@@ -405,7 +405,7 @@ size_t astts_op_resnet_conv_stats_floats(int32_t b, int32_t t);
 int astts_op_resnet_conv_supported(int32_t cin, int32_t cout, int32_t groups, int32_t taps);
 int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
                          const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
-                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t c, int32_t taps,
+                         const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
                          float eps, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler

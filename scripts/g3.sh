@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "resnet_conv" 2>&1 | tail -3
 timeout 900 python -m pytest tests/test_synth_gpu.py tests/test_bench_shapes_gpu.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do timeout 300 python scripts/flow_only.py; done
-timeout 600 bash scripts/g2.sh 2>&1 | grep -E "launches|rconv|groupnorm|gemm_tile<2, 2, 1, 1" | head

@@ -640,8 +640,9 @@ def test_conv1d_snake_matches_definition(c, l, taps, dil):
     assert float((acc2.cpu() - (0.5 * ref2).float()).abs().max()) / float(ref2.abs().max()) < 3e-3
 
 
-@pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 33, True), (1, 1, False), (2, 688, True)])
-def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged):
+@pytest.mark.parametrize("b,t,ragged,cin", [(2, 70, True, 256), (16, 344, False, 256), (3, 33, True, 256), (1, 1, False, 256), (2, 688, True, 256),
+                                             (2, 70, True, 512), (16, 344, False, 512)])
+def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged, cin):
     """A ResnetBlock1D as three astts_op_resnet_conv launches (GroupNorm statistics taken by the producing convolution's epilogue,
     normalise + Mish + time-embedding add + mask applied by the consumer) against the fp64 definition (oracle semantics: statistics
     over the valid frames of each sequence) and against the five launches it replaces (conv, groupnorm, conv, groupnorm, conv)."""
@@ -653,8 +654,8 @@ def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged)
     g = torch.Generator().manual_seed(b * 100 + t)
     lens = torch.tensor([t] + [max(1, t - 9 * (i + 1)) for i in range(b - 1)]) if ragged else torch.full((b,), t)
     m = (torch.arange(t)[None, :] < lens[:, None]).float()[..., None]
-    x = torch.randn(b, t, c, generator=g) * m
-    w1, w2, wr = (torch.randn(c, c, k, generator=g) / math.sqrt(c * k) for k in (3, 3, 1))
+    x = torch.randn(b, t, cin, generator=g) * m                      # cin = 512: the up blocks' [x | skip] concat
+    w1, w2, wr = (torch.randn(c, ci, k, generator=g) / math.sqrt(ci * k) for ci, k in ((cin, 3), (c, 3), (cin, 1)))
     b1, b2_, br = (0.1 * torch.randn(c, generator=g) for _ in range(3))
     g1, be1, g2, be2 = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g), 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
     tproj = torch.randn(b, c, generator=g)
