@@ -16,6 +16,8 @@
 // output channels 32 w .. 32 w + 31 (= group w).  The (32 + halo) x 256 input tile is staged once in LDS as fp16; every wave
 // streams its own 32-column weight slice (fragment order, astts_op_conv_pack_frag) through registers one tap ahead: no weight
 // byte is fetched twice by a workgroup.  Grid = ceil(T / 32) x sequences (176 workgroups at 16 x 344).
+// Tried and dropped: 64 frames x 128 channels per workgroup of four waves (192 workgroups, half the weight stream each): the flow
+// solve got 1.2 ms SLOWER -- as with the split feed-forward form, the weight stream is not what a launch waits for.
 #include "common.h"
 
 namespace astts {
