@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "resnet_conv" 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_synth_gpu.py tests/test_bench_shapes_gpu.py -x -q -m gpu 2>&1 | tail -3
-for i in 1 2; do ASTTS_RCONV_MT=1 timeout 300 python scripts/flow_only.py; timeout 300 python scripts/flow_only.py; done
+PROBE_B=64 PROBE_TS=300 PROBE_ITERS=2 timeout 900 python scripts/fullsize_probe.py 2>&1 | tail -2
+timeout 900 python scripts/ragged_probe.py 2>&1 | tail -3
