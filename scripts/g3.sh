@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-PROBE_B=64 PROBE_TS=300 PROBE_ITERS=2 timeout 900 python scripts/fullsize_probe.py 2>&1 | tail -2
-timeout 900 python scripts/ragged_probe.py 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_synth_gpu.py -x -q -m gpu -k "end_to_end" -s 2>&1 | grep -E "parity|passed|failed|Error|error" | tail -8

@@ -178,11 +178,18 @@ def test_hift_vocoder_matches_oracle():
     assert float(wav.abs().max()) <= cfg.audio_limit + 1e-6
 
 
-def test_engine_end_to_end_shapes_and_stage_parity():
+@pytest.mark.parametrize("sample_rate", [22050, 24000])
+def test_engine_end_to_end_shapes_and_stage_parity(sample_rate):
+    """22 050 Hz is what the reference scripts save (tts_with_rag.py:197); 24 000 Hz is the rate `north_star`'s target names
+    (`value_24khz` in bench.py): the length regulator then makes 93.75 mel frames per second of tokens instead of 86.13 and the NSF
+    source integrates f0 at the other rate -- flow and vocoder held to the oracle at both."""
+    import dataclasses
+
     from astts.synth.model import SynthEngine
     from oracle import synth as osyn
 
     cfg, W = _cfg_and_weights()
+    cfg = dataclasses.replace(cfg, sample_rate=sample_rate)
     eng = SynthEngine(W, cfg, DEV)
     g = torch.Generator().manual_seed(4)
     b, tt, tp, ts = 2, 10, 16, 20
@@ -210,6 +217,14 @@ def test_engine_end_to_end_shapes_and_stage_parity():
     mel_ref = osyn.flow_decode(W["flow"], cfg, all_tok, torch.full((b,), tp + ts), timbre_mel, spk_t, z, tmp + tm)
     _close(mel.cpu(), mel_ref, TOL_MEL, float(mel_ref.abs().max()))
     assert torch.isfinite(wav).all() and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
+    assert tm == int(ts / cfg.token_rate * sample_rate / cfg.hop)
+    # vocoder at this rate: the oracle's mel and source through both decoders (the f0 -> phase map amplifies f0 differences)
+    f0_ref = osyn.hift_f0(W["hift"], cfg, mel_ref)
+    src_ref = osyn.hift_source(W["hift"], cfg, f0_ref, phase0, noise)
+    src = eng.hift.source(d(f0_ref), d(phase0), d(noise)).cpu()
+    assert float((src - src_ref).abs().max()) < 1e-4
+    wav_ref = osyn.hift_decode(W["hift"], cfg, mel_ref, src_ref)
+    _close(eng.hift.decode(d(mel_ref), d(src_ref)).cpu(), wav_ref, TOL_WAV, 1.0, tag=sample_rate)
 
 
 def test_pipelined_batches_are_bit_identical_to_sequential():
