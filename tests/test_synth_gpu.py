@@ -655,3 +655,74 @@ def test_hift_vocoder_production_widths_match_oracle():
     snr = _snr_db(wav_ref, wav)
     print(f"[parity] waveform SNR {snr:.1f} dB")
     assert snr > 40.0 and float(wav.abs().max()) <= cfg.audio_limit + 1e-6
+
+
+def test_stream_pipe_classes_and_autotuned_pipeline():
+    """ops.stream_pipe_classes groups streams by command-processor pipe with a launch-chain probe (queues that share a pipe run
+    chains ~2.4x slower each); PipelinedSynth.autotune builds its pipeline on one stream per pipe.  Properties: every candidate
+    lands in exactly one class, two chains on streams of DIFFERENT classes do not slow each other, and the autotuned pipeline
+    returns the sequential results bit for bit."""
+    import threading
+    import time
+
+    from astts import _lib, ops
+    from astts.synth.model import PipelinedSynth, SynthEngine
+
+    dev = torch.device(DEV)
+    classes = ops.stream_pipe_classes(candidates=8, device=dev)
+    flat = [s for c in classes for s in c]
+    assert len(flat) == 8 and len({s.cuda_stream for s in flat}) == 8 and 1 <= len(classes) <= 8
+    lib = _lib.load()
+
+    def chains(group, count=300):
+        torch.cuda.synchronize()
+
+        def one(st):
+            _lib.check(lib.astts_stream_chain(count, 3, 64, int(st.cuda_stream)))
+            st.synchronize()
+        th = [threading.Thread(target=one, args=(s,)) for s in group]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return (time.perf_counter() - t0) / count
+
+    if len(classes) >= 2:
+        a, b = classes[0][0], classes[1][0]
+        chains([a]); chains([b])
+        alone = max(min(chains([a]), chains([a])), min(chains([b]), chains([b])))
+        both = min(chains([a, b]), chains([a, b]))
+        print(f"[pipes] {len(classes)} pipes; chain alone {alone * 1e6:.1f} us / launch, two chains on two pipes {both * 1e6:.1f} us / launch")
+        assert both < 1.6 * alone
+    cfg, W = _cfg_and_weights()
+    eng = SynthEngine(W, cfg, DEV)
+    g = torch.Generator().manual_seed(17)
+    b, tt, tp, ts = 2, 10, 16, 24
+    d = lambda t, dt=None: t.to(DEV) if dt is None else t.to(DEV, dt)
+    tmp, tm = cfg.mel_frames_for_tokens(tp), cfg.mel_frames_for_tokens(ts)
+    nh = cfg.nb_harmonics + 1
+    ph = (torch.rand(b, nh, generator=g) * 2 - 1) * math.pi
+    ph[:, 0] = 0
+    args = (d(torch.randint(0, cfg.text_vocab, (b, tt), generator=g)), d(torch.full((b,), tt), torch.int32),
+            d(torch.randn(b, cfg.spk_dim, generator=g)), d(torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)), ts,
+            d(torch.rand(ts, b, 2, generator=g)), d(torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)),
+            d(torch.randn(b, tmp, cfg.mel, generator=g)), d(torch.randn(b, cfg.spk_dim, generator=g)),
+            d(torch.randn(b, tmp + tm, cfg.mel, generator=g)), d(ph), d(torch.randn(b, tm * cfg.upsample_total, nh, generator=g)))
+    ref = eng.tts(*args)
+    torch.cuda.synchronize()
+    pipe = PipelinedSynth.autotune(eng, args, depths=(2, 3), trials=1, steps=2)
+    assert pipe.tuned_ms_per_batch > 0 and pipe.front_stream is not None
+    streams = [pipe.s_render, *pipe.s_lm]
+    assert len({s.cuda_stream for s in streams}) == len(streams)
+    with torch.cuda.stream(pipe.front_stream):
+        outs = []
+        for _ in range(5):
+            r = pipe.submit(*args)
+            if r is not None:
+                outs.append(r)
+        outs += pipe.drain()
+    torch.cuda.synchronize()
+    assert len(outs) == 5
+    for o in outs:
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])
