@@ -138,6 +138,7 @@ _SIGS.update({   # fused transformer-block front half of the flow estimator (csr
     "astts_op_resnet_conv_stats_floats": (c_size_t, [c_int32, c_int32]),
     "astts_op_resnet_conv_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "astts_op_resnet_conv": (c_int32, [c_void_p] * 14 + [c_int32] * 4 + [c_float, c_void_p]),
+    "astts_op_resnet_conv_pf": (c_int32, [c_void_p] * 14 + [c_int32] * 4 + [c_float, c_void_p, ctypes.c_uint32, c_void_p]),
     "astts_op_conv1d_snake_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_conv1d_snake": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
                                         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -176,18 +176,22 @@ struct Ctx {
 
     // ResnetBlock1D on x [b2, t, cin] (already masked) -> out [b2, t, C]
     // `tproj` [b2, C]: this block's time projection for the current Euler step (precomputed for all steps by astts_flow_solve)
-    int resnet(const astts_flow_resnet_t& r, const float* tproj, const float* x, const int* lens, int t, float* out) const {
+    // `next_w` / `next_bytes`: the weight image the launch after this block reads first (its first transformer block's q|k|v image)
+    int resnet(const astts_flow_resnet_t& r, const float* tproj, const float* x, const int* lens, int t, float* out,
+               const void* next_w = nullptr, uint32_t next_bytes = 0) const {
         const int C = h->cfg.channels, G = h->cfg.groups;
         const int64_t rows = (int64_t)b2 * t;
         if (r.c1_frag && r.c2_frag && r.res_frag && astts_op_resnet_conv_supported(r.c1.cin, r.c1.n, G, r.c1.taps) &&
             astts_op_resnet_conv_supported(r.c2.cin, r.c2.n, G, r.c2.taps) && astts_op_resnet_conv_supported(r.res.cin, r.res.n, G, r.res.taps)) {
             // three launches, GroupNorm + Mish folded into the convolutions (ops_resnet_conv.hip)
-            RUN(astts_op_resnet_conv(x, r.c1_frag, r.c1.bias, B.r1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     B.rstat1, lens, b2, t, r.c1.cin, r.c1.taps, 1e-5f, st));
-            RUN(astts_op_resnet_conv(B.r1, r.c2_frag, r.c2.bias, B.r2, B.rstat1, r.g1_w, r.g1_b, tproj, nullptr, nullptr, nullptr, nullptr,
-                                     B.rstat2, lens, b2, t, r.c2.cin, r.c2.taps, 1e-5f, st));
-            return astts_op_resnet_conv(x, r.res_frag, r.res.bias, out, nullptr, nullptr, nullptr, nullptr, B.r2, B.rstat2, r.g2_w, r.g2_b,
-                                        nullptr, lens, b2, t, r.res.cin, r.res.taps, 1e-5f, st);
+            // every launch requests the NEXT one's (cold) weights into L2 while it runs
+            auto wbytes = [](const astts_weight_t& w) { return (uint32_t)((size_t)w.n * w.taps * w.cin_pad * 2); };
+            RUN(astts_op_resnet_conv_pf(x, r.c1_frag, r.c1.bias, B.r1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        B.rstat1, lens, b2, t, r.c1.cin, r.c1.taps, 1e-5f, r.c2_frag, wbytes(r.c2), st));
+            RUN(astts_op_resnet_conv_pf(B.r1, r.c2_frag, r.c2.bias, B.r2, B.rstat1, r.g1_w, r.g1_b, tproj, nullptr, nullptr, nullptr, nullptr,
+                                        B.rstat2, lens, b2, t, r.c2.cin, r.c2.taps, 1e-5f, r.res_frag, wbytes(r.res), st));
+            return astts_op_resnet_conv_pf(x, r.res_frag, r.res.bias, out, nullptr, nullptr, nullptr, nullptr, B.r2, B.rstat2, r.g2_w, r.g2_b,
+                                           nullptr, lens, b2, t, r.res.cin, r.res.taps, 1e-5f, next_w, next_bytes, st);
         }
         RUN(gemm(x, 0, r.c1, nullptr, B.r1, 0, rows, t, t, 1, 1, ASTTS_ACT_NONE));
         RUN(astts_op_groupnorm_ex(B.r1, lens, r.g1_w, r.g1_b, tproj, B.r1h, 1, b2, t, C, G, 1e-5f, 1, B.gn_ws, B.gn_ws_bytes, st));
@@ -340,9 +344,10 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
         int tt = t;
         const int* L = B.lens_full;
 
+        const uint32_t qkv_bytes = 3u * (uint32_t)c.heads * 64u * (uint32_t)C * 2u;     // one block's q|k|v image
         for (size_t i = 0; i < h->down.size(); ++i) {
             const astts_flow::Block& blk = h->down[i];
-            RUN(k.resnet(blk.res, tproj_of(), block_in, L, tt, other));     // never in place: every GEMM block reads whole input rows
+            RUN(k.resnet(blk.res, tproj_of(), block_in, L, tt, other, blk.tfm.empty() ? nullptr : blk.tfm[0].qkv_frag, qkv_bytes));     // never in place: every GEMM block reads whole input rows
             { float* sw = cur; cur = other; other = sw; }
             for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
                 const bool more = ti + 1 < blk.tfm.size();
@@ -369,7 +374,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
         }
         for (size_t mi = 0; mi < h->mid.size(); ++mi) {
             const astts_flow::Block& blk = h->mid[mi];
-            RUN(k.resnet(blk.res, tproj_of(), cur, L, tt, other));
+            RUN(k.resnet(blk.res, tproj_of(), cur, L, tt, other, blk.tfm.empty() ? nullptr : blk.tfm[0].qkv_frag, qkv_bytes));
             float* sw = cur; cur = other; other = sw;
             for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
                 const bool more = ti + 1 < blk.tfm.size();
@@ -391,7 +396,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             hipLaunchKernelGGL(flow_concat_skip, dim3(grid_for((int64_t)b2 * tt * 2 * (C / 4))), dim3(256), 0, st, up_src, up_bs,
                                skips[n_skips], L, B.xin, b2, tt, C);
             ASTTS_CHECK_LAUNCH();
-            RUN(k.resnet(blk.res, tproj_of(), B.xin, L, tt, cur));
+            RUN(k.resnet(blk.res, tproj_of(), B.xin, L, tt, cur, blk.tfm.empty() ? nullptr : blk.tfm[0].qkv_frag, qkv_bytes));
             for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
                 const bool more = ti + 1 < blk.tfm.size();
                 RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : nullptr,

@@ -55,6 +55,8 @@ struct RconvArgs {
     const int* lens;          // [b] valid frames or null (all)
     int t, taps;
     float eps;
+    const char* pf;           // L2 prefetch of the next launch's weights (one range; see tfm_attn_fused), or null
+    unsigned pf_bytes;
 };
 
 // merge the per-tile triples of sequence bb, group g, in tile order -> (mean, rstd)
@@ -103,6 +105,17 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
     };
     const int nunits = a.taps * KC;
     load_unit(0, wf[0]);
+    unsigned pf_sink = 0;
+    if (a.pf) {   // workgroups of one XCD (linear ids congruent mod 8) split the range, one 128-byte line per thread
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+        const unsigned slot = lin >> 3, nslots = max((nwg + 7) >> 3, 1u);
+        const unsigned lines = (a.pf_bytes + 127) >> 7;
+        const unsigned per = (lines + nslots - 1) / nslots;
+        for (unsigned i = tid; i < per; i += 512) {
+            const unsigned ln = slot * per + i;
+            if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf + ((size_t)ln << 7));
+        }
+    }
     // TPR threads per row (one float4 each), RPP rows per pass; a thread keeps one column group (4 channels)
     const int col = (tid % TPR) * 4, r0 = tid / TPR;
     float4 v[NPASS];
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
             a.out[(seq + t) * RC_C + f] = o;
         }
     }
+    if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = 0.0f;               // never true: keeps the prefetch loads alive
 }
 
 }  // namespace astts
@@ -247,6 +261,14 @@ int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bi
                          const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
                          const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
                          float eps, astts_stream_t stream) {
+    return astts_op_resnet_conv_pf(x, w_frag_f16, bias, out, in_stats, in_gamma, in_beta, in_add, res, res_stats, res_gamma, res_beta, out_stats,
+                                   lens, b, t, cin, taps, eps, nullptr, 0, stream);
+}
+
+int astts_op_resnet_conv_pf(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
+                            const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
+                            const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
+                            float eps, const void* pf_ptr, uint32_t pf_bytes, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w_frag_f16 && out && x != out, ASTTS_ERR_INVALID, "astts_op_resnet_conv: null / aliased pointer");
     ASTTS_REQUIRE(astts_op_resnet_conv_supported(cin, RC_C, 8, taps), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_resnet_conv: cin=%d taps=%d (256 or 512 input channels, 1 or 3 taps)", cin, taps);
@@ -256,7 +278,12 @@ int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bi
     ASTTS_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_f16 | (uintptr_t)out | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)in_add) & 15) == 0,
                   ASTTS_ERR_INVALID, "astts_op_resnet_conv: operands must be 16-byte aligned");
     RconvArgs a{x, (const _Float16*)w_frag_f16, bias, out, in_stats, in_gamma, in_beta, in_add, res, res_stats, res_gamma, res_beta, out_stats,
-                lens, t, taps, eps};
+                lens, t, taps, eps, nullptr, 0u};
+    static const bool pf_on = !(getenv("ASTTS_TFM_PREFETCH") && atoi(getenv("ASTTS_TFM_PREFETCH")) == 0);
+    if (pf_ptr && pf_on) {
+        a.pf = (const char*)pf_ptr;
+        a.pf_bytes = pf_bytes;
+    }
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(32 + 2) * (cin + 8) * sizeof(_Float16);
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * cin * RC_C * taps);

@@ -407,6 +407,11 @@ int astts_op_resnet_conv(const float* x, const void* w_frag_f16, const float* bi
                          const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
                          const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
                          float eps, astts_stream_t stream);
+/* Same, plus an L2 prefetch of one range (the next launch's weights). */
+int astts_op_resnet_conv_pf(const float* x, const void* w_frag_f16, const float* bias, float* out, const float* in_stats, const float* in_gamma,
+                            const float* in_beta, const float* in_add, const float* res, const float* res_stats, const float* res_gamma,
+                            const float* res_beta, float* out_stats, const int32_t* lens, int32_t b, int32_t t, int32_t cin, int32_t taps,
+                            float eps, const void* pf_ptr, uint32_t pf_bytes, astts_stream_t stream);
 
 /* ---- flow-matching solver engine: the reference's hot loop #3: ConditionalCFM.solve_euler
  * -> ConditionalDecoder.forward (cosyvoice/flow/flow_matching.py + decoder.py [EXT], behind
