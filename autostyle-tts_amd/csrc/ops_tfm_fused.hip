@@ -53,7 +53,9 @@ struct TfmAttnArgs {
     unsigned pf_bytes[3];    // touched one 128-byte line per thread by the workgroups of each XCD at the start of phase 2
 };
 
-__global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
+// The kernel body: workgroup L of 2 * heads * b.  Every wave returns from it (no early exit: tfm_block_fused continues with the
+// feed-forward phase); seq_out / unit_out: this workgroup's sequence and its index (head * 2 + query half) among the sequence's.
+__device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out, int* unit_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
@@ -346,7 +348,9 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
         mp[33 * 64] = l_run;
     }
     __syncthreads();
-    if (tile < 0 || part > 0) return;
+    *seq_out = b;
+    *unit_out = head * 2 + qs;
+    if (!(tile < 0 || part > 0)) {
     for (int hp = 1; hp < parts; ++hp) {
         const float* mp = sM + (size_t)(ntile == 5 ? hp - 1 : wid - 4) * 34 * 64 + lane;
         const float m_p = mp[32 * 64], l_p = mp[33 * 64];
@@ -383,7 +387,13 @@ __global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
         if (fr < T)
             *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + r * TF_KS + seg);
     }
+    }
     if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = (_Float16)0.0f;     // never true: keeps the prefetch loads alive
+}
+
+__global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
+    int seq, unit;
+    tfm_attn_body(a, &seq, &unit);
 }
 
 // row-major fp16 [rows][k] (astts_op_pack_weight image) -> fragment order [rows / 32][k / 16 k-steps][64 lanes][8]:
@@ -444,15 +454,16 @@ struct TfmFfnArgs {
 // WO: the attention's output projection + residual (the launch between tfm_attn_fused and this one: 8.5 us + boundary) runs as a
 // prologue here: x' = x + attn Wo^T + bo is formed in LDS (fp32), normalised from there, and added back in the epilogue; it is
 // never written to memory.
+// The kernel body for the 32-row tile [m0, mend) (mend - m0 <= 32: rows at or beyond mend are neither read as themselves nor
+// written); rot_seed spreads the chunk order over the workgroups of an XCD.
 template <bool WO>
-__global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
+__device__ __forceinline__ void tfm_ffn_body(const TfmFfnArgs& a, const int64_t m0, const int64_t mend, const unsigned rot_seed) {
     extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     _Float16* sA = tf_smem;                          // [32][264] normalised rows
     _Float16* sH = sA + 32 * TF_AS;                  // [2][32][264] one 256-wide chunk of the hidden activations
     float* sB1 = reinterpret_cast<float*>(sH + 2 * 32 * FF_HS);   // [hidden]
-    const int64_t m0 = (int64_t)blockIdx.x * 32;
     const int nchunk = a.hidden >> 8;
     const int ksteps2 = a.hidden >> 4;               // k-steps of a W2 tile
 
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
     const int srow = tid >> 4, sseg = (tid & 15) * 4;
     float4 r[4];
     {
-        const float* p = a.x + min(m0 + srow, a.m - 1) * TF_C + sseg;
+        const float* p = a.x + min(m0 + srow, mend - 1) * TF_C + sseg;
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + 64 * i);
     }
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
     // weights are cold in L2 (56 blocks x 2 MB per estimator pass), and with one common order all workgroups wait for the same
     // HBM lines chunk after chunk; rotated, the whole weight image is requested at once.  (The sum over chunks is taken in that
     // order.)
-    const int rot = (int)((blockIdx.x >> 3) % (unsigned)nchunk);
+    const int rot = (int)(rot_seed % (unsigned)nchunk);
     auto wrap = [&](int j) { return j >= nchunk ? j - nchunk : j; };
     half8 w1f[16], w2f[16];
     const _Float16* w1p = a.w1 + ((int64_t)wid * 16 * 64 + lane) * 8;             // hidden tile 8 j + wid: + j * 8 tiles
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
         const _Float16* wop = a.wo + ((int64_t)wid * (a.k0 >> 4) * 64 + lane) * 8;
         half8 at[4];
         {
-            const _Float16* p = a.attn + min(m0 + srow, a.m - 1) * a.k0 + (tid & 15) * 8;
+            const _Float16* p = a.attn + min(m0 + srow, mend - 1) * a.k0 + (tid & 15) * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i * 128 < a.k0) at[i] = *reinterpret_cast<const half8*>(p + 128 * i);
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int re = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        xr[e] = WO ? sX[re * 260 + f] : a.x[min(m0 + re, a.m - 1) * TF_C + f];
+        xr[e] = WO ? sX[re * 260 + f] : a.x[min(m0 + re, mend - 1) * TF_C + f];
     }
     const float b2 = a.b2 ? a.b2[f] : 0.0f;
     {
@@ -683,9 +694,15 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int64_t row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (row < a.m) a.out[row * TF_C + f] = (xr[e] + b2) + acc2[e];
+        if (row < mend) a.out[row * TF_C + f] = (xr[e] + b2) + acc2[e];
     }
     if (pf_sink == 0x9e3779b9u && a.m < 0) a.out[0] = 0.0f;               // never true: keeps the prefetch loads alive
+}
+
+template <bool WO>
+__global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    tfm_ffn_body<WO>(a, m0, min(m0 + 32, a.m), blockIdx.x >> 3);
 }
 
 }  // namespace astts
