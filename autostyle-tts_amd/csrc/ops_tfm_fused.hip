@@ -53,8 +53,9 @@ struct TfmAttnArgs {
     unsigned pf_bytes[3];    // touched one 128-byte line per thread by the workgroups of each XCD at the start of phase 2
 };
 
-// The kernel body: workgroup L of 2 * heads * b.  Every wave returns from it (no early exit: tfm_block_fused continues with the
-// feed-forward phase); seq_out / unit_out: this workgroup's sequence and its index (head * 2 + query half) among the sequence's.
+// The kernel body: workgroup L of 2 * heads * b.  Every wave returns from it (no early exit, so that a caller can continue in the
+// same launch: the one-launch block kernel measured in DESIGN.md did); seq_out / unit_out: this workgroup's sequence and its index
+// (head * 2 + query half) among the sequence's.
 __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out, int* unit_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
