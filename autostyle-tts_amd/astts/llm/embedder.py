@@ -84,9 +84,11 @@ class LlamaEmbedder:
             self.norm = f("model.norm.weight")
             head = state["model.embed_tokens.weight"] if cfg.tie_embeddings else state["lm_head.weight"]
             self.head = PackedWeight(head, None, dev)
-            inv = llama3_inv_freq(cfg)
-            fr = torch.arange(max(max_length, 16) + 64, dtype=torch.float32)[:, None] * inv[None, :]
-            self.cos, self.sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+            self._rope_tables(max(max_length, 16) + 64)
+
+    def _rope_tables(self, n: int) -> None:
+        fr = torch.arange(n, dtype=torch.float32)[:, None] * llama3_inv_freq(self.cfg)[None, :]
+        self.cos, self.sin = fr.cos().to(self.device).contiguous(), fr.sin().to(self.device).contiguous()
 
     # ------------------------------------------------------------------ the decoder stack
     def hidden(self, ids: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -94,8 +96,8 @@ class LlamaEmbedder:
         (== outputs.hidden_states[-1] of LlamaModel)."""
         cfg = self.cfg
         b, t = ids.shape
-        if t > self.cos.shape[0]:
-            raise ValueError(f"sequence of {t} tokens exceeds the RoPE table ({self.cos.shape[0]})")
+        if t > self.cos.shape[0]:       # the untruncated generation prompt (milvus/search_json.py:178) can exceed max_length
+            self._rope_tables((t + 255) // 256 * 256)
         hq, hk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
         x = ops.embedding(self.embed, ids.to(self.device))
         for L in self.L:
@@ -163,8 +165,12 @@ Answer:"""
         """milvus/search_json.py:154-198: greedy continuation of the few-shot prompt, decoded (prompt included, as there),
         stripped and lower-cased."""
         prompt = self.EMOTION_PROMPT.format(text, text)
-        out = self.generate_greedy(self._encode(prompt), max_new_tokens)
-        return self.tokenizer.decode(out).strip().lower()
+        out = self.generate_greedy(list(self.tokenizer.encode(prompt)), max_new_tokens)     # untruncated: only get_embedding truncates there
+        try:
+            label = self.tokenizer.decode(out, skip_special_tokens=True)                   # search_json.py:191
+        except TypeError:                                                                  # stand-in tokenizers have no special tokens
+            label = self.tokenizer.decode(out)
+        return label.strip().lower()
 
     def combined_embedding(self, emotion_text: str, biography_text: str) -> np.ndarray:
         """milvus/search_json.py:201-229 / src/search_milvus.py:214-221: [emotion | biography] float32, un-normalised."""

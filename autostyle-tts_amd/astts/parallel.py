@@ -48,7 +48,7 @@ def sharded_search(search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, 
     (StyleBank.search_device on GPUs).  Returns the full (idx [Q,k], score [Q,k]) on every rank.
     The ids travel as int64; scores ride along bit-cast inside the same all-gather."""
     nq = queries.shape[0]
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return search_fn(queries, k)
     world, rank = dist.get_world_size(), dist.get_rank()
     b, e, per = shard_bounds(nq, world, rank)
@@ -93,7 +93,7 @@ def bank_sharded_search(local_search_fn: Callable[[torch.Tensor, int], Tuple[tor
     different ranks exactly as the oracle does."""
     idx, sc = local_search_fn(queries, k)
     gidx = torch.where(idx >= 0, idx + int(row_offset), idx)
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return merge_topk(sc.to(torch.float64), gidx, k)
     world = dist.get_world_size()
     packed = torch.cat([gidx, sc.to(torch.float64).contiguous().view(torch.int64)], dim=1).contiguous()     # [Q, 2k] int64

@@ -305,26 +305,27 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
     // ---- the time path of every Euler step, hoisted out of the dependent chain (it depends on the schedule only): time
     // embedding -> MLP -> Mish (every ResnetBlock1D applies Mish before its own projection) for all n_steps x 2B rows in one
     // pass, then ONE projection GEMM per ResNet block over all steps: ~20 launches per solve instead of 21 per step.
-    ASTTS_REQUIRE(n_steps <= FLOW_MAX_STEPS, ASTTS_ERR_INVALID, "astts_flow_solve: n_steps=%d (at most %d)", n_steps, FLOW_MAX_STEPS);
-    const int64_t trows = (int64_t)n_steps * b2;
+    // Solves with more than FLOW_MAX_STEPS steps evaluate it chunk by chunk (the workspace holds FLOW_MAX_STEPS steps).
     for (int s = 0; s < n_steps; ++s) {
-        hipLaunchKernelGGL(flow_fill_time, dim3((b2 + 63) / 64), dim3(64), 0, st, B.tv + (size_t)s * b2, t_host[s], b2);
-        ASTTS_CHECK_LAUNCH();
-    }
-    RUN(astts_op_time_embedding(B.tv, B.temb0, (int)trows, c.time_in, 1000.0f, st));
-    RUN(k.linear(B.temb0, 0, c.t1, nullptr, B.temb1, 0, trows, ASTTS_ACT_SILU));
-    RUN(k.linear(B.temb1, 0, c.t2, nullptr, B.temb2, 0, trows, ASTTS_ACT_NONE));
-    RUN(astts_op_elementwise(ASTTS_EL_MISH, B.temb2, nullptr, nullptr, nullptr, B.temb2, trows * c.time_dim, 1, c.time_dim, 0.0f, 0.0f, st));
-    {
-        size_t ri = 0;
+      const int s0 = s - s % FLOW_MAX_STEPS, sl = s - s0;
+      const int64_t trows = (int64_t)(n_steps - s0 < FLOW_MAX_STEPS ? n_steps - s0 : FLOW_MAX_STEPS) * b2;
+      if (sl == 0) {
+        for (int j = 0; j < (int)(trows / b2); ++j) {
+            hipLaunchKernelGGL(flow_fill_time, dim3((b2 + 63) / 64), dim3(64), 0, st, B.tv + (size_t)j * b2, t_host[s0 + j], b2);
+            ASTTS_CHECK_LAUNCH();
+        }
+        RUN(astts_op_time_embedding(B.tv, B.temb0, (int)trows, c.time_in, 1000.0f, st));
+        RUN(k.linear(B.temb0, 0, c.t1, nullptr, B.temb1, 0, trows, ASTTS_ACT_SILU));
+        RUN(k.linear(B.temb1, 0, c.t2, nullptr, B.temb2, 0, trows, ASTTS_ACT_NONE));
+        RUN(astts_op_elementwise(ASTTS_EL_MISH, B.temb2, nullptr, nullptr, nullptr, B.temb2, trows * c.time_dim, 1, c.time_dim, 0.0f, 0.0f, st));
+        size_t rj = 0;
         for (const std::vector<astts_flow::Block>* grp : {&h->down, &h->mid, &h->up})
             for (const astts_flow::Block& blk : *grp)
-                RUN(k.linear(B.temb2, 0, blk.res.mlp, nullptr, B.tproj + (ri++) * (size_t)trows * C, 0, trows, ASTTS_ACT_NONE));
-    }
-
-    for (int s = 0; s < n_steps; ++s) {
+                RUN(k.linear(B.temb2, 0, blk.res.mlp, nullptr, B.tproj + (rj++) * (size_t)trows * C, 0, trows, ASTTS_ACT_NONE));
+      }
+      {
         size_t ri = 0;      // ResNet block counter of this estimator pass (down, mid, up order: the order of the table above)
-        auto tproj_of = [&]() { return B.tproj + ((ri++) * (size_t)trows + (size_t)s * b2) * C; };
+        auto tproj_of = [&]() { return B.tproj + ((ri++) * (size_t)trows + (size_t)sl * b2) * C; };
         hipLaunchKernelGGL(flow_pack_input, dim3(grid_for((int64_t)b2 * t * 4 * mel)), dim3(256), 0, st, x, mu, spk, cond,
                            B.lens_full, B.xin, b, t, mel);
         ASTTS_CHECK_LAUNCH();
@@ -379,8 +380,14 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
             for (size_t ti = 0; ti < blk.tfm.size(); ++ti) {
                 const bool more = ti + 1 < blk.tfm.size();
                 // after the last transformer block of a mid block comes the next mid block's first convolution
-                const astts_weight_t* nc = (!more && mi + 1 < h->mid.size()) ? &h->mid[mi + 1].res.c1 : nullptr;
-                RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : (nc ? nc->w : nullptr),
+                // (its fragment-order image when that ResNet block takes the three-launch path, else the row-major one)
+                const astts_flow_resnet_t* nr = (!more && mi + 1 < h->mid.size()) ? &h->mid[mi + 1].res : nullptr;
+                const astts_weight_t* nc = nr ? &nr->c1 : nullptr;
+                const void* nw = !nr ? nullptr
+                                 : (nr->c1_frag && nr->c2_frag && nr->res_frag && astts_op_resnet_conv_supported(nc->cin, nc->n, c.groups, nc->taps) &&
+                                    astts_op_resnet_conv_supported(nr->c2.cin, nr->c2.n, c.groups, nr->c2.taps) &&
+                                    astts_op_resnet_conv_supported(nr->res.cin, nr->res.n, c.groups, nr->res.taps)) ? nr->c1_frag : nc->w;
+                RUN(k.tfm(blk.tfm[ti], cur, other, L, tt, more ? blk.tfm[ti + 1].qkv_frag : nw,
                           more ? (uint32_t)(3u * (uint32_t)c.heads * 64u * (uint32_t)C * 2u)
                                : (nc ? (uint32_t)((size_t)nc->n * nc->taps * nc->cin_pad * 2) : 0u)));
             }
@@ -425,6 +432,7 @@ int astts_flow_solve(astts_flow_t* h, float* x, const float* mu, const float* sp
         RUN(k.mask(B.d, B.lens_full, t, mel));
         // x += dt * ((1 + r) d_cond - r d_uncond)
         RUN(astts_op_elementwise(ASTTS_EL_CFG_EULER, x, B.d, nullptr, nullptr, x, (int64_t)b * t * mel, t, mel, dt_host[s], cfg_rate, st));
+      }
     }
     return ASTTS_OK;
 }

@@ -248,12 +248,11 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
                                         (uintptr_t)y | (uintptr_t)acc) & 15) == 0, ASTTS_ERR_INVALID,
                   "astts_op_conv1d_snake: bad shape b=%d l=%d or operands not 16-byte aligned", b, l);
     ASTTS_REQUIRE(x != y && x != (const void*)acc, ASTTS_ERR_INVALID, "astts_op_conv1d_snake: the output may not alias the input (halo rows)");
-    static bool attr = false;
-    if (!attr) {
-        attr = true;
+    static std::once_flag attr;     // several host threads launch (PipelinedSynth): nobody may launch before the attribute is set
+    std::call_once(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    }
+    });
     ConvLdsArgs a{x, alpha, (const _Float16*)w_frag_f16, bias, res, y, acc, l, taps, dil, x_f16, y_f16, acc_add, acc_scale};
     hipStream_t st = (hipStream_t)stream;
     const int halo = dil * (taps - 1) / 2;

@@ -748,12 +748,11 @@ int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const flo
                       "astts_op_tfm_ffn_fused: attention rows without a projection weight, or operands not 16-byte aligned");
         ASTTS_REQUIRE(k0 == 256 || k0 == 512, ASTTS_ERR_UNSUPPORTED, "astts_op_tfm_ffn_fused: k0=%d (256 or 512)", k0);
     }
-    static bool attr = false;
-    if (!attr) {
-        attr = true;
+    static std::once_flag attr;     // several host threads launch (PipelinedSynth): nobody may launch before the attribute is set
+    std::call_once(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    }
+    });
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float) + (wo ? 32 * 260 * sizeof(float) : 0);
     TfmFfnArgs a{x, (const _Float16*)w1_frag_f16, b1, (const _Float16*)w2_frag_f16, b2, out, (const _Float16*)attn_f16,
@@ -792,11 +791,10 @@ int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const 
                   "astts_op_tfm_attn_fused: operands must be 16-byte aligned");
     const int nch = (t + 31) / 32, tkp = nch * 32;
     const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_KS) * sizeof(_Float16);
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    });
     TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale, getenv("ASTTS_TFM_BALANCE") ? atoi(getenv("ASTTS_TFM_BALANCE")) : 1,
                   {nullptr, nullptr, nullptr}, {0u, 0u, 0u}};
     static const bool pf_on = !(getenv("ASTTS_TFM_PREFETCH") && atoi(getenv("ASTTS_TFM_PREFETCH")) == 0);

@@ -114,19 +114,25 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
                       f"oracle/ fp32 torch-CPU: lm {t1 - t0:.1f} s, flow {t2 - t1:.1f} s, vocoder {t3 - t2:.1f} s"}
 
 
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def launch_ranks(n, argv, timeout=None):
     """Self-launcher for `python bench.py --gpus N` (no torch.distributed.run around it): one child process per GPU with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, same command line.  The parent never touches HIP (no
     torch.cuda call before or after: children are fresh interpreters started with subprocess, nothing is exec'ed from a
     process that has initialised the GPU).  Rank 0's stdout (the ONE JSON line) is relayed; every child's stderr passes
     through.  Returns 0 only if every rank exited 0; a failing rank takes the others down."""
-    import socket
     import subprocess
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ)
@@ -217,6 +223,9 @@ def main():
     ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
+    ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("ASTTS_BENCH_FORCE_DIST")),
+                    help="initialise torch.distributed (backend nccl = RCCL) even for ONE rank, so that the id all-gather and the "
+                         "bank-sharded merge run through librccl on a single GPU (also: ASTTS_BENCH_FORCE_DIST=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,10 +242,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                      # --force-dist on one GPU: a one-rank RCCL communicator
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
@@ -394,6 +407,26 @@ def main():
 
     eidx, _ = oknn.knn_search(bank16, q_host, args.topk)
     ids_ok = bool(np.array_equal(out_idx.cpu().numpy(), eidx))
+    # ---- the collectives of the path, checked (untimed): the ids every rank holds after the all-gather are the oracle's for the
+    # rank that produced them, and the bank-sharded stress mode (each rank holds N/W rows, one all-gather of [Q, k] (row, fp64
+    # score) pairs + local merge) returns the unsharded ids
+    gathered_ok = bank_sharded_ok = None
+    if dist is not None:
+        from astts.parallel import bank_sharded_search, shard_bounds
+
+        allids = gather_style_ids(out_idx, dist).cpu().numpy().reshape(world, args.batch, args.topk)
+        gathered_ok = all(bool(np.array_equal(allids[r], oknn.knn_search(bank16, make_queries(bank16, args.batch, seed=r), args.topk)[0]))
+                          for r in range(world))
+        rb, re, _ = shard_bounds(args.bank_rows, world, rank)
+        sb_shard = StyleBank(bank16[rb:re], device=dev)
+
+        def local(qq, kk):
+            i, _, s64 = sb_shard.search_device(qq, min(kk, re - rb), return_f64=True)
+            return i, s64
+
+        bidx, _ = bank_sharded_search(local, q_dev, args.topk, rb, dist)
+        bank_sharded_ok = bool(np.array_equal(bidx.cpu().numpy(), eidx))
+        del sb_shard
 
     # ---- roofline: HIP events (on each launch's own stream) around every launch of the profiled kernel kinds, ONE SEQUENTIAL
     # step per kind (one batch at a time on one stream: the mode `sequential_ms_per_step` / `stages_ms` are measured in; the
@@ -411,9 +444,14 @@ def main():
         return {"ms_per_step": ms, "launches": n, "work": work, "dropped": dropped}
 
     prof = {name: profiled(kind, step_sequential) for name, kind in kinds.items()}
-    dom = max(prof, key=lambda k: prof[k]["ms_per_step"])
+    # which kind is "dominant" must be the same on every rank (the passes below differ per kind): decide on the MAX over ranks
+    kind_ms = torch.tensor([prof[k]["ms_per_step"] for k in kinds], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(kind_ms, op=dist.ReduceOp.MAX)
+    kind_ms = dict(zip(kinds, kind_ms.tolist()))
+    dom = max(kind_ms, key=kind_ms.get)
     if dom == "gemm_tile":      # a family of tiles with different shapes: the single dominant KERNEL is the decode GEMV
-        dom = "lm_gemv" if prof["lm_gemv"]["ms_per_step"] > 0.5 * prof["gemm_tile"]["ms_per_step"] else dom
+        dom = "lm_gemv" if kind_ms["lm_gemv"] > 0.5 * kind_ms["gemm_tile"] else dom
     seq = prof[dom]
     # the dominant kernel again, inside the PIPELINED schedule of the timed region (same pipeline object, same inputs, a few more
     # steps): the decode kernels are timed by their own dispatch timestamps (hipExtLaunchKernelGGL events -- no extra packet in
@@ -422,10 +460,12 @@ def main():
     if dom in ("lm_gemv", "lm_attn"):
         k_p = 2          # 2 x 14 445 launches: inside the profiler's 40 000-launch event budget
 
-        def pipelined_steps():
+        def pipelined_steps():      # collective-free (retrieval + submit only): a profiling pass must not add all-gathers
             with torch.cuda.stream(pipe.front_stream):
                 for _ in range(k_p):
-                    step()
+                    sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
+                    take(pipe.submit(inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok,
+                                     inp.timbre_mel, inp.spk_timbre, inp.z, inp.phase0, inp.noise))
                 take(pipe.drain())
 
         pip = profiled(kinds[dom], pipelined_steps)
@@ -516,7 +556,10 @@ def main():
             "value": total_audio / dt,
             "unit": "audio-s/wall-s",
             "n_gpus": world,
-            "rccl_world_size": world if dist is not None else 1,
+            "rccl_world_size": dist.get_world_size() if dist is not None else None,
+            "rccl_backend": dist.get_backend() if dist is not None else None,
+            "gathered_ids_match_oracle": gathered_ok,
+            "bank_sharded_ids_match_oracle": bank_sharded_ok,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
