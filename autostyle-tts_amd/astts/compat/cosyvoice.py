@@ -144,16 +144,26 @@ class CosyVoice:
             yield {"tts_speech": self._render(tokens, flow_prompt)}
 
     # ------------------------------------------------------------------ ragged batches (many segments in one pass)
-    def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True):
+    def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True, fixed_tokens=None, draws=None, forced=None):
         """``requests``: list of (text_ids [1, Tt] = prompt text + segment text, n_segment_text_tokens, lm_prompt,
         flow_prompt).  All segments go through ONE left-padded LM batch (per-row EOS window, tokens truncated at
         each row's EOS), one ragged flow-matching batch and the vocoder.  Returns one FloatTensor[1, n] per request,
-        each what the one-at-a-time path produces for that segment up to sampling draws."""
+        each what the one-at-a-time path produces for that segment up to sampling draws.
+
+        Explicit control of the stochastic parts (SURVEY.md 7 "hard parts": throughput runs need fixed-length decode, parity
+        needs injectable randomness), all per request, in request order:
+          ``fixed_tokens[i]``  decode exactly that many speech tokens (EOS ignored) instead of the 2x..20x text-length window;
+          ``draws[i]``         {"u": [n, 2], "z": [1, Tm_total, mel], "phase0": [1, nh], "noise": [1, L, nh]} instead of draws
+                               from the instance generator (``make_draws`` builds them from a seed);
+          ``forced[i]``        teacher forcing: int tokens [n] that replace the sampled ones.
+        The tokens and mels of the last call stay in ``self.last_tokens`` / ``self.last_mels`` (CPU)."""
         cfg, dev, eng = self.cfg, self.device, self.engine
         out = [None] * len(requests)
+        self.last_tokens, self.last_mels = [None] * len(requests), [None] * len(requests)
         # length bucketing (SURVEY.md 8e): a group is padded to its longest row in every stage, so rows of similar text
         # length go together; results return in request order
-        order = sorted(range(len(requests)), key=lambda i: -requests[i][1]) if bucket else list(range(len(requests)))
+        key = (lambda i: -fixed_tokens[i]) if fixed_tokens is not None else (lambda i: -requests[i][1])
+        order = sorted(range(len(requests)), key=key) if bucket else list(range(len(requests)))
         for g0 in range(0, len(requests), max_batch):
             idxs = order[g0:g0 + max_batch]
             grp = [requests[i] for i in idxs]
@@ -161,50 +171,93 @@ class CosyVoice:
             texts = [r[0].view(-1) for r in grp]
             spk_lm = torch.cat([r[2].spk_embedding for r in grp], 0)
             pre, ks = eng.lm.prefix_ragged(texts, spk_lm, [r[2].speech_tokens.view(-1) for r in grp])
-            min_len = [self.min_token_text_ratio * r[1] for r in grp]
             cap = cfg.max_positions - pre.shape[0] - 100
-            max_len = [max(min(self.max_token_text_ratio * r[1], cap), m + 1) for r, m in zip(grp, min_len)]
+            if fixed_tokens is not None:
+                max_len = [max(1, min(int(fixed_tokens[i]), cap)) for i in idxs]      # the position tables bound prefix + tokens, as below
+                min_len = list(max_len)
+            else:
+                min_len = [self.min_token_text_ratio * r[1] for r in grp]
+                max_len = [max(min(self.max_token_text_ratio * r[1], cap), m + 1) for r, m in zip(grp, min_len)]
             n_steps = max(max_len)
-            u = torch.rand(n_steps, b, 2, generator=self._gen).to(dev)
+            if draws is not None:
+                u = torch.zeros(n_steps, b, 2)
+                for j, i in enumerate(idxs):
+                    u[:max_len[j], j] = draws[i]["u"][:max_len[j]]
+                u = u.to(dev)
+            else:
+                u = torch.rand(n_steps, b, 2, generator=self._gen).to(dev)
+            ft = None
+            if forced is not None:
+                ft = torch.zeros(b, n_steps, dtype=torch.int32)
+                for j, i in enumerate(idxs):
+                    ft[j, :max_len[j]] = forced[i][:max_len[j]].to(torch.int32)
+                ft = ft.to(dev)
             eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
-            toks = eng.lm.decode(pre, n_steps, u, ignore_eos=eos_min, key_start=ks).cpu()       # one sync per group
+            toks = eng.lm.decode(pre, n_steps, u, ignore_eos=eos_min, key_start=ks, forced_tokens=ft).cpu()       # one sync per group
             gen_tokens = []
             for i in range(b):
                 row = toks[i, :max_len[i]]
-                eos = (row >= cfg.speech_vocab).nonzero()
+                eos = (row >= cfg.speech_vocab).nonzero() if fixed_tokens is None else torch.empty(0)
                 n = int(eos[0]) if eos.numel() else max_len[i]
                 gen_tokens.append(row[:max(n, 1)].to(torch.int32))
-            all_tok, pmels, zs, draws = [], [], [], []
+            all_tok, pmels, zs, dr = [], [], [], []
             for i, r in enumerate(grp):
                 fp = r[3]
                 n_gen = cfg.mel_frames_for_tokens(int(gen_tokens[i].numel()))
                 tmp = int(fp.mel.shape[1])
-                _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen)
+                if draws is not None:
+                    d = draws[idxs[i]]
+                    z, phase0, noise = d["z"][:, :tmp + n_gen], d["phase0"], d["noise"][:, :n_gen * cfg.upsample_total]
+                else:
+                    _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen)
                 all_tok.append(torch.cat([fp.speech_tokens.view(-1).to(torch.int32), gen_tokens[i]]))
                 pmels.append(fp.mel[0])
                 zs.append(z[0])
-                draws.append((phase0, noise))
+                dr.append((phase0, noise))
             spk_flow = torch.cat([r[3].spk_embedding for r in grp], 0)
             mels = eng.flow.decode_ragged(all_tok, pmels, spk_flow, zs)
             for i in range(b):      # vocoder per row: its conv stack has no length masks (3 % of the time)
-                wav = eng.hift.forward(mels[i][None], draws[i][0].to(dev), draws[i][1].to(dev))
+                wav = eng.hift.forward(mels[i][None], dr[i][0].to(dev), dr[i][1].to(dev))
                 out[idxs[i]] = wav.cpu()
+                self.last_tokens[idxs[i]] = gen_tokens[i]
+                self.last_mels[idxs[i]] = mels[i].cpu()
         return out
 
-    def inference_tts_with_st_batch(self, items, max_batch: int = 32):
+    def make_draws(self, n_tokens: int, prompt_mel_frames: int, seed: int):
+        """The stochastic inputs of one segment (sampling uniforms, CFM start noise, source phases / noise) from a seed."""
+        cfg = self.cfg
+        g = torch.Generator().manual_seed(seed)
+        nh = cfg.nb_harmonics + 1
+        n_gen = cfg.mel_frames_for_tokens(n_tokens)
+        phase0 = (torch.rand(1, nh, generator=g) * 2 - 1) * math.pi
+        phase0[:, 0] = 0
+        return {"u": torch.rand(n_tokens, 2, generator=g), "z": torch.randn(1, prompt_mel_frames + n_gen, cfg.mel, generator=g),
+                "phase0": phase0, "noise": torch.randn(1, n_gen * cfg.upsample_total, nh, generator=g)}
+
+    def inference_tts_with_st_batch(self, items, max_batch: int = 32, split: bool = True, **controls):
         """Batched form of inference_tts_with_st for drivers that know all their work up front
         (tts_with_rag.py:172 loops 64 rows one by one).  ``items``: list of (tts_text, style_text, style_wav_16k,
-        timbre_wav_16k) -> list (per item) of lists (per text segment) of {'tts_speech': FloatTensor[1, n]}."""
+        timbre_wav_16k) -> list (per item) of lists (per text segment) of {'tts_speech': FloatTensor[1, n]}.
+        ``controls`` (fixed_tokens / draws / forced, per text segment; ``split=False`` keeps one segment per item so that they
+        line up with the items) go to ``synthesize_batch``; the prompts of an item are featurised once per distinct tensor."""
         fe = self.frontend
         reqs, owner = [], []
+        cache = {}
+
+        def prompt(w):
+            k = id(w)
+            if k not in cache:
+                cache[k] = fe.prompt(w)
+            return cache[k]
+
         for k, (tts_text, style_text, style_wav, timbre_wav) in enumerate(items):
-            style, timbre = fe.prompt(style_wav), fe.prompt(timbre_wav)
+            style, timbre = prompt(style_wav), prompt(timbre_wav)
             style_ids = fe.text_ids(style_text)
-            for seg in text_normalize(tts_text, fe.tokenizer, split=True):
+            for seg in text_normalize(tts_text, fe.tokenizer, split=split):
                 seg_ids = fe.text_ids(seg)
                 reqs.append((torch.cat([style_ids, seg_ids], dim=1), seg_ids.shape[1], style, timbre))
                 owner.append(k)
-        wavs = self.synthesize_batch(reqs, max_batch)
+        wavs = self.synthesize_batch(reqs, max_batch, **controls)
         out = [[] for _ in items]
         for k, w in zip(owner, wavs):
             out[k].append({"tts_speech": w})

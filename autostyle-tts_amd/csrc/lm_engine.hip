@@ -176,13 +176,14 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     const int d = c.d;
     const int dpad = (int)align_up((size_t)d, 64), fpad = (int)align_up((size_t)c.ffn, 64);
     // Which step engine: "v2" = the decode-step kernels of lm_step.hip (4 launches fewer per step, one memory round trip per
-    // kernel, 8-column workgroups for 8-row batches, key-split attention merged by its consumer), "v1" = the operator chain
-    // below.  v2 is built around batches of <= 8 rows (the benchmark batch); wider batches keep v1, whose split-K FFN-out
-    // projection covers the chip at 16-32 rows.  ASTTS_LM_ENGINE=v1|v2 forces one (tests compare the two).
+    // kernel, 8-column workgroups, key-split attention merged by its consumer) for every batch of <= 32 rows: a row's arithmetic
+    // there does not depend on the number of rows (lm_step.hip, FORM 2), so 8-, 16- and 32-row chains agree bit for bit.
+    // "v1" = the operator chain below (round 1), kept as the second implementation the tests compare with.
+    // ASTTS_LM_ENGINE=v1|v2 forces one.
     const char* env = getenv("ASTTS_LM_ENGINE");           // read per call: tests switch engines inside one process
     const int forced = !env ? 0 : (!strcmp(env, "v1") ? 1 : (!strcmp(env, "v2") ? 2 : 0));
     const bool v2_ok = c.kv_f16 && c.pos_f16 && (d % 64) == 0 && (c.ffn % 64) == 0 && d <= 1024;
-    if (v2_ok && (forced == 2 || (forced == 0 && b <= 8)))
+    if (v2_ok && forced != 1)
         return decode_v2(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, uniforms, forced_tokens, eos_min_steps, eos_min_rows,
                          tokens_out, logits_out, workspace, st);
     char* ws = (char*)workspace;

@@ -67,7 +67,8 @@ struct AttnArgs {
 int lm_gemv_launch(const GemvArgs& a, hipStream_t st);
 int lm_attn_launch(const AttnArgs& a, hipStream_t st);
 void lm_step_set_attrs();   // one-off hipFuncSetAttribute calls (outside any capture)
-// the kernel variant lm_gemv_launch picks: bit 0 = 8-column diagonal form (m <= 8), bits 1.. = row tiles (1 or 2)
+// the kernel variant lm_gemv_launch picks: bits 0-1 = form (0: 16 columns, 1: diagonal 8 x 8 for m <= 8, 2: halved 8 columns),
+// bits 2.. = row tiles of 16 (1 or 2)
 int lm_gemv_variant(const GemvArgs& a);
 
 }  // namespace astts

@@ -1,6 +1,6 @@
 // lm_step.hip -- decode-step kernels of the acoustic transformer (see lm_step.h for the design rules).
 //
-//   lm_gemv<MT, HALF8, XM, NL> out[m, n] = epilogue( LN?(x)[m, :] . W[n, :] ),  m <= 16*MT rows (the decode batch)
+//   lm_gemv<MT, FORM, XM, NL>  out[m, n] = epilogue( LN?(x)[m, :] . W[n, :] ),  m <= 16*MT rows (the decode batch)
 //   lm_attn                    one new query per (row, head) against the fp16 KV cache, relative-position scores
 //
 // Arithmetic follows the operator-by-operator step (AcousticLM.step_logits / gemm_skinny16 / attn_relpos_decode): fp16
@@ -47,15 +47,26 @@ __device__ __forceinline__ float wsum64(float v) {
     return v;
 }
 
-// HALF8: m <= 8.  MFMA row i = r + 8h carries x[r][h*Kc + ...], MFMA column j = c + 8h' carries W[n0 + c][h'*Kc + ...]
-// (Kc = kpad / 2): the two diagonal 8x8 blocks of the 16x16 product are the two K halves of an 8-row x 8-column tile,
-// the off-diagonal blocks are never read.  The block owns 8 columns instead of 16.
+// FORM 0: 16 columns per workgroup, every wave walks whole K lines (MT row tiles of 16).
+// FORM 1 ("diagonal", m <= 8): MFMA row i = r + 8h carries x[r][h*Kc + ...], MFMA column j = c + 8h' carries
+// W[n0 + c][h'*Kc + ...] (Kc = kpad / 2): the two diagonal 8x8 blocks of the 16x16 product are the two K halves of an
+// 8-row x 8-column tile, the off-diagonal blocks are never read.  The block owns 8 columns instead of 16.
+// FORM 2 ("halved", m <= 16 MT): the same 8-column weight fragments (column j = c + 8h' carries K half h'), one MFMA per K
+// half of the rows: accumulator [t][h] = x[rows of tile t][half h] . W^T, of which the columns of half h are used.  Two (MT
+// = 1) or four (MT = 2) MFMAs per weight fragment, half of each product unused -- the matrix pipe is idle in this kernel
+// anyway; what it buys is the 8-column grid (twice the workgroups) for 16- and 32-row batches.  A row's sum is formed in
+// exactly the order of FORM 1 (per wave: its lines in ascending order per K half; then waves 0..7, half 0 + half 1 each), so
+// a row's result does not depend on how many rows share the launch: 8-, 16- and 32-row batches agree bit for bit.
 // XM: input form -- 0 fp32 rows (optional gather / embedding pre-transform / LayerNorm), 1 fp16 rows, 2 the split-key
 // partials of lm_attn (merged while staging).  NL: weight lines a wave keeps in flight (2 for K <= 1024 at 16 columns: the
 // kernel then fits two workgroups per CU, e.g. the 257 workgroups of the output head in one wave of blocks).
-template <int MT, bool HALF8, int XM, int NL>
-__global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
+template <int MT, int FORM, int XM, int NL>
+__global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(GemvArgs a) {
     constexpr bool XF16 = XM != 0;
+    constexpr bool HALF8 = FORM != 0;                          // K halved over MFMA columns, 8 output columns per workgroup
+    constexpr bool DIAG = FORM == 1;
+    constexpr int RH = DIAG ? 8 : 16 * MT;                     // LDS row offset of the second K half
+    constexpr int NACC = FORM == 2 ? 2 * MT : MT;              // accumulators per wave
     extern __shared__ __attribute__((aligned(16))) char gv_smem[];
     pin_args(a);
     LM_STAMP(a, 0);
@@ -67,9 +78,9 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
     const int Kc = HALF8 ? (a.kpad >> 1) : a.kpad;          // K elements per MFMA row
     const int lines = Kc >> 6;
     const int xs = Kc + 8;                                    // LDS row stride in halfs (16-byte skew)
-    const int lrows = HALF8 ? 16 : M;
+    const int lrows = HALF8 ? 2 * RH : M;
     _Float16* sx = reinterpret_cast<_Float16*>(gv_smem);      // [lrows][xs]
-    float* red = reinterpret_cast<float*>(gv_smem + (((size_t)lrows * xs * 2 + 15) & ~(size_t)15));  // [8][MT][4][64]
+    float* red = reinterpret_cast<float*>(gv_smem + (((size_t)lrows * xs * 2 + 15) & ~(size_t)15));  // [8][NACC][4][64]
 
     // ---- (0) everything this block will need from memory, issued before anything waits
     // weights: lane (c, g) owns bytes [32g, 32g + 32) of its row in every 128-byte line (two 16x16x32 k-steps)
@@ -77,24 +88,33 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
                                  : a.w + (int64_t)(n0 + c) * a.kpad + g * 16;
     // input row of this wave (fp32 path, K <= 1024: 4 float4 per lane) -- needed first, so issued first
     constexpr int MAXV = 4;
+    constexpr int RPW = DIAG ? 1 : 2 * MT;                    // rows a wave stages (rows wid, wid + 8, ...): ALL prefetched up front
     const bool vec_ok = !XF16 && a.k <= 1024 && (a.k & 3) == 0 && (a.ldx & 3) == 0 && ((uintptr_t)a.x & 15) == 0;
     const int nv = (a.kpad + 255) >> 8;
-    float4 v0[MAXV];
+    float4 v0[XF16 ? 1 : RPW][MAXV];
     if constexpr (!XF16) {
-        if (vec_ok && wid < M) {
-            const int64_t src = a.gather ? (int64_t)a.gather[wid] : (int64_t)wid;
-            const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+        if (vec_ok) {
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int k = lane * 4 + i * 256;
-                v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < nv && k < a.k) v0[i] = *reinterpret_cast<const float4*>(xr + k);
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int mr = wid + rr * GV_WAVES;
+                if (mr < M) {
+                    const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
+                    const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+#pragma unroll
+                    for (int i = 0; i < MAXV; ++i) {
+                        const int k = lane * 4 + i * 256;
+                        v0[rr][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (i < nv && k < a.k) v0[rr][i] = *reinterpret_cast<const float4*>(xr + k);
+                    }
+                }
             }
         }
     }
     // fp16 input (already an MFMA operand image: FFN hidden; XM == 2: the attention partials, merged here): 16-byte
     // pieces of 8 K positions, up to 8 per thread
-    constexpr int XP = XM == 2 ? 2 : 8;
+    // (the halved form takes fp16 rows by LDS-DMA instead: no staging registers, every piece of every row in flight at once)
+    constexpr int XP = XM == 2 ? (DIAG ? 2 : 4) : 8;
+    const bool x_dma = XM == 1 && FORM == 2 && a.k == a.kpad && (Kc & 511) == 0;
     half8 xh[XM == 1 ? XP : 1];
     float4 po[XM == 2 ? XP : 1][2][2];                         // [piece][split][8 floats]
     float2 pml[XM == 2 ? XP : 1][2];
@@ -102,15 +122,26 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
     const int npieces = M * kp8;
     if constexpr (XM == 1) {
         const _Float16* xb = reinterpret_cast<const _Float16*>(a.x);
+        if (x_dma) {
+            // one wave instruction moves 1 KB = 512 consecutive K positions of one row into its (row, K half) line of the image
+            const int ppr = a.kpad >> 9;                     // 1 KB pieces per row
+            for (int p = wid; p < M * ppr; p += GV_WAVES) {
+                const int row = p / ppr, k0 = (p - row * ppr) << 9;
+                const int hh = k0 >= Kc ? 1 : 0;
+                __builtin_amdgcn_global_load_lds(xb + (int64_t)row * a.ldx + k0 + lane * 8,
+                                                 (__attribute__((address_space(3))) void*)(sx + (size_t)(row + RH * hh) * xs + (k0 - hh * Kc)), 16, 0, 0);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const int q = tid + i * 512;
-            if (q < npieces) {
-                const int row = q / kp8, kk = (q - row * kp8) << 3;
-                half8 z;
+            for (int i = 0; i < XP; ++i) {
+                const int q = tid + i * 512;
+                if (q < npieces) {
+                    const int row = q / kp8, kk = (q - row * kp8) << 3;
+                    half8 z;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-                xh[i] = kk < a.k ? *reinterpret_cast<const half8*>(xb + (int64_t)row * a.ldx + kk) : z;
+                    for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+                    xh[i] = kk < a.k ? *reinterpret_cast<const half8*>(xb + (int64_t)row * a.ldx + kk) : z;
+                }
             }
         }
     }
@@ -157,12 +188,15 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
         }
     }
     // epilogue operands of the thread's output element
-    constexpr int NOUT = HALF8 ? 64 : MT * 256;
+    constexpr int NOUT = DIAG ? 64 : (FORM == 2 ? MT * 128 : MT * 256);
     const bool owner = tid < NOUT;
     int on, om;                                               // output column / row of this thread
-    if constexpr (HALF8) {
+    if constexpr (DIAG) {
         on = n0 + (tid & 7);
         om = (tid >> 3) & 7;
+    } else if constexpr (FORM == 2) {
+        on = n0 + (tid & 7);
+        om = tid >> 3;
     } else {
         const int t = tid >> 8, e = (tid >> 6) & 3;
         on = n0 + (lane & 15);
@@ -184,7 +218,7 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
         h4[0] = (_Float16)o.x; h4[1] = (_Float16)o.y; h4[2] = (_Float16)o.z; h4[3] = (_Float16)o.w;
         if constexpr (HALF8) {
             const int hh = k >= Kc ? 1 : 0;
-            *reinterpret_cast<half4*>(sx + (size_t)(mr + 8 * hh) * xs + (k - hh * Kc)) = h4;
+            *reinterpret_cast<half4*>(sx + (size_t)(mr + RH * hh) * xs + (k - hh * Kc)) = h4;
         } else {
             *reinterpret_cast<half4*>(sx + (size_t)mr * xs + k) = h4;
         }
@@ -192,26 +226,44 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
     auto put8 = [&](int row, int kk, half8 hv) {              // 8 consecutive K positions of row `row`
         if constexpr (HALF8) {
             const int hh = kk >= Kc ? 1 : 0;
-            *reinterpret_cast<half8*>(sx + (size_t)(row + 8 * hh) * xs + (kk - hh * Kc)) = hv;
+            *reinterpret_cast<half8*>(sx + (size_t)(row + RH * hh) * xs + (kk - hh * Kc)) = hv;
         } else {
             *reinterpret_cast<half8*>(sx + (size_t)row * xs + kk) = hv;
         }
     };
     if constexpr (XM == 1) {
+        if (x_dma) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and its weight lines) have landed
+        } else {
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const int q = tid + i * 512;
-            if (q < npieces) {
-                const int row = q / kp8;
-                put8(row, (q - row * kp8) << 3, xh[i]);
+            for (int i = 0; i < XP; ++i) {
+                const int q = tid + i * 512;
+                if (q < npieces) {
+                    const int row = q / kp8;
+                    put8(row, (q - row * kp8) << 3, xh[i]);
+                }
             }
-        }
-        for (int q = tid + XP * 512; q < npieces; q += 512) {   // rows beyond the prefetched pieces (m > 8 with K = 4096)
-            const int row = q / kp8, kk = (q - row * kp8) << 3;
-            half8 z;
+            for (int q0 = XP * 512; q0 < npieces; q0 += XP * 512) {   // rows beyond the prefetched pieces, a batch of loads at a time
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-            put8(row, kk, kk < a.k ? *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.x) + (int64_t)row * a.ldx + kk) : z);
+                for (int i = 0; i < XP; ++i) {
+                    const int q = q0 + tid + i * 512;
+                    if (q < npieces) {
+                        const int row = q / kp8, kk = (q - row * kp8) << 3;
+                        half8 z;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+                        xh[i] = kk < a.k ? *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.x) + (int64_t)row * a.ldx + kk) : z;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XP; ++i) {
+                    const int q = q0 + tid + i * 512;
+                    if (q < npieces) {
+                        const int row = q / kp8;
+                        put8(row, (q - row * kp8) << 3, xh[i]);
+                    }
+                }
+            }
         }
     } else if constexpr (XM == 2) {
         // merge the two key-range partials of lm_attn: out = (o0 w0 + o1 w1) / (l0 w0 + l1 w1), w_s = exp(m_s - max m)
@@ -235,20 +287,31 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
                 put8(row, (q - row * kp8) << 3, merge(po[i], pml[i]));
             }
         }
-        for (int q = tid + XP * 512; q < npieces; q += 512) {   // m > 8 rows
-            const int row = q / kp8, kk = (q - row * kp8) << 3;
-            const int hd = kk >> 6, dd = kk & 63;
-            const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+        for (int q0 = XP * 512; q0 < npieces; q0 += XP * 512) {   // more rows: a batch of loads at a time
             const float* pob = reinterpret_cast<const float*>(a.x);
-            float4 o[2][2];
-            float2 ml[2];
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                o[sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
-                o[sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
-                ml[sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
+            for (int i = 0; i < XP; ++i) {
+                const int q = q0 + tid + i * 512;
+                if (q < npieces) {
+                    const int row = q / kp8, kk = (q - row * kp8) << 3;
+                    const int hd = kk >> 6, dd = kk & 63;
+                    const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp) {
+                        po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
+                        po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
+                        pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
+                    }
+                }
             }
-            put8(row, kk, merge(o, ml));
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int q = q0 + tid + i * 512;
+                if (q < npieces) {
+                    const int row = q / kp8;
+                    put8(row, (q - row * kp8) << 3, merge(po[i], pml[i]));
+                }
+            }
         }
     } else {
         // register path: wave w owns rows w, w + 8, ... (the first one was prefetched above)
@@ -321,18 +384,9 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
             }
         };
         if (vec_ok) {
-            if (wid < M) stage_row(v0, wid);
-            for (int mr = wid + GV_WAVES; mr < M; mr += GV_WAVES) {
-                const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
-                const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
 #pragma unroll
-                for (int i = 0; i < MAXV; ++i) {
-                    const int k = lane * 4 + i * 256;
-                    v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < nv && k < a.k) v0[i] = *reinterpret_cast<const float4*>(xr + k);
-                }
-                stage_row(v0, mr);
-            }
+            for (int rr = 0; rr < RPW; ++rr)
+                if (wid + rr * GV_WAVES < M) stage_row(v0[rr], wid + rr * GV_WAVES);
         } else {
             // general path (any K / alignment; no embedding pre-transform): scalar, two-pass statistics
             for (int mr = wid; mr < M; mr += GV_WAVES) {
@@ -359,7 +413,7 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
                     }
                     if constexpr (HALF8) {
                         const int hh = k >= Kc ? 1 : 0;
-                        sx[(size_t)(mr + 8 * hh) * xs + (k - hh * Kc)] = (_Float16)v;
+                        sx[(size_t)(mr + RH * hh) * xs + (k - hh * Kc)] = (_Float16)v;
                     } else {
                         sx[(size_t)mr * xs + k] = (_Float16)v;
                     }
@@ -372,17 +426,22 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
     LM_STAMP(a, 3);
 
     // ---- (2) MFMAs: A fragments from LDS, B fragments are the prefetched weight registers
-    float4v acc[MT];
+    float4v acc[NACC];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.0f;
-    const _Float16* arow[MT];
+    const _Float16* arow[NACC];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        int mr = t * 16 + c;
-        if constexpr (!HALF8) {
-            if (mr >= M) mr = M - 1;
+    for (int t = 0; t < NACC; ++t) {
+        int mr;
+        if constexpr (FORM == 2) {
+            mr = (t >> 1) * 16 + c + RH * (t & 1);            // accumulator (row tile t / 2, K half t % 2)
+        } else {
+            mr = t * 16 + c;
+            if constexpr (!HALF8) {
+                if (mr >= M) mr = M - 1;
+            }
         }
         arow[t] = sx + (size_t)mr * xs + g * 16;
     }
@@ -392,7 +451,7 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
             const int line = wid + (pass * NL + i) * GV_WAVES;
             if (line < lines) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
+                for (int t = 0; t < NACC; ++t) {
                     const half8 fa0 = *reinterpret_cast<const half8*>(arow[t] + line * 64);
                     const half8 fa1 = *reinterpret_cast<const half8*>(arow[t] + line * 64 + 8);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[i][0], acc[t], 0, 0, 0);
@@ -413,17 +472,23 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
     LM_STAMP(a, 4);
     // ---- (3) cross-wave reduction + epilogue
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[((wid * MT + t) * 4 + e) * 64 + lane] = acc[t][e];
+        for (int e = 0; e < 4; ++e) red[((wid * NACC + t) * 4 + e) * 64 + lane] = acc[t][e];
     __syncthreads();
     if (live) {
         float v = 0.0f;
-        if constexpr (HALF8) {
+        if constexpr (DIAG) {
             const int r = om, cc = tid & 7;
             const int e = r & 3, la = 16 * (r >> 2) + cc, lb2 = la + 40;      // D[r][c] and D[r + 8][c + 8]
 #pragma unroll
             for (int w = 0; w < GV_WAVES; ++w) v += red[(w * 4 + e) * 64 + la] + red[(w * 4 + e) * 64 + lb2];
+        } else if constexpr (FORM == 2) {
+            const int t = om >> 4, r = om & 15, cc = tid & 7;
+            const int e = r & 3, la = 16 * (r >> 2) + cc;                     // D0[r][c] (K half 0) and D1[r][c + 8] (K half 1)
+#pragma unroll
+            for (int w = 0; w < GV_WAVES; ++w)
+                v += red[((w * NACC + 2 * t) * 4 + e) * 64 + la] + red[((w * NACC + 2 * t + 1) * 4 + e) * 64 + la + 8];
         } else {
             const int t = tid >> 8, e = (tid >> 6) & 3;
 #pragma unroll
@@ -444,12 +509,14 @@ __global__ __launch_bounds__(512, NL <= 2 ? 4 : 2) void lm_gemv(GemvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Decode attention, one (row, head) per block.  8 lanes share a key (lane sub = tid & 7 owns dims [8 sub, 8 sub + 8):
+// Decode attention, one (row, head, key half) per block.  8 lanes share a key (lane sub = tid & 7 owns dims [8 sub, 8 sub + 8):
 // one 16-byte load each of K, V and the position row), 64 keys per pass of the 512 threads, AT_U passes per chunk with
-// ALL of a chunk's K, position and V loads issued before the first score is formed: one memory round trip per 512 keys
-// (the ~400 keys of a benchmark step: one round trip for the whole kernel; K, then softmax, then V took three).
-// Chunks are combined by the usual running maximum / running sum.
-static constexpr int AT_U = 8;
+// ALL of a chunk's K, position and V loads issued before the first score is formed: one memory round trip per 256 keys
+// (a benchmark step has <= 434 keys = <= 256 per key half: one round trip for the whole kernel; K, then softmax, then V took
+// three).  Chunks are combined by the usual running maximum / running sum.  AT_U = 4 (was 8): 48 instead of 96 staging
+// registers = two workgroups per CU, which is what 16- and 32-row batches (512 / 1024 workgroups) need; the chunk size is part
+// of a row's arithmetic (when the running maximum moves), so it is ONE constant for every batch size.
+static constexpr int AT_U = 4;
 
 __device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
     float s = 0.0f;
@@ -458,7 +525,7 @@ __device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
     return s;
 }
 
-__global__ __launch_bounds__(512) void lm_attn(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void lm_attn(AttnArgs a) {
     __shared__ float s_m[8];
     __shared__ float s_l[8];
     __shared__ __attribute__((aligned(16))) float s_o[8][64];
@@ -589,62 +656,66 @@ __global__ __launch_bounds__(512) void lm_attn(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-static size_t gemv_lds_bytes(int lrows, int kc, int mt) {
-    return (((size_t)lrows * (kc + 8) * 2 + 15) & ~(size_t)15) + (size_t)GV_WAVES * mt * 4 * 64 * sizeof(float);
+static size_t gemv_lds_bytes(int lrows, int kc, int nacc) {
+    return (((size_t)lrows * (kc + 8) * 2 + 15) & ~(size_t)15) + (size_t)GV_WAVES * nacc * 4 * 64 * sizeof(float);
 }
 
-// 8-column form: twice the workgroups.  Measured (scripts/micro/decode_chain.hip, per launch incl. the 1.45 us boundary): it
+// 8-column forms: twice the workgroups.  Measured (scripts/micro/decode_chain.hip, per launch incl. the 1.45 us boundary): it
 // pays where the 16-column grid leaves CUs idle (n = 1024: 64 -> 128 workgroups; the deep FFN-out projection 7.5 -> 6.0-6.4 us
 // with no split-K hand-off) and costs where the 16-column grid already covers the chip (n = 3072 / 4096: 5.7 -> 8.9 us, every
-// workgroup stages the whole input and a CU then ingests 96 KB instead of 64).
+// workgroup stages the whole input and a CU then ingests 96 KB instead of 64).  The choice depends on the projection's shape
+// only, never on the row count: a row's arithmetic is then the same in 8-, 16- and 32-row batches.
 static int half8_max_blocks() {
     static const int v = [] { const char* e = getenv("ASTTS_LM_HALF8_MAX_BLOCKS"); return e ? atoi(e) : 256; }();
     return v;
 }
 
+// bits 0-1: form (0 = 16 columns, 1 = diagonal 8 x 8, 2 = halved 8 columns), bits 2..: row tiles of 16 (forms 0 and 2)
 int lm_gemv_variant(const GemvArgs& a) {
-    const bool half8 = a.m <= 8 && (a.kpad % 128) == 0 && (a.n + 7) / 8 <= half8_max_blocks();
+    const bool halved = (a.kpad % 128) == 0 && (a.n + 7) / 8 <= half8_max_blocks();
     const int mt = a.m <= 16 ? 1 : 2;
-    return (half8 ? 1 : 0) | (mt << 1);
+    const int form = !halved ? 0 : (a.m <= 8 ? 1 : 2);
+    return form | (mt << 2);
 }
 
-template <int MT, bool HALF8, int XM>
+template <int MT, int FORM, int XM>
 static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {   // first use (never inside a capture: lm_step_set_attrs() visits every variant up front)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, HALF8, XM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, HALF8, XM, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static std::once_flag attr;   // first use (never inside a capture: lm_step_set_attrs() visits every variant up front)
+    std::call_once(attr, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, FORM, XM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, FORM, XM, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     if (grid.x == 0) return;
     // bench-only launch profiler: algorithmic bytes of a decode GEMV = its weight image, streamed once
     hipEvent_t e0, e1;
     if (prof_events(ASTTS_PROF_GEMM_SKINNY, (double)a.n * a.kpad * 2.0, &e0, &e1)) {
-        if (lines_per_wave <= 2) hipExtLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
-        else hipExtLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 8>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
+        if (lines_per_wave <= 2) hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
         return;
     }
-    if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 2>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((lm_gemv<MT, HALF8, XM, 8>), grid, dim3(512), lds, st, a);
+    if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), lds, st, a);
 }
 
-template <int MT, bool HALF8>
+template <int MT, int FORM>
 static void gemv_launch_xm(const GemvArgs& a, int xm, dim3 grid, size_t lds, int lpw, hipStream_t st) {
-    if (xm == 0) gemv_launch_nl<MT, HALF8, 0>(a, grid, lds, lpw, st);
-    else if (xm == 1) gemv_launch_nl<MT, HALF8, 1>(a, grid, lds, lpw, st);
-    else gemv_launch_nl<MT, HALF8, 2>(a, grid, lds, lpw, st);
+    if (xm == 0) gemv_launch_nl<MT, FORM, 0>(a, grid, lds, lpw, st);
+    else if (xm == 1) gemv_launch_nl<MT, FORM, 1>(a, grid, lds, lpw, st);
+    else gemv_launch_nl<MT, FORM, 2>(a, grid, lds, lpw, st);
 }
 
 void lm_step_set_attrs() {
-    static bool done = false;
-    if (done) return;
-    GemvArgs z{};
-    for (int xm = 0; xm < 3; ++xm) {   // grid 0: sets the attributes, launches nothing
-        gemv_launch_xm<1, true>(z, xm, dim3(0), 0, 2, nullptr);
-        gemv_launch_xm<1, false>(z, xm, dim3(0), 0, 2, nullptr);
-        gemv_launch_xm<2, false>(z, xm, dim3(0), 0, 2, nullptr);
-    }
-    done = true;
+    static std::once_flag done;
+    std::call_once(done, [] {
+        GemvArgs z{};
+        for (int xm = 0; xm < 3; ++xm) {   // grid 0: sets the attributes, launches nothing
+            gemv_launch_xm<1, 1>(z, xm, dim3(0), 0, 2, nullptr);
+            gemv_launch_xm<1, 2>(z, xm, dim3(0), 0, 2, nullptr);
+            gemv_launch_xm<2, 2>(z, xm, dim3(0), 0, 2, nullptr);
+            gemv_launch_xm<1, 0>(z, xm, dim3(0), 0, 2, nullptr);
+            gemv_launch_xm<2, 0>(z, xm, dim3(0), 0, 2, nullptr);
+        }
+    });
 }
 
 int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
@@ -660,14 +731,22 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
     ASTTS_REQUIRE(!a0.pre_g || (a0.k <= 1024 && (a0.k & 3) == 0 && (a0.ldx & 3) == 0 && ((uintptr_t)a0.x & 15) == 0), ASTTS_ERR_INVALID,
                   "lm_gemv: the embedding pre-transform needs k <= 1024 and aligned rows");
     lm_step_set_attrs();
-    // rows are taken in chunks whose fp16 image fits the LDS (only m > 16 with K = 4096 needs two launches)
-    int rows = a0.m;
-    for (;;) {
+    auto shape_of = [&](int rows, int* form, int* mt, int* kc, size_t* lds) {
         GemvArgs t = a0;
         t.m = rows;
         const int var = lm_gemv_variant(t);
-        const int kc = (var & 1) ? a0.kpad / 2 : a0.kpad;
-        if (gemv_lds_bytes((var & 1) ? 16 : rows, kc, var >> 1) <= 160 * 1024) break;
+        *form = var & 3;
+        *mt = var >> 2;
+        *kc = *form ? a0.kpad / 2 : a0.kpad;
+        const int lrows = *form == 1 ? 16 : (*form == 2 ? 32 * *mt : rows);
+        *lds = gemv_lds_bytes(lrows, *kc, *form == 2 ? 2 * *mt : *mt);
+    };
+    // rows are taken in chunks whose fp16 image fits the LDS (only m > 16 with K = 4096 needs two launches)
+    int rows = a0.m, form, mt, kc;
+    size_t lds;
+    for (;;) {
+        shape_of(rows, &form, &mt, &kc, &lds);
+        if (lds <= 160 * 1024) break;
         ASTTS_REQUIRE(rows > 1, ASTTS_ERR_INVALID, "lm_gemv: kpad=%d does not fit the LDS image", a0.kpad);
         rows = rows > 16 ? 16 : rows / 2;
     }
@@ -688,16 +767,14 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
             if (a.out16) a.out16 += (int64_t)r0 * a0.ldo16;
         }
         a.advance = a0.advance && r0 + rows >= a0.m;
-        const int var = lm_gemv_variant(a);
-        const bool half8 = var & 1;
-        const int mt = var >> 1;
-        const int kc = half8 ? a.kpad / 2 : a.kpad;
-        const size_t lds = gemv_lds_bytes(half8 ? 16 : a.m, kc, mt);
-        const dim3 grid((a.n + (half8 ? 7 : 15)) / (half8 ? 8 : 16));
+        // the form of the FIRST chunk serves every chunk (a short last chunk must not change the arithmetic of its rows)
+        const dim3 grid((a.n + (form ? 7 : 15)) / (form ? 8 : 16));
         const int lpw = ((kc >> 6) + GV_WAVES - 1) / GV_WAVES;
-        if (half8) gemv_launch_xm<1, true>(a, xm, grid, lds, lpw, st);
-        else if (mt == 1) gemv_launch_xm<1, false>(a, xm, grid, lds, lpw, st);
-        else gemv_launch_xm<2, false>(a, xm, grid, lds, lpw, st);
+        if (form == 1) gemv_launch_xm<1, 1>(a, xm, grid, lds, lpw, st);
+        else if (form == 2 && mt == 1) gemv_launch_xm<1, 2>(a, xm, grid, lds, lpw, st);
+        else if (form == 2) gemv_launch_xm<2, 2>(a, xm, grid, lds, lpw, st);
+        else if (mt == 1) gemv_launch_xm<1, 0>(a, xm, grid, lds, lpw, st);
+        else gemv_launch_xm<2, 0>(a, xm, grid, lds, lpw, st);
     }
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

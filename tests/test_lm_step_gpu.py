@@ -159,3 +159,106 @@ def test_fullsize_v2_is_deterministic_and_row_independent():
         sub = [1, 4, 6]
         t3 = lm.decode(pre[:, sub].contiguous(), steps, u[:, sub].contiguous(), True, None)
         assert torch.equal(t3, t1[sub])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Long-context regimes.  The oracle's teacher-forced logits of EVERY step come from causal passes over
+# prefix (+) emb(forced[:-1]) (query chunks of 256 against the caches of the earlier chunks: the oracle's relative-position
+# tensor is tq x tk x d), not from a 250-step loop: seconds on the host.
+def _oracle_forced_logits(sd, cfg, text, tlen, spk, prompt, forced, chunk=256):
+    from oracle import synth as osyn
+
+    pre = osyn.lm_prefix(sd, cfg, text, tlen, spk, prompt)
+    s0 = pre.shape[1]
+    emb = sd["speech_embedding.weight"][forced[:, :-1].long()]
+    x = torch.cat([pre, emb], 1)
+    caches, outs = None, []
+    with torch.no_grad():
+        for t0 in range(0, x.shape[1], chunk):
+            lg, caches = osyn.lm_forward(sd, cfg, x[:, t0:t0 + chunk], caches)
+            outs.append(lg)
+    return torch.cat(outs, 1)[:, s0 - 1:], s0          # [B, steps, V + 1]: step s is predicted from position s0 - 1 + s
+
+
+def _forced_case(cfg, sd, b, tt, tp, steps, seed, engine):
+    from astts.synth.model import AcousticLM
+
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
+    tlen = torch.full((b,), tt)
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    ref, s0 = _oracle_forced_logits(sd, cfg, text, tlen, spk, prompt, forced)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre = lm.prefix(text.to(DEV), tlen.to(DEV, torch.int32), spk.to(DEV), prompt.to(DEV))
+    with _engine(engine):
+        toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True)
+    assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    scale = float(ref.abs().max())
+    err = (logits.cpu() - ref).abs().amax(dim=(0, 2)) / scale          # per step
+    return err, s0
+
+
+def test_fullsize_v2_bench_geometry_every_step_vs_oracle():
+    """The benchmark's decode (BASELINE config 2: B=8, Tt=32, Tp=150, 250 tokens, CosyVoice-300M widths): 184 -> 433 keys,
+    i.e. up to four 64-key passes per key-split half of lm_attn.  Logits of all 250 steps against the oracle."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import make_lm_weights
+
+    cfg = SynthConfig()
+    sd = make_lm_weights(cfg, 0)
+    err, s0 = _forced_case(cfg, sd, 8, 32, 150, 250, 31, "v2")
+    assert s0 == 185
+    print(f"bench geometry v2: keys {s0}..{s0 + 249}; logits rel err vs oracle max {float(err.max()):.2e} (step {int(err.argmax())}), "
+          f"first {float(err[0]):.2e}, last {float(err[-1]):.2e}")
+    assert float(err.max()) < 3e-3
+
+
+@pytest.mark.parametrize("engine,b,tp", [("v2", 3, 1100), ("v2", 8, 1300), ("v1", 32, 1690), ("v2", 32, 1690), ("v2", 16, 1100)])
+def test_tiny_long_context_vs_oracle(engine, b, tp):
+    """> 1 024 keys: each key-split half of lm_attn walks more than one 512-key chunk (csrc/lm_step.hip chunk loop); v1's
+    attn_relpos_decode at the ~1 700 keys x 32 rows of the long-form probe (BASELINE config 3); the same for the wide v2 forms."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig.tiny().with_(max_positions=2048)
+    sd = make_all(cfg, 0)["llm"]
+    steps = 6
+    err, s0 = _forced_case(cfg, sd, b, 7, tp, steps, 500 + b, engine)
+    print(f"tiny long context {engine} b={b}: keys {s0}..{s0 + steps - 1}; logits rel err vs oracle {float(err.max()):.2e}")
+    assert float(err.max()) < 3e-3
+
+
+@pytest.mark.parametrize("rows", [12, 16, 20, 32])
+def test_fullsize_v2_rows_do_not_depend_on_the_batch_width(rows):
+    """The decode step's arithmetic for a row is the same in 8-, 16- and 32-row launches (csrc/lm_step.hip: the projection
+    form is chosen by shape, the halved 8-column forms sum in the order of the diagonal form, attention is per (row, head)):
+    teacher-forced logits of rows 0..7 taken from a wide batch equal those of the 8-row batch BIT FOR BIT, at CosyVoice-300M
+    widths, with a context long enough for both key halves of lm_attn."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import AcousticLM
+    from astts.synth.weights import make_lm_weights
+
+    cfg = SynthConfig()
+    sd = make_lm_weights(cfg, 0)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    g = torch.Generator().manual_seed(90 + rows)
+    tt, tp, steps = 20, 130, 10
+    text = torch.randint(0, cfg.text_vocab, (rows, tt), generator=g).to(DEV)
+    tlen = torch.full((rows,), tt, dtype=torch.int32, device=DEV)
+    spk = torch.randn(rows, cfg.spk_dim, generator=g).to(DEV)
+    prompt = torch.randint(0, cfg.speech_vocab, (rows, tp), generator=g).to(DEV)
+    forced = torch.randint(0, cfg.speech_vocab, (rows, steps), generator=g).to(DEV)
+    u = torch.rand(steps, rows, 2, generator=g).to(DEV)
+    pre = lm.prefix(text, tlen, spk, prompt)                      # shared prefix VALUES (the prefill picks GEMM tiles by row count)
+    with _engine("v2"):
+        _, wide = lm.decode(pre, steps, u, True, forced, return_logits=True)
+        for sl in (slice(0, 8), slice(rows - 8, rows), slice(3, 7)):
+            _, narrow = lm.decode(pre[:, sl].contiguous(), steps, u[:, sl].contiguous(), True, forced[sl].contiguous(), return_logits=True)
+            assert torch.equal(narrow, wide[sl]), (rows, sl)
+        # free running as well: tokens of the rows agree
+        t_w = lm.decode(pre, steps, u, True, None)
+        t_n = lm.decode(pre[:, :8].contiguous(), steps, u[:, :8].contiguous(), True, None)
+        assert torch.equal(t_n, t_w[:8])
