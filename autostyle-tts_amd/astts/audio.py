@@ -191,3 +191,21 @@ def mel_spectrogram(wav: torch.Tensor, sr: int = 22050, n_fft: int = 1024, hop: 
     fb = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
     mel = torch.matmul(fb, mag)
     return torch.log(torch.clamp(mel, min=1e-5)).transpose(1, 2).contiguous()
+
+
+def whisper_log_mel(wav16k: torch.Tensor, n_mels: int = 128) -> torch.Tensor:
+    """The input features of the reference's speech tokenizer ("whisper-style 128-bin log-mel of 16 k
+    audio"; upstream frontend._extract_speech_token calls whisper.log_mel_spectrogram(speech, n_mels=128)): periodic Hann
+    window of 400, hop 160, centred (reflect) STFT with the last frame dropped, POWER spectrum, Slaney mel (0 .. 8 kHz),
+    log10(clamp(., 1e-10)), floor at max - 8, (x + 4) / 4.  wav [B, n] or [n] at 16 kHz -> [B, n_mels, n // 160] (any device).
+    Pinned against transformers' WhisperFeatureExtractor (tests/test_oracle_synth_blocks.py); a real speech-tokenizer model plugs
+    in behind ``Frontend(speech_tokenizer=...)`` and takes exactly this tensor."""
+    w = wav16k if wav16k.dim() == 2 else wav16k[None]
+    w = w.to(torch.float32)
+    window = torch.hann_window(400, periodic=True, device=w.device)
+    spec = torch.stft(w, 400, hop_length=160, win_length=400, window=window, center=True, pad_mode="reflect", return_complex=True)
+    power = (spec.real ** 2 + spec.imag ** 2)[..., :-1]
+    fb = torch.from_numpy(mel_filterbank(16000, 400, n_mels, 0.0, 8000.0)).to(w.device)
+    log_spec = torch.log10(torch.clamp(torch.matmul(fb, power), min=1e-10))
+    log_spec = torch.maximum(log_spec, log_spec.amax(dim=(1, 2), keepdim=True) - 8.0)
+    return (log_spec + 4.0) / 4.0

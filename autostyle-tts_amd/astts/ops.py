@@ -69,7 +69,7 @@ class LmConfig(ctypes.Structure):
 
 class LmGlobals(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("speech_emb", "embed_w", "embed_b", "embed_ln_g", "embed_ln_b", "after_g", "after_b",
-                                        "head_w", "head_b")]
+                                        "head_w", "head_b", "embed_table")]
 
 
 class LmLayer(ctypes.Structure):

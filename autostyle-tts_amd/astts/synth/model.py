@@ -239,9 +239,13 @@ class AcousticLM:
             c = ops.LmConfig(body.d, body.heads, cfg.lm_ffn, len(body.L), cfg.speech_vocab + 1, cfg.speech_vocab, body.center,
                              body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps, 1, 1,
                              1 if body.fold_ln else 0)
+            # the decode step's input projection acts on a table lookup: speech_emb[tok] W^T + b is a row of the table
+            # speech_emb W^T + b, formed once here (the same fp16 MFMA products, on the GPU) and gathered by the step
+            self.embed_table = ops.linear(self.speech_emb, body.embed).contiguous()
             g = ops.LmGlobals(self.speech_emb.data_ptr(), body.embed.data.data_ptr(), body.embed.bias.data_ptr(),
                               body.embed_ln[0].data_ptr(), body.embed_ln[1].data_ptr(), body.after[0].data_ptr(),
-                              body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr())
+                              body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr(),
+                              self.embed_table.data_ptr())
             arr = (ops.LmLayer * len(body.L))()
             for i, L in enumerate(body.L):
                 arr[i] = ops.LmLayer(L["n1"][0].data_ptr(), L["n1"][1].data_ptr(), L["wqkv"].data.data_ptr(), L["wqkv"].bias.data_ptr(),
@@ -412,7 +416,7 @@ class _TfmBlock:
         self.heads = heads
         # norm1's scale / shift are folded into the fused q|k|v projection (W' = W diag(gamma), b' = W beta: fold_layernorm), so
         # that the fused LayerNorm + projection + attention kernel (ops.tfm_attn_fused) normalises without them; the unfused
-        # path (T > 352) runs the plain LayerNorm kernel with the identity affine on the same weights.
+        # path (T > 384) runs the plain LayerNorm kernel with the identity affine on the same weights.
         wqkv = torch.cat([sd[p + ".attn1.to_q.weight"], sd[p + ".attn1.to_k.weight"], sd[p + ".attn1.to_v.weight"]], 0).float().cpu()
         wqkv, bqkv = fold_layernorm(wqkv, torch.zeros(wqkv.shape[0]), sd[p + ".norm1.weight"].float().cpu(), sd[p + ".norm1.bias"].float().cpu())
         c = int(wqkv.shape[1])

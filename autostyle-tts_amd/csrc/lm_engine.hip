@@ -20,7 +20,8 @@ struct astts_lm {
 
 using namespace astts;
 
-// ---- v2: one decode step = sampler + embed + 14 x (QKV, attention, out-proj, FFN-in, FFN-out) + head = 73 launches
+// ---- v2: one decode step = sampler + 14 x (QKV, attention, out-proj, FFN-in, FFN-out) + head = 72 launches (73 without
+// the projected embedding table)
 static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max, int32_t b,
                      int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                      const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, hipStream_t st) {
@@ -71,10 +72,13 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
         const int pos = pos0 + s;
         // embed projection: speech_embedding[tok] -> Linear.  Its LayerNorm -> ReLU -> * sqrt(d) runs inside layer 0's QKV
         // kernel (pre-transform of the staged rows; workgroup 0 writes the result to xa, the residual stream).
+        // With the projected table (globals.embed_table = speech_emb W^T + b, formed at load) the projection is a gather as well.
         GemvArgs a = gemv();
-        a.x = g.speech_emb; a.gather = tok; a.ldx = d; a.w = (const _Float16*)g.embed_w; a.bias = g.embed_b; a.out = h1; a.ldo = d;
-        a.n = d; a.k = d; a.kpad = d;
-        if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+        if (!g.embed_table) {
+            a.x = g.speech_emb; a.gather = tok; a.ldx = d; a.w = (const _Float16*)g.embed_w; a.bias = g.embed_b; a.out = h1; a.ldo = d;
+            a.n = d; a.k = d; a.kpad = d;
+            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+        }
         float* x = xa;
         float* y = xb;
         for (int l = 0; l < c.layers; ++l) {
@@ -82,7 +86,9 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             _Float16* kvc = (_Float16*)kv_cache[l];
             a = gemv();             // LN1 + QKV: q -> `q`, K|V -> cache row `pos`
             if (l == 0) {
-                a.x = h1; a.pre_g = g.embed_ln_g; a.pre_b = g.embed_ln_b; a.pre_scale = sqrtf((float)d); a.pre_out = x;
+                a.x = g.embed_table ? g.embed_table : h1;
+                a.gather = g.embed_table ? tok : nullptr;
+                a.pre_g = g.embed_ln_g; a.pre_b = g.embed_ln_b; a.pre_scale = sqrtf((float)d); a.pre_out = x;
             } else {
                 a.x = x;
             }

@@ -18,7 +18,7 @@
 //   phase 2  each wave takes one 32-query tile: S^T = K Q^T, online softmax in the log2 domain, O^T += V^T P^T exactly as
 //            attn_mha_flash (ops_attention.hip), but K and V^T are read from LDS where phase 1 left them: no staging, no
 //            barrier, no global load in the key loop.
-// LDS: K [TKP][72] + V^T [64][TKP + 4] + A [2][32][264] + Q [192][72] halfs = 154 KB at T = 344 (TKP = 352): T <= 352.
+// LDS: K [TKP][72] + V^T [64][TKP + 4] + A [2][32][264] + Q [192][64] halfs = 151 KB at T = 344 (TKP = 352), 159.5 KB at TKP = 384: T <= 384.
 #include "common.h"
 
 namespace astts {
@@ -28,7 +28,13 @@ static constexpr int TF_DH = 64;
 static constexpr int TF_KS = 72;           // halfs per K / Q row in LDS (conflict-free ds_read_b128, as FA_KS)
 static constexpr int TF_AS = TF_C + 8;     // halfs per staged A row
 static constexpr int TF_QROWS = 192;       // queries per workgroup (6 tiles of 32)
-static constexpr int TF_MAX_T = 352;
+static constexpr int TF_QS = 64;           // halfs per Q row in LDS: unpadded, 16-byte pieces XOR-swizzled by the row (tf_q)
+static constexpr int TF_MAX_T = 384;       // 24 kHz, config 2: 749 frames -> 375 after the down block
+
+// Q rows (and the output tile transposed through them) are touched a handful of times per workgroup, K rows once per key tile:
+// the 8-half row padding goes to K only, Q rows are 128 bytes with piece p of row r stored at piece p ^ (r & 7) (two-way
+// conflicts at worst) -- 3 KB less LDS, which is what lets T = 384 keys (K + V^T = 105 KB) fit beside staging and Q.
+__device__ __forceinline__ int tf_q(int row, int col) { return row * TF_QS + ((((col >> 3) ^ row) & 7) << 3) + (col & 7); }
 
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k + 15), result on every lane: four row rotations on the VALU.
 // (__shfl_xor compiles to ds_bpermute_b32: an LDS round trip of ~100 cycles per step, eight steps per staged chunk.)
@@ -90,7 +96,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     _Float16* sK = tf_smem;                          // [tkp][72]
     _Float16* sVt = sK + (size_t)tkp * TF_KS;        // [64][vs]
     _Float16* sA = sVt + (size_t)TF_DH * vs;         // [2][32][264]
-    _Float16* sQ = sA + 2 * 32 * TF_AS;              // [192][72]
+    _Float16* sQ = sA + 2 * 32 * TF_AS;              // [192][64], swizzled (tf_q)
     const int len = a.lens ? min(a.lens[b], T) : T;
     const float* xb = a.x + (int64_t)b * T * TF_C;
     const int hd = a.heads * TF_DH;
@@ -191,13 +197,14 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s0 + s], af[s], acc, 0, 0, 0);
                 }
-                _Float16* kp = role == 0 ? sK + (size_t)(ch * 32 + c) * TF_KS : sQ + (size_t)((ch - qch0) * 32 + c) * TF_KS;
-                kp += (wid & 1) * 32 + 4 * hh;
+                _Float16* kp = sK + (size_t)(ch * 32 + c) * TF_KS + (wid & 1) * 32 + 4 * hh;
+                const int qr = (ch - qch0) * 32 + c;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     half4 h4;
                     h4[0] = (_Float16)acc[4 * g]; h4[1] = (_Float16)acc[4 * g + 1]; h4[2] = (_Float16)acc[4 * g + 2]; h4[3] = (_Float16)acc[4 * g + 3];
-                    *reinterpret_cast<half4*>(kp + 8 * g) = h4;
+                    if (role == 0) *reinterpret_cast<half4*>(kp + 8 * g) = h4;
+                    else *reinterpret_cast<half4*>(sQ + tf_q(qr, (wid & 1) * 32 + 4 * hh + 8 * g)) = h4;
                 }
             }
         }
@@ -259,13 +266,13 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     const int jb1 = tile >= 0 ? min((nkt * (part + 1) / parts) * 32, len) : 0;
     const int tsafe = tile >= 0 ? tile : 0;
     const int q0 = (qch0 + tsafe) * 32;                 // first frame of this wave's query tile
-    _Float16* qrow = sQ + (size_t)(tsafe * 32) * TF_KS;   // this tile's Q rows; reused by its owner as the output transpose buffer
+    _Float16* qrow = sQ + (size_t)(tsafe * 32) * TF_QS;   // this tile's Q rows (32 rows: the swizzle is tile-local); reused by its owner as the output transpose buffer
     half8 qf[4];
     {
         const float qscale = a.scale * 1.44269504088896341f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const half8 raw = *reinterpret_cast<const half8*>(qrow + c * TF_KS + 16 * s + 8 * hh);
+            const half8 raw = *reinterpret_cast<const half8*>(qrow + tf_q(c, 16 * s + 8 * hh));
 #pragma unroll
             for (int i = 0; i < 8; ++i) qf[s][i] = (_Float16)((float)raw[i] * qscale);
         }
@@ -377,7 +384,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
             half4 h4;
             h4[0] = (_Float16)(ot[dt][4 * g] * inv); h4[1] = (_Float16)(ot[dt][4 * g + 1] * inv);
             h4[2] = (_Float16)(ot[dt][4 * g + 2] * inv); h4[3] = (_Float16)(ot[dt][4 * g + 3] * inv);
-            *reinterpret_cast<half4*>(qrow + c * TF_KS + dt * 32 + 8 * g + 4 * hh) = h4;
+            *reinterpret_cast<half4*>(qrow + tf_q(c, dt * 32 + 8 * g + 4 * hh)) = h4;
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
@@ -386,7 +393,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
         const int r = i * 8 + (lane >> 3), seg = (lane & 7) * 8;
         const int fr = q0 + r;
         if (fr < T)
-            *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + r * TF_KS + seg);
+            *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + tf_q(r, seg));
     }
     }
     if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = (_Float16)0.0f;     // never true: keeps the prefetch loads alive
@@ -770,7 +777,7 @@ int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const flo
     return ASTTS_OK;
 }
 
-/* 1 when astts_op_tfm_attn_fused serves this shape (channels 256, head dim 64, t <= 352), else 0 */
+/* 1 when astts_op_tfm_attn_fused serves this shape (channels 256, head dim 64, t <= 384), else 0 */
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t) {
     return c == TF_C && heads >= 1 && heads <= 16 && t >= 1 && t <= TF_MAX_T ? 1 : 0;
 }
@@ -790,7 +797,7 @@ int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const 
     ASTTS_REQUIRE(b >= 1 && (((uintptr_t)x | (uintptr_t)wqkv_frag_f16 | (uintptr_t)out_f16) & 15) == 0, ASTTS_ERR_INVALID,
                   "astts_op_tfm_attn_fused: operands must be 16-byte aligned");
     const int nch = (t + 31) / 32, tkp = nch * 32;
-    const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_KS) * sizeof(_Float16);
+    const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_QS) * sizeof(_Float16);
     static std::once_flag attr;
     std::call_once(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

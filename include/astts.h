@@ -299,6 +299,9 @@ typedef struct {
     const float* embed_ln_g; const float* embed_ln_b; /* llm.embed.out.1 */
     const float* after_g; const float* after_b;       /* llm.after_norm */
     const void* head_w; const float* head_b;         /* llm_decoder */
+    const float* embed_table;                /* optional [speech_vocab, d] fp32 = speech_emb x embed_w^T + embed_b, formed once at
+                                              * load: the decode step then gathers its rows instead of running the projection
+                                              * (one launch per step less); NULL: the projection runs every step */
 } astts_lm_globals_t;
 typedef struct {
     const float* n1_g; const float* n1_b;
@@ -351,7 +354,7 @@ int astts_op_mean_pool(const float* x, const int32_t* lens, float* out, int32_t 
  * transformer block of the flow estimator in one launch (csrc/ops_tfm_fused.hip): x fp32 [b, t, c] -> out fp16
  * [b, t, heads*64].  wqkv_frag: the q | k | v weight [3*heads*64, c] re-ordered by astts_op_tfm_pack_frag (from the row-major
  * astts_op_pack_weight image) into MFMA fragment order; bias fp32 [3*heads*64] or NULL, lens int32 [b] or NULL.  Serves
- * c == 256, t <= 352 (astts_op_tfm_attn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the caller runs
+ * c == 256, t <= 384 (astts_op_tfm_attn_fused_supported); otherwise ASTTS_ERR_UNSUPPORTED and the caller runs
  * astts_op_layernorm_ex + astts_op_gemm_ex + astts_op_attn_mha_ex on the row-major weight. */
 int astts_op_tfm_pack_frag(const void* w_f16, void* out_f16, int32_t rows, int32_t k, astts_stream_t stream);
 int astts_op_tfm_attn_fused_supported(int32_t c, int32_t heads, int32_t t);

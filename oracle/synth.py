@@ -97,18 +97,24 @@ def relpos_encoder(sd: SD, p: str, x: torch.Tensor, lens: torch.Tensor, heads: i
         h = F.relu(h)
     h = h * math.sqrt(d)
     pe = rel_pos_table(d, max_pos)
-    n1, n2 = norm_names
     fn = {"relu": F.relu, "swish": F.silu}[act]
     new_caches = []
     for i in range(layers):
-        q = f"{p}.encoders.{i}"
-        a, kv = relpos_attention(sd, q + ".self_attn", _ln(sd, f"{q}.{n1}", h, eps), heads, pe, max_pos, lens, causal,
-                                 None if caches is None else caches[i])
+        h, kv = relpos_layer(sd, f"{p}.encoders.{i}", h, heads, pe, max_pos, lens, causal, norm_names, fn, eps,
+                             None if caches is None else caches[i])
         new_caches.append(kv)
-        h = h + a
-        f = _lin(sd, q + ".feed_forward.w_2", fn(_lin(sd, q + ".feed_forward.w_1", _ln(sd, f"{q}.{n2}", h, eps))))
-        h = h + f
     return _ln(sd, p + ".after_norm", h, eps), new_caches
+
+
+def relpos_layer(sd: SD, q: str, h: torch.Tensor, heads: int, pe: torch.Tensor, center: int, lens: torch.Tensor, causal: bool,
+                 norm_names: Tuple[str, str], fn, eps: float, cache=None):
+    """One pre-norm encoder layer (no macaron feed-forward, no convolution module): h += attn(LN(h)); h += W2 act(W1 LN(h)).
+    Pinned against transformers' FastSpeech2ConformerEncoderLayer (tests/test_oracle_synth_blocks.py)."""
+    n1, n2 = norm_names
+    a, kv = relpos_attention(sd, q + ".self_attn", _ln(sd, f"{q}.{n1}", h, eps), heads, pe, center, lens, causal, cache)
+    h = h + a
+    f = _lin(sd, q + ".feed_forward.w_2", fn(_lin(sd, q + ".feed_forward.w_1", _ln(sd, f"{q}.{n2}", h, eps))))
+    return h + f, kv
 
 
 # ----------------------------------------------------------------------------------------- LM
@@ -362,11 +368,11 @@ def hift_source(sd: SD, cfg, f0: torch.Tensor, phase0: torch.Tensor, noise: torc
     return torch.tanh(F.linear(src, sd["m_source.l_linear.weight"], sd["m_source.l_linear.bias"])).squeeze(-1)
 
 
-def hift_decode(sd: SD, cfg, mel: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
-    """mel [B, Tm, 80], source [B, L] -> waveform [B, L]."""
-    win = torch.hann_window(16, periodic=True)
-    spec = torch.stft(source, 16, 4, 16, window=win, return_complex=True)
-    s_stft = torch.cat([spec.real, spec.imag], dim=1).transpose(1, 2)  # [B, F, 18]
+def hift_trunk(sd: SD, cfg, mel: torch.Tensor, s_stft: torch.Tensor) -> torch.Tensor:
+    """The HiFi-GAN trunk of HiFT: conv_pre -> per stage [leaky-relu -> ConvTranspose1d -> + source branch -> mean of the
+    parallel resblocks] -> leaky-relu(0.01): mel [B, Tm, 80], s_stft [B, F, 18] -> [B, L / 4 + 1, C] (the input of conv_post).
+    With a silent source branch and leaky-relu in place of Snake this IS the HiFi-GAN generator trunk: pinned against
+    transformers' SpeechT5HifiGan (tests/test_oracle_synth_blocks.py)."""
     x = _conv(sd, "conv_pre", mel, pad=3)
     n_up = len(cfg.up_rates)
     nk = len(cfg.res_kernels)
@@ -386,7 +392,15 @@ def hift_decode(sd: SD, cfg, mel: torch.Tensor, source: torch.Tensor) -> torch.T
             y = _resblock(sd, f"resblocks.{i * nk + kk}", x, k, cfg.res_dils)
             xs = y if xs is None else xs + y
         x = xs / nk
-    x = F.leaky_relu(x)  # default slope 0.01, as upstream
+    return F.leaky_relu(x)  # default slope 0.01, as upstream
+
+
+def hift_decode(sd: SD, cfg, mel: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+    """mel [B, Tm, 80], source [B, L] -> waveform [B, L]."""
+    win = torch.hann_window(16, periodic=True)
+    spec = torch.stft(source, 16, 4, 16, window=win, return_complex=True)
+    s_stft = torch.cat([spec.real, spec.imag], dim=1).transpose(1, 2)  # [B, F, 18]
+    x = hift_trunk(sd, cfg, mel, s_stft)
     x = _conv(sd, "conv_post", x, pad=3)
     mag = torch.clip(torch.exp(x[..., :9]), max=1e2)
     ph = torch.sin(x[..., 9:])

@@ -1,0 +1,176 @@
+"""Generates tests/golden/synth_blocks.npz: inputs, weights and expected outputs of the PUBLISHED building blocks that
+oracle/synth.py restates, produced by independent third-party implementations of the same blocks in transformers
+(the reference's own synthesis code is a private CosyVoice fork that exists nowhere in this environment:
+/root/reference/tts_with_rag.py:1-2,18-19,159,195):
+
+  rel-pos attention  FastSpeech2ConformerAttention + FastSpeech2ConformerRelPositionalEncoding and
+                     Wav2Vec2ConformerSelfAttention("relative") + Wav2Vec2ConformerRelPositionalEmbedding
+                     (espnet's RelPositionMultiHeadedAttention incl. pos_bias_u / pos_bias_v and the rel-shift)
+                                                         -> oracle.synth.relpos_attention / rel_pos_table      (a13, a14)
+  encoder layer      FastSpeech2ConformerEncoderLayer (pre-norm, no macaron / convolution module)
+                                                         -> oracle.synth.relpos_layer (residual / norm order)  (a13, a14)
+  Snake              dac Snake1d                         -> oracle.synth._snake                               (a15)
+  HiFi-GAN resblock  speecht5 HifiGanResidualBlock       -> oracle.synth._resblock (structure: dilations, paddings, residuals)
+  HiFi-GAN trunk     SpeechT5HifiGan (conv_pre, leaky-relu, ConvTranspose1d padding (k - u) / 2, mean over the parallel
+                     resblocks, final leaky-relu 0.01)   -> oracle.synth.hift_trunk with a silent source path
+  Whisper log-mel    WhisperFeatureExtractor(feature_size=128) -> astts.audio.whisper_log_mel / mel_filterbank (a12)
+
+Run in the BUILD container only (python tests/golden/make_synth_block_fixtures.py).  The .npz is data: seeded random
+weights and inputs in, the third-party outputs out.  Nothing of transformers travels."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "autostyle-tts_amd")]
+
+
+def t2n(sd, prefix):
+    return {prefix + k: v.detach().float().numpy() for k, v in sd.items()}
+
+
+def relpos_fastspeech2(out):
+    from transformers import FastSpeech2ConformerConfig
+    from transformers.models.fastspeech2_conformer import modeling_fastspeech2_conformer as m
+
+    torch.manual_seed(11)
+    d, heads, b, t = 96, 4, 3, 29
+    cfg = FastSpeech2ConformerConfig(hidden_size=d)
+    mc = {"num_attention_heads": heads, "attention_dropout_rate": 0.0, "positional_dropout_rate": 0.0}
+    att = m.FastSpeech2ConformerAttention(cfg, mc).eval()
+    pos = m.FastSpeech2ConformerRelPositionalEncoding(cfg, mc).eval()
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() > 1 else 0.2))
+        x = torch.randn(b, t, d)
+        lens = torch.tensor([t, t - 6, 11])
+        mask = (torch.arange(t)[None, :] < lens[:, None]).long()[:, None, :]           # (batch, 1, time)
+        _, pos_emb = pos(x)
+        y, _ = att(x, attention_mask=mask, pos_emb=pos_emb)
+    out.update(t2n(att.state_dict(), "fs2."))
+    out.update({"fs2.x": x.numpy(), "fs2.lens": lens.numpy(), "fs2.pos_emb": pos_emb.numpy(), "fs2.y": y.numpy(),
+                "fs2.heads": np.int64(heads)})
+    print("fastspeech2 rel-pos attention:", tuple(y.shape), "pos_emb", tuple(pos_emb.shape))
+
+
+def encoder_layer(out):
+    """Pre-norm conformer layer without the macaron feed-forward and the convolution module = the layer of espnet's
+    TransformerEncoder with rel-pos attention (what CosyVoice's text encoder, token encoder and LM body stack)."""
+    from transformers import FastSpeech2ConformerConfig
+    from transformers.models.fastspeech2_conformer import modeling_fastspeech2_conformer as m
+
+    torch.manual_seed(16)
+    d, heads, b, t, ffn = 64, 2, 2, 21, 160
+    cfg = FastSpeech2ConformerConfig(hidden_size=d, use_macaron_style_in_conformer=False, use_cnn_in_conformer=False,
+                                     positionwise_conv_kernel_size=1)
+    mc = {"num_attention_heads": heads, "attention_dropout_rate": 0.0, "positional_dropout_rate": 0.0, "dropout_rate": 0.0,
+          "linear_units": ffn, "normalize_before": True, "concat_after": False}
+    lay = m.FastSpeech2ConformerEncoderLayer(cfg, mc).eval()
+    lay.conv_module = None            # transformers 5.15 reads the attribute even when the module is configured off
+    pos = m.FastSpeech2ConformerRelPositionalEncoding(cfg, mc).eval()
+    with torch.no_grad():
+        for n_, p in lay.named_parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() > 1 else 0.2) + (1.0 if n_.endswith("layer_norm.weight") else 0.0))
+        x = torch.randn(b, t, d)
+        lens = torch.tensor([t, 13])
+        mask = (torch.arange(t)[None, :] < lens[:, None]).long()[:, None, :]
+        _, pos_emb = pos(x)
+        y = lay(x, pos_emb=pos_emb, attention_mask=mask)[0]
+    out.update(t2n(lay.state_dict(), "enc."))
+    out.update({"enc.x": x.numpy(), "enc.lens": lens.numpy(), "enc.y": y.numpy(), "enc.heads": np.int64(heads)})
+    print("conformer encoder layer:", tuple(y.shape), sorted(k for k in lay.state_dict())[:4], "...")
+
+
+def relpos_wav2vec2(out):
+    from transformers import Wav2Vec2ConformerConfig
+    from transformers.models.wav2vec2_conformer import modeling_wav2vec2_conformer as w
+
+    torch.manual_seed(12)
+    d, heads, b, t = 64, 2, 2, 37
+    cfg = Wav2Vec2ConformerConfig(hidden_size=d, num_attention_heads=heads, position_embeddings_type="relative",
+                                  attention_dropout=0.0, max_source_positions=100)
+    att = w.Wav2Vec2ConformerSelfAttention(cfg).eval()
+    pos = w.Wav2Vec2ConformerRelPositionalEmbedding(cfg).eval()
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() > 1 else 0.2))
+        x = torch.randn(b, t, d)
+        rel = pos(x)
+        y, _ = att(x, attention_mask=None, relative_position_embeddings=rel)
+    out.update(t2n(att.state_dict(), "w2v."))
+    out.update({"w2v.x": x.numpy(), "w2v.pos_emb": rel.numpy(), "w2v.y": y.numpy(), "w2v.heads": np.int64(heads)})
+    print("wav2vec2-conformer rel-pos attention:", tuple(y.shape))
+
+
+def snake(out):
+    from transformers.models.dac.modeling_dac import Snake1d
+
+    torch.manual_seed(13)
+    s = Snake1d(24).eval()
+    with torch.no_grad():
+        s.alpha.copy_(torch.rand_like(s.alpha) * 3 + 0.05)
+        x = torch.randn(2, 24, 50) * 2
+        y = s(x)
+    out.update({"snake.alpha": s.alpha.detach().view(-1).numpy(), "snake.x": x.numpy(), "snake.y": y.numpy()})
+
+
+def hifigan(out):
+    from transformers import SpeechT5HifiGan, SpeechT5HifiGanConfig
+    from transformers.models.speecht5.modeling_speecht5 import HifiGanResidualBlock
+
+    torch.manual_seed(14)
+    # one residual block at each kernel size HiFT uses
+    for k in (3, 7, 11):
+        rb = HifiGanResidualBlock(12, k, (1, 3, 5), 0.1).eval()
+        with torch.no_grad():
+            for p in rb.parameters():
+                p.copy_(torch.randn_like(p) * 0.2)
+            x = torch.randn(2, 12, 90)
+            y = rb(x)
+        out.update(t2n(rb.state_dict(), f"rb{k}."))
+        out.update({f"rb{k}.x": x.numpy(), f"rb{k}.y": y.numpy()})
+    # the generator trunk: conv_pre -> 2 x [leaky-relu -> ConvTranspose1d(16, stride 8, padding 4) -> mean of 3 resblocks] -> leaky-relu
+    cfg = SpeechT5HifiGanConfig(model_in_dim=10, upsample_initial_channel=32, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16],
+                                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, leaky_relu_slope=0.1,
+                                normalize_before=False)
+    g = SpeechT5HifiGan(cfg).eval()
+    grabbed = {}
+    g.conv_post.register_forward_pre_hook(lambda mod, args: grabbed.__setitem__("pre_post", args[0].detach().clone()))
+    with torch.no_grad():
+        for p in g.parameters():
+            p.copy_(torch.randn_like(p) * 0.15)
+        mel = torch.randn(2, 6, 10)                         # (batch, frames, mel)
+        wav = g(mel)
+    sd = {k: v for k, v in g.state_dict().items() if k not in ("mean", "scale")}
+    out.update(t2n(sd, "gan."))
+    out.update({"gan.mel": mel.numpy(), "gan.pre_post": grabbed["pre_post"].numpy(), "gan.wav": wav.numpy()})
+    print("hifigan trunk:", tuple(grabbed["pre_post"].shape), "->", tuple(wav.shape))
+
+
+def whisper(out):
+    from transformers import WhisperFeatureExtractor
+
+    fe = WhisperFeatureExtractor(feature_size=128)
+    g = torch.Generator().manual_seed(15)
+    n = 16000 * 2 + 123
+    t = torch.arange(n) / 16000.0
+    wav = (0.4 * torch.sin(2 * np.pi * 220 * t) + 0.2 * torch.sin(2 * np.pi * 1870 * t + 1.0) + 0.05 * torch.randn(n, generator=g)).numpy()
+    feats = fe(wav, sampling_rate=16000, return_tensors="np", padding="do_not_pad")["input_features"][0]     # [128, frames]
+    out.update({"whisper.wav": wav.astype(np.float32), "whisper.features": feats.astype(np.float32),
+                "whisper.mel_filters": np.asarray(fe.mel_filters, np.float32)})                              # [201, 128]
+    print("whisper log-mel:", feats.shape)
+
+
+if __name__ == "__main__":
+    fx = {}
+    relpos_fastspeech2(fx)
+    relpos_wav2vec2(fx)
+    encoder_layer(fx)
+    snake(fx)
+    hifigan(fx)
+    whisper(fx)
+    path = os.path.join(ROOT, "tests", "golden", "synth_blocks.npz")
+    np.savez_compressed(path, **fx)
+    print("->", path, os.path.getsize(path) // 1024, "KB,", len(fx), "arrays")

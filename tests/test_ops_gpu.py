@@ -485,11 +485,13 @@ def test_new_entry_points_validate_arguments():
     assert rc == _lib.ERR_WORKSPACE
 
 
-@pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 352, True), (1, 33, False), (2, 1, False)])
+@pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 352, True), (1, 33, False), (2, 1, False),
+                                        (16, 375, False), (3, 384, True), (8, 353, True)])
 def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
     """astts_op_tfm_attn_fused (LayerNorm + q|k|v projection + masked MHA of a flow-estimator transformer block in one launch)
     against the fp32 definition and against the three-launch path it replaces (layernorm -> linear -> attn_mha) on the same
-    folded weights.  Shapes: the benchmark's (16 sequences x 344 frames), the largest supported T, ragged lengths, tiny T."""
+    folded weights.  Shapes: the benchmark's (16 sequences x 344 frames at 22.05 kHz, x 375 at 24 kHz), the largest supported T
+    (384), ragged lengths, tiny T."""
     import torch.nn.functional as F
 
     from astts import ops
@@ -501,7 +503,7 @@ def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
     gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
     w = torch.randn(3 * heads * 64, c, generator=g) / 16
     lens = torch.tensor([t] + [max(1, t - 7 * (i + 1)) for i in range(b - 1)]) if ragged else torch.full((b,), t)
-    assert ops.tfm_attn_fused_supported(c, heads, t) and not ops.tfm_attn_fused_supported(c, heads, 353)
+    assert ops.tfm_attn_fused_supported(c, heads, t) and not ops.tfm_attn_fused_supported(c, heads, 385)
     wf, bf = fold_layernorm(w, torch.zeros(w.shape[0]), gamma, beta)
     pw = ops.PackedWeight(wf, bf)
     ld = lens.to(DEV, torch.int32)
