@@ -61,14 +61,20 @@ __device__ __forceinline__ float wsum64(float v) {
 // partials of lm_attn (merged while staging).  NL: weight lines a wave keeps in flight (2 for K <= 1024 at 16 columns: the
 // kernel then fits two workgroups per CU, e.g. the 257 workgroups of the output head in one wave of blocks).
 template <int MT, int FORM, int XM, int NL>
-__global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(GemvArgs a) {
+__global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(const void* p_x, const _Float16* p_w, const float* p_x2, const int* p_gather, int p_m, int p_n, int p_k, int p_kpad, int p_ldx,
+                                                                                                                GemvArgs a_in) {
+    // The first 13 dwords of the kernarg segment are what the FIRST global loads need (input rows, weight lines).  As explicit
+    // leading parameters they are PRELOADED into SGPRs by the command processor (-amdgpu-kernarg-preload-count, Makefile): the
+    // wave issues those loads without waiting for an s_load of its arguments (a cold scalar-cache miss, ~0.5-1 us in a kernel
+    // that lasts 3-5).  The struct behind them carries the same fields again (ignored) and everything else.
+    GemvArgs a = a_in;
+    a.x = p_x; a.w = p_w; a.x2 = p_x2; a.gather = p_gather; a.m = p_m; a.n = p_n; a.k = p_k; a.kpad = p_kpad; a.ldx = p_ldx;
     constexpr bool XF16 = XM != 0;
     constexpr bool HALF8 = FORM != 0;                          // K halved over MFMA columns, 8 output columns per workgroup
     constexpr bool DIAG = FORM == 1;
     constexpr int RH = DIAG ? 8 : 16 * MT;                     // LDS row offset of the second K half
     constexpr int NACC = FORM == 2 ? 2 * MT : MT;              // accumulators per wave
     extern __shared__ __attribute__((aligned(16))) char gv_smem[];
-    pin_args(a);
     LM_STAMP(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
             fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
         }
     }
+    pin_args(a);            // the remaining arguments: ONE wide scalar load + ONE wait, behind the loads issued above
     // LayerNorm parameters of the lanes' k positions (same positions for every row)
     float4 lg[MAXV], lb[MAXV];
     if constexpr (!XF16) {
@@ -525,10 +532,14 @@ __device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
     return s;
 }
 
-__global__ __launch_bounds__(512, 4) void lm_attn(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float16* p_kv, const _Float16* p_postab, const int* p_kstart, int p_b, int p_ldq,
+                                                  int p_ldp, int p_center, int p_d, int p_pos, AttnArgs a_in) {
     __shared__ float s_m[8];
     __shared__ float s_l[8];
     __shared__ __attribute__((aligned(16))) float s_o[8][64];
+    AttnArgs a = a_in;      // leading parameters: preloaded into SGPRs (see lm_gemv; 14 dwords is the most the hardware preloads)
+    a.q = p_q; a.kv = p_kv; a.postab = p_postab; a.kstart = p_kstart; a.b = p_b; a.ldq = p_ldq; a.ldp = p_ldp; a.center = p_center;
+    a.d = p_d; a.pos = p_pos;
     pin_args(a);
     LM_STAMP(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -678,6 +689,9 @@ int lm_gemv_variant(const GemvArgs& a) {
     return form | (mt << 2);
 }
 
+#define GV_LEAD(a) (a).x, (a).w, (a).x2, (a).gather, (a).m, (a).n, (a).k, (a).kpad, (a).ldx     // the preloaded leading kernel arguments
+#define AT_LEAD(a) (a).q, (a).kv, (a).postab, (a).kstart, (a).b, (a).ldq, (a).ldp, (a).center, (a).d, (a).pos
+
 template <int MT, int FORM, int XM>
 static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st) {
     static std::once_flag attr;   // first use (never inside a capture: lm_step_set_attrs() visits every variant up front)
@@ -689,12 +703,12 @@ static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_p
     // bench-only launch profiler: algorithmic bytes of a decode GEMV = its weight image, streamed once
     hipEvent_t e0, e1;
     if (prof_events(ASTTS_PROF_GEMM_SKINNY, (double)a.n * a.kpad * 2.0, &e0, &e1)) {
-        if (lines_per_wave <= 2) hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
-        else hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, a);
+        if (lines_per_wave <= 2) hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, GV_LEAD(a), a);
+        else hipExtLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, GV_LEAD(a), a);
         return;
     }
-    if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), lds, st, a);
+    if (lines_per_wave <= 2) hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 2>), grid, dim3(512), lds, st, GV_LEAD(a), a);
+    else hipLaunchKernelGGL((lm_gemv<MT, FORM, XM, 8>), grid, dim3(512), lds, st, GV_LEAD(a), a);
 }
 
 template <int MT, int FORM>
@@ -790,9 +804,9 @@ int lm_attn_launch(const AttnArgs& a, hipStream_t st) {
     const double keys = (double)((a.st ? 0 : a.pos) + 1);
     hipEvent_t e0, e1;
     if (prof_events(ASTTS_PROF_ATTN_DECODE, keys * a.d * 2.0 * (2.0 * a.b + 1.0), &e0, &e1))
-        hipExtLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, e0, e1, 0, AT_LEAD(a), a);
     else
-        hipLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(lm_attn, dim3(a.h, a.b, a.ksplit), dim3(512), 0, st, AT_LEAD(a), a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -329,7 +329,8 @@ def main():
     cob = {}
     if args.steps >= 2:
         main_pipe = pipe
-        pipe = PipelinedSynth.autotune(eng, sample, depths=((2, 2),), trials=2, steps=max(2, min(args.steps, 8)),
+        cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
+        pipe = PipelinedSynth.autotune(eng, sample, depths=cob_cfgs, trials=2, steps=max(2, min(args.steps, 8)),
                                        front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
         with torch.cuda.stream(pipe.front_stream):
             for _ in range(args.warmup):
@@ -348,7 +349,7 @@ def main():
             t = torch.tensor([dtc], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtc = float(t.item())
-        cob = {"ms_per_step": 1e3 * dtc / args.steps, "dt": dtc}
+        cob = {"ms_per_step": 1e3 * dtc / args.steps, "dt": dtc, "chains": pipe.depth, "batches_per_chain": pipe.cobatch}
         pipe = main_pipe
 
     # ---- stage breakdown (one more step with events on the current stream)
@@ -581,8 +582,10 @@ def main():
             "waveform_finite_and_clamped": wav_ok,
             "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
-                                               "note": "same K steps, LM stages of 2 consecutive batches co-batched into one 16-row decode "
-                                                       "chain (outputs bit-identical per batch); reported beside `value`, not as it"} if cob else None),
+                                               "decode_chains": cob["chains"], "batches_per_chain": cob["batches_per_chain"],
+                                               "note": "same K steps, LM stages of consecutive batches co-batched into one 16- or 32-row decode "
+                                                       "chain (a row's tokens do not depend on the chain's width: outputs bit-identical per batch); "
+                                                       "the fastest of (2 chains x 2 batches, 2 x 4, 1 x 4) by calibration; reported beside `value`, not as it"} if cob else None),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "sequential_ms_per_step": round(sum(stages.values()), 3),
             "roofline": roof,

@@ -1,8 +1,12 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_lm_step_gpu.py tests/test_configs_gpu.py tests/test_synth_gpu.py -x -q -m gpu 2>&1 | tail -8
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r03_bench2.json 2> gpurun_out/r03_bench2.err; tail -c 600 gpurun_out/r03_bench2.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r03_bench2.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step','stages_ms','sequential_ms_per_step')}); print(d['cobatched_lm_side_measurement']); print(d['value_24khz']); 
-PY
+for i in 1 2; do
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 8 200 2>&1 | head -1
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 200 2>&1 | head -1
+done
+DC_NOSTATE=1 DC_OPS=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 8 100
+DC_NOSTATE=1 DC_OPS=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 100
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 16 100 | head -1
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 16 100 | head -1
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 32 100 | head -1
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 32 100 | head -1
+DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 200 2>&1 | grep "TWO\|2 conc\|3 conc"

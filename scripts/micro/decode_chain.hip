@@ -75,7 +75,7 @@ struct Layer {
     float *bqkv, *bo, *b1, *b2, *n1g, *n1b, *n2g, *n2b, *u, *v;
 };
 struct Model {
-    int d = 1024, heads = 16, ffn = 4096, layers = 14, vocab = 4097, center = 2048, tmax = 512;
+    int d = 1024, heads = 16, ffn = 4096, layers = 14, vocab = 4097, center = 2048, tmax = getenv("DC_TMAX") ? atoi(getenv("DC_TMAX")) : 512;
     std::vector<Layer> L;
     _Float16* head;
     float *head_b, *ag, *ab;
@@ -254,14 +254,14 @@ int main(int argc, char** argv) {
         const int d = m.d;
         auto G = [&]() { GemvArgs a; memset(&a, 0, sizeof(a)); a.st = g_nostate ? nullptr : c.st; a.pos = 305; a.m = b; a.ln_eps = 1e-5f; return a; };
         auto run = [&](const char* name, const std::function<void(int)>& op) {
-            hipLaunchKernelGGL(set_state, dim3(1), dim3(1), 0, st, c.st, 120, pos0);
+            hipLaunchKernelGGL(set_state, dim3(1), dim3(1), 0, st, c.st, getenv("DC_STEP") ? atoi(getenv("DC_STEP")) : 120, pos0);
             for (int i = 0; i < 28; ++i) op(i % 14);
             CK(hipStreamSynchronize(st));
             const int n = 14 * 40;
             const double t = time_ms(st, [&] { for (int i = 0; i < n; ++i) op(i % 14); });
             printf("  %-28s %.2f us per launch (incl. ~1.45 us boundary)\n", name, t * 1e3 / n);
         };
-        printf("B=%d, single operators (step 120: %d keys):\n", b, pos0 + 121);
+        printf("B=%d, single operators (step %d: %d keys):\n", b, getenv("DC_STEP") ? atoi(getenv("DC_STEP")) : 120, pos0 + 1 + (getenv("DC_STEP") ? atoi(getenv("DC_STEP")) : 120));
         run("qkv  (LN, n=3072, k=1024)", [&](int l) { const Layer& L = m.L[l]; GemvArgs a = G(); a.x = (l & 1) ? c.x1 : c.x0; a.ldx = d; a.ln_g = L.n1g; a.ln_b = L.n1b; if (g_lnplain) { a.ln_g = nullptr; a.ln_b = nullptr; a.ln_plain = 1; } a.w = L.wqkv; a.bias = L.bqkv; a.out = c.q; a.ldo = d;
             a.kv = c.kv[l]; a.n_split = d; a.ldkv = 2 * d; a.n = 3 * d; a.k = d; a.kpad = d; if (lm_gemv_launch(a, st)) exit(2); });
         run("attn", [&](int l) { const Layer& L = m.L[l]; AttnArgs t; memset(&t, 0, sizeof(t));

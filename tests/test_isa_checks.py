@@ -16,7 +16,8 @@ def _asm(src, tmp_path):
     if not (shutil.which(HIPCC) or os.path.exists(HIPCC)):
         pytest.skip("hipcc not available")
     out = tmp_path / (os.path.basename(src) + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", src, "-o", str(out)],
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm",
+                    "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", src, "-o", str(out)],
                    check=True, cwd=CSRC, timeout=600)
     return out.read_text()
 
@@ -49,3 +50,20 @@ def test_splitk_partials_are_drained_before_the_arrival_barrier(tmp_path):
         assert any(l.startswith("s_waitcnt vmcnt(0)") for l in between[:bar]), f"{name}: no vmcnt(0) drain between the sc1 store and s_barrier"
         # and the last arriver takes an agent-scope acquire before re-reading the partials
         assert any(l.startswith("buffer_inv sc1") for l in lines[atomics[0]:]), name
+
+
+def test_decode_step_kernels_get_their_leading_arguments_preloaded(tmp_path):
+    """lm_gemv / lm_attn (lm_step.hip) pass what their first global loads need as explicit leading parameters so that the command
+    processor preloads them into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile): 13 / 14 dwords (14 is the hardware's limit).  A by-value struct
+    parameter is NOT preloaded (length 0), so a refactor back to `lm_gemv(GemvArgs)` would silently lose 5 % of the decode step."""
+    with open(os.path.join(CSRC, "Makefile")) as f:
+        assert "-amdgpu-kernarg-preload-count=16" in f.read()
+    asm = _asm(os.path.join(CSRC, "lm_step.hip"), tmp_path)
+    found = {}
+    for m in re.finditer(r"\.amdhsa_kernel (_Z\w+)\n(.*?)\.end_amdhsa_kernel", asm, flags=re.S):
+        n = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length\s+(\d+)", m.group(2))
+        found[m.group(1)] = int(n.group(1)) if n else 0
+    gemv = {k: v for k, v in found.items() if "lm_gemv" in k}
+    attn = {k: v for k, v in found.items() if "lm_attn" in k}
+    assert len(gemv) >= 10 and all(v == 13 for v in gemv.values()), gemv
+    assert len(attn) == 1 and all(v == 14 for v in attn.values()), attn
