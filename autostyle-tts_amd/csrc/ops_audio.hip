@@ -178,7 +178,12 @@ struct SampleArgs {
 // (i = tid + 1024 n) in every pass up to the gather, so those passes need no barrier between them; the three radix-select
 // histograms and every hand-over variable have their own LDS (zeroed once, up front): 11 workgroup barriers instead of 22.
 static constexpr int RS_NT = 1024;
-__global__ __launch_bounds__(RS_NT) void ras_sample(SampleArgs a) {
+// Leading parameters = what the first loads (the row's logits, its EOS window) need: preloaded into SGPRs by the command
+// processor (-amdgpu-kernarg-preload-count, csrc/Makefile; a by-value struct is not), the struct carries the rest.
+__global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const int* p_eos_min_rows, int p_v, int p_hist_len, int p_eos, int p_ignore_eos,
+                                                    SampleArgs a_in) {
+    SampleArgs a = a_in;
+    a.logits = p_logits; a.eos_min_rows = p_eos_min_rows; a.v = p_v; a.hist_len = p_hist_len; a.eos = p_eos; a.ignore_eos = p_ignore_eos;
     extern __shared__ float prob[];  // [V rounded up to a multiple of 16]
     __shared__ float red_max[RS_NT / 64], red_sum[RS_NT / 64];
     __shared__ float sh_s[RS_NT];
@@ -534,7 +539,8 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
     SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, nullptr, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a.logits, a.eos_min_rows, a.v,
+                       a.hist_len, a.eos, a.ignore_eos, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -549,7 +555,8 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
                   ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
     SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
-    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a.logits, a.eos_min_rows, a.v,
+                       a.hist_len, a.eos, a.ignore_eos, a);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -77,7 +77,12 @@ __device__ __forceinline__ void rc_merge(const float* stats, int bb, int ntile, 
 }
 
 template <int CIN>
-__global__ __launch_bounds__(512, 1) void rconv_lds(RconvArgs a) {
+// Leading parameters = what the first loads need: preloaded into SGPRs by the command processor (-amdgpu-kernarg-preload-count,
+// csrc/Makefile; a by-value struct is not), the struct carries the rest.
+__global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Float16* p_w, const float* p_in_stats, const int* p_lens, int p_t, int p_taps,
+                                                    float p_eps, RconvArgs a_in) {
+    RconvArgs a = a_in;
+    a.x = p_x; a.w = p_w; a.in_stats = p_in_stats; a.lens = p_lens; a.t = p_t; a.taps = p_taps; a.eps = p_eps;
     extern __shared__ __attribute__((aligned(16))) _Float16 rc_smem[];
     __shared__ float s_in[8][2], s_res[8][2];
     constexpr int RS = CIN + 8;                       // halfs per staged row
@@ -287,8 +292,8 @@ int astts_op_resnet_conv_pf(const float* x, const void* w_frag_f16, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(32 + 2) * (cin + 8) * sizeof(_Float16);
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * cin * RC_C * taps);
-    if (cin == RC_C) hipLaunchKernelGGL(rconv_lds<256>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(rconv_lds<512>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a);
+    if (cin == RC_C) hipLaunchKernelGGL(rconv_lds<256>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
+    else hipLaunchKernelGGL(rconv_lds<512>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

@@ -399,7 +399,12 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = (_Float16)0.0f;     // never true: keeps the prefetch loads alive
 }
 
-__global__ __launch_bounds__(512, 2) void tfm_attn_fused(TfmAttnArgs a) {
+// Leading parameters = what the first loads (weight fragments, the sequence's rows) need: preloaded into SGPRs by the command
+// processor (-amdgpu-kernarg-preload-count, csrc/Makefile; a by-value struct is not), the struct carries the rest.
+__global__ __launch_bounds__(512, 2) void tfm_attn_fused(const float* p_x, const _Float16* p_w, const float* p_bias, const int* p_lens, int p_b, int p_heads,
+                                                         int p_t, float p_eps, float p_scale, TfmAttnArgs a_in) {
+    TfmAttnArgs a = a_in;
+    a.x = p_x; a.w = p_w; a.bias = p_bias; a.lens = p_lens; a.b = p_b; a.heads = p_heads; a.t = p_t; a.eps = p_eps; a.scale = p_scale;
     int seq, unit;
     tfm_attn_body(a, &seq, &unit);
 }
@@ -708,7 +713,10 @@ __device__ __forceinline__ void tfm_ffn_body(const TfmFfnArgs& a, const int64_t 
 }
 
 template <bool WO>
-__global__ __launch_bounds__(512, 1) void tfm_ffn_fused(TfmFfnArgs a) {
+__global__ __launch_bounds__(512, 1) void tfm_ffn_fused(const float* p_x, const _Float16* p_w1, const _Float16* p_attn, const _Float16* p_wo, int64_t p_m,
+                                                        int p_hidden, int p_k0, float p_eps, TfmFfnArgs a_in) {
+    TfmFfnArgs a = a_in;      // leading parameters: preloaded into SGPRs (see tfm_attn_fused)
+    a.x = p_x; a.w1 = p_w1; a.attn = p_attn; a.wo = p_wo; a.m = p_m; a.hidden = p_hidden; a.k0 = p_k0; a.eps = p_eps;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
     tfm_ffn_body<WO>(a, m0, min(m0 + 32, a.m), blockIdx.x >> 3);
 }
@@ -770,8 +778,8 @@ int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const flo
         a.pf_bytes = pf_bytes;
     }
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden + (wo ? 2.0 * (double)m * TF_C * k0 : 0.0));
-    if (wo) hipLaunchKernelGGL(tfm_ffn_fused<true>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(tfm_ffn_fused<false>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a);
+    if (wo) hipLaunchKernelGGL(tfm_ffn_fused<true>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a.x, a.w1, a.attn, a.wo, a.m, a.hidden, a.k0, a.eps, a);
+    else hipLaunchKernelGGL(tfm_ffn_fused<false>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a.x, a.w1, a.attn, a.wo, a.m, a.hidden, a.k0, a.eps, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
@@ -814,7 +822,7 @@ int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const 
     // the other query half's workgroup is this kernel's overhead, not work)
     const double flops = (double)b * heads * (3.0 * 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);
     const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, st, flops);
-    hipLaunchKernelGGL(tfm_attn_fused, dim3(2 * heads * b), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(tfm_attn_fused, dim3(2 * heads * b), dim3(512), lds, st, a.x, a.w, a.bias, a.lens, a.b, a.heads, a.t, a.eps, a.scale, a);
     if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

@@ -1,12 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 8 200 2>&1 | head -1
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 200 2>&1 | head -1
-done
-DC_NOSTATE=1 DC_OPS=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 8 100
-DC_NOSTATE=1 DC_OPS=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 100
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 16 100 | head -1
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 16 100 | head -1
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain 32 100 | head -1
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 32 100 | head -1
-DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 ./scripts/micro/decode_chain_pl 8 200 2>&1 | grep "TWO\|2 conc\|3 conc"
+timeout 1100 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | grep -v "^$" > gpurun_out/r03_full_3.log; tail -2 gpurun_out/r03_full_3.log
+FLOW_N=3 python3 scripts/flow_only.py 2>&1 | tail -1
+timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r03_bench3.json 2> gpurun_out/r03_bench3.err; tail -c 400 gpurun_out/r03_bench3.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03_bench3.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','stages_ms','sequential_ms_per_step')}); print(d['cobatched_lm_side_measurement']); print(d['value_24khz']); print(d['roofline']['frac'], d['roofline']['avg_us'], d['roofline']['sequential'])
+PY
