@@ -120,6 +120,8 @@ FLOW_RESAMPLE_NONE, FLOW_RESAMPLE_CONV, FLOW_RESAMPLE_DOWN, FLOW_RESAMPLE_UP = r
 _SIGS.update({
     "astts_stream_spin": (c_int32, [c_int32, c_void_p]),
     "astts_stream_chain": (c_int32, [c_int32, c_int32, c_int32, c_void_p]),
+    "astts_stream_create_cu_mask": (c_int32, [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]),
+    "astts_stream_destroy": (c_int32, [c_void_p]),
     "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
                                     ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
     "astts_flow_destroy": (c_int32, [c_void_p]),
@@ -591,6 +593,21 @@ def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: floa
                                         hist_len, history.stride(0) if history is not None else 0, top_k, top_p,
                                         win_size, tau_r, eos_id, 1 if ignore_eos else 0, _st()))
     return out
+
+
+def cu_masked_stream(cus, device=None) -> "torch.cuda.ExternalStream":
+    """A torch stream whose kernels run only on the CUs listed in ``cus`` (iterable of CU indices, or an int n = the first n).
+    Kept alive for the life of the process (the pipeline that uses it owns it)."""
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    ids = list(range(cus)) if isinstance(cus, int) else [int(c) for c in cus]
+    words = (max(ids) // 32) + 1
+    arr = (ctypes.c_uint32 * words)()
+    for c in ids:
+        arr[c // 32] |= 1 << (c % 32)
+    out = c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(_L().astts_stream_create_cu_mask(arr, words, ctypes.byref(out)))
+    return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 def concurrent_streams(n: int, priority: int = 0, candidates: int = 16, device=None, protect: int = 2) -> list:

@@ -142,6 +142,21 @@ int astts_stream_spin(int32_t microseconds, astts_stream_t stream) {
     return ASTTS_OK;
 }
 
+/* A stream whose kernels run on a subset of the CUs (hipExtStreamCreateWithCUMask): bit i of mask[i / 32] enables CU i.
+ * Experiments with CU partitions between the pipeline's stages (scripts/cu_mask_probe.py); destroyed by astts_stream_destroy. */
+int astts_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, astts_stream_t* out) {
+    ASTTS_REQUIRE(mask && out && n_words >= 1 && n_words <= 32, ASTTS_ERR_INVALID, "astts_stream_create_cu_mask: bad arguments");
+    hipStream_t st;
+    ASTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
+    *out = (astts_stream_t)st;
+    return ASTTS_OK;
+}
+
+int astts_stream_destroy(astts_stream_t stream) {
+    ASTTS_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ASTTS_OK;
+}
+
 /* `count` dependent busy-wait kernels of `microseconds` each on `stream`, one workgroup of `threads` threads per launch x `blocks`
  * workgroups: a stand-in for a launch chain (LM decode) when probing which streams really run side by side -- two streams
  * whose hardware queues sit on one command-processor pipe overlap long kernels but take turns at every kernel boundary. */

@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
+    ap.add_argument("--no-cobatch", action="store_true", help="skip the co-batched side measurement (16 / 32-row decode chains): profiling "
+                    "runs use it so that the kernel population is the timed region's")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("ASTTS_BENCH_FORCE_DIST")),
                     help="initialise torch.distributed (backend nccl = RCCL) even for ONE rank, so that the id all-gather and the "
                          "bank-sharded merge run through librccl on a single GPU (also: ASTTS_BENCH_FORCE_DIST=1)")
@@ -327,8 +329,8 @@ def main():
     # ---- side measurement (NOT `value`): the same K steps with the LM stages of two consecutive batches co-batched into one
     # 16-row decode chain (PipelinedSynth(cobatch=2); every batch's output stays bit-identical, tests/test_synth_gpu.py)
     cob = {}
-    if args.steps >= 2:
-        main_pipe = pipe
+    main_pipe = pipe
+    if args.steps >= 2 and not args.no_cobatch:
         cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
         pipe = PipelinedSynth.autotune(eng, sample, depths=cob_cfgs, trials=2, steps=max(2, min(args.steps, 8)),
                                        front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
@@ -384,7 +386,7 @@ def main():
     knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
     traffic_table = {}
     traffic_file = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
         try:                                                 # FETCH_SIZE, own pass; cannot be collected inside this run)
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_table = json.load(f)

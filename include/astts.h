@@ -61,6 +61,10 @@ int astts_prof_read(int32_t kind, double* ms_sum, int64_t* launches, double* wor
 int astts_stream_spin(int32_t microseconds, astts_stream_t stream);
 /* `count` dependent busy-wait launches (`blocks` workgroups, `microseconds` each): a launch-chain stand-in for stream probing */
 int astts_stream_chain(int32_t count, int32_t microseconds, int32_t blocks, astts_stream_t stream);
+/* A stream restricted to the CUs whose bit is set (bit i of mask[i / 32] = CU i; hipExtStreamCreateWithCUMask): CU partitions
+ * between concurrent stages.  The caller destroys it with astts_stream_destroy once nothing is in flight on it. */
+int astts_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, astts_stream_t* out);
+int astts_stream_destroy(astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",
