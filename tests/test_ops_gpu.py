@@ -697,3 +697,24 @@ def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged,
         assert e_ref < 4e-3 and e_five < 4e-3, (i, e_ref, e_five)
     assert torch.equal(out, ops.resnet_conv(xg, pr, fr, lens=lg, res_gn=(h2, s2, gd[2], gd[3])).cpu())
     assert bool(torch.isfinite(out).all())
+
+
+def test_cu_masked_stream_runs_kernels_with_the_same_results():
+    """astts_stream_create_cu_mask (CU partitions between concurrent stages: scripts/cu_mask_probe.py): a GEMM enqueued on a
+    stream restricted to 64 CUs gives the bits of the unrestricted launch, and a bad mask is refused."""
+    import ctypes
+
+    from astts import _lib, ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(300, 256, generator=g).half().to(DEV)
+    pw = ops.PackedWeight(torch.randn(512, 256, generator=g) / 16, torch.randn(512, generator=g))
+    ref = ops.linear(x, pw)
+    torch.cuda.synchronize()
+    st = ops.cu_masked_stream(64)
+    with torch.cuda.stream(st):
+        out = ops.linear(x, pw)
+    st.synchronize()
+    assert torch.equal(out, ref)
+    h = ctypes.c_void_p()
+    assert _lib.load().astts_stream_create_cu_mask(None, 8, ctypes.byref(h)) == _lib.ERR_INVALID
