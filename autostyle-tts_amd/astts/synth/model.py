@@ -142,6 +142,8 @@ class AcousticLM:
         hw, hb = fold_layernorm(sd["llm_decoder.weight"].float().cpu(), sd["llm_decoder.bias"].float().cpu(),
                                 sd["llm.after_norm.weight"].float().cpu(), sd["llm.after_norm.bias"].float().cpu())
         self.head = PackedWeight(hw, hb, device)
+        import threading
+        self._eng_lock = threading.Lock()
 
     def prefix(self, text: torch.Tensor, text_lens: torch.Tensor, spk: torch.Tensor, prompt_tokens: torch.Tensor) -> torch.Tensor:
         """-> time-major [S0, B, d]: sos | spk | text_encoder(text) | task_id | speech_emb(prompt)."""
@@ -231,6 +233,12 @@ class AcousticLM:
 
     # ---- C++ decode engine (libastts astts_lm_*): same fused step, issued without Python in the loop
     def _engine(self):
+        if getattr(self, "_eng", None) is not None:
+            return self._eng
+        with self._eng_lock:            # decode groups run on several host threads: ONE of them builds the handle and its table
+            return self._engine_locked()
+
+    def _engine_locked(self):
         if getattr(self, "_eng", None) is None:
             import ctypes
 
@@ -242,6 +250,7 @@ class AcousticLM:
             # the decode step's input projection acts on a table lookup: speech_emb[tok] W^T + b is a row of the table
             # speech_emb W^T + b, formed once here (the same fp16 MFMA products, on the GPU) and gathered by the step
             self.embed_table = ops.linear(self.speech_emb, body.embed).contiguous()
+            torch.cuda.current_stream(self.device).synchronize()     # one-off: decode chains on OTHER streams read the table
             g = ops.LmGlobals(self.speech_emb.data_ptr(), body.embed.data.data_ptr(), body.embed.bias.data_ptr(),
                               body.embed_ln[0].data_ptr(), body.embed_ln[1].data_ptr(), body.after[0].data_ptr(),
                               body.after[1].data_ptr(), self.head.data.data_ptr(), self.head.bias.data_ptr(),

@@ -24,6 +24,16 @@ namespace astts {
 #define LM_STAMP(a, i) do { } while (0)
 #endif
 
+// Wave priority.  A decode-step wave that shares a SIMD with a wave of another stream's kernel (the render stage of an earlier
+// batch: co-resident whenever LDS and registers allow) loses the VALU-issue arbitration to it at equal priority (older wave wins):
+// beside a background that keeps every SIMD issuing, the decode step went 394 -> 755 us in the chain benchmark
+// (scripts/micro/decode_chain.hip, DC_BG=1); with s_setprio 3 at kernel entry: 413 us.  The kernels are a few microseconds long and
+// mostly waiting for memory, so the background loses next to nothing.  -DLM_SETPRIO=0 builds without it (A/B).
+#ifndef LM_SETPRIO
+#define LM_SETPRIO 3
+#endif
+#define LM_RAISE_PRIO() do { if (LM_SETPRIO) __builtin_amdgcn_s_setprio(LM_SETPRIO); } while (0)
+
 // Kernel arguments: hipcc loads the fields of a by-value argument struct lazily, each s_load_dword right before its first
 // use and followed by its own s_waitcnt -- in a kernel with this much control flow that is ~15 SERIALISED scalar-cache
 // misses on a cold kernarg segment (measured: 1.4 us from the first instruction to the last up-front load issued, a third
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
     // leading parameters they are PRELOADED into SGPRs by the command processor (-amdgpu-kernarg-preload-count, Makefile): the
     // wave issues those loads without waiting for an s_load of its arguments (a cold scalar-cache miss, ~0.5-1 us in a kernel
     // that lasts 3-5).  The struct behind them carries the same fields again (ignored) and everything else.
+    LM_RAISE_PRIO();
     GemvArgs a = a_in;
     a.x = p_x; a.w = p_w; a.x2 = p_x2; a.gather = p_gather; a.m = p_m; a.n = p_n; a.k = p_k; a.kpad = p_kpad; a.ldx = p_ldx;
     constexpr bool XF16 = XM != 0;
@@ -537,6 +548,7 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
     __shared__ float s_m[8];
     __shared__ float s_l[8];
     __shared__ __attribute__((aligned(16))) float s_o[8][64];
+    LM_RAISE_PRIO();
     AttnArgs a = a_in;      // leading parameters: preloaded into SGPRs (see lm_gemv; 14 dwords is the most the hardware preloads)
     a.q = p_q; a.kv = p_kv; a.postab = p_postab; a.kstart = p_kstart; a.b = p_b; a.ldq = p_ldq; a.ldp = p_ldp; a.center = p_center;
     a.d = p_d; a.pos = p_pos;

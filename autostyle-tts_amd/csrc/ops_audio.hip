@@ -182,6 +182,7 @@ static constexpr int RS_NT = 1024;
 // processor (-amdgpu-kernarg-preload-count, csrc/Makefile; a by-value struct is not), the struct carries the rest.
 __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const int* p_eos_min_rows, int p_v, int p_hist_len, int p_eos, int p_ignore_eos,
                                                     SampleArgs a_in) {
+    __builtin_amdgcn_s_setprio(3);     // a decode-chain kernel: wins the VALU arbitration against co-resident render waves (lm_step.hip)
     SampleArgs a = a_in;
     a.logits = p_logits; a.eos_min_rows = p_eos_min_rows; a.v = p_v; a.hist_len = p_hist_len; a.eos = p_eos; a.ignore_eos = p_ignore_eos;
     extern __shared__ float prob[];  // [V rounded up to a multiple of 16]

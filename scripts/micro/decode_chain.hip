@@ -128,6 +128,25 @@ static Ctx make_ctx(const Model& m, int b, unsigned seed) {
     return c;
 }
 
+// ---- synthetic "render" background (DC_BG=1): 256 workgroups x 512 threads of arithmetic, ~25 us per launch, back to back on
+// its own stream, with a chosen LDS footprint (DC_BG_LDS_KB) and register footprint (DC_BG_REGS=1: ~256 VGPRs per wave): how much
+// of the decode chain's slow-down inside the pipeline is co-residency?
+template <int NREG>
+__global__ __launch_bounds__(512, NREG > 64 ? 2 : 4) void bg_kernel(const float* __restrict__ in, int iters, float* sink) {
+    extern __shared__ float bg_lds[];
+    if (threadIdx.x == 0) bg_lds[0] = 1.0f;
+    float r[NREG];
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) r[k] = in[(threadIdx.x + k * 64) & 8191];
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) r[k] = r[k] * 1.0001f + r[(k + 1) % NREG];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) s += r[k];
+    if (s == 12345.678f) *sink = s;
+}
+
 static int g_ksplit = 1, g_lnplain = 0;
 static int g_nostate = 0, g_pos = 305;   // DC_NOSTATE=1: positions as kernel arguments (no device-side step state)
 // one decode step: 14 x (QKV, attention, Wo, W1, W2) + head.  Returns the number of launches.
@@ -275,6 +294,41 @@ int main(int argc, char** argv) {
             if (lm_gemv_launch(a, st)) exit(2); });
         run("head (LN, n=4097, k=1024)", [&](int l) { GemvArgs a = G(); a.x = c.x0; a.ldx = d; a.ln_g = m.ag; a.ln_b = m.ab; if (g_lnplain) { a.ln_g = nullptr; a.ln_b = nullptr; a.ln_plain = 1; } a.w = m.head; a.bias = m.head_b; a.out = c.lg; a.ldo = m.vocab; a.n = m.vocab; a.k = d; a.kpad = d;
             if (lm_gemv_launch(a, st)) exit(2); });
+        return 0;
+    }
+    if (getenv("DC_BG")) {
+        const size_t lds = (size_t)(getenv("DC_BG_LDS_KB") ? atoi(getenv("DC_BG_LDS_KB")) : 150) * 1024;
+        const bool regs = getenv("DC_BG_REGS") && atoi(getenv("DC_BG_REGS"));
+        const int wgs = getenv("DC_BG_WGS") ? atoi(getenv("DC_BG_WGS")) : 256;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bg_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bg_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        float* bin = rand32(8192, 77, 1.f);
+        float* sink = dalloc<float>(1);
+        hipStream_t sbg;
+        CK(hipStreamCreateWithFlags(&sbg, hipStreamNonBlocking));
+        auto one = [&]() {
+            if (regs) hipLaunchKernelGGL(bg_kernel<192>, dim3(wgs), dim3(512), lds, sbg, bin, 14, sink);
+            else hipLaunchKernelGGL(bg_kernel<32>, dim3(wgs), dim3(512), lds, sbg, bin, 90, sink);
+        };
+        for (int i = 0; i < 10; ++i) one();
+        CK(hipStreamSynchronize(sbg));
+        const double each = time_ms(sbg, [&] { for (int i = 0; i < 50; ++i) one(); }) * 1e3 / 50;
+        reset(c0, s0);
+        for (int i = 0; i < 20; ++i) enqueue_step(m, c0, s0, 0);
+        CK(hipStreamSynchronize(s0));
+        reset(c0, s0);
+        const int n_bg = (int)(steps * 1500.0 / each) + 100;          // enough to outlast the chain even at 1.5 ms per step
+        std::thread th([&] { for (int i = 0; i < n_bg; ++i) one(); });
+        std::this_thread::sleep_for(std::chrono::milliseconds(3));
+        auto w0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < steps; ++i) enqueue_step(m, c0, s0, 0);
+        CK(hipStreamSynchronize(s0));
+        auto w1 = std::chrono::steady_clock::now();
+        th.join();
+        const bool still = hipStreamQuery(sbg) == hipErrorNotReady;
+        CK(hipStreamSynchronize(sbg));
+        printf("B=%d chain beside a background of %d x 512-thread workgroups, %zu KB LDS, %s registers, %.1f us per launch (%s): %.1f us per step\n", b, wgs,
+               lds >> 10, regs ? "~256" : "~40", each, still ? "outlasted the chain" : "ENDED EARLY", std::chrono::duration<double, std::micro>(w1 - w0).count() / steps);
         return 0;
     }
     // ---- eager
