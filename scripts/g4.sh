@@ -1,8 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_lm_step_gpu.py tests/test_synth_gpu.py -q -m gpu -x --tb=short 2>&1 | tail -2
-for i in 1 2; do timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r03_bench4.json 2> gpurun_out/r03_bench4.err; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r03_bench4.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step','stages_ms','sequential_ms_per_step')}); print(d['cobatched_lm_side_measurement']['value'], d['cobatched_lm_side_measurement']['decode_chains'], d['cobatched_lm_side_measurement']['batches_per_chain']); print(d['value_24khz']['value']); print(d['roofline']['frac'], d['roofline']['avg_us'])
-PY
-done
+X="DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 DC_BG=1"
+for cfg in "127 96" "127 128" "127 160" "127 192" "100 160" "80 160" "80 128" "80 96"; do set -- $cfg; env $X DC_BG_LDS_KB=$1 DC_BG_NREG=$2 ./scripts/micro/decode_chain 8 100; done

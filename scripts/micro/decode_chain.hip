@@ -306,8 +306,15 @@ int main(int argc, char** argv) {
         float* sink = dalloc<float>(1);
         hipStream_t sbg;
         CK(hipStreamCreateWithFlags(&sbg, hipStreamNonBlocking));
+        const int nreg = getenv("DC_BG_NREG") ? atoi(getenv("DC_BG_NREG")) : (regs ? 192 : 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bg_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bg_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bg_kernel<160>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         auto one = [&]() {
-            if (regs) hipLaunchKernelGGL(bg_kernel<192>, dim3(wgs), dim3(512), lds, sbg, bin, 14, sink);
+            if (nreg >= 192) hipLaunchKernelGGL(bg_kernel<192>, dim3(wgs), dim3(512), lds, sbg, bin, 14, sink);
+            else if (nreg >= 160) hipLaunchKernelGGL(bg_kernel<160>, dim3(wgs), dim3(512), lds, sbg, bin, 17, sink);
+            else if (nreg >= 128) hipLaunchKernelGGL(bg_kernel<128>, dim3(wgs), dim3(512), lds, sbg, bin, 21, sink);
+            else if (nreg >= 96) hipLaunchKernelGGL(bg_kernel<96>, dim3(wgs), dim3(512), lds, sbg, bin, 28, sink);
             else hipLaunchKernelGGL(bg_kernel<32>, dim3(wgs), dim3(512), lds, sbg, bin, 90, sink);
         };
         for (int i = 0; i < 10; ++i) one();
@@ -327,8 +334,8 @@ int main(int argc, char** argv) {
         th.join();
         const bool still = hipStreamQuery(sbg) == hipErrorNotReady;
         CK(hipStreamSynchronize(sbg));
-        printf("B=%d chain beside a background of %d x 512-thread workgroups, %zu KB LDS, %s registers, %.1f us per launch (%s): %.1f us per step\n", b, wgs,
-               lds >> 10, regs ? "~256" : "~40", each, still ? "outlasted the chain" : "ENDED EARLY", std::chrono::duration<double, std::micro>(w1 - w0).count() / steps);
+        printf("B=%d chain beside a background of %d x 512-thread workgroups, %zu KB LDS, %d live values per lane, %.1f us per launch (%s): %.1f us per step\n", b, wgs,
+               lds >> 10, nreg, each, still ? "outlasted the chain" : "ENDED EARLY", std::chrono::duration<double, std::micro>(w1 - w0).count() / steps);
         return 0;
     }
     // ---- eager
