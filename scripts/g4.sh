@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-X="DC_NOSTATE=1 DC_KSPLIT=2 DC_LNPLAIN=1 DC_BG=1"
-for cfg in "127 96" "127 128" "127 160" "127 192" "100 160" "80 160" "80 128" "80 96"; do set -- $cfg; env $X DC_BG_LDS_KB=$1 DC_BG_NREG=$2 ./scripts/micro/decode_chain 8 100; done
+timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -x --tb=short -k "tfm_attn" 2>&1 | tail -1
+ASTTS_TFM_ATTN_SPLIT=2 timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -x --tb=short -k "tfm_attn" 2>&1 | tail -1
+for sp in 1 2 1 2; do ASTTS_TFM_ATTN_SPLIT=$sp timeout 900 python bench.py --no-cpu-baseline --no-24khz --no-cobatch > gpurun_out/r03_bench5.json 2> gpurun_out/r03_bench5.err; python - <<PY
+import json
+d=json.loads(open('gpurun_out/r03_bench5.json').read().strip().splitlines()[-1])
+print("split $sp:", {k:d[k] for k in ('value','ms_per_step','stages_ms')})
+PY
+done
