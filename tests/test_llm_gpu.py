@@ -161,3 +161,34 @@ def test_search_milvus_cli_end_to_end(capsys):
     finally:
         if old is not None:
             os.environ["ASTTS_ALLOW_RANDOM_INIT"] = old
+
+
+def test_emotion_label_decodes_without_special_tokens_and_with_the_untruncated_prompt():
+    """milvus/search_json.py:178-191: the generation prompt is encoded WITHOUT truncation (only get_embedding truncates to 512)
+    and the continuation is decoded with skip_special_tokens=True.  A recording tokenizer stands in for the Llama tokenizer."""
+    from astts.llm.config import LlamaShape
+    from astts.llm.embedder import LlamaEmbedder
+    from astts.llm.weights import make_llama_weights
+
+    cfg = LlamaShape.tiny()
+
+    class Tok:
+        def __init__(self):
+            self.decoded = None
+
+        def encode(self, text):
+            return [cfg.bos_token_id] + [3 + (hash(w) % (cfg.vocab - 3)) for w in text.split()]
+
+        def decode(self, ids, skip_special_tokens=False):
+            self.decoded = (list(ids), skip_special_tokens)
+            return " Happy " if skip_special_tokens else "<|begin_of_text|> Happy <|end_of_text|>"
+
+    tok = Tok()
+    emb = LlamaEmbedder(make_llama_weights(cfg, 7), cfg, device=DEV, tokenizer=tok, max_length=16)
+    text = " ".join(f"w{i}" for i in range(40))                      # prompt far beyond max_length = 16 and the first RoPE table
+    label = emb.generate_emotion_label(text, max_new_tokens=2)
+    assert label == "happy"
+    ids, skipped = tok.decoded
+    assert skipped is True
+    assert len(ids) >= len(tok.encode(emb.EMOTION_PROMPT.format(text, text)))     # nothing was cut off the prompt
+    assert emb.get_embedding(text).shape == (cfg.hidden,)                          # the embedding path still truncates and works

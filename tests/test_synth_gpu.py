@@ -384,6 +384,32 @@ def test_flow_solver_engine_is_bit_identical_to_operator_path(b, t, ragged, wide
         assert float((out * ~keep).abs().max()) == 0.0
 
 
+def test_flow_solver_with_more_euler_steps_than_one_time_path_chunk():
+    """astts_flow_solve evaluates the time path (embedding -> MLP -> per-ResNet projection) for 32 Euler steps at a time; a solve
+    with more steps walks it chunk by chunk (40 = 32 + 8) and must still equal the operator-by-operator solve -- which projects
+    all 40 steps' rows in one GEMM, so the comparison allows the rounding of another row tile (fp16 intermediates over 40 Euler
+    steps: 1e-4 observed, bar 1e-3 = a fifth of the flow stage's oracle tolerance)."""
+    import dataclasses
+
+    from astts.synth.model import FlowDecoder
+
+    cfg, W = _cfg_and_weights()
+    cfg = dataclasses.replace(cfg, cfm_steps=40)
+    fd = FlowDecoder(W["flow"], cfg, torch.device(DEV))
+    g = torch.Generator().manual_seed(77)
+    b, t = 2, 45
+    z = torch.randn(b, t, cfg.mel, generator=g).to(DEV)
+    mu = torch.randn(b, t, cfg.mel, generator=g).to(DEV)
+    cond = torch.randn(b, t, cfg.mel, generator=g).to(DEV)
+    spk = torch.randn(b, cfg.mel, generator=g).to(DEV)
+    ref = fd.solve_ops(z.clone(), mu, spk, cond, None)
+    out = fd.solve(z.clone(), mu, spk, cond, None)
+    assert torch.isfinite(out).all()
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    print(f"40-step solve, engine vs operator path: rel diff {err:.2e}")
+    assert err < 1e-3
+
+
 def test_no_kernel_writes_outside_its_output_tensor():
     """scripts/oob_check.py guard-bands every tensor the operator wrappers allocate (4 KiB of pattern on both sides)
     and runs LM prefix + decode, the flow decoder (both host paths, fixed and ragged) and the vocoder."""
