@@ -344,8 +344,14 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s0));
     reset(c0, s0);
     int nl = 0;
-    double ms = time_ms(s0, [&] { for (int i = 0; i < steps; ++i) nl = enqueue_step(m, c0, s0, 0); });
-    printf("B=%d eager:            %.1f us per step (%d launches, %.2f us per launch), keys %d..%d\n", b, ms * 1e3 / steps, nl, ms * 1e3 / steps / nl, pos0, pos0 + steps);
+    double host_eager = 0.0;
+    double ms = time_ms(s0, [&] {
+        auto h0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < steps; ++i) nl = enqueue_step(m, c0, s0, 0);
+        host_eager = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+    });
+    printf("B=%d eager:            %.1f us per step (%d launches, %.2f us per launch), keys %d..%d; HOST time of the enqueue loop: %.1f us per step = %.2f us per launch\n", b, ms * 1e3 / steps, nl, ms * 1e3 / steps / nl, pos0, pos0 + steps,
+           host_eager / steps, host_eager / steps / nl);
     // ---- graph, R steps per replay
     for (int R : {1, 8}) {
         hipGraph_t g;
@@ -362,9 +368,14 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(s0));
         reset(c0, s0);
         const int reps = steps / R;
-        ms = time_ms(s0, [&] { for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s0)); });
-        printf("B=%d graph R=%d:        %.1f us per step (capture %.2f ms, instantiate %.2f ms)\n", b, R, ms * 1e3 / (reps * R),
-               std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        double host_us = 0.0;
+        ms = time_ms(s0, [&] {
+            auto h0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s0));
+            host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+        });
+        printf("B=%d graph R=%d:        %.1f us per step (capture %.2f ms, instantiate %.2f ms); HOST time of the launch loop: %.1f us per step = %.2f us per kernel node\n", b, R, ms * 1e3 / (reps * R),
+               std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), host_us / (reps * R), host_us / (reps * R) / nl);
         if (R == 8) {
             // two chains, each with its own buffers, graph and stream, launched from two host threads
             hipGraph_t g1;
