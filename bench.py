@@ -427,8 +427,10 @@ def main():
             i, _, s64 = sb_shard.search_device(qq, min(kk, re - rb), return_f64=True)
             return i, s64
 
-        bidx, _ = bank_sharded_search(local, q_dev, args.topk, rb, dist)
-        bank_sharded_ok = bool(np.array_equal(bidx.cpu().numpy(), eidx))
+        # bank-sharded mode: EVERY rank searches the same queries (rank 0's) against its own rows
+        q0_host = make_queries(bank16, args.batch, seed=0)
+        bidx, _ = bank_sharded_search(local, torch.from_numpy(q0_host).to(dev), args.topk, rb, dist)
+        bank_sharded_ok = bool(np.array_equal(bidx.cpu().numpy(), oknn.knn_search(bank16, q0_host, args.topk)[0]))
         del sb_shard
 
     # ---- roofline: HIP events (on each launch's own stream) around every launch of the profiled kernel kinds, ONE SEQUENTIAL
