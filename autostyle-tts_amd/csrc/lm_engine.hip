@@ -47,6 +47,7 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     float* part_o = (float*)take(astts_op_gemm_fused_workspace_bytes());   // [b][heads][2][64] + [b][heads][2][2] (v1's split-K area)
     float* part_ml = part_o + (size_t)b * c.heads * 2 * 64;
     const float scale = 0.125f;
+    const KvLayout lay = KvLayout::time_major(b, d);
     auto gemv = [&]() {
         GemvArgs a;
         memset(&a, 0, sizeof(a));
@@ -93,14 +94,14 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
                 a.x = x;
             }
             a.ldx = d; with_ln(a, L.n1_g, L.n1_b);
-            a.w = (const _Float16*)L.wqkv; a.bias = L.bqkv; a.out = q; a.ldo = d; a.kv = kvc; a.n_split = d; a.ldkv = 2 * d; a.pos = pos;
+            a.w = (const _Float16*)L.wqkv; a.bias = L.bqkv; a.out = q; a.ldo = d; a.kv = kvc; a.n_split = d; a.kv_t = lay.t; a.kv_b = lay.b; a.kv_h = lay.h; a.kv_v = lay.v; a.pos = pos;
             a.n = 3 * d; a.k = d; a.kpad = d;
             if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             AttnArgs t;
             memset(&t, 0, sizeof(t));
             t.q = q; t.kv = kvc; t.postab = (const _Float16*)L.pos; t.bias_u = L.bias_u; t.bias_v = L.bias_v; t.kstart = key_start;
             t.part_o = part_o; t.part_ml = part_ml; t.ksplit = 2; t.b = b; t.h = c.heads; t.ldq = d; t.ldp = c.pos_ld; t.center = c.pos_center;
-            t.d = d; t.scale = scale; t.pos = pos;
+            t.d = d; t.scale = scale; t.pos = pos; t.kv_t = lay.t; t.kv_b = lay.b; t.kv_h = lay.h; t.kv_v = lay.v;
             if ((rc = lm_attn_launch(t, st)) != ASTTS_OK) return rc;
             a = gemv();             // out-proj on the merged attention partials + residual
             a.x = part_o; a.x2 = part_ml; a.x_mode = 2; a.w = (const _Float16*)L.wo; a.bias = L.bo; a.res = x; a.ldr = d; a.out = y; a.ldo = d;

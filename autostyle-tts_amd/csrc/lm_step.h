@@ -35,11 +35,13 @@ struct GemvArgs {
     const float* res;         // fp32 [m][ldr] or null
     float* out;               // fp32 [m][ldo] or null
     _Float16* out16;          // fp16 [m][ldo16] or null (both may be given)
-    _Float16* kv;             // columns >= n_split: kv[((pos0 + step) * m + row) * ldkv + n - n_split]  (time-major cache)
+    _Float16* kv;             // columns >= n_split go to the KV cache: column c = n - n_split of row r lands at
+                              //   kv[(pos0 + step) * kv_t + r * kv_b + ((c % d) / 64) * kv_h + (c / d) * kv_v + c % 64],  d = (n - n_split) / 2
     LmStep* st;               // optional device-side step state (kv row = pos0 + step; advanced by block 0 when `advance`); null: `pos`
     unsigned long long* stamps;  // micro-benchmark builds only (LM_STAMPS)
     float ln_eps, pre_scale;
-    int m, n, k, kpad, ldx, ldr, ldo, ldo16, n_split, ldkv;
+    int m, n, k, kpad, ldx, ldr, ldo, ldo16, n_split;
+    int kv_t, kv_b, kv_h, kv_v;  // cache strides in halfs: time step, row, head, K -> V (see KvLayout)
     int x_mode, relu, advance, stamp_slot;
     int ln_plain;             // LayerNorm without scale / shift (folded into w / bias at load); ln_g must then be null
     int pos;                  // kv row when st is null
@@ -47,7 +49,7 @@ struct GemvArgs {
 
 struct AttnArgs {
     const float* q;           // [b][ldq] fp32 (the q third of the QKV projection)
-    const _Float16* kv;       // [t][b][2d]: k | v, time-major
+    const _Float16* kv;       // key j of (row r, head hd): kv[j * kv_t + r * kv_b + hd * kv_h + 0..63], its value kv_v halfs further
     const _Float16* postab;   // [2*center+1][ldp] position projections of this layer
     const float* bias_u;
     const float* bias_v;
@@ -58,9 +60,20 @@ struct AttnArgs {
     const LmStep* st;         // optional device-side step state; null: `pos`
     unsigned long long* stamps;
     int b, h, ldq, ldo, ldp, center, d;
+    int kv_t, kv_b, kv_h, kv_v;  // cache strides in halfs (KvLayout)
     float scale;
     int ksplit, stamp_slot;
     int pos;                  // absolute position of the query (= index of the newest key) when st is null
+};
+
+// The two cache layouts the step kernels are used with (any strides work: multiples of 8 halfs).
+//   time-major [t][b][2d] (k | v): what the prefill GEMM writes -- one 128-byte piece per (key, row, head), b * 4d bytes apart
+//   head-major [b][h][2][t_max][64]: a (row, head)'s keys and values are two contiguous streams -- what lm_attn wants at long
+//   context (32 rows x ~1 000 keys: the time-major pieces are 128 KB apart and the kernel stalls at ~4 TB/s)
+struct KvLayout {
+    int t, b, h, v;
+    static KvLayout time_major(int rows, int d) { return {rows * 2 * d, 2 * d, 64, d}; }
+    static KvLayout head_major(int heads, int t_max) { return {64, heads * 2 * t_max * 64, 2 * t_max * 64, t_max * 64}; }
 };
 
 // launchers (no allocation, no synchronisation; graph-capturable).  Return ASTTS_OK or ASTTS_ERR_*.

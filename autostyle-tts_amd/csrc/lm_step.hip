@@ -7,6 +7,7 @@
 // MFMA operands, fp32 accumulation, fp32 LayerNorm / softmax.  Only the fp32 summation ORDER of a dot product differs
 // between the variants (which K lines a wave owns), never which products are formed.
 #include "lm_step.h"
+#include "xlane.h"
 
 #include <hip/hip_ext.h>
 
@@ -42,20 +43,17 @@ namespace astts {
 __device__ __forceinline__ void pin_args(const GemvArgs& a) {
     asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.gather), "s"(a.pre_g), "s"(a.pre_b), "s"(a.pre_out), "s"(a.ln_g), "s"(a.ln_b), "s"(a.w),
                  "s"(a.bias), "s"(a.res), "s"(a.out), "s"(a.out16), "s"(a.kv), "s"(a.st), "s"(a.m), "s"(a.n), "s"(a.k), "s"(a.kpad), "s"(a.ldx),
-                 "s"(a.ldr), "s"(a.ldo), "s"(a.ldo16), "s"(a.n_split), "s"(a.ldkv), "s"(a.x_mode), "s"(a.relu), "s"(a.pos), "s"(a.ln_plain));
+                 "s"(a.ldr), "s"(a.ldo), "s"(a.ldo16), "s"(a.n_split), "s"(a.kv_t), "s"(a.kv_b), "s"(a.kv_h), "s"(a.kv_v), "s"(a.x_mode), "s"(a.relu), "s"(a.pos), "s"(a.ln_plain));
 }
 __device__ __forceinline__ void pin_args(const AttnArgs& a) {
-    asm volatile("" ::"s"(a.q), "s"(a.kv), "s"(a.postab), "s"(a.bias_u), "s"(a.bias_v), "s"(a.kstart), "s"(a.out), "s"(a.part_o), "s"(a.part_ml),
-                 "s"(a.st), "s"(a.b), "s"(a.h), "s"(a.ldq), "s"(a.ldo), "s"(a.ldp), "s"(a.center), "s"(a.d), "s"(a.scale), "s"(a.ksplit), "s"(a.pos));
+    asm volatile("" ::"s"(a.q), "s"(a.kv), "s"(a.bias_u), "s"(a.bias_v), "s"(a.kstart), "s"(a.out), "s"(a.part_o), "s"(a.part_ml),
+                 "s"(a.st), "s"(a.h), "s"(a.ldq), "s"(a.ldo), "s"(a.ldp), "s"(a.kv_t), "s"(a.kv_b), "s"(a.kv_h), "s"(a.kv_v), "s"(a.scale), "s"(a.ksplit), "s"(a.pos));
 }
 
 static constexpr int GV_WAVES = 8;
 
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+// sum over the wave, butterfly order 32, 16, ..., 1 -- as VALU lane exchanges (xlane.h), not ds_bpermute round trips: same bits
+__device__ __forceinline__ float wsum64(float v) { return wave_sum_desc(v); }
 
 // FORM 0: 16 columns per workgroup, every wave walks whole K lines (MT row tiles of 16).
 // FORM 1 ("diagonal", m <= 8): MFMA row i = r + 8h carries x[r][h*Kc + ...], MFMA column j = c + 8h' carries
@@ -516,7 +514,8 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         if (a.relu) v = fmaxf(v, 0.0f);
         v += e_res;
         if (a.kv && on >= a.n_split) {
-            a.kv[((int64_t)kv_pos * M + om) * a.ldkv + (on - a.n_split)] = (_Float16)v;
+            const int dd = (a.n - a.n_split) >> 1, c = on - a.n_split, isv = c >= dd ? 1 : 0, cc = c - isv * dd;
+            a.kv[(int64_t)kv_pos * a.kv_t + (int64_t)om * a.kv_b + (int64_t)(cc >> 6) * a.kv_h + (int64_t)isv * a.kv_v + (cc & 63)] = (_Float16)v;
         } else {
             if (a.out) a.out[(int64_t)om * a.ldo + on] = v;
             if (a.out16) a.out16[(int64_t)om * a.ldo16 + on] = (_Float16)v;
@@ -543,15 +542,15 @@ __device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
     return s;
 }
 
-__global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float16* p_kv, const _Float16* p_postab, const int* p_kstart, int p_b, int p_ldq,
-                                                  int p_ldp, int p_center, int p_d, int p_pos, AttnArgs a_in) {
+__global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float16* p_kv, const _Float16* p_pos0, const int* p_kstart, int p_kv_t, int p_kv_b,
+                                                  int p_kv_h, int p_kv_v, int p_ldq, int p_ldp, AttnArgs a_in) {
     __shared__ float s_m[8];
     __shared__ float s_l[8];
     __shared__ __attribute__((aligned(16))) float s_o[8][64];
     LM_RAISE_PRIO();
     AttnArgs a = a_in;      // leading parameters: preloaded into SGPRs (see lm_gemv; 14 dwords is the most the hardware preloads)
-    a.q = p_q; a.kv = p_kv; a.postab = p_postab; a.kstart = p_kstart; a.b = p_b; a.ldq = p_ldq; a.ldp = p_ldp; a.center = p_center;
-    a.d = p_d; a.pos = p_pos;
+    a.q = p_q; a.kv = p_kv; a.kstart = p_kstart; a.kv_t = p_kv_t; a.kv_b = p_kv_b; a.kv_h = p_kv_h; a.kv_v = p_kv_v; a.ldq = p_ldq; a.ldp = p_ldp;
+    const _Float16* pos_row0 = p_pos0;                       // the position table's row of relative position 0 (postab + center * ldp)
     pin_args(a);
     LM_STAMP(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -568,10 +567,10 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
         ks0 = ks_first + (int)blockIdx.z * half;
         kend = min(len, ks0 + half);
     }
-    const int64_t trow = (int64_t)a.b * 2 * a.d;              // one time step of the cache
-    const _Float16* kb = a.kv + (int64_t)bb * 2 * a.d + head * 64 + sub * 8;
-    const _Float16* vb = kb + a.d;
-    const _Float16* pb = a.postab + head * 64 + sub * 8;
+    const int64_t trow = a.kv_t;                              // one time step of the cache (KvLayout)
+    const _Float16* kb = a.kv + (int64_t)bb * a.kv_b + (int64_t)head * a.kv_h + sub * 8;
+    const _Float16* vb = kb + a.kv_v;
+    const _Float16* pb = pos_row0 + head * 64 + sub * 8;
     float qu[8], qv[8];
     {
         const float* qp = a.q + (int64_t)bb * a.ldq + head * 64 + sub * 8;
@@ -600,7 +599,7 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
             const int j = j0 + u * 64 + kg;
             if (j < kend) {
                 kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)j * trow);
-                pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - j + a.center) * a.ldp);
+                pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - j) * a.ldp);
                 vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)j * trow);
             }
         }
@@ -612,14 +611,13 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
             const int j = j0 + u * 64 + kg;
             // the 8 lanes of a key group hold partial dots of the same key (an invalid key is invalid on all 8)
             float t = j < kend ? dot8(qu, kk[u]) + dot8(qv, pp[u]) : 0.0f;
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
+            t = xadd<1>(t);
+            t = xadd<2>(t);
+            t = xadd<4>(t);
             s[u] = j < kend ? t : -INFINITY;
             m_new = fmaxf(m_new, s[u]);
         }
-#pragma unroll
-        for (int off = 8; off <= 32; off <<= 1) m_new = fmaxf(m_new, __shfl_xor(m_new, off, 64));   // the wave's maximum
+        m_new = xmax<32>(xmax<16>(xmax<8>(m_new)));             // the wave's maximum
         if (m_new > -INFINITY) {                               // wave-uniform; false only while the wave has seen no valid key
             const float sc_old = m_run == -INFINITY ? 0.0f : __expf(m_run - m_new);
             l_run *= sc_old;
@@ -640,12 +638,9 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
     }
     LM_STAMP(a, 2);
     // sum over the key groups of the wave (lanes with equal `sub`); l_run is per key group and equal on its 8 lanes
+    l_run = xadd<32>(xadd<16>(xadd<8>(l_run)));               // steps 8, 16, 32 as before (xlane.h: VALU exchanges, same bits)
 #pragma unroll
-    for (int off = 8; off <= 32; off <<= 1) {
-        l_run += __shfl_xor(l_run, off, 64);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off, 64);
-    }
+    for (int e = 0; e < 8; ++e) o[e] = xadd<32>(xadd<16>(xadd<8>(o[e])));
     if (lane < 8) {
         *reinterpret_cast<float4*>(&s_o[wid][lane * 8]) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(&s_o[wid][lane * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
@@ -702,7 +697,7 @@ int lm_gemv_variant(const GemvArgs& a) {
 }
 
 #define GV_LEAD(a) (a).x, (a).w, (a).x2, (a).gather, (a).m, (a).n, (a).k, (a).kpad, (a).ldx     // the preloaded leading kernel arguments
-#define AT_LEAD(a) (a).q, (a).kv, (a).postab, (a).kstart, (a).b, (a).ldq, (a).ldp, (a).center, (a).d, (a).pos
+#define AT_LEAD(a) (a).q, (a).kv, (a).postab + (int64_t)(a).center * (a).ldp, (a).kstart, (a).kv_t, (a).kv_b, (a).kv_h, (a).kv_v, (a).ldq, (a).ldp
 
 template <int MT, int FORM, int XM>
 static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st) {
@@ -810,6 +805,8 @@ int lm_attn_launch(const AttnArgs& a, hipStream_t st) {
     ASTTS_REQUIRE(a.q && a.kv && a.postab && a.bias_u && a.bias_v, ASTTS_ERR_INVALID, "lm_attn: null pointer");
     ASTTS_REQUIRE(a.b >= 1 && a.h >= 1 && a.d == a.h * 64 && (a.ldq & 3) == 0 && (a.ldp & 7) == 0, ASTTS_ERR_INVALID,
                   "lm_attn: bad shape b=%d h=%d d=%d", a.b, a.h, a.d);
+    ASTTS_REQUIRE(a.kv_t > 0 && ((a.kv_t | a.kv_b | a.kv_h | a.kv_v) & 7) == 0, ASTTS_ERR_INVALID,
+                  "lm_attn: cache strides (%d, %d, %d, %d) must be multiples of 8 halfs (KvLayout)", a.kv_t, a.kv_b, a.kv_h, a.kv_v);
     ASTTS_REQUIRE(a.ksplit == 1 ? a.out != nullptr : (a.ksplit == 2 && a.part_o && a.part_ml), ASTTS_ERR_INVALID,
                   "lm_attn: ksplit=%d needs %s", a.ksplit, a.ksplit == 1 ? "out" : "the partial buffers (ksplit 1 or 2)");
     // algorithmic bytes: the fp16 K and V rows of every (row, head) + the position rows of every head, each read once

@@ -10,6 +10,7 @@
 // cosyvoice.utils.common.ras_sampling arithmetic behind tts_with_rag.py:195.
 #include "common.h"
 #include "toplist.h"
+#include "xlane.h"
 
 namespace astts {
 
@@ -206,8 +207,7 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
         prob[i] = x;
         mx = fmaxf(mx, x);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = xmax<1>(xmax<2>(xmax<4>(xmax<8>(xmax<16>(xmax<32>(mx))))));      // xlane.h: VALU lane exchanges instead of six ds_bpermute round trips
     if (lane == 0) red_max[wid] = mx;
     __syncthreads();
     mx = red_max[0];
@@ -219,8 +219,7 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
         prob[i] = e;
         sum += e;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum_desc(sum);                                            // same butterfly order (32, 16, ..., 1), same bits
     if (lane == 0) red_sum[wid] = sum;
     __syncthreads();
     float tot = 0.0f;      // fixed summation order (wave partials 0..15): same bits on every run

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512, NREG > 64 ? 2 : 4) void bg_kernel(const float*
 }
 
 static int g_ksplit = 1, g_lnplain = 0;
+static KvLayout g_lay = {0, 0, 0, 0};
 static int g_nostate = 0, g_pos = 305;   // DC_NOSTATE=1: positions as kernel arguments (no device-side step state)
 // one decode step: 14 x (QKV, attention, Wo, W1, W2) + head.  Returns the number of launches.
 static int enqueue_step(const Model& m, Ctx& c, hipStream_t st, int slot0) {
@@ -165,12 +166,12 @@ static int enqueue_step(const Model& m, Ctx& c, hipStream_t st, int slot0) {
         const Layer& L = m.L[l];
         GemvArgs a = G();   // LN1 + QKV -> q, K|V into the cache
         a.x = x; a.ldx = d; a.ln_g = L.n1g; a.ln_b = L.n1b; if (g_lnplain) { a.ln_g = nullptr; a.ln_b = nullptr; a.ln_plain = 1; } a.w = L.wqkv; a.bias = L.bqkv; a.out = c.q; a.ldo = d;
-        a.kv = c.kv[l]; a.n_split = d; a.ldkv = 2 * d; a.n = 3 * d; a.k = d; a.kpad = d;
+        a.kv = c.kv[l]; a.n_split = d; a.kv_t = g_lay.t; a.kv_b = g_lay.b; a.kv_h = g_lay.h; a.kv_v = g_lay.v; a.n = 3 * d; a.k = d; a.kpad = d;
         if (lm_gemv_launch(a, st)) exit(2);
         AttnArgs t;
         memset(&t, 0, sizeof(t));
         t.q = c.q; t.kv = c.kv[l]; t.postab = L.pos; t.bias_u = L.u; t.bias_v = L.v; t.out = c.ao; t.st = g_nostate ? nullptr : c.st; t.pos = g_pos; t.b = b; t.h = m.heads;
-        t.ldq = d; t.ldo = d; t.ldp = d; t.center = m.center; t.d = d; t.scale = 0.125f; t.stamps = c.stamps; t.stamp_slot = slot++;
+        t.ldq = d; t.ldo = d; t.ldp = d; t.center = m.center; t.d = d; t.kv_t = g_lay.t; t.kv_b = g_lay.b; t.kv_h = g_lay.h; t.kv_v = g_lay.v; t.scale = 0.125f; t.stamps = c.stamps; t.stamp_slot = slot++;
         t.ksplit = g_ksplit; t.part_o = c.part_o; t.part_ml = c.part_ml;
         if (lm_attn_launch(t, st)) exit(2);
         a = G();            // Wo + residual
@@ -210,6 +211,8 @@ int main(int argc, char** argv) {
     const int steps = argc > 2 ? atoi(argv[2]) : 200;
     const int pos0 = 185;
     if (getenv("DC_KSPLIT")) g_ksplit = atoi(getenv("DC_KSPLIT"));
+    g_lay = getenv("DC_KVHM") && atoi(getenv("DC_KVHM")) ? KvLayout::head_major(16, getenv("DC_TMAX") ? atoi(getenv("DC_TMAX")) : 512) : KvLayout::time_major(b, 1024);
+    printf("cache layout: %s\n", g_lay.t == 64 ? "head-major" : "time-major");
     if (getenv("DC_NOSTATE")) g_nostate = 1;
     if (getenv("DC_LNPLAIN")) g_lnplain = 1;
     lm_step_set_attrs();
@@ -282,10 +285,10 @@ int main(int argc, char** argv) {
         };
         printf("B=%d, single operators (step %d: %d keys):\n", b, getenv("DC_STEP") ? atoi(getenv("DC_STEP")) : 120, pos0 + 1 + (getenv("DC_STEP") ? atoi(getenv("DC_STEP")) : 120));
         run("qkv  (LN, n=3072, k=1024)", [&](int l) { const Layer& L = m.L[l]; GemvArgs a = G(); a.x = (l & 1) ? c.x1 : c.x0; a.ldx = d; a.ln_g = L.n1g; a.ln_b = L.n1b; if (g_lnplain) { a.ln_g = nullptr; a.ln_b = nullptr; a.ln_plain = 1; } a.w = L.wqkv; a.bias = L.bqkv; a.out = c.q; a.ldo = d;
-            a.kv = c.kv[l]; a.n_split = d; a.ldkv = 2 * d; a.n = 3 * d; a.k = d; a.kpad = d; if (lm_gemv_launch(a, st)) exit(2); });
+            a.kv = c.kv[l]; a.n_split = d; a.kv_t = g_lay.t; a.kv_b = g_lay.b; a.kv_h = g_lay.h; a.kv_v = g_lay.v; a.n = 3 * d; a.k = d; a.kpad = d; if (lm_gemv_launch(a, st)) exit(2); });
         run("attn", [&](int l) { const Layer& L = m.L[l]; AttnArgs t; memset(&t, 0, sizeof(t));
             t.q = c.q; t.kv = c.kv[l]; t.postab = L.pos; t.bias_u = L.u; t.bias_v = L.v; t.out = c.ao; t.st = g_nostate ? nullptr : c.st; t.pos = 305; t.b = b; t.h = m.heads;
-            t.ldq = d; t.ldo = d; t.ldp = d; t.center = m.center; t.d = d; t.scale = 0.125f; t.ksplit = g_ksplit; t.part_o = c.part_o; t.part_ml = c.part_ml; if (lm_attn_launch(t, st)) exit(2); });
+            t.ldq = d; t.ldo = d; t.ldp = d; t.center = m.center; t.d = d; t.kv_t = g_lay.t; t.kv_b = g_lay.b; t.kv_h = g_lay.h; t.kv_v = g_lay.v; t.scale = 0.125f; t.ksplit = g_ksplit; t.part_o = c.part_o; t.part_ml = c.part_ml; if (lm_attn_launch(t, st)) exit(2); });
         run("wo   (f16 x, n=1024, k=1024)", [&](int l) { const Layer& L = m.L[l]; GemvArgs a = G(); a.x = c.ao; a.x_mode = 1; a.ldx = d; if (g_ksplit == 2) { a.x = c.part_o; a.x2 = c.part_ml; a.x_mode = 2; } a.w = L.wo; a.bias = L.bo; a.res = c.x0; a.ldr = d; a.out = c.x1; a.ldo = d; a.n = d; a.k = d; a.kpad = d;
             if (lm_gemv_launch(a, st)) exit(2); });
         run("w1   (LN, n=4096, k=1024)", [&](int l) { const Layer& L = m.L[l]; GemvArgs a = G(); a.x = c.x1; a.ldx = d; a.ln_g = L.n2g; a.ln_b = L.n2b; if (g_lnplain) { a.ln_g = nullptr; a.ln_b = nullptr; a.ln_plain = 1; } a.w = L.w1; a.bias = L.b1; a.out16 = c.ff; a.ldo16 = m.ffn; a.relu = 1;
