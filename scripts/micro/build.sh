@@ -20,3 +20,5 @@ hipcc -O2 --offload-arch=gfx950 coherence.hip -o coherence
 #                       hipGraph replay, one chain vs two concurrent ones; decode_chain_stamps: in-kernel s_memrealtime stamps
 hipcc $F -std=c++17 decode_chain.hip -o decode_chain
 hipcc $F -std=c++17 -DLM_STAMPS decode_chain.hip -o decode_chain_stamps
+#   xlane_probe         csrc/xlane.h (DPP / v_permlane swaps) against __shfl_xor: bit equality and the latency of a 64-lane sum
+hipcc $F -std=c++17 -Wno-unused-result xlane_probe.hip -o xlane_probe
