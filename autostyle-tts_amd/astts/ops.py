@@ -122,6 +122,7 @@ _SIGS.update({
     "astts_stream_chain": (c_int32, [c_int32, c_int32, c_int32, c_void_p]),
     "astts_stream_create_cu_mask": (c_int32, [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]),
     "astts_stream_destroy": (c_int32, [c_void_p]),
+    "astts_selftest_xlane": (c_int32, [ctypes.POINTER(c_int32), c_void_p]),
     "astts_flow_create": (c_int32, [ctypes.POINTER(FlowConfig), ctypes.POINTER(FlowBlock), ctypes.POINTER(FlowBlock),
                                     ctypes.POINTER(FlowBlock), ctypes.POINTER(c_void_p)]),
     "astts_flow_destroy": (c_int32, [c_void_p]),
@@ -593,6 +594,13 @@ def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: floa
                                         hist_len, history.stride(0) if history is not None else 0, top_k, top_p,
                                         win_size, tau_r, eos_id, 1 if ignore_eos else 0, _st()))
     return out
+
+
+def selftest_xlane() -> int:
+    """Number of words in which csrc/xlane.h's lane exchanges differ from __shfl_xor (0 = the decode-step reductions are intact)."""
+    out = c_int32(-1)
+    _lib.check(_L().astts_selftest_xlane(ctypes.byref(out), _st()))
+    return int(out.value)
 
 
 def cu_masked_stream(cus, device=None) -> "torch.cuda.ExternalStream":

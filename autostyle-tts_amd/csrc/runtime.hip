@@ -1,5 +1,6 @@
 // runtime.hip -- error reporting, ABI version, and the bench-only launch profiler of libastts.so
 #include "common.h"
+#include "xlane.h"
 
 #include <mutex>
 #include <vector>
@@ -82,6 +83,34 @@ using namespace astts;
 
 namespace astts {
 // wall_clock64 ticks at 100 MHz on gfx9
+// csrc/xlane.h against __shfl_xor: slots 0..5 = the six butterfly offsets, 6 = 64-lane sum (steps 32..1), 7 = maximum over the
+// lanes with equal (lane & 7) (steps 8, 16, 32), 8 = sum in ascending steps 1, 2, 4 (as the decode attention's score reduction)
+__global__ void xlane_selftest(unsigned seed, int* mismatches) {
+    unsigned h = (threadIdx.x + blockIdx.x * blockDim.x) * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    float v = ((float)(h & 0xffffff) / 8388608.0f - 1.0f) * (1.0f + (float)(h >> 28));
+    asm volatile("" : "+v"(v));     // a value, not an expression: the shuffle form's first add must not be contracted with this product
+    float ref[9], got[9];
+    ref[0] = __shfl_xor(v, 1, 64); got[0] = lane_xor<1>(v);
+    ref[1] = __shfl_xor(v, 2, 64); got[1] = lane_xor<2>(v);
+    ref[2] = __shfl_xor(v, 4, 64); got[2] = lane_xor<4>(v);
+    ref[3] = __shfl_xor(v, 8, 64); got[3] = lane_xor<8>(v);
+    ref[4] = __shfl_xor(v, 16, 64); got[4] = lane_xor<16>(v);
+    ref[5] = __shfl_xor(v, 32, 64); got[5] = lane_xor<32>(v);
+    float s = v;
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    ref[6] = s; got[6] = wave_sum_desc(v);
+    float m = v;
+    for (int off = 8; off <= 32; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    ref[7] = m; got[7] = xmax<32>(xmax<16>(xmax<8>(v)));
+    float t = v;
+    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+    ref[8] = t; got[8] = xadd<4>(xadd<2>(xadd<1>(v)));
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (__builtin_bit_cast(unsigned, ref[i]) != __builtin_bit_cast(unsigned, got[i])) atomicAdd(mismatches + i, 1);
+}
+
 __global__ void spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
@@ -154,6 +183,33 @@ int astts_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, astts_str
 
 int astts_stream_destroy(astts_stream_t stream) {
     ASTTS_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ASTTS_OK;
+}
+
+int astts_selftest_xlane(int32_t* mismatches, astts_stream_t stream) {
+    ASTTS_REQUIRE(mismatches, ASTTS_ERR_INVALID, "astts_selftest_xlane: null pointer");
+    int* d = nullptr;
+    ASTTS_CHECK_HIP(hipMalloc(&d, 9 * sizeof(int)));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d, 0, 9 * sizeof(int), st);
+    for (unsigned seed = 1; e == hipSuccess && seed <= 4; ++seed) {
+        hipLaunchKernelGGL(astts::xlane_selftest, dim3(64), dim3(512), 0, st, seed * 7919u, d);
+        e = hipGetLastError();
+    }
+    int h[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        astts::set_error("astts_selftest_xlane: %s", hipGetErrorString(e));
+        return ASTTS_ERR_HIP;
+    }
+    int total = 0;
+    for (int i = 0; i < 9; ++i) total += h[i];
+    if (total)      // left in the error string for whoever looks (the call itself succeeds: the count is the result)
+        astts::set_error("astts_selftest_xlane: mismatches per check (xor 1, 2, 4, 8, 16, 32, sum 32..1, max 8..32, sum 1..4): %d %d %d %d %d %d %d %d %d",
+                         h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+    *mismatches = total;
     return ASTTS_OK;
 }
 

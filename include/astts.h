@@ -65,6 +65,11 @@ int astts_stream_chain(int32_t count, int32_t microseconds, int32_t blocks, astt
  * between concurrent stages.  The caller destroys it with astts_stream_destroy once nothing is in flight on it. */
 int astts_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, astts_stream_t* out);
 int astts_stream_destroy(astts_stream_t stream);
+/* Self-test of the cross-lane exchanges of csrc/xlane.h (DPP modifiers, v_permlane16_swap / v_permlane32_swap) against
+ * __shfl_xor on pseudo-random values: every butterfly offset and the composed 64-lane sums / maxima must agree bit for bit.
+ * *mismatches = number of differing words (0 = the decode-step reductions compute what their shuffle form computed).
+ * Synchronises the stream. */
+int astts_selftest_xlane(int32_t* mismatches, astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",

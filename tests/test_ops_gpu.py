@@ -718,3 +718,14 @@ def test_cu_masked_stream_runs_kernels_with_the_same_results():
     assert torch.equal(out, ref)
     h = ctypes.c_void_p()
     assert _lib.load().astts_stream_create_cu_mask(None, 8, ctypes.byref(h)) == _lib.ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_lane_exchanges_equal_the_shuffle_form():
+    """csrc/xlane.h: the decode-step reductions exchange lanes with DPP modifiers and v_permlane16/32_swap instead of
+    ds_bpermute.  The library's self-test compares every butterfly offset and the composed sums / maxima with __shfl_xor on
+    pseudo-random values: bit for bit (the swaps are inline assembly because the compiler folded the builtin's two results
+    into one -- this is the guard for that)."""
+    from astts import ops
+
+    assert ops.selftest_xlane() == 0
