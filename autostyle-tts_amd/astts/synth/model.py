@@ -278,19 +278,30 @@ class AcousticLM:
             return 0
         return int(ignore_eos)
 
-    def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
-                      forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False,
-                      key_start: Optional[torch.Tensor] = None):
+    def prefill(self, prefix: torch.Tensor, n_steps: int, key_start: Optional[torch.Tensor] = None):
+        """The part of a decode call that does not depend on the sampler: the KV cache of the prefix and the logits of its last
+        position, on the CURRENT stream.  -> state for `decode_prefilled` (which may run on another stream: the pipeline enqueues
+        this on its front stream so that a decode chain is nothing but its steps)."""
+        s0, b = prefix.shape[0], prefix.shape[1]
+        cache = self.new_cache(b, s0 + n_steps)
+        hid = self.forward_new(prefix, cache, 0, key_start)
+        logits0 = self.logits(hid[-1]).contiguous()
+        return {"cache": cache, "logits0": logits0, "s0": s0, "b": b, "n_steps": n_steps, "key_start": key_start}
+
+    @staticmethod
+    def prefill_tensors(state):
+        return list(state["cache"]) + [state["logits0"]] + ([state["key_start"]] if state["key_start"] is not None else [])
+
+    def decode_prefilled(self, state, uniforms: torch.Tensor, ignore_eos: bool = True, forced_tokens: Optional[torch.Tensor] = None,
+                         return_logits: bool = False):
+        """The decode steps of `prefill`'s state (b <= 32 rows) on the current stream: one C++ call, no host synchronisation."""
         import ctypes
 
         from .. import _lib
         lib = _lib.load()
         eng = self._engine()
-        s0, b = prefix.shape[0], prefix.shape[1]
+        cache, logits0, s0, b, n_steps, key_start = (state[k] for k in ("cache", "logits0", "s0", "b", "n_steps", "key_start"))
         t_max = s0 + n_steps
-        cache = self.new_cache(b, t_max)
-        hid = self.forward_new(prefix, cache, 0, key_start)
-        logits0 = self.logits(hid[-1]).contiguous()
         need = int(lib.astts_lm_workspace_bytes(eng, b))
         ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = ws.data_ptr()
@@ -307,6 +318,11 @@ class AcousticLM:
                                        None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
         self._keepalive = (cache, ws, logits0, forced, u, key_start, ignore_eos)   # buffers referenced by kernels still in flight
         return (toks, lg_out) if return_logits else toks
+
+    def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
+                      forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False,
+                      key_start: Optional[torch.Tensor] = None):
+        return self.decode_prefilled(self.prefill(prefix, n_steps, key_start), uniforms, ignore_eos, forced_tokens, return_logits)
 
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
                forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True,
@@ -856,6 +872,13 @@ class SynthEngine:
         pre = self.lm.prefix(text, text_lens, lm_spk, lm_prompt_tokens)
         return self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
 
+    # the same in two halves (<= 32 rows): what precedes the first sampled token, and the decode steps (PipelinedSynth)
+    def tts_prefill(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int):
+        return self.lm.prefill(self.lm.prefix(text, text_lens, lm_spk, lm_prompt_tokens), n_tokens)
+
+    def tts_decode(self, state, uniforms, forced_tokens=None) -> torch.Tensor:
+        return self.lm.decode_prefilled(state, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
+
     def tts_render(self, toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise):
         cfg = self.cfg
         all_tok = torch.cat([flow_prompt_tokens.to(torch.int32), toks], dim=1)
@@ -885,7 +908,8 @@ class PipelinedSynth:
     waveform are bit-identical to running it alone (tested)."""
 
     def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None,
-                 cobatch: int = 1, render_depth: int = 1, pipe_classes=None):
+                 cobatch: int = 1, render_depth: int = 1, pipe_classes=None, front_prefill: Optional[bool] = None):
+        import os
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
@@ -939,6 +963,7 @@ class PipelinedSynth:
         self._fifo = deque()
         self._pending = []                  # batches waiting for their (co-batched) LM stage to be launched
         self.cobatch = max(1, int(cobatch))
+        self.front_prefill = (os.environ.get("ASTTS_PIPE_FRONT_PREFILL", "1") != "0") if front_prefill is None else bool(front_prefill)
         self._i = 0
 
     @classmethod
@@ -1003,12 +1028,21 @@ class PipelinedSynth:
         for t in lm_args:
             if isinstance(t, torch.Tensor):
                 t.record_stream(stream)
-        stream.wait_stream(cur)             # after the concatenations above were enqueued
         sizes = [int(g["lm"][0].shape[0]) for g in group]
+        # ``front_prefill`` (default; ASTTS_PIPE_FRONT_PREFILL=0 or front_prefill=False: the whole LM stage on the chain): prefix
+        # assembly + prefill (text encoder, 14 layers over the prefix, first logits: ~4.7 ms of a chain's ~106 ms per batch, big-tile
+        # GEMM launches) are enqueued HERE, on the caller's stream, and the chain is its decode steps only.  The chains are what
+        # bounds the pipelined step: 95.5 -> 93.9 ms per batch (scripts/front_prefill_probe.py, alternating in one process, 4 of 4)
+        state = None
+        if self.front_prefill and sum(sizes) <= 32:
+            state = self.eng.tts_prefill(*lm_args[:5])
+            for t in self.eng.lm.prefill_tensors(state):
+                t.record_stream(stream)
+        stream.wait_stream(cur)             # after the concatenations (and the prefill) above were enqueued
 
         def lm_stage():
             with torch.cuda.device(self.eng.device), torch.cuda.stream(stream):
-                toks = self.eng.tts_tokens(*lm_args)
+                toks = self.eng.tts_tokens(*lm_args) if state is None else self.eng.tts_decode(state, lm_args[5])
                 parts = list(torch.split(toks, sizes, 0)) if len(sizes) > 1 else [toks]
                 ev = torch.cuda.Event()
                 ev.record(stream)

@@ -584,7 +584,7 @@ def main():
             "knn_roofline": knn_roof,
             "ids_match_oracle": ids_ok,
             "waveform_finite_and_clamped": wav_ok,
-            "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
+            "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + LM prefix / prefill + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
                                                "decode_chains": cob["chains"], "batches_per_chain": cob["batches_per_chain"],
                                                "note": "same K steps, LM stages of consecutive batches co-batched into one 16- or 32-row decode "

@@ -457,8 +457,10 @@ def test_fullsize_pipeline_and_cobatching_are_bit_identical_to_sequential():
     args = (text, tlen, spk_s, style_tok, Ts, u, timbre_tok, timbre_mel, spk_t, z, phase0, noise)
     ref = eng.tts(*args)
     torch.cuda.synchronize()
-    for depth, cob in ((2, 1), (2, 2), (1, 3)):
-        pipe = PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob)
+    # front_prefill: the LM prefill enqueued on the caller's stream (default) or on the decode chain with the steps
+    for depth, cob, fp in ((2, 1, True), (2, 1, False), (2, 2, True), (1, 3, False)):
+        pipe = PipelinedSynth(eng, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob, front_prefill=fp)
+        assert pipe.front_prefill is fp
         outs = []
         with torch.cuda.stream(pipe.front_stream):
             for _ in range(9):
@@ -469,7 +471,7 @@ def test_fullsize_pipeline_and_cobatching_are_bit_identical_to_sequential():
         torch.cuda.synchronize()
         assert len(outs) == 9
         for o in outs:
-            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, cob)
+            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (depth, cob, fp)
 
 
 def test_fullsize_lm_logits_match_oracle():
