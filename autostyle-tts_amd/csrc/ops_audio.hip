@@ -197,6 +197,17 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
     const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
+    // operands of the LAST phases, requested now: the two uniforms and the repetition window of the token log were dependent
+    // global round trips at the very end of the kernel (~1 us each on a kernel of 11)
+    const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
+    const bool win_in_wave = a.hist_len - h0 <= 64;
+    float u_first = 0.0f, u_second = 0.0f;
+    int hwin = -1;
+    if (wid == 0) {
+        u_first = a.u[bb * 2];
+        u_second = a.u[bb * 2 + 1];
+        if (win_in_wave && h0 + lane < a.hist_len) hwin = a.history[(int64_t)bb * a.hist_ld + h0 + lane];
+    }
     for (int i = tid; i < 3 * 2048; i += RS_NT) (&hist[0][0])[i] = 0u;
     if (tid == 0) s_cnt = 0;
     if (tid < 16 && ((a.v + 15) & ~15) - 16 + tid >= a.v) prob[((a.v + 15) & ~15) - 16 + tid] = 0.0f;   // tail of the last 16-chunk
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
                 ++cnt;
             }
         }
-        const float target = a.u[bb * 2] * cum;
+        const float target = u_first * cum;
         float run = 0.0f;
         int tok = sh_i[cnt > 0 ? cnt - 1 : 0];
         bool found = false;
@@ -355,12 +366,15 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
             }
         }
         // repetition check: lane j compares the j-th token of the window (one round trip, not `win` dependent ones)
-        const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
         int rep = 0;
-        for (int i0 = h0; i0 < a.hist_len; i0 += 64) {
-            const int i = i0 + lane;
-            const bool hit = i < a.hist_len && a.history[(int64_t)bb * a.hist_ld + i] == tok;
-            rep += __popcll(__ballot(hit));
+        if (win_in_wave) {
+            rep = __popcll(__ballot(hwin == tok));           // lanes outside the window hold -1
+        } else {
+            for (int i0 = h0; i0 < a.hist_len; i0 += 64) {
+                const int i = i0 + lane;
+                const bool hit = i < a.hist_len && a.history[(int64_t)bb * a.hist_ld + i] == tok;
+                rep += __popcll(__ballot(hit));
+            }
         }
         if (lane == 0) {
             s_tok = tok;
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
         // repetition detected: random sampling from the full distribution, id order, inverse CDF with u2.  The running sum is
         // the oracle's sequential fp32 accumulation (a parallel scan rounds differently), taken 16 elements per LDS round trip
         // with ONE comparison per chunk: ~20 us worst case (an LDS read + compare + branch per element took 270 us).
-        const float target = a.u[bb * 2 + 1];
+        const float target = u_second;
         float run = 0.0f;
         int tok = -1;
         const int vpad = (a.v + 15) & ~15;

@@ -1,6 +1,7 @@
 // toplist.h -- wave-distributed sorted top-C list (shared by the kNN selection and the LM sampler).
 #pragma once
 #include "common.h"
+#include "xlane.h"
 
 namespace astts {
 
@@ -27,8 +28,8 @@ struct TopList {
         for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
             for (int j = k >> 1; j > 0; j >>= 1) {
-                T os = __shfl_xor(s, j, 64);
-                int oi = __shfl_xor(idx, j, 64);
+                T os = lane_xor_dyn(s, j);          // j is a constant after unrolling: DPP / permlane swap (xlane.h), not ds_bpermute
+                int oi = lane_xor_dyn(idx, j);
                 const bool up = (lane & k) == 0;     // this block ends best-first
                 const bool lower = (lane & j) == 0;  // lower lane of the pair
                 const bool other_better = better<T>(os, oi, s, idx);

@@ -51,6 +51,26 @@ __device__ __forceinline__ float lane_xor(float v) {
     }
 }
 
+// the same exchange for 32-bit integers and doubles (two words), and with the offset as a run-time value that is a constant
+// after unrolling (the bitonic sort of toplist.h): the switch folds away
+template <int OFF> __device__ __forceinline__ int lane_xor(int v) { return __builtin_bit_cast(int, lane_xor<OFF>(__builtin_bit_cast(float, v))); }
+template <int OFF> __device__ __forceinline__ double lane_xor(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const float lo = lane_xor<OFF>(__builtin_bit_cast(float, (unsigned)u)), hi = lane_xor<OFF>(__builtin_bit_cast(float, (unsigned)(u >> 32)));
+    return __builtin_bit_cast(double, ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32) | __builtin_bit_cast(unsigned, lo));
+}
+template <typename T>
+__device__ __forceinline__ T lane_xor_dyn(T v, int off) {
+    switch (off) {
+        case 1: return lane_xor<1>(v);
+        case 2: return lane_xor<2>(v);
+        case 4: return lane_xor<4>(v);
+        case 8: return lane_xor<8>(v);
+        case 16: return lane_xor<16>(v);
+        default: return lane_xor<32>(v);
+    }
+}
+
 // op(v, value of lane ^ OFF) for a COMMUTATIVE op: the row swaps need no select (a' op b' is the same pair on both sides)
 template <int OFF, typename Op>
 __device__ __forceinline__ float lane_xor_op(float v, Op op) {
