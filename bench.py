@@ -114,6 +114,27 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
                       f"oracle/ fp32 torch-CPU: lm {t1 - t0:.1f} s, flow {t2 - t1:.1f} s, vocoder {t3 - t2:.1f} s"}
 
 
+_JSON_OUT = None
+
+
+def json_only_stdout():
+    """Reserve the process's stdout for the ONE JSON line.  Libraries write there too -- RCCL prints its version banner
+    ("RCCL version : ...", five lines) to C stdout, and with a pipe for stdout those lines are flushed at exit, i.e. AFTER the
+    JSON line.  From here on file descriptor 1 is stderr; `emit_json` writes to the descriptor stdout had."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
+def emit_json(obj):
+    out = json_only_stdout()
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def free_port():
     import socket
 
@@ -200,9 +221,9 @@ def stub_main(args, world, rank):
     if os.environ.get("ASTTS_BENCH_STUB_FAIL_RANK") == str(rank):
         raise SystemExit(3)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world,
-                          "rccl_world_size": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "ranks_seen": gathered, "data": "stub (launcher test)"}))
+        emit_json({"metric": "stub", "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world,
+                   "rccl_world_size": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                   "ranks_seen": gathered, "data": "stub (launcher test)"})
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -239,6 +260,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                          f"or plainly as `python bench.py --gpus {args.gpus}` (self-launching)")
+    json_only_stdout()        # every rank: nothing but rank 0's JSON line reaches stdout (RCCL's banner, library chatter -> stderr)
     if os.environ.get("ASTTS_BENCH_STUB"):
         return stub_main(args, world, rank)
     torch.cuda.set_device(local_rank)
@@ -598,7 +620,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)
-        print(json.dumps(res))
+        emit_json(res)
     if dist is not None:
         dist.destroy_process_group()
 
