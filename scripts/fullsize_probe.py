@@ -4,7 +4,7 @@ import torch
 from astts.synth.config import SynthConfig
 from astts.synth.weights import make_all
 from astts.synth.model import SynthEngine
-cfg=SynthConfig()
+cfg=SynthConfig(sample_rate=int(os.environ.get("PROBE_SR","22050")))
 t0=time.time(); W=make_all(cfg,0); print('weights', time.time()-t0, sum(v.numel() for sd in W.values() for v in sd.values())/1e6,'M params')
 t0=time.time(); eng=SynthEngine(W,cfg,'cuda'); torch.cuda.synchronize(); print('engine', time.time()-t0)
 del W
