@@ -118,6 +118,23 @@ def relpos_layer(sd: SD, q: str, h: torch.Tensor, heads: int, pe: torch.Tensor, 
 
 
 # ----------------------------------------------------------------------------------------- LM
+def nucleus(p: torch.Tensor, top_k: int, top_p: float):
+    """The candidate set of upstream's nucleus_sampling [EXT cosyvoice/utils/common.py]: probabilities in descending order (ties:
+    lower id first), a token is added while the mass of those ALREADY added is < top_p and fewer than top_k were added.
+    -> (ids in rank order, how many of them form the nucleus, their fp32 mass accumulated in rank order).
+    Pinned against transformers' TopPLogitsWarper (tests/test_oracle_synth_blocks.py): the same set, cut at top_k."""
+    order = sorted(range(p.numel()), key=lambda i: (-float(p[i]), i))[:top_k]
+    cnt = 0
+    cum32 = torch.tensor(0.0)
+    for idx in order:
+        if float(cum32) < top_p and cnt < top_k:
+            cum32 = cum32 + p[idx]
+            cnt += 1
+        else:
+            break
+    return order, cnt, cum32
+
+
 def ras_sample(logits: torch.Tensor, history: torch.Tensor, u: torch.Tensor, top_k: int, top_p: float, win: int,
                tau_r: float, eos: int, ignore_eos: bool) -> torch.Tensor:
     """Repetition-aware sampling with injected uniforms u[b] = (u1, u2); definition in csrc/ops_audio.hip."""
@@ -128,15 +145,7 @@ def ras_sample(logits: torch.Tensor, history: torch.Tensor, u: torch.Tensor, top
             lg[eos] = float("-inf")
         e = torch.exp(lg - lg.max())
         p = e * (1.0 / e.sum())
-        order = sorted(range(p.numel()), key=lambda i: (-float(p[i]), i))[:top_k]
-        cum, cnt = 0.0, 0
-        cum32 = torch.tensor(0.0)
-        for idx in order:
-            if float(cum32) < top_p and cnt < top_k:
-                cum32 = cum32 + p[idx]
-                cnt += 1
-            else:
-                break
+        order, cnt, cum32 = nucleus(p, top_k, top_p)
         target = u[b, 0] * cum32
         run = torch.tensor(0.0)
         tok = order[cnt - 1]

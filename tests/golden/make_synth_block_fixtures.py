@@ -14,6 +14,7 @@ oracle/synth.py restates, produced by independent third-party implementations of
   HiFi-GAN trunk     SpeechT5HifiGan (conv_pre, leaky-relu, ConvTranspose1d padding (k - u) / 2, mean over the parallel
                      resblocks, final leaky-relu 0.01)   -> oracle.synth.hift_trunk with a silent source path
   Whisper log-mel    WhisperFeatureExtractor(feature_size=128) -> astts.audio.whisper_log_mel / mel_filterbank (a12)
+  nucleus set        TopPLogitsWarper (generation/logits_process.py) -> oracle.synth.nucleus (the sampler's candidate set)  (a13)
 
 Run in the BUILD container only (python tests/golden/make_synth_block_fixtures.py).  The .npz is data: seeded random
 weights and inputs in, the third-party outputs out.  Nothing of transformers travels."""
@@ -163,6 +164,27 @@ def whisper(out):
     print("whisper log-mel:", feats.shape)
 
 
+def nucleus_sets(out):
+    """Top-p candidate sets of transformers' TopPLogitsWarper on seeded logits of three shapes (flat, peaked, with exact ties):
+    upstream's nucleus_sampling adds tokens in descending probability while the mass already added is < top_p -- the smallest
+    prefix reaching top_p, which is what the warper keeps -- and stops at top_k entries."""
+    from transformers.generation.logits_process import TopPLogitsWarper
+
+    g = torch.Generator().manual_seed(17)
+    v = 4097
+    flat = torch.randn(6, v, generator=g) * 0.7
+    peaked = torch.randn(6, v, generator=g) * 4.0
+    tied = torch.round(torch.randn(4, v, generator=g) * 3.0) / 2.0          # many exactly equal logits
+    logits = torch.cat([flat, peaked, tied], 0)
+    kept = {}
+    for top_p in (0.8, 0.5, 0.95):
+        w = TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=1)
+        sc = w(None, logits.clone())
+        kept[top_p] = torch.isfinite(sc).numpy()
+    out.update({"nucleus.logits": logits.numpy(), "nucleus.kept_p80": kept[0.8], "nucleus.kept_p50": kept[0.5], "nucleus.kept_p95": kept[0.95]})
+    print("top-p sets:", {k: v_.sum(1).tolist() for k, v_ in kept.items()})
+
+
 if __name__ == "__main__":
     fx = {}
     relpos_fastspeech2(fx)
@@ -171,6 +193,7 @@ if __name__ == "__main__":
     snake(fx)
     hifigan(fx)
     whisper(fx)
+    nucleus_sets(fx)
     path = os.path.join(ROOT, "tests", "golden", "synth_blocks.npz")
     np.savez_compressed(path, **fx)
     print("->", path, os.path.getsize(path) // 1024, "KB,", len(fx), "arrays")

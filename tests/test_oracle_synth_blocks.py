@@ -167,3 +167,37 @@ def test_encoder_layer_matches_fastspeech2_conformer_layer(fx):
     for i in range(b):
         n = int(lens[i])
         assert _rel(y[i, :n], ref[i, :n]) < 2e-5, i
+
+
+@pytest.mark.parametrize("key,top_p", [("nucleus.kept_p80", 0.8), ("nucleus.kept_p50", 0.5), ("nucleus.kept_p95", 0.95)])
+def test_nucleus_set_matches_transformers_top_p_warper(fx, key, top_p):
+    """oracle.synth.nucleus (the candidate set of the sampler, a13) against TopPLogitsWarper: without a top_k cap the two keep the
+    same tokens; with upstream's cap (25) the nucleus is the 25 most probable of that set, in (probability desc, id asc) order.
+    Rows 0-11: continuous logits (flat and peaked), exact id sets.  Rows 12-15: many exactly tied logits -- which of several tied
+    tokens falls inside is an ordering convention (ours: lower id first), so those compare the kept VALUES, not the ids (and allow the
+    cut to fall one token apart: fp32 accumulation order)."""
+    logits = torch.from_numpy(fx["nucleus.logits"])
+    kept = fx[key]
+    v = logits.shape[1]
+    for r in range(logits.shape[0]):
+        lg = logits[r]
+        e = torch.exp(lg - lg.max())
+        p = e * (1.0 / e.sum())
+        order, cnt, cum = osyn.nucleus(p, v, top_p)
+        ids = order[:cnt]
+        ref = np.nonzero(kept[r])[0]
+        if r < 12:
+            assert sorted(ids) == ref.tolist(), (r, cnt, len(ref))
+        else:
+            # thousands of tied tokens deep, the fp32 running mass depends on the order of accumulation (ours descending as
+            # upstream's loop, the warper's an ascending cumsum): the cut may fall one token apart
+            assert abs(cnt - len(ref)) <= 1, (r, cnt, len(ref))
+            n = min(cnt, len(ref))
+            mine = sorted((float(lg[i]) for i in ids), reverse=True)[:n]
+            theirs = sorted((float(lg[i]) for i in ref), reverse=True)[:n]
+            assert mine == theirs, r
+        assert float(cum) >= top_p and float(cum) - float(p[ids[-1]]) < top_p          # the shortest prefix that reaches top_p
+        o25, c25, _ = osyn.nucleus(p, 25, top_p)
+        assert o25[:c25] == order[:min(cnt, 25)] and c25 == min(cnt, 25)
+        # rank order: probability descending, lower id first among equals
+        assert all((float(p[a]), -a) >= (float(p[b]), -b) for a, b in zip(order[:cnt - 1], order[1:cnt]))
