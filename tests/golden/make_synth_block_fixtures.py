@@ -14,6 +14,7 @@ oracle/synth.py restates, produced by independent third-party implementations of
   HiFi-GAN trunk     SpeechT5HifiGan (conv_pre, leaky-relu, ConvTranspose1d padding (k - u) / 2, mean over the parallel
                      resblocks, final leaky-relu 0.01)   -> oracle.synth.hift_trunk with a silent source path
   Whisper log-mel    WhisperFeatureExtractor(feature_size=128) -> astts.audio.whisper_log_mel / mel_filterbank (a12)
+  transformer block  torch.nn.TransformerEncoderLayer(norm_first=True, gelu) -> oracle.synth._tfm_block (the estimator's BasicTransformerBlock) (a14)
   nucleus set        TopPLogitsWarper (generation/logits_process.py) -> oracle.synth.nucleus (the sampler's candidate set)  (a13)
 
 Run in the BUILD container only (python tests/golden/make_synth_block_fixtures.py).  The .npz is data: seeded random
@@ -164,6 +165,33 @@ def whisper(out):
     print("whisper log-mel:", feats.shape)
 
 
+def prenorm_transformer_block(out):
+    """torch.nn.TransformerEncoderLayer(norm_first=True, activation="gelu") = the arithmetic of diffusers' BasicTransformerBlock as
+    the Matcha / CosyVoice estimator configures it (self-attention without q/k/v bias, out-projection with bias, exact-erf GELU
+    feed-forward, pre-LayerNorm, two residuals) -> oracle.synth._tfm_block."""
+    torch.manual_seed(18)
+    d, heads, ffn, b, t = 128, 2, 512, 3, 37
+    lay = torch.nn.TransformerEncoderLayer(d, heads, ffn, dropout=0.0, activation="gelu", batch_first=True, norm_first=True).eval()
+    with torch.no_grad():
+        for n_, p in lay.named_parameters():
+            p.copy_(torch.randn_like(p) * (0.15 if p.dim() > 1 else 0.2) + (1.0 if n_.startswith("norm") and n_.endswith("weight") else 0.0))
+        lay.self_attn.in_proj_bias.zero_()
+        x = torch.randn(b, t, d)
+        lens = torch.tensor([t, 20, 9])
+        pad = torch.arange(t)[None, :] >= lens[:, None]
+        y = lay(x, src_key_padding_mask=pad)
+    sd = lay.state_dict()
+    wq, wk, wv = sd["self_attn.in_proj_weight"].chunk(3, 0)
+    out.update({"tfm.x": x.numpy(), "tfm.lens": lens.numpy(), "tfm.y": y.detach().numpy(), "tfm.heads": np.int64(heads),
+                "tfm.norm1.weight": sd["norm1.weight"].numpy(), "tfm.norm1.bias": sd["norm1.bias"].numpy(),
+                "tfm.attn1.to_q.weight": wq.numpy(), "tfm.attn1.to_k.weight": wk.numpy(), "tfm.attn1.to_v.weight": wv.numpy(),
+                "tfm.attn1.to_out.0.weight": sd["self_attn.out_proj.weight"].numpy(), "tfm.attn1.to_out.0.bias": sd["self_attn.out_proj.bias"].numpy(),
+                "tfm.norm3.weight": sd["norm2.weight"].numpy(), "tfm.norm3.bias": sd["norm2.bias"].numpy(),
+                "tfm.ff.net.0.proj.weight": sd["linear1.weight"].numpy(), "tfm.ff.net.0.proj.bias": sd["linear1.bias"].numpy(),
+                "tfm.ff.net.2.weight": sd["linear2.weight"].numpy(), "tfm.ff.net.2.bias": sd["linear2.bias"].numpy()})
+    print("pre-norm transformer block:", tuple(y.shape))
+
+
 def nucleus_sets(out):
     """Top-p candidate sets of transformers' TopPLogitsWarper on seeded logits of three shapes (flat, peaked, with exact ties):
     upstream's nucleus_sampling adds tokens in descending probability while the mass already added is < top_p -- the smallest
@@ -194,6 +222,7 @@ if __name__ == "__main__":
     hifigan(fx)
     whisper(fx)
     nucleus_sets(fx)
+    prenorm_transformer_block(fx)
     path = os.path.join(ROOT, "tests", "golden", "synth_blocks.npz")
     np.savez_compressed(path, **fx)
     print("->", path, os.path.getsize(path) // 1024, "KB,", len(fx), "arrays")

@@ -201,3 +201,18 @@ def test_nucleus_set_matches_transformers_top_p_warper(fx, key, top_p):
         assert o25[:c25] == order[:min(cnt, 25)] and c25 == min(cnt, 25)
         # rank order: probability descending, lower id first among equals
         assert all((float(p[a]), -a) >= (float(p[b]), -b) for a, b in zip(order[:cnt - 1], order[1:cnt]))
+
+
+def test_estimator_transformer_block_matches_torch_prenorm_encoder_layer(fx):
+    """oracle.synth._tfm_block (the BasicTransformerBlock of the flow estimator, a14: pre-LayerNorm self-attention without q/k/v bias
+    + out-projection, pre-LayerNorm GELU feed-forward, two residuals, key padding mask) against
+    torch.nn.TransformerEncoderLayer(norm_first=True, activation="gelu") with the same weights.  Valid positions only (what a
+    padded query row holds is masked downstream)."""
+    sd = {k[len("tfm."):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("tfm.") and k not in ("tfm.x", "tfm.lens", "tfm.y", "tfm.heads")}
+    sd = {"blk." + k: v for k, v in sd.items()}
+    x, lens, ref = torch.from_numpy(fx["tfm.x"]), torch.from_numpy(fx["tfm.lens"]), torch.from_numpy(fx["tfm.y"])
+    y = osyn._tfm_block(sd, "blk", x, lens, int(fx["tfm.heads"]))
+    for b in range(x.shape[0]):
+        n = int(lens[b])
+        err = float((y[b, :n] - ref[b, :n]).abs().max()) / float(ref[b, :n].abs().max())
+        assert err < 2e-5, (b, err)
