@@ -14,6 +14,7 @@ oracle/synth.py restates, produced by independent third-party implementations of
   HiFi-GAN trunk     SpeechT5HifiGan (conv_pre, leaky-relu, ConvTranspose1d padding (k - u) / 2, mean over the parallel
                      resblocks, final leaky-relu 0.01)   -> oracle.synth.hift_trunk with a silent source path
   Whisper log-mel    WhisperFeatureExtractor(feature_size=128) -> astts.audio.whisper_log_mel / mel_filterbank (a12)
+  prompt log-mel     transformers.audio_utils.mel_filter_bank / spectrogram -> astts.audio.mel_filterbank / mel_spectrogram (a12 / a14)
   transformer block  torch.nn.TransformerEncoderLayer(norm_first=True, gelu) -> oracle.synth._tfm_block (the estimator's BasicTransformerBlock) (a14)
   nucleus set        TopPLogitsWarper (generation/logits_process.py) -> oracle.synth.nucleus (the sampler's candidate set)  (a13)
 
@@ -192,6 +193,26 @@ def prenorm_transformer_block(out):
     print("pre-norm transformer block:", tuple(y.shape))
 
 
+def prompt_mel(out):
+    """transformers.audio_utils (mel_filter_bank norm / scale "slaney", spectrogram with power 1, natural log, floor 1e-5) on the
+    matcha-style prompt mel's parameters: 22 050 Hz, n_fft = win = 1024, hop 256, 80 bins over 0-8 kHz, reflect padding of
+    (n_fft - hop) / 2 and no centring -> astts.audio.mel_filterbank / mel_spectrogram (the flow's prompt features)."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+
+    fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0, sampling_rate=22050,
+                         norm="slaney", mel_scale="slaney")
+    g = torch.Generator().manual_seed(19)
+    n = 16000
+    t = torch.arange(n) / 22050.0
+    wav = (0.4 * torch.sin(2 * np.pi * 330 * t) + 0.15 * torch.sin(2 * np.pi * 2750 * t + 0.5) + 0.1 * torch.randn(n, generator=g)).numpy().astype(np.float32)
+    pad = (1024 - 256) // 2
+    y = np.pad(wav.astype(np.float64), (pad, pad), mode="reflect")
+    s = spectrogram(y, window_function(1024, "hann", periodic=True), frame_length=1024, hop_length=256, fft_length=1024, power=1.0,
+                    center=False, mel_filters=fb, mel_floor=1e-5, log_mel="log")
+    out.update({"pmel.wav": wav, "pmel.filters": fb.T.astype(np.float32), "pmel.logmel": s.T.astype(np.float32)})
+    print("prompt mel:", s.T.shape)
+
+
 def nucleus_sets(out):
     """Top-p candidate sets of transformers' TopPLogitsWarper on seeded logits of three shapes (flat, peaked, with exact ties):
     upstream's nucleus_sampling adds tokens in descending probability while the mass already added is < top_p -- the smallest
@@ -222,6 +243,7 @@ if __name__ == "__main__":
     hifigan(fx)
     whisper(fx)
     nucleus_sets(fx)
+    prompt_mel(fx)
     prenorm_transformer_block(fx)
     path = os.path.join(ROOT, "tests", "golden", "synth_blocks.npz")
     np.savez_compressed(path, **fx)

@@ -216,3 +216,17 @@ def test_estimator_transformer_block_matches_torch_prenorm_encoder_layer(fx):
         n = int(lens[b])
         err = float((y[b, :n] - ref[b, :n]).abs().max()) / float(ref[b, :n].abs().max())
         assert err < 2e-5, (b, err)
+
+
+def test_prompt_mel_matches_transformers_audio_utils(fx):
+    """astts.audio.mel_filterbank / mel_spectrogram (the matcha-style log-mel of the flow's prompt: 22 050 Hz, n_fft 1024, hop 256,
+    80 Slaney bins over 0-8 kHz, reflect padding, natural log with floor 1e-5) against transformers.audio_utils.  The HIP kernel
+    astts_op_mel_spectrogram is held to this host definition in tests/test_ops_gpu.py."""
+    from astts.audio import mel_filterbank, mel_spectrogram
+
+    fb = mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+    assert fb.shape == fx["pmel.filters"].shape and float(np.abs(fb - fx["pmel.filters"]).max()) < 1e-7
+    m = mel_spectrogram(torch.from_numpy(fx["pmel.wav"])[None])[0].numpy()
+    ref = fx["pmel.logmel"]
+    assert m.shape == ref.shape
+    assert float(np.abs(m - ref).max()) < 1e-4, float(np.abs(m - ref).max())
