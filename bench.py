@@ -553,7 +553,7 @@ def main():
                inp24.spk_timbre, inp24.z, inp24.phase0, inp24.noise)
         front24 = lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
         pipe24 = PipelinedSynth.autotune(eng24, s24, depths=(main_pipe.depth,), trials=2, steps=4, front=front24)
-        k24 = max(4, min(args.steps, 8))
+        k24 = max(4, args.steps)          # the same K as `value` (pipeline fill and drain are inside both timed regions: equal shares)
         with torch.cuda.stream(pipe24.front_stream):
             for _ in range(2):
                 front24()
