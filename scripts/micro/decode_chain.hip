@@ -409,9 +409,21 @@ int main(int argc, char** argv) {
             // N chains (3, 4, 6), each on its own stream and host thread: how far does chain-level concurrency scale?
             std::vector<Ctx> cs;
             std::vector<hipStream_t> ss(8);
+            // DC_CUMASK=1: chain i runs on the CUs whose index is congruent to i modulo the number of chains of the 2-chain test
+            // (even / odd); DC_CUMASK=2: contiguous halves.  Do two chains stack their workgroups on the same CUs otherwise?
+            const int cumask = getenv("DC_CUMASK") ? atoi(getenv("DC_CUMASK")) : 0;
             for (int i = 0; i < 8; ++i) {
                 cs.push_back(make_ctx(m, b, 300 + 100 * i));
-                CK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+                if (cumask && i < 2) {
+                    uint32_t mask[8];
+                    for (int w = 0; w < 8; ++w) {
+                        if (cumask == 1) mask[w] = i == 0 ? 0x55555555u : 0xaaaaaaaau;
+                        else mask[w] = ((w < 4) == (i == 0)) ? 0xffffffffu : 0u;
+                    }
+                    CK(hipExtStreamCreateWithCUMask(&ss[i], 8, mask));
+                } else {
+                    CK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+                }
             }
             for (int rep = 0; rep < 2; ++rep)
             for (int nc : {2, 3, 4, 5, 6, 8}) {
