@@ -52,6 +52,14 @@ __device__ __forceinline__ void pin_args(const AttnArgs& a) {
 
 static constexpr int GV_WAVES = 8;
 
+// Weight lines are read once per launch by one workgroup.  -DLM_NT_WEIGHTS loads them with the non-temporal policy (the guide's
+// "nt-weights" row); A/B in scripts/micro/decode_chain.hip.
+#ifdef LM_NT_WEIGHTS
+#define LM_WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const half8*>(p))
+#else
+#define LM_WLOAD(p) (*reinterpret_cast<const half8*>(p))
+#endif
+
 // sum over the wave, butterfly order 32, 16, ..., 1 -- as VALU lane exchanges (xlane.h), not ds_bpermute round trips: same bits
 __device__ __forceinline__ float wsum64(float v) { return wave_sum_desc(v); }
 
@@ -184,8 +192,8 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
     for (int i = 0; i < NL; ++i) {
         const int line = wid + i * GV_WAVES;
         if (line < lines) {
-            fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
-            fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+            fb[i][0] = LM_WLOAD(wrow + line * 64);
+            fb[i][1] = LM_WLOAD(wrow + line * 64 + 8);
         }
     }
     pin_args(a);            // the remaining arguments: ONE wide scalar load + ONE wait, behind the loads issued above
@@ -480,8 +488,8 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         for (int i = 0; i < NL; ++i) {
             const int line = wid + ((pass + 1) * NL + i) * GV_WAVES;
             if (line < lines) {
-                fb[i][0] = *reinterpret_cast<const half8*>(wrow + line * 64);
-                fb[i][1] = *reinterpret_cast<const half8*>(wrow + line * 64 + 8);
+                fb[i][0] = LM_WLOAD(wrow + line * 64);
+                fb[i][1] = LM_WLOAD(wrow + line * 64 + 8);
             }
         }
     }

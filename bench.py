@@ -75,17 +75,28 @@ class SynthInputs:
         self.audio_seconds = b * self.tm * cfg.upsample_total / cfg.sample_rate
 
 
-def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
-    """The oracle (kind "port": this build's fp32 PyTorch-CPU restatement, oracle/) timed on the host cores on a
-    BOUNDED sample of the same workload: one utterance (B=1) at the config-2 shapes but Ts=25 speech tokens
-    (0.5 s of audio) instead of 250, plus the retrieval of the same 8 queries."""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, weights, bank16, q_host, k, ts=250):
+    """The oracle (kind "port": this build's fp32 PyTorch-CPU restatement, oracle/) timed on the host cores on a BOUNDED sample
+    of the same workload: ONE full-length utterance of the config-2 batch (B=1 of the 8: Tt=32, 150-token prompt, Ts=250 speech
+    tokens = 5 s of audio, the same shapes the GPU step runs for each of its 8 rows) plus the retrieval of the same 8 queries."""
     from oracle import knn as oknn
     from oracle import synth as osyn
 
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
-    b, tt, tp, ts = 1, 32, 150, 25
+    b, tt, tp = 1, 32, 150
     text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g)
     tlen = torch.full((b,), tt)
     spk = torch.randn(b, cfg.spk_dim, generator=g)
@@ -101,6 +112,7 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
     with torch.no_grad():
         oknn.knn_search_fast_f32(bank16.astype(np.float32),
                                  (1.0 / np.linalg.norm(bank16.astype(np.float64), axis=1)).astype(np.float32), q_host, k)
+        tk = time.perf_counter()
         pre = osyn.lm_prefix(weights["llm"], cfg, text, tlen, spk, tok_p)
         toks, _ = osyn.lm_decode(weights["llm"], cfg, pre, ts, u, True, None)
         t1 = time.perf_counter()
@@ -109,9 +121,10 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, budget_s=25.0):
         wav = osyn.hift_forward(weights["hift"], cfg, mel, ph, noise)
     t3 = time.perf_counter()
     audio = wav.shape[1] / cfg.sample_rate
-    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "kind": "port",
-            "sample": f"B=1 utterance, Tt={tt}, {tp}-token prompt, Ts={ts} tokens ({audio:.2f} s audio) + kNN of 8 queries; "
-                      f"oracle/ fp32 torch-CPU: lm {t1 - t0:.1f} s, flow {t2 - t1:.1f} s, vocoder {t3 - t2:.1f} s"}
+    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "cpu": cpu_model_string(), "kind": "port",
+            "sample": f"one full-length utterance of the batch (B=1, Tt={tt}, {tp}-token prompt, Ts={ts} tokens = {audio:.2f} s of audio) "
+                      f"+ kNN of the 8 queries; oracle/ fp32 torch-CPU",
+            "stage_seconds": {"knn": round(tk - t0, 4), "lm": round(t1 - tk, 2), "flow": round(t2 - t1, 2), "vocoder": round(t3 - t2, 2)}}
 
 
 _JSON_OUT = None

@@ -18,7 +18,12 @@ hipcc -O2 --offload-arch=gfx950 glds_check.hip -o glds_check
 hipcc -O2 --offload-arch=gfx950 coherence.hip -o coherence
 #   decode_chain        the LM decode step as a stand-alone launch chain (csrc/lm_step.hip): per-operator periods, eager vs
 #                       hipGraph replay, one chain vs two concurrent ones; decode_chain_stamps: in-kernel s_memrealtime stamps
-hipcc $F -std=c++17 decode_chain.hip -o decode_chain
-hipcc $F -std=c++17 -DLM_STAMPS decode_chain.hip -o decode_chain_stamps
+L="-mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=16"      # as csrc/Makefile builds lm_step.hip
+hipcc $F $L -std=c++17 decode_chain.hip -o decode_chain
+hipcc $F $L -std=c++17 -DLM_STAMPS decode_chain.hip -o decode_chain_stamps
+#   decode_chain_nt     weight lines loaded with the non-temporal policy (A/B of the guide's "nt-weights" row)
+hipcc $F $L -std=c++17 -DLM_NT_WEIGHTS decode_chain.hip -o decode_chain_nt
+#   cu_census           which CUs a hipExtStreamCreateWithCUMask stream really gets, per mask pattern
+hipcc -O2 --offload-arch=gfx950 cu_census.hip -o cu_census
 #   xlane_probe         csrc/xlane.h (DPP / v_permlane swaps) against __shfl_xor: bit equality and the latency of a 64-lane sum
 hipcc $F -std=c++17 -Wno-unused-result xlane_probe.hip -o xlane_probe

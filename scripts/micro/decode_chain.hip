@@ -418,6 +418,11 @@ int main(int argc, char** argv) {
                     uint32_t mask[8];
                     for (int w = 0; w < 8; ++w) {
                         if (cumask == 1) mask[w] = i == 0 ? 0x55555555u : 0xaaaaaaaau;
+                        else if (cumask == 3) {      // both chains share the DC_CUMASK_N highest mask bits (bit b = CU b / 8 of XCC b % 8: cu_census)
+                            const int n = getenv("DC_CUMASK_N") ? atoi(getenv("DC_CUMASK_N")) : 64;
+                            mask[w] = 0u;
+                            for (int bit = 0; bit < 32; ++bit) if (w * 32 + bit >= 256 - n) mask[w] |= 1u << bit;
+                        }
                         else mask[w] = ((w < 4) == (i == 0)) ? 0xffffffffu : 0u;
                     }
                     CK(hipExtStreamCreateWithCUMask(&ss[i], 8, mask));

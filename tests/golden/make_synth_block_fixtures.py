@@ -17,6 +17,8 @@ oracle/synth.py restates, produced by independent third-party implementations of
   prompt log-mel     transformers.audio_utils.mel_filter_bank / spectrogram -> astts.audio.mel_filterbank / mel_spectrogram (a12 / a14)
   transformer block  torch.nn.TransformerEncoderLayer(norm_first=True, gelu) -> oracle.synth._tfm_block (the estimator's BasicTransformerBlock) (a14)
   nucleus set        TopPLogitsWarper (generation/logits_process.py) -> oracle.synth.nucleus (the sampler's candidate set)  (a13)
+  CFM t-grid + CFG   Qwen2_5OmniToken2WavDiTModel.sample (sway_coefficient -1 = the cosine grid; guided + (guided - null) g)
+                                                         -> oracle.synth.cfm_t_grid / cfg_combine  (a14; own file cfm_grid_cfg.npz)
 
 Run in the BUILD container only (python tests/golden/make_synth_block_fixtures.py).  The .npz is data: seeded random
 weights and inputs in, the third-party outputs out.  Nothing of transformers travels."""
@@ -234,7 +236,76 @@ def nucleus_sets(out):
     print("top-p sets:", {k: v_.sum(1).tolist() for k, v_ in kept.items()})
 
 
+def cfm_grid_and_cfg():
+    """The time grid and the classifier-free-guidance combination of a flow-matching sampler, as transformers'
+    Qwen2_5OmniToken2WavDiTModel.sample codes them (models/qwen2_5_omni/modeling_qwen2_5_omni.py: `time_embedding += sway * (cos(pi/2 t)
+    - 1 + t)`, `guided + (guided - null) * guidance_scale`).  `sample` is run UNBOUND on a stand-in model whose forward is a seeded
+    closed-form map (cond half | uncond half), with the module's ODE solver replaced by a recorder: what is recorded is the grid the
+    solver is handed and the guided velocity `sample`'s own ode_function returns for probe states.  -> tests/golden/cfm_grid_cfg.npz"""
+    from transformers.models.qwen2_5_omni import modeling_qwen2_5_omni as m
+
+    g = torch.Generator().manual_seed(23)
+    mel, b, t_code, repeats = 12, 3, 9, 2
+    a_c = torch.randn(mel, mel, generator=g) * 0.4
+    a_u = torch.randn(mel, mel, generator=g) * 0.4
+    rec = {"dc": [], "du": [], "x": [], "t": [], "guided": []}
+
+    class StandIn:
+        mel_dim = mel
+
+        class config:
+            max_position_embeddings = 1 << 20
+
+        def __init__(self):
+            self.repeats = repeats
+
+        def __call__(self, hidden_states, quantized_code, speaker_embedding, condition_vector, time_step, apply_cfg=True, **kw):
+            assert apply_cfg
+            d_c = torch.tanh(hidden_states @ a_c + time_step) + 0.1 * condition_vector.mean()
+            d_u = torch.sin(hidden_states @ a_u - time_step)
+            rec["dc"].append(d_c.clone()); rec["du"].append(d_u.clone()); rec["x"].append(hidden_states.clone())
+            rec["t"].append(torch.as_tensor(time_step).clone())
+            return torch.cat([d_c, d_u], dim=0)
+
+    class Recorder:
+        def __init__(self, function, initial_value):
+            self.function, self.initial_value = function, initial_value
+
+        def integrate(self, time_points):
+            rec["grid"] = time_points.clone()
+            x = self.initial_value
+            for i, t in enumerate(time_points[:-1]):
+                v = self.function(t, x)
+                rec["guided"].append(v.clone())
+                x = x + (time_points[i + 1] - t) * v          # any trajectory will do: the probes only have to differ
+            return torch.stack([x] * len(time_points))
+
+    solver = m.RungeKutta4ODESolver
+    m.RungeKutta4ODESolver = Recorder
+    try:
+        torch.manual_seed(5)
+        out = {}
+        for name, steps, scale in (("a", 11, 0.7), ("b", 6, 0.5)):
+            for k in rec:
+                rec[k] = [] if k != "grid" else None
+            m.Qwen2_5OmniToken2WavDiTModel.sample(StandIn(), conditioning_vector=torch.randn(b, 7, generator=g),
+                                                  reference_mel_spectrogram=torch.randn(b, t_code * repeats, mel, generator=g),
+                                                  quantized_code=torch.zeros(b, t_code, dtype=torch.long), num_steps=steps,
+                                                  guidance_scale=scale, sway_coefficient=-1.0)
+            out.update({f"{name}.grid": rec["grid"].numpy(), f"{name}.scale": np.float64(scale), f"{name}.dc": torch.stack(rec["dc"]).numpy(),
+                        f"{name}.du": torch.stack(rec["du"]).numpy(), f"{name}.guided": torch.stack(rec["guided"]).numpy()})
+            print("cfm grid", name, rec["grid"].numpy().round(4).tolist())
+    finally:
+        m.RungeKutta4ODESolver = solver
+    path = os.path.join(ROOT, "tests", "golden", "cfm_grid_cfg.npz")
+    np.savez_compressed(path, **out)
+    print("->", path, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
+    if "--cfm" in sys.argv:
+        cfm_grid_and_cfg()
+        sys.exit(0)
     fx = {}
     relpos_fastspeech2(fx)
     relpos_wav2vec2(fx)

@@ -230,3 +230,24 @@ def test_prompt_mel_matches_transformers_audio_utils(fx):
     ref = fx["pmel.logmel"]
     assert m.shape == ref.shape
     assert float(np.abs(m - ref).max()) < 1e-4, float(np.abs(m - ref).max())
+
+
+def test_cfm_time_grid_and_cfg_match_transformers_dit_sampler():
+    """oracle.synth.cfm_t_grid / cfg_combine (a14: the cosine-warped Euler grid and the guidance formula of ConditionalCFM) against
+    what transformers' Qwen2_5OmniToken2WavDiTModel.sample hands its ODE solver at sway_coefficient = -1 and what its ode_function
+    returns for recorded (conditional, unconditional) velocities -- tests/golden/cfm_grid_cfg.npz (make_synth_block_fixtures.py --cfm).
+    That sampler lists `num_steps` POINTS (n - 1 intervals); the oracle's argument is the number of Euler steps."""
+    fx = np.load(os.path.join(GOLD, "cfm_grid_cfg.npz"))
+    for name in ("a", "b"):
+        grid = fx[f"{name}.grid"]
+        mine = osyn.cfm_t_grid(len(grid) - 1).numpy()
+        assert mine.shape == grid.shape and float(np.abs(mine - grid).max()) < 2e-7, (name, np.abs(mine - grid).max())
+        assert mine[0] == 0.0 and abs(float(mine[-1]) - 1.0) < 1e-7 and np.all(np.diff(mine) > 0)
+        g = osyn.cfg_combine(torch.from_numpy(fx[f"{name}.dc"]), torch.from_numpy(fx[f"{name}.du"]), float(fx[f"{name}.scale"])).numpy()
+        ref = fx[f"{name}.guided"]
+        assert g.shape == ref.shape and float(np.abs(g - ref).max()) < 5e-6 * float(np.abs(ref).max()), np.abs(g - ref).max()
+    # the benchmark's solve: 10 steps at rate 0.7 (SynthConfig defaults) is case "a"
+    from astts.synth.config import SynthConfig
+
+    c = SynthConfig()
+    assert c.cfm_steps == len(fx["a.grid"]) - 1 and abs(c.cfg_rate - float(fx["a.scale"])) < 1e-12
