@@ -91,13 +91,24 @@ class CosyVoice:
         tlen = torch.tensor([text_ids.shape[1]], dtype=torch.int32, device=dev)
         pre = lm.prefix(text_ids.to(dev), tlen, lm_prompt.spk_embedding.to(dev), lm_prompt.speech_tokens.to(dev))
         min_len = self.min_token_text_ratio * n_tts_text
-        max_len = min(self.max_token_text_ratio * n_tts_text, cfg.max_positions - pre.shape[0] - 100)
+        max_len = self._cap_tokens(self.max_token_text_ratio * n_tts_text, pre.shape[0])
         max_len = max(max_len, min_len + 1)
         u = torch.rand(max_len, 1, 2, generator=self._gen).to(dev)
         toks = lm.decode(pre, max_len, u, ignore_eos=min_len)[0].cpu()       # one sync per segment
         eos = (toks >= cfg.speech_vocab).nonzero()
         n = int(eos[0]) if eos.numel() else max_len
         return toks[:max(n, 1)][None, :].to(torch.int32)
+
+    def _cap_tokens(self, want: int, prefix_len: int, what: str = "this segment") -> int:
+        """The relative-position tables bound prefix + generated tokens (SynthConfig.max_positions).  Upstream's tables extend, so a
+        capped request is a divergence: it is reported, never silent."""
+        cap = self.cfg.max_positions - int(prefix_len) - 100
+        if want > cap:
+            warnings.warn(f"CosyVoice: {what} may generate up to {want} speech tokens (upstream's {self.max_token_text_ratio}x text-length "
+                          f"limit) but the position tables (SynthConfig.max_positions = {self.cfg.max_positions}) leave room for {max(cap, 1)} "
+                          f"after a {int(prefix_len)}-position prefix: output capped.  Build the engine with a larger max_positions.",
+                          RuntimeWarning, stacklevel=3)
+        return max(1, min(int(want), cap))
 
     def _render(self, tokens: torch.Tensor, flow_prompt: PromptFeatures) -> torch.Tensor:
         cfg, dev, eng = self.cfg, self.device, self.engine
@@ -171,13 +182,13 @@ class CosyVoice:
             texts = [r[0].view(-1) for r in grp]
             spk_lm = torch.cat([r[2].spk_embedding for r in grp], 0)
             pre, ks = eng.lm.prefix_ragged(texts, spk_lm, [r[2].speech_tokens.view(-1) for r in grp])
-            cap = cfg.max_positions - pre.shape[0] - 100
             if fixed_tokens is not None:
-                max_len = [max(1, min(int(fixed_tokens[i]), cap)) for i in idxs]      # the position tables bound prefix + tokens, as below
+                max_len = [self._cap_tokens(int(fixed_tokens[i]), pre.shape[0], f"request {i}") for i in idxs]   # the position tables bound prefix + tokens
                 min_len = list(max_len)
             else:
                 min_len = [self.min_token_text_ratio * r[1] for r in grp]
-                max_len = [max(min(self.max_token_text_ratio * r[1], cap), m + 1) for r, m in zip(grp, min_len)]
+                max_len = [max(self._cap_tokens(self.max_token_text_ratio * r[1], pre.shape[0], f"request {i}"), m + 1)
+                           for i, r, m in zip(idxs, grp, min_len)]
             n_steps = max(max_len)
             if draws is not None:
                 u = torch.zeros(n_steps, b, 2)

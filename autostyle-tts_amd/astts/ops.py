@@ -64,7 +64,7 @@ _SIGS = {
 class LmConfig(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("d", "heads", "ffn", "layers", "vocab_out", "speech_vocab", "pos_center", "pos_ld",
                                        "top_k", "ras_win")] + [(n, c_float) for n in ("top_p", "ras_tau", "eps")] + \
-               [("kv_f16", c_int32), ("pos_f16", c_int32), ("ln_folded", c_int32)]
+               [("kv_f16", c_int32), ("pos_f16", c_int32), ("ln_folded", c_int32), ("eos_policy", c_int32)]
 
 
 class LmGlobals(ctypes.Structure):
@@ -585,14 +585,18 @@ def istft16(y: torch.Tensor, mag_clip: float = 100.0, audio_limit: float = 0.99)
 
 
 def ras_sample(logits, history, hist_len: int, uniforms, top_k: int, top_p: float, win_size: int, tau_r: float,
-               eos_id: int, ignore_eos: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               eos_id: int, ignore_eos: bool, out: Optional[torch.Tensor] = None, eos_policy: str = "mask") -> torch.Tensor:
+    """``ignore_eos``: EOS may not be produced at this step; ``eos_policy`` says how: "mask" removes the EOS logit before the softmax,
+    "reject" is upstream's re-draw until the token is not EOS (SynthConfig.eos_policy)."""
+    if eos_policy not in ("mask", "reject"):
+        raise ValueError(f"eos_policy {eos_policy!r}: expected 'mask' or 'reject'")
     logits = _f32(logits)
     b, v = logits.shape
     if out is None:
         out = torch.empty((b,), dtype=torch.int32, device=logits.device)
     _lib.check(_L().astts_op_ras_sample(logits.data_ptr(), _p(history), _f32(uniforms).data_ptr(), out.data_ptr(), b, v,
                                         hist_len, history.stride(0) if history is not None else 0, top_k, top_p,
-                                        win_size, tau_r, eos_id, 1 if ignore_eos else 0, _st()))
+                                        win_size, tau_r, eos_id, (1 if ignore_eos else 0) | (2 if eos_policy == "reject" else 0), _st()))
     return out
 
 

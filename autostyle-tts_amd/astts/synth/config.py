@@ -28,6 +28,10 @@ class SynthConfig:
     top_p: float = 0.8
     ras_win: int = 10
     ras_tau: float = 0.1
+    # While a row may not stop yet (upstream: the first min_len = 2 x text-length steps), "reject" = upstream's sampling_ids: sample
+    # again until the token is not EOS (EOS keeps its probability, its nucleus slot and its share of top_p); "mask" = remove the EOS
+    # logit before the softmax (this build's rounds 1-3).  Different distributions inside that window: DESIGN.md section 2.
+    eos_policy: str = "reject"
     # ---- flow-matching decoder (MaskedDiffWithXvec + ConditionalCFM)
     flow_dim: int = 512
     flow_heads: int = 8
@@ -57,7 +61,15 @@ class SynthConfig:
     lrelu_slope: float = 0.1
     audio_limit: float = 0.99
     ln_eps: float = 1e-5
-    max_positions: int = 2048         # size of the per-layer relative-position tables
+    # Size of the per-layer relative-position tables (rows for rel = -max_positions .. max_positions): an LM context (prefix +
+    # generated tokens) may not exceed it.  Upstream's espnet encoding extends on demand; here the tables are formed at load, sized
+    # for a 30 s style prompt (1 500 tokens) + an 80-token segment's 20x window (1 600) + text, and the drop-in surface WARNS when a
+    # request is capped by them (compat/cosyvoice.py); pass a larger value for longer contexts (117 MB of fp16 tables per 2 048).
+    max_positions: int = 4096
+
+    def __post_init__(self):
+        if self.eos_policy not in ("mask", "reject"):
+            raise ValueError(f"SynthConfig.eos_policy {self.eos_policy!r}: expected 'mask' or 'reject'")
 
     @property
     def est_time_dim(self) -> int:

@@ -158,6 +158,9 @@ class AcousticLM:
         return torch.cat([sos, spk_e, enc, task, pe], dim=1).transpose(0, 1).contiguous()
 
     def new_cache(self, b: int, t_max: int) -> List[torch.Tensor]:
+        if t_max > self.body.center:      # relative positions 0 .. t_max - 1 must be rows of the tables
+            raise ValueError(f"AcousticLM: a context of {t_max} positions exceeds the relative-position tables "
+                             f"(SynthConfig.max_positions = {self.body.center})")
         return [torch.empty((t_max, b, 2 * self.body.d), dtype=torch.float16, device=self.device) for _ in self.body.L]
 
     def prefix_ragged(self, texts: List[torch.Tensor], spk: torch.Tensor, prompts: List[torch.Tensor]):
@@ -246,7 +249,7 @@ class AcousticLM:
             body, cfg = self.body, self.cfg
             c = ops.LmConfig(body.d, body.heads, cfg.lm_ffn, len(body.L), cfg.speech_vocab + 1, cfg.speech_vocab, body.center,
                              body.L[0]["pos"].stride(0), cfg.top_k, cfg.ras_win, cfg.top_p, cfg.ras_tau, body.eps, 1, 1,
-                             1 if body.fold_ln else 0)
+                             1 if body.fold_ln else 0, 1 if cfg.eos_policy == "reject" else 0)
             # the decode step's input projection acts on a table lookup: speech_emb[tok] W^T + b is a row of the table
             # speech_emb W^T + b, formed once here (the same fp16 MFMA products, on the GPU) and gathered by the step
             self.embed_table = ops.linear(self.speech_emb, body.embed).contiguous()
@@ -385,7 +388,7 @@ class AcousticLM:
             if return_logits:
                 all_logits.append(cur)
             tok = ops.ras_sample(cur, toks, s, uniforms[s], cfg.top_k, cfg.top_p, cfg.ras_win, cfg.ras_tau,
-                                 cfg.speech_vocab, s < self._eos_min(ignore_eos, n_steps))
+                                 cfg.speech_vocab, s < self._eos_min(ignore_eos, n_steps), eos_policy=cfg.eos_policy)
             if forced_tokens is not None:
                 tok = forced_tokens[:, s].to(torch.int32).contiguous()
             toks[:, s] = tok

@@ -66,7 +66,7 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
                                              cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
                                              hipMemcpyDeviceToDevice, st));
         int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
-                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, s < eos_min_steps ? 1 : 0, eos_min_rows, forced_tokens,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, (s < eos_min_steps ? 1 : 0) | (c.eos_policy ? 2 : 0), eos_min_rows, forced_tokens,
                                         st);
         if (rc != ASTTS_OK) return rc;
         if (s + 1 == n_steps) break;
@@ -221,7 +221,7 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                                              cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
                                              hipMemcpyDeviceToDevice, st));
         int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
-                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, s < eos_min_steps ? 1 : 0, eos_min_rows, forced_tokens,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, (s < eos_min_steps ? 1 : 0) | (c.eos_policy ? 2 : 0), eos_min_rows, forced_tokens,
                                         st);
         if (rc != ASTTS_OK) return rc;
         if (s + 1 == n_steps) break;

@@ -156,11 +156,12 @@ __global__ __launch_bounds__(256) void istft16(const float* __restrict__ y, floa
 
 // ------------------------------------------------------------------ repetition-aware sampling
 // One block per batch row.  Definition (mirrored by oracle/synth.py::ras_sample):
-//   p = softmax(logits) (eos masked when ignore_eos); sort descending (ties: lower id first);
+//   p = softmax(logits) (eos masked when ignore_eos asks for the "mask" policy); sort descending (ties: lower id first);
 //   nucleus = shortest prefix with cumulative p >= top_p, at most top_k entries;
 //   token = inverse-CDF pick from the renormalised nucleus with uniform u1;
 //   if token occurs >= win*tau_r times among the last `win` decoded tokens:
 //       token = inverse-CDF pick from the full p (id order) with uniform u2.
+//   "reject" policy (ignore_eos bit 1): EOS keeps its logit; the draw is upstream's re-draw loop in closed form (see the kernel).
 struct SampleArgs {
     const float* logits;  // [B, V]
     const int* history;   // [B, hist_ld] decoded tokens so far
@@ -196,7 +197,12 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
     __shared__ int s_sel_bin[3], s_sel_rem[3], s_cnt;
     const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (int64_t)bb * a.v;
-    const bool mask_eos = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : (a.ignore_eos != 0);
+    // ignore_eos: bit 0 = EOS may not be produced at this step (scalar form; with eos_min_rows the window is per row), bit 1 = the
+    // policy inside that window: 0 "mask" (the EOS logit is removed before the softmax), 1 "reject" (upstream's sampling_ids: draw
+    // again until the token is not EOS -- EOS keeps its probability, its place in the nucleus and its share of top_p / top_k)
+    const bool eos_window = a.eos_min_rows ? (a.hist_len < a.eos_min_rows[bb]) : ((a.ignore_eos & 1) != 0);
+    const bool reject = eos_window && (a.ignore_eos & 2) != 0;
+    const bool mask_eos = eos_window && !reject;
     // operands of the LAST phases, requested now: the two uniforms and the repetition window of the token log were dependent
     // global round trips at the very end of the kernel (~1 us each on a kernel of 11)
     const int h0 = a.hist_len > a.win ? a.hist_len - a.win : 0;
@@ -349,36 +355,75 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
                 ++cnt;
             }
         }
-        const float target = u_first * cum;
-        float run = 0.0f;
-        int tok = sh_i[cnt > 0 ? cnt - 1 : 0];
-        bool found = false;
-#pragma unroll 8
-        for (int r = 0; r < kk; ++r) {
-            const float pr = sh_s[r];
-            const int ir = sh_i[r];
-            if (r < cnt) {
-                run += pr;
-                if (!found && run > target) {
-                    tok = ir;
-                    found = true;
+        // repetitions of a token among the last `win` decoded ones: lane j compares the j-th token of the window (one round trip,
+        // not `win` dependent ones); `t` is wave-uniform
+        auto repeated = [&](int t) -> bool {
+            int rep = 0;
+            if (win_in_wave) {
+                rep = __popcll(__ballot(hwin == t));         // lanes outside the window hold -1
+            } else {
+                for (int i0 = h0; i0 < a.hist_len; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool hit = i < a.hist_len && a.history[(int64_t)bb * a.hist_ld + i] == t;
+                    rep += __popcll(__ballot(hit));
                 }
             }
-        }
-        // repetition check: lane j compares the j-th token of the window (one round trip, not `win` dependent ones)
-        int rep = 0;
-        if (win_in_wave) {
-            rep = __popcll(__ballot(hwin == tok));           // lanes outside the window hold -1
-        } else {
-            for (int i0 = h0; i0 < a.hist_len; i0 += 64) {
-                const int i = i0 + lane;
-                const bool hit = i < a.hist_len && a.history[(int64_t)bb * a.hist_ld + i] == tok;
-                rep += __popcll(__ballot(hit));
+            return (float)rep >= (float)a.win * a.tau_r;
+        };
+        int tok;
+        bool fallback;
+        if (!reject) {
+            const float target = u_first * cum;
+            float run = 0.0f;
+            tok = sh_i[cnt > 0 ? cnt - 1 : 0];
+            bool found = false;
+#pragma unroll 8
+            for (int r = 0; r < kk; ++r) {
+                const float pr = sh_s[r];
+                const int ir = sh_i[r];
+                if (r < cnt) {
+                    run += pr;
+                    if (!found && run > target) {
+                        tok = ir;
+                        found = true;
+                    }
+                }
             }
+            fallback = repeated(tok);
+        } else {
+            // "reject": the closed form of upstream's re-draw loop (one pass = nucleus draw, repetition check, full-distribution
+            // draw when repeated; start over while the result is EOS).  One pass ends on a nucleus entry t that is neither EOS nor
+            // repeated with probability p_t / cum, in the fallback with rho = sum over the repeated entries of p_t / cum, and the
+            // fallback ends off EOS with probability 1 - p_eos.  Conditioned on "not EOS": weights a_t = p_t for the direct entries and
+            // F = (sum of the repeated p_t) (1 - p_eos) for the fallback -- drawn with u1 in rank order, the fallback last.
+            const float p_eos = prob[a.eos];
+            float asum = 0.0f, prep = 0.0f;
+            unsigned long long direct = 0ull;               // rank r is a direct entry (wave-uniform)
+            for (int r = 0; r < cnt; ++r) {
+                const float pr = sh_s[r];
+                const int ir = sh_i[r];
+                if (ir == a.eos) continue;
+                if (repeated(ir)) {
+                    prep += pr;
+                } else {
+                    asum += pr;
+                    direct |= 1ull << r;
+                }
+            }
+            const float target = u_first * (asum + prep * (1.0f - p_eos));
+            float run = 0.0f;
+            tok = -1;
+            for (int r = 0; r < cnt && tok < 0; ++r) {
+                if (direct >> r & 1ull) {
+                    run += sh_s[r];
+                    if (run > target) tok = sh_i[r];
+                }
+            }
+            fallback = tok < 0;                             // also: a nucleus that holds nothing but EOS
         }
         if (lane == 0) {
             s_tok = tok;
-            s_bcast = ((float)rep >= (float)a.win * a.tau_r) ? 1.0f : 0.0f;
+            s_bcast = fallback ? 1.0f : 0.0f;
         }
     }
     __syncthreads();
@@ -386,7 +431,10 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
         // repetition detected: random sampling from the full distribution, id order, inverse CDF with u2.  The running sum is
         // the oracle's sequential fp32 accumulation (a parallel scan rounds differently), taken 16 elements per LDS round trip
         // with ONE comparison per chunk: ~20 us worst case (an LDS read + compare + branch per element took 270 us).
-        const float target = u_second;
+        // "reject": the same walk over the distribution without EOS (its term is skipped; the target scales by 1 - p_eos).
+        const float p_skip = reject ? prob[a.eos] : 0.0f;
+        if (reject) prob[a.eos] = 0.0f;                      // only this thread reads prob from here on
+        const float target = reject ? u_second * (1.0f - p_skip) : u_second;
         float run = 0.0f;
         int tok = -1;
         const int vpad = (a.v + 15) & ~15;

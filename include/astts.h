@@ -274,6 +274,9 @@ int astts_op_resample_poly(const float* x, const float* kern, float* y, int32_t 
                            int32_t width, astts_stream_t stream);
 int astts_op_mel_spectrogram(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
                              int32_t n_fft, int32_t hop, int32_t n_mels, float log_floor, astts_stream_t stream);
+/* Repetition-aware sampling with injected uniforms [b, 2] (definition: csrc/ops_audio.hip, mirrored by oracle/synth.py::ras_sample).
+ * ignore_eos: bit 0 = EOS may not be produced at this step (with eos_min_rows: per row, while hist_len < eos_min_rows[b]); bit 1 = the
+ * policy inside that window: 0 mask, 1 reject (astts_lm_config_t.eos_policy). */
 int astts_op_ras_sample(const float* logits, const int32_t* history, const float* uniforms, int32_t* out_tokens,
                         int32_t b, int32_t vocab, int32_t hist_len, int32_t hist_ld, int32_t top_k, float top_p,
                         int32_t win_size, float tau_r, int32_t eos_id, int32_t ignore_eos, astts_stream_t stream);
@@ -301,6 +304,9 @@ typedef struct {
     int32_t ln_folded;       /* 1: the scale / shift of norm1, norm2 and after_norm are folded into wqkv, w1 and the head
                               * (W' = W diag(gamma), b' = b + W beta, done by the host at load); the n*_g / n*_b / after_*
                               * arrays then hold ones / zeros and the step kernels normalise without reading them */
+    int32_t eos_policy;      /* what "EOS may not be produced yet" means: 0 = mask (the EOS logit is removed before the softmax),
+                              * 1 = reject (upstream TransformerLM.sampling_ids [EXT]: sample again until the token is not EOS; EOS
+                              * keeps its probability and its place in the nucleus) -- see astts_op_ras_sample */
 } astts_lm_config_t;
 typedef struct {
     const float* speech_emb;                 /* [speech_vocab, d] */

@@ -156,33 +156,73 @@ def nucleus(p: torch.Tensor, top_k: int, top_p: float):
 
 
 def ras_sample(logits: torch.Tensor, history: torch.Tensor, u: torch.Tensor, top_k: int, top_p: float, win: int,
-               tau_r: float, eos: int, ignore_eos: bool) -> torch.Tensor:
-    """Repetition-aware sampling with injected uniforms u[b] = (u1, u2); definition in csrc/ops_audio.hip."""
+               tau_r: float, eos: int, ignore_eos: bool, eos_policy: str = "mask") -> torch.Tensor:
+    """Repetition-aware sampling with injected uniforms u[b] = (u1, u2); definition in csrc/ops_audio.hip.
+
+    ``ignore_eos``: EOS may not be produced at this step (upstream: step < min_len).  ``eos_policy`` "mask": the EOS logit is removed
+    before the softmax.  "reject": upstream's sampling_ids [EXT cosyvoice/llm/llm.py] -- one pass = nucleus draw, repetition check,
+    full-distribution draw when the drawn token repeats; passes are repeated with fresh randomness while the result is EOS.  With
+    injected uniforms that loop is taken in closed form: conditioned on "not EOS", a pass ends on nucleus entry t (neither EOS nor
+    repeated) with weight p_t, or in the fallback with weight (sum of the repeated entries' p) (1 - p_eos); u1 picks among those in rank
+    order (fallback last), and the fallback draws with u2 from the distribution without EOS.  Same distribution as the loop."""
     out = []
+    reject = ignore_eos and eos_policy == "reject"
     for b in range(logits.shape[0]):
         lg = logits[b].clone().float()
-        if ignore_eos:
+        if ignore_eos and not reject:
             lg[eos] = float("-inf")
         e = torch.exp(lg - lg.max())
         p = e * (1.0 / e.sum())
         order, cnt, cum32 = nucleus(p, top_k, top_p)
-        target = u[b, 0] * cum32
-        run = torch.tensor(0.0)
-        tok = order[cnt - 1]
-        for idx in order[:cnt]:
-            run = run + p[idx]
-            if bool(run > target):
-                tok = idx
-                break
         hist = history[b].tolist()[-win:] if history.shape[1] > 0 else []
-        if sum(1 for t in hist if t == tok) >= win * tau_r:
+
+        def repeated(t):
+            return sum(1 for h in hist if h == t) >= win * tau_r
+
+        if not reject:
+            target = u[b, 0] * cum32
+            run = torch.tensor(0.0)
+            tok = order[cnt - 1]
+            for idx in order[:cnt]:
+                run = run + p[idx]
+                if bool(run > target):
+                    tok = idx
+                    break
+            fallback = repeated(tok)
+            skip = -1
+            target2 = u[b, 1]
+        else:
+            asum, prep = torch.tensor(0.0), torch.tensor(0.0)
+            direct = []
+            for idx in order[:cnt]:
+                if idx == eos:
+                    continue
+                if repeated(idx):
+                    prep = prep + p[idx]
+                else:
+                    asum = asum + p[idx]
+                    direct.append(idx)
+            target = u[b, 0] * (asum + prep * (1.0 - p[eos]))
+            run = torch.tensor(0.0)
+            tok = -1
+            for idx in direct:
+                run = run + p[idx]
+                if bool(run > target):
+                    tok = idx
+                    break
+            fallback = tok < 0
+            skip = eos
+            target2 = u[b, 1] * (1.0 - p[eos])
+        if fallback:
             run = torch.tensor(0.0)
             pick, last = -1, 0
             for i in range(p.numel()):
+                if i == skip:
+                    continue
                 if float(p[i]) > 0:
                     last = i
                 run = run + p[i]
-                if bool(run > u[b, 1]):
+                if bool(run > target2):
                     pick = i
                     break
             tok = pick if pick >= 0 else last
@@ -229,7 +269,7 @@ def lm_decode(sd: SD, cfg, prefix: torch.Tensor, n_steps: int, uniforms: torch.T
     for s in range(n_steps):
         all_logits.append(cur)
         tok = ras_sample(cur, toks[:, :s], uniforms[s], cfg.top_k, cfg.top_p, cfg.ras_win, cfg.ras_tau,
-                         cfg.speech_vocab, ignore_eos)
+                         cfg.speech_vocab, ignore_eos, getattr(cfg, "eos_policy", "mask"))
         if forced_tokens is not None:
             tok = forced_tokens[:, s].to(torch.int32)
         toks[:, s] = tok

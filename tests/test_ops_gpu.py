@@ -312,6 +312,47 @@ def test_ras_sample_matches_definition():
         assert out.tolist() == ref.tolist()
 
 
+def test_ras_sample_reject_policy_matches_definition():
+    """eos_policy "reject" (upstream's re-draw until the token is not EOS, in closed form: oracle.synth.ras_sample): EOS inside the
+    nucleus, EOS holding most of the mass (the nucleus is EOS alone: the draw falls through to the distribution without EOS),
+    repeated tokens inside the nucleus, both uniforms across their range; never returns EOS; and equals the "mask" policy's answer
+    only by accident (the policies are different distributions)."""
+    from astts import ops
+    from oracle import synth as osyn
+
+    g = torch.Generator().manual_seed(21)
+    b, v, eos = 16, 4097, 4096
+    logits = torch.randn(b, v, generator=g) * 3
+    logits[0, eos] = logits[0].max() + 1.0                  # EOS is the most likely token
+    logits[1, eos] = logits[1].max() + 12.0                 # ... and nearly everything: the nucleus holds EOS only
+    logits[2, eos] = logits[2].topk(5).values[-1]           # EOS in the middle of the nucleus
+    logits[3] = -30.0
+    logits[3, [eos, 7]] = torch.tensor([5.0, 0.0])          # EOS + one token
+    hist = torch.randint(0, 4096, (b, 64), generator=g, dtype=torch.int32)
+    differs = 0
+    for hist_len in (0, 5, 40):
+        if hist_len:
+            for r in range(0, b, 2):                        # repeated tokens inside the nucleus of every other row
+                top = logits[r].topk(3).indices
+                hist[r, hist_len - 1] = int(top[0]) if int(top[0]) != eos else int(top[1])
+                hist[r, hist_len - 2] = int(top[2]) if int(top[2]) != eos else int(top[1])
+        for u_fix in (None, (0.0, 0.0), (0.999999, 0.999999), (0.5, 0.0)):
+            u = torch.rand(b, 2, generator=g)
+            if u_fix is not None:
+                u[:, 0], u[:, 1] = u_fix
+            out = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, eos, True, eos_policy="reject").cpu()
+            ref = osyn.ras_sample(logits, hist[:, :hist_len], u, 25, 0.8, 10, 0.1, eos, True, "reject")
+            assert out.tolist() == ref.tolist(), (hist_len, u_fix)
+            assert int(out.max()) < eos
+            masked = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, eos, True).cpu()
+            differs += int((masked != out).sum())
+            # outside the window the policy bit changes nothing
+            free_r = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, eos, False, eos_policy="reject").cpu()
+            free_m = ops.ras_sample(logits.to(DEV), hist.to(DEV), hist_len, u.to(DEV), 25, 0.8, 10, 0.1, eos, False).cpu()
+            assert free_r.tolist() == free_m.tolist()
+    assert differs > 0
+
+
 def test_ras_sample_repetition_path_every_row():
     """The repetition branch (inverse CDF over the FULL distribution in id order, sequential fp32 running sum) for every row
     (win = 0 makes the repetition test pass trivially), with u2 across the range, u2 -> 1 (the sum may never exceed the target:

@@ -251,3 +251,54 @@ def test_cfm_time_grid_and_cfg_match_transformers_dit_sampler():
 
     c = SynthConfig()
     assert c.cfm_steps == len(fx["a.grid"]) - 1 and abs(c.cfg_rate - float(fx["a.scale"])) < 1e-12
+
+
+def test_reject_policy_has_the_distribution_of_upstreams_redraw_loop():
+    """oracle.synth.ras_sample(eos_policy="reject") takes upstream's `while True: top_ids = ras_sampling(...); if EOS not in top_ids:
+    break` [EXT cosyvoice/llm/llm.py sampling_ids] in closed form with two injected uniforms.  Here the loop itself is simulated
+    (fresh randomness per pass, nucleus draw -> repetition check -> full-distribution draw) and its empirical distribution is held
+    against the closed form's over random (u1, u2), together with the analytic one:
+        P(t) = [N(t) (1 - R(t)) + rho p(t)] / (1 - N(eos) - rho p(eos)),  N = renormalised nucleus, rho = sum of N over repeated t."""
+    g = torch.Generator().manual_seed(3)
+    v, eos, top_k, top_p, win, tau = 12, 11, 5, 0.8, 4, 0.25
+    logits = torch.tensor([[1.2, 0.1, 2.0, -1.0, 0.7, 1.9, -0.5, 0.3, -2.0, 0.9, 0.0, 1.6]])
+    hist = torch.tensor([[7, 2, 3, 5]], dtype=torch.int32)          # tokens 2 and 5 (both in the nucleus) are "repeated"
+    p = torch.softmax(logits[0], 0)
+    order, cnt, cum = osyn.nucleus(p, top_k, top_p)
+    assert eos in order[:cnt]
+    nuc = {t: float(p[t] / cum) for t in order[:cnt]}
+    rep = {t for t in range(v) if t in (2, 3, 5, 7)}
+    rho = sum(w for t, w in nuc.items() if t in rep)
+    z = 1.0 - nuc[eos] - rho * float(p[eos])
+    analytic = np.array([((nuc.get(t, 0.0) if t not in rep else 0.0) + rho * float(p[t])) / z if t != eos else 0.0 for t in range(v)])
+    assert abs(analytic.sum() - 1.0) < 1e-6
+    n = 40000
+    # the loop, simulated
+    rng = np.random.default_rng(0)
+    ids = list(nuc)
+    w = np.array([nuc[t] for t in ids])
+    pn = p.double().numpy()
+    pn = pn / pn.sum()
+    counts_loop = np.zeros(v)
+    for _ in range(n):
+        while True:
+            t = ids[rng.choice(len(ids), p=w / w.sum())]
+            if t in rep:
+                t = int(rng.choice(v, p=pn))
+            if t != eos:
+                break
+        counts_loop[t] += 1
+    # the closed form over random uniforms
+    counts_cf = np.zeros(v)
+    us = torch.rand(n, 1, 2, generator=g)
+    for i in range(n):
+        counts_cf[int(osyn.ras_sample(logits, hist, us[i], top_k, top_p, win, tau, eos, True, "reject")[0])] += 1
+    assert counts_cf[eos] == 0 and counts_loop[eos] == 0
+    tol = 4.0 * np.sqrt(analytic * (1 - analytic) / n) + 1e-4      # four standard deviations per token
+    assert np.all(np.abs(counts_cf / n - analytic) < tol), (counts_cf / n, analytic)
+    assert np.all(np.abs(counts_loop / n - analytic) < tol), (counts_loop / n, analytic)
+    # and the "mask" policy is a different distribution (EOS gives up its nucleus slot): the reason both exist
+    counts_m = np.zeros(v)
+    for i in range(4000):
+        counts_m[int(osyn.ras_sample(logits, hist, us[i], top_k, top_p, win, tau, eos, True, "mask")[0])] += 1
+    assert np.abs(counts_m / 4000 - analytic).max() > 0.02

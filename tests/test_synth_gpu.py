@@ -108,9 +108,9 @@ def test_lm_teacher_forced_logits_and_sampling():
     toks_free, logits_free = osyn.lm_decode(sd, cfg, pre_ref, steps, u, True, None)
     for s in range(steps):
         got = ops.ras_sample(logits_free[:, s].to(DEV), toks_free.to(DEV), s, u[s].to(DEV), cfg.top_k, cfg.top_p, cfg.ras_win,
-                             cfg.ras_tau, cfg.speech_vocab, True).cpu()
+                             cfg.ras_tau, cfg.speech_vocab, True, eos_policy=cfg.eos_policy).cpu()
         assert got.tolist() == toks_free[:, s].tolist()
-    assert int(toks_free.max()) < cfg.speech_vocab          # EOS is masked in fixed-length decode
+    assert int(toks_free.max()) < cfg.speech_vocab          # EOS is never produced in fixed-length decode (either policy)
 
 
 def test_flow_estimator_and_cfm_match_oracle():
