@@ -8,6 +8,14 @@ the hot path: this driver takes the 6144-d query vectors p
 Input rows {zh_text, speaker}; output rows {zh_text, speaker, retrieved_file_id, retrieved_text, distance}
 (top-1, ``distance`` = cosine similarity), "N/A" rows when nothing is found, "Error" rows on failure -- as :423-449.
 All queries of the file go to the GPU as ONE batch (the reference loops them one by one).
+
+Data-parallel form (BASELINE config 4: the IEMOCAP test set over the 8 GPUs of a node):
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m astts.cli.search_json --input_json ... (same flags)
+
+one process per GPU, the bank replicated; rank r searches rows [r ceil(Q/W), (r+1) ceil(Q/W)) of the input, ONE all-gather of the
+retrieved (style id, similarity) pairs over RCCL (astts.parallel.sharded_search), and rank 0 writes the JSONL in input order -- the
+file is identical to the one-process run's.
 """
 import argparse
 import json
@@ -16,6 +24,7 @@ import traceback
 
 import numpy as np
 
+from astts import parallel
 from astts.compat.pymilvus import MilvusClient
 
 
@@ -29,26 +38,46 @@ def read_input_json(path):
     return rows
 
 
-def main(args):
-    client = MilvusClient(args.db_path)
+def main(args, client=None):
+    import torch
+
+    dist, rank, world, local = parallel.init_from_env()
+    if dist is not None and dist.get_backend() == "nccl":
+        torch.cuda.set_device(local)
+    client = client or MilvusClient(args.db_path)
     rows = read_input_json(args.input_json)
     q = np.load(args.query_npy).astype(np.float32)
     if q.shape[0] != len(rows):
         raise SystemExit(f"{args.query_npy}: {q.shape[0]} vectors for {len(rows)} input rows")
     # rows without text are skipped, as the reference does (milvus/search_json.py:385-387) -- together with their query vector
     keep = [i for i, r in enumerate(rows) if r.get("zh_text", "").strip()]
-    for i in sorted(set(range(len(rows))) - set(keep)):
-        print(f"Skipping empty text for speaker '{rows[i].get('speaker', 'UNKNOWN_SPEAKER')}'.")
+    if rank == 0:
+        for i in sorted(set(range(len(rows))) - set(keep)):
+            print(f"Skipping empty text for speaker '{rows[i].get('speaker', 'UNKNOWN_SPEAKER')}'.")
     rows = [rows[i] for i in keep]
     q = q[keep]
     results = []
-    try:
-        hits = client.search(collection_name=args.collection_name, data=q, limit=1, filter=None,
-                             output_fields=["file_id", "text"]) if len(rows) else []
-    except Exception as e:  # noqa: BLE001
-        print(f"Error during search: {e}")
-        traceback.print_exc()
-        hits = None
+    hits = []
+    if len(rows):
+        dev = parallel.comm_device(dist)
+
+        def search_fn(q_local, k):      # this rank's shard of the queries against its replica of the bank
+            idx, score = client.search_rows(collection_name=args.collection_name, data=q_local.cpu().numpy(), limit=k, filter=None)
+            if idx.shape[1] < k:        # fewer rows than k (an empty collection): pad, -1 = no hit
+                pad = k - idx.shape[1]
+                idx = np.concatenate([idx, np.full((idx.shape[0], pad), -1, np.int64)], 1)
+                score = np.concatenate([score, np.zeros((score.shape[0], pad), np.float32)], 1)
+            return torch.from_numpy(idx).to(dev), torch.from_numpy(score).to(dev)
+
+        try:
+            idx, score = parallel.sharded_search(search_fn, torch.from_numpy(q).to(dev), 1, dist)
+            hits = client.hits_from_rows(args.collection_name, idx.cpu().numpy(), score.cpu().numpy(), ["file_id", "text"])
+        except Exception as e:  # noqa: BLE001
+            if dist is not None:        # a rank that fails alone would leave the others inside the collective: fail the job
+                raise
+            print(f"Error during search: {e}")
+            traceback.print_exc()
+            hits = None
     for i, sample in enumerate(rows):
         zh_text = sample.get("zh_text", "").strip()
         speaker = sample.get("speaker", "UNKNOWN_SPEAKER")
@@ -63,7 +92,7 @@ def main(args):
         else:
             rec = {"zh_text": zh_text, "speaker": speaker, "retrieved_file_id": "N/A", "retrieved_text": "N/A", "distance": "N/A"}
         results.append(rec)
-    if args.output_file:
+    if args.output_file and rank == 0:      # every rank holds every record after the all-gather; one of them writes
         out_dir = os.path.dirname(args.output_file)
         if out_dir:
             os.makedirs(out_dir, exist_ok=True)
@@ -71,6 +100,8 @@ def main(args):
             for r in results:
                 f.write(json.dumps(r, ensure_ascii=False) + "\n")
         print(f"Search results saved to '{args.output_file}'.")
+    if dist is not None:
+        dist.barrier()
     return results
 
 
@@ -87,3 +118,4 @@ def build_parser():
 
 if __name__ == "__main__":
     main(build_parser().parse_args())
+    parallel.shutdown()

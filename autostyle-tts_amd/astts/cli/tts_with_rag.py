@@ -13,7 +13,16 @@ Reference behaviour kept (file:line in /root/reference/tts_with_rag.py):
     never defines (dead code in the reference, :98-148) and is not reproduced.
 Additions (the reference hard-codes /apdcephfs_cq10 paths): --model_dir, --timbre_dir, --whisper_timbre_wav, and
 --batch_size N: rows are independent, so N of them share one ragged GPU batch (left-padded LM prefixes, per-row EOS
-windows, masked flow matching); file names and contents layout are unchanged.
+windows, masked flow matching); file names and contents layout are unchanged; --seed S: row cnt draws its randomness from its
+own stream (S, cnt) instead of the process-wide generator, so a row's audio does not depend on the rows before it.
+
+Data-parallel form (BASELINE config 4; the reference's loop :172-197 has no cross-row state):
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m astts.cli.tts_with_rag --corresponding_json ... (same flags)
+
+one process per GPU, model replicated; rank r synthesises rows [r ceil(Q/W), (r+1) ceil(Q/W)) and writes ITS OWN wavs under the
+global row number ``cnt`` into the one result directory (rank 0's time stamp, broadcast); no audio crosses GPUs.  Rows are always
+seeded per row here (--seed, default 0): the files equal those of the one-process run with the same --seed and --batch_size.
 """
 import argparse
 import json
@@ -63,14 +72,30 @@ def output_name(cnt, style_wav_path, speaker, i):
 
 
 def tts_for_infer(args, cosyvoice=None, now=None):
-    from astts import audio
+    from astts import audio, parallel
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
-    result_dir = args.result_dir + "_" + (now or datetime.now()).strftime("%m%d%H%M")
+    dist, rank, world, local = parallel.init_from_env()
+    if cosyvoice is None:
+        kw = {}
+        if dist is not None and dist.get_backend() == "nccl":
+            import torch
+            torch.cuda.set_device(local)
+            kw["device"] = torch.device("cuda", local)
+        cosyvoice = CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None, **kw)
+    stamp = parallel.broadcast_object((now or datetime.now()).strftime("%m%d%H%M"), dist)      # one directory for all ranks
+    result_dir = args.result_dir + "_" + stamp
     os.makedirs(result_dir, exist_ok=True)
     written = []
-    items = get_text_and_wav(args.corresponding_json, args.timbre_dir)
+    all_items = get_text_and_wav(args.corresponding_json, args.timbre_dir)
+    seed = getattr(args, "seed", None)
+    if dist is not None and seed is None:
+        seed = 0                     # ranks share nothing: without per-row streams every rank would replay the same draws
+    first, last, _ = parallel.shard_bounds(len(all_items), world, rank)
+    items = all_items[first:last]    # this rank's rows; global row number = first + position + 1
+
+    def row_seed(cnt):
+        return None if seed is None else int(seed) * 1000003 + cnt
 
     def wavs_of(item):
         style_wav = load_wav(item["style_wav_path"], 16000)
@@ -79,14 +104,17 @@ def tts_for_infer(args, cosyvoice=None, now=None):
 
     bs = max(1, int(getattr(args, "batch_size", 1)))
     if bs == 1:     # the reference's schedule: one utterance at a time (tts_with_rag.py:172-197)
-        for cnt, item in enumerate(items, start=1):
+        for cnt, item in enumerate(items, start=first + 1):
             print(item)
             style_wav, timbre_wav = wavs_of(item)
+            kw = {} if seed is None else {"seed": row_seed(cnt)}
             for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
-                                                                  timbre_wav, stream=False)):
+                                                                  timbre_wav, stream=False, **kw)):
                 path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
                 audio.write_wav(path, j["tts_speech"], 22050)
                 written.append(path)
+        if dist is not None:
+            dist.barrier()
         return written
     # batched schedule: same files, same names; rows are independent so they share ragged GPU batches
     for c0 in range(0, len(items), bs):
@@ -94,11 +122,14 @@ def tts_for_infer(args, cosyvoice=None, now=None):
         for item in chunk:
             print(item)
         reqs = [(it["tts_text"], it["style_wav_text"], *wavs_of(it)) for it in chunk]
-        for k, segs in enumerate(cosyvoice.inference_tts_with_st_batch(reqs, max_batch=bs)):
+        kw = {} if seed is None else {"seeds": [row_seed(first + c0 + k + 1) for k in range(len(chunk))]}
+        for k, segs in enumerate(cosyvoice.inference_tts_with_st_batch(reqs, max_batch=bs, **kw)):
             for i, j in enumerate(segs):
-                path = os.path.join(result_dir, output_name(c0 + k + 1, chunk[k]["style_wav_path"], chunk[k]["speaker"], i))
+                path = os.path.join(result_dir, output_name(first + c0 + k + 1, chunk[k]["style_wav_path"], chunk[k]["speaker"], i))
                 audio.write_wav(path, j["tts_speech"], 22050)
                 written.append(path)
+    if dist is not None:
+        dist.barrier()
     return written
 
 
@@ -113,6 +144,8 @@ def build_parser():
     parser.add_argument("--timbre_dir", default=REF_TIMBRE_DIR)
     parser.add_argument("--whisper_timbre_wav", default=os.path.join(REF_TIMBRE_DIR, WHISPER_TIMBRE_FILE))
     parser.add_argument("--batch_size", type=int, default=1, help="rows synthesised per ragged GPU batch (1 = the reference's schedule)")
+    parser.add_argument("--seed", type=int, default=None,
+                        help="per-row random streams (row cnt draws from (seed, cnt)); always on in a data-parallel run (default 0 there)")
     return parser
 
 
@@ -128,3 +161,5 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+    from astts import parallel
+    parallel.shutdown()

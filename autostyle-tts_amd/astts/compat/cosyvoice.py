@@ -75,8 +75,14 @@ class CosyVoice:
         self.min_token_text_ratio, self.max_token_text_ratio = 2, 20
 
     # ------------------------------------------------------------------ one text segment
-    def _draws(self, n_tok: int, n_mel_total: int, n_mel_gen: int):
-        cfg, g = self.cfg, self._gen
+    @staticmethod
+    def segment_generator(seed: int, segment: int) -> torch.Generator:
+        """The random stream of text segment ``segment`` of an item synthesised under ``seed`` (drivers: one seed per input row, so
+        that a row's draws do not depend on the batch, the rank or the rows before it)."""
+        return torch.Generator().manual_seed((int(seed) * 1000003 + int(segment)) & ((1 << 62) - 1))
+
+    def _draws(self, n_tok: int, n_mel_total: int, n_mel_gen: int, gen: Optional[torch.Generator] = None):
+        cfg, g = self.cfg, gen or self._gen
         nh = cfg.nb_harmonics + 1
         u = torch.rand(max(n_tok, 1), 1, 2, generator=g)
         z = torch.randn(1, n_mel_total, cfg.mel, generator=g)
@@ -85,7 +91,7 @@ class CosyVoice:
         noise = torch.randn(1, n_mel_gen * cfg.upsample_total, nh, generator=g)
         return u, z, phase0, noise
 
-    def _lm_tokens(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures) -> torch.Tensor:
+    def _lm_tokens(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures, gen: Optional[torch.Generator] = None) -> torch.Tensor:
         """LM decode with EOS: masked for the first 2x text tokens, capped at 20x (upstream ratios)."""
         cfg, dev, lm = self.cfg, self.device, self.engine.lm
         tlen = torch.tensor([text_ids.shape[1]], dtype=torch.int32, device=dev)
@@ -93,7 +99,7 @@ class CosyVoice:
         min_len = self.min_token_text_ratio * n_tts_text
         max_len = self._cap_tokens(self.max_token_text_ratio * n_tts_text, pre.shape[0])
         max_len = max(max_len, min_len + 1)
-        u = torch.rand(max_len, 1, 2, generator=self._gen).to(dev)
+        u = torch.rand(max_len, 1, 2, generator=gen or self._gen).to(dev)
         toks = lm.decode(pre, max_len, u, ignore_eos=min_len)[0].cpu()       # one sync per segment
         eos = (toks >= cfg.speech_vocab).nonzero()
         n = int(eos[0]) if eos.numel() else max_len
@@ -110,11 +116,11 @@ class CosyVoice:
                           RuntimeWarning, stacklevel=3)
         return max(1, min(int(want), cap))
 
-    def _render(self, tokens: torch.Tensor, flow_prompt: PromptFeatures) -> torch.Tensor:
+    def _render(self, tokens: torch.Tensor, flow_prompt: PromptFeatures, gen: Optional[torch.Generator] = None) -> torch.Tensor:
         cfg, dev, eng = self.cfg, self.device, self.engine
         n_gen = cfg.mel_frames_for_tokens(tokens.shape[1])
         tmp = flow_prompt.mel.shape[1]
-        _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen)
+        _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen, gen)
         all_tok = torch.cat([flow_prompt.speech_tokens.to(torch.int32), tokens], dim=1).to(dev)
         tl = torch.tensor([all_tok.shape[1]], dtype=torch.int32, device=dev)
         mel = eng.flow.decode(all_tok, tl, flow_prompt.mel.to(dev), flow_prompt.spk_embedding.to(dev), z.to(dev), tmp + n_gen)
@@ -147,12 +153,12 @@ class CosyVoice:
         for wav in stream_render(tokens.view(-1), StreamConsts.for_config(cfg), flow_mel, eng.hift.f0, source, eng.hift.decode):
             yield wav.cpu()
 
-    def _emit(self, tokens: torch.Tensor, flow_prompt: PromptFeatures, stream: bool) -> Iterator[Dict[str, torch.Tensor]]:
+    def _emit(self, tokens: torch.Tensor, flow_prompt: PromptFeatures, stream: bool, gen: Optional[torch.Generator] = None) -> Iterator[Dict[str, torch.Tensor]]:
         if stream:
             for wav in self._render_stream(tokens, flow_prompt):
                 yield {"tts_speech": wav}
         else:
-            yield {"tts_speech": self._render(tokens, flow_prompt)}
+            yield {"tts_speech": self._render(tokens, flow_prompt, gen)}
 
     # ------------------------------------------------------------------ ragged batches (many segments in one pass)
     def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True, fixed_tokens=None, draws=None, forced=None):
@@ -165,7 +171,9 @@ class CosyVoice:
         needs injectable randomness), all per request, in request order:
           ``fixed_tokens[i]``  decode exactly that many speech tokens (EOS ignored) instead of the 2x..20x text-length window;
           ``draws[i]``         {"u": [n, 2], "z": [1, Tm_total, mel], "phase0": [1, nh], "noise": [1, L, nh]} instead of draws
-                               from the instance generator (``make_draws`` builds them from a seed);
+                               from the instance generator (``make_draws`` builds them from a seed), or a ``torch.Generator``
+                               that the request's draws are taken from (``segment_generator``: what the one-at-a-time path
+                               draws for the same segment under the same seed);
           ``forced[i]``        teacher forcing: int tokens [n] that replace the sampled ones.
         The tokens and mels of the last call stay in ``self.last_tokens`` / ``self.last_mels`` (CPU)."""
         cfg, dev, eng = self.cfg, self.device, self.engine
@@ -193,7 +201,8 @@ class CosyVoice:
             if draws is not None:
                 u = torch.zeros(n_steps, b, 2)
                 for j, i in enumerate(idxs):
-                    u[:max_len[j], j] = draws[i]["u"][:max_len[j]]
+                    d = draws[i]
+                    u[:max_len[j], j] = torch.rand(max_len[j], 2, generator=d) if isinstance(d, torch.Generator) else d["u"][:max_len[j]]
                 u = u.to(dev)
             else:
                 u = torch.rand(n_steps, b, 2, generator=self._gen).to(dev)
@@ -216,7 +225,9 @@ class CosyVoice:
                 fp = r[3]
                 n_gen = cfg.mel_frames_for_tokens(int(gen_tokens[i].numel()))
                 tmp = int(fp.mel.shape[1])
-                if draws is not None:
+                if draws is not None and isinstance(draws[idxs[i]], torch.Generator):
+                    _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen, draws[idxs[i]])
+                elif draws is not None:
                     d = draws[idxs[i]]
                     z, phase0, noise = d["z"][:, :tmp + n_gen], d["phase0"], d["noise"][:, :n_gen * cfg.upsample_total]
                 else:
@@ -245,14 +256,19 @@ class CosyVoice:
         return {"u": torch.rand(n_tokens, 2, generator=g), "z": torch.randn(1, prompt_mel_frames + n_gen, cfg.mel, generator=g),
                 "phase0": phase0, "noise": torch.randn(1, n_gen * cfg.upsample_total, nh, generator=g)}
 
-    def inference_tts_with_st_batch(self, items, max_batch: int = 32, split: bool = True, **controls):
+    def inference_tts_with_st_batch(self, items, max_batch: int = 32, split: bool = True, seeds=None, **controls):
         """Batched form of inference_tts_with_st for drivers that know all their work up front
         (tts_with_rag.py:172 loops 64 rows one by one).  ``items``: list of (tts_text, style_text, style_wav_16k,
         timbre_wav_16k) -> list (per item) of lists (per text segment) of {'tts_speech': FloatTensor[1, n]}.
         ``controls`` (fixed_tokens / draws / forced, per text segment; ``split=False`` keeps one segment per item so that they
-        line up with the items) go to ``synthesize_batch``; the prompts of an item are featurised once per distinct tensor."""
+        line up with the items) go to ``synthesize_batch``; the prompts of an item are featurised once per distinct tensor.
+        ``seeds``: one integer per item -- segment k of item i then draws from ``segment_generator(seeds[i], k)``, exactly what
+        ``inference_tts_with_st(..., seed=seeds[i])`` draws for it: an item's randomness is its own, whatever batch or rank it is in."""
         fe = self.frontend
         reqs, owner = [], []
+        gens = [] if seeds is not None else None
+        if seeds is not None and "draws" in controls:
+            raise ValueError("inference_tts_with_st_batch: pass seeds or draws, not both")
         cache = {}
 
         def prompt(w):
@@ -264,10 +280,14 @@ class CosyVoice:
         for k, (tts_text, style_text, style_wav, timbre_wav) in enumerate(items):
             style, timbre = prompt(style_wav), prompt(timbre_wav)
             style_ids = fe.text_ids(style_text)
-            for seg in text_normalize(tts_text, fe.tokenizer, split=split):
+            for n_seg, seg in enumerate(text_normalize(tts_text, fe.tokenizer, split=split)):
                 seg_ids = fe.text_ids(seg)
                 reqs.append((torch.cat([style_ids, seg_ids], dim=1), seg_ids.shape[1], style, timbre))
                 owner.append(k)
+                if gens is not None:
+                    gens.append(self.segment_generator(seeds[k], n_seg))
+        if gens is not None:
+            controls["draws"] = gens
         wavs = self.synthesize_batch(reqs, max_batch, **controls)
         out = [[] for _ in items]
         for k, w in zip(owner, wavs):
@@ -276,16 +296,19 @@ class CosyVoice:
 
     # ------------------------------------------------------------------ public generators
     def inference_tts_with_st(self, tts_text: str, style_text: str, style_wav_16k: torch.Tensor,
-                              timbre_wav_16k: torch.Tensor, stream: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
+                              timbre_wav_16k: torch.Tensor, stream: bool = False, seed: Optional[int] = None) -> Iterator[Dict[str, torch.Tensor]]:
+        """``seed`` (an addition to the reference's signature): the item's own random stream (``segment_generator``) instead of
+        the instance generator."""
         fe = self.frontend
         style = fe.prompt(style_wav_16k)
         timbre = fe.prompt(timbre_wav_16k)
         style_ids = fe.text_ids(style_text)
-        for seg in text_normalize(tts_text, fe.tokenizer, split=True):
+        for n_seg, seg in enumerate(text_normalize(tts_text, fe.tokenizer, split=True)):
             seg_ids = fe.text_ids(seg)
             text_ids = torch.cat([style_ids, seg_ids], dim=1)
-            toks = self._lm_tokens(text_ids, seg_ids.shape[1], style)       # step 1: style tokens
-            yield from self._emit(toks, timbre, stream)                      # step 2: render with the timbre
+            gen = None if seed is None else self.segment_generator(seed, n_seg)
+            toks = self._lm_tokens(text_ids, seg_ids.shape[1], style, gen)  # step 1: style tokens
+            yield from self._emit(toks, timbre, stream, gen)                 # step 2: render with the timbre
 
     def inference_zero_shot(self, tts_text: str, prompt_text: str, prompt_wav_16k: torch.Tensor,
                             stream: bool = False) -> Iterator[Dict[str, torch.Tensor]]:

@@ -229,6 +229,16 @@ class MilvusClient:
                output_fields: Optional[Sequence[str]] = None, search_params: Optional[dict] = None,
                anns_field: Optional[str] = None, metric_type: Optional[str] = None,
                param: Optional[dict] = None, **_kw) -> List[List[Dict[str, Any]]]:
+        idx, score = self.search_rows(collection_name, data, filter=filter, limit=limit, search_params=search_params,
+                                      anns_field=anns_field, metric_type=metric_type, param=param)
+        return self.hits_from_rows(collection_name, idx, score, output_fields)
+
+    def search_rows(self, collection_name: str, data, filter: Optional[str] = "", limit: int = 10, search_params: Optional[dict] = None,
+                    anns_field: Optional[str] = None, metric_type: Optional[str] = None, param: Optional[dict] = None, **_kw):
+        """The arithmetic half of ``search``: -> (row index int64 [Q, k], cosine similarity fp32 [Q, k]) as numpy arrays, -1 = no hit
+        (k = min(limit, rows); k = 0 columns for an empty collection).  Row index == style id.  The data-parallel drivers shard
+        THIS call over the ranks and all-gather its result (astts.parallel.sharded_search); ``hits_from_rows`` turns rows into the
+        pymilvus result shape wherever the records are written."""
         c = self._get(collection_name)
         if filter:
             raise MilvusException(1, "filter expressions are not implemented by astts (the reference only passes None)")
@@ -244,7 +254,7 @@ class MilvusClient:
             raise MilvusException(1100, f"vector dimension mismatch, expected vector size(byte) {c.dim * 4}, "
                                         f"actual {q.shape[-1] * 4}")
         if len(c.pks) == 0:
-            return [[] for _ in range(q.shape[0])]
+            return np.zeros((q.shape[0], 0), np.int64), np.zeros((q.shape[0], 0), np.float32)
         if limit < 1:
             raise MilvusException(1, f"limit {limit} is invalid")
         k = min(int(limit), len(c.pks))
@@ -255,10 +265,16 @@ class MilvusClient:
             raise MilvusException(1100, f"limit {limit} is not supported by this build: at most {KNN_MAX_K} hits per query "
                                         f"(collection holds {len(c.pks)} rows)")
         idx, score = c.bank().search(q, k)
+        return np.asarray(idx, dtype=np.int64), np.asarray(score, dtype=np.float32)
+
+    def hits_from_rows(self, collection_name: str, idx, score, output_fields: Optional[Sequence[str]] = None) -> List[List[Dict[str, Any]]]:
+        """(row index [Q, k], similarity [Q, k]) -> ``list[Q]`` of ``list[<= k]`` of {'id', 'distance', 'entity', 'row'}."""
+        c = self._get(collection_name)
+        idx, score = np.asarray(idx), np.asarray(score)
         out: List[List[Dict[str, Any]]] = []
-        for qi in range(q.shape[0]):
+        for qi in range(idx.shape[0]):
             hits = []
-            for j in range(k):
+            for j in range(idx.shape[1]):
                 row = int(idx[qi, j])
                 if row < 0:
                     continue

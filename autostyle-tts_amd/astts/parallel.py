@@ -102,3 +102,52 @@ def bank_sharded_search(local_search_fn: Callable[[torch.Tensor, int], Tuple[tor
     rows = allp[:, :, :k].permute(1, 0, 2).reshape(packed.shape[0], world * k)
     scores = allp[:, :, k:].contiguous().view(torch.float64).permute(1, 0, 2).reshape(packed.shape[0], world * k)
     return merge_topk(scores, rows, k)
+
+
+# --------------------------------------------------------------------------------------------- driver-side helpers
+def init_from_env(backend: Optional[str] = None):
+    """The process group of a driver launched as ``python -m torch.distributed.run --nproc-per-node N -m astts.cli.<driver>`` (one
+    process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment).  -> (dist, rank, world, local_rank) with
+    ``dist`` = ``torch.distributed`` once initialised, ``None`` in a plain one-process run (no WORLD_SIZE, or WORLD_SIZE = 1 and no
+    ASTTS_FORCE_DIST).  Backend: "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo" (the CPU tests); ``ASTTS_DIST_BACKEND``
+    or ``backend`` overrides.  The caller selects its GPU (``cuda:local_rank``) BEFORE the first collective."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and os.environ.get("ASTTS_FORCE_DIST") != "1":
+        return None, 0, 1, 0
+    import torch.distributed as dist
+
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        be = backend or os.environ.get("ASTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if be == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(be, rank=rank, world_size=world)
+    return dist, rank, world, local
+
+
+def broadcast_object(obj, dist, src: int = 0):
+    """One small Python object from ``src`` to every rank (e.g. the time stamp of a result directory, so that the ranks agree)."""
+    if dist is None:
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def comm_device(dist) -> torch.device:
+    """Where a tensor must live to enter a collective of ``dist``'s backend."""
+    if dist is not None and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def shutdown() -> None:
+    """End of a driver process: leave the process group if one was formed."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
