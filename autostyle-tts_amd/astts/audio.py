@@ -202,6 +202,21 @@ def whisper_log_mel(wav16k: torch.Tensor, n_mels: int = 128) -> torch.Tensor:
     in behind ``Frontend(speech_tokenizer=...)`` and takes exactly this tensor."""
     w = wav16k if wav16k.dim() == 2 else wav16k[None]
     w = w.to(torch.float32)
+    if w.is_cuda:              # astts_op_whisper_log_mel (HIP): the same definition as the host path below (tests hold both to the fixture)
+        from . import _lib
+        lib = _lib.load()
+        key = ("whisper", n_mels, w.device.index)
+        tabs = _KERNEL_CACHE.get(key)
+        if tabs is None:
+            tabs = _KERNEL_CACHE[key] = (torch.hann_window(400, periodic=True).to(w.device),
+                                         torch.from_numpy(mel_filterbank(16000, 400, n_mels, 0.0, 8000.0)).contiguous().to(w.device))
+        w = w.contiguous()
+        b, n = w.shape
+        out = torch.empty((b, n_mels, n // 160), dtype=torch.float32, device=w.device)
+        ws = torch.empty((max(int(lib.astts_op_whisper_log_mel_workspace_bytes(b)), 4),), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.astts_op_whisper_log_mel(w.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), out.data_ptr(), b, n, 400, 160, n_mels,
+                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return out
     window = torch.hann_window(400, periodic=True, device=w.device)
     spec = torch.stft(w, 400, hop_length=160, win_length=400, window=window, center=True, pad_mode="reflect", return_complex=True)
     power = (spec.real ** 2 + spec.imag ** 2)[..., :-1]

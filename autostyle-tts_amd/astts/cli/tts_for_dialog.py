@@ -69,16 +69,33 @@ def tts_for_infer(args, cosyvoice=None):
     result_dir = args.result_dir + "_" + (args.time_tag or datetime.now().strftime("%m%d%H%M"))
     os.makedirs(result_dir, exist_ok=True)
     written = []
-    cnt = 0
-    for zh_text, style_text, file_id, style_path, speaker, timbre_path in _entries(args):
-        cnt += 1
-        style_wav = load_wav(style_path, 16000)
-        timbre_wav = load_wav(timbre_path, 16000)
-        print(zh_text, style_text, speaker)
-        for i, j in enumerate(cosyvoice.inference_tts_with_st(zh_text, style_text, style_wav, timbre_wav, stream=False)):
-            path = os.path.join(result_dir, f"{cnt}_{file_id}_to_{speaker}_{i}.wav")
-            audio.write_wav(path, j["tts_speech"], 22050)
-            written.append(path)
+    bs = max(1, int(getattr(args, "batch_size", 1)))
+    entries = list(_entries(args))
+    wav_cache = {}
+
+    def wav16(path):            # one tensor per file: the batched surface featurises each distinct prompt tensor once
+        if path not in wav_cache:
+            wav_cache[path] = load_wav(path, 16000)
+        return wav_cache[path]
+
+    if bs == 1:     # the reference's schedule (tts_for_dialog.py:172-190)
+        for cnt, (zh_text, style_text, file_id, style_path, speaker, timbre_path) in enumerate(entries, start=1):
+            print(zh_text, style_text, speaker)
+            for i, j in enumerate(cosyvoice.inference_tts_with_st(zh_text, style_text, wav16(style_path), wav16(timbre_path), stream=False)):
+                path = os.path.join(result_dir, f"{cnt}_{file_id}_to_{speaker}_{i}.wav")
+                audio.write_wav(path, j["tts_speech"], 22050)
+                written.append(path)
+        return written
+    for c0 in range(0, len(entries), bs):       # turns are independent: `batch_size` of them share ragged GPU batches
+        chunk = entries[c0:c0 + bs]
+        for zh_text, style_text, _, _, speaker, _ in chunk:
+            print(zh_text, style_text, speaker)
+        out = cosyvoice.inference_tts_with_st_batch([(e[0], e[1], wav16(e[3]), wav16(e[5])) for e in chunk], max_batch=bs)
+        for k, segs in enumerate(out):
+            for i, j in enumerate(segs):
+                path = os.path.join(result_dir, f"{c0 + k + 1}_{chunk[k][2]}_to_{chunk[k][4]}_{i}.wav")
+                audio.write_wav(path, j["tts_speech"], 22050)
+                written.append(path)
     return written
 
 
@@ -125,6 +142,7 @@ def build_parser():
     p.add_argument("--allow_random_init", action="store_true",
                    help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     p.add_argument("--time_tag", default=None, help="suffix of the result directory (default: now as MMDDHHMM, as the reference)")
+    p.add_argument("--batch_size", type=int, default=1, help="dialogue turns per ragged GPU batch (1 = the reference's schedule)")
     return p
 
 

@@ -28,22 +28,53 @@ def tts_for_infer(args, cosyvoice=None):
     from astts import audio
     from astts.compat.cosyvoice import CosyVoice, load_wav
 
-    cosyvoice = cosyvoice or CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None)
+    from astts import parallel
+
+    dist, rank, world, local = parallel.init_from_env()
+    if cosyvoice is None:
+        kw = {}
+        if dist is not None and dist.get_backend() == "nccl":
+            torch.cuda.set_device(local)
+            kw["device"] = torch.device("cuda", local)
+        cosyvoice = CosyVoice(args.model_dir, allow_random_init=True if getattr(args, "allow_random_init", False) else None, **kw)
     style = os.path.basename(args.style_wav_path)[:-4]
     timbre = os.path.basename(args.timbre_wav_path)[:-4]
-    lines = get_text(args.txt_path)
+    all_lines = get_text(args.txt_path)
+    first, last, _ = parallel.shard_bounds(len(all_lines), world, rank)      # data-parallel run: this rank's lines (global numbering kept)
+    lines = all_lines[first:last]
     style_wav = load_wav(args.style_wav_path, 16000)
     timbre_wav = load_wav(args.timbre_wav_path, 16000)
     os.makedirs(args.result_dir, exist_ok=True)
+    seed = getattr(args, "seed", None)
+    if dist is not None and seed is None:
+        seed = 0
     written = []
-    for cnt, line in enumerate(lines, start=1):
-        segs = [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, args.style_wav_text, style_wav, timbre_wav, stream=False)]
+
+    def save(cnt, segs):
         if not segs:
-            continue
+            return
         wav = segs[-1] if args.keep_last_segment_only else torch.cat(segs, dim=1)
         path = os.path.join(args.result_dir, f"{style}_{cnt}_to_{timbre}.wav")
         audio.write_wav(path, wav, 22050)
         written.append(path)
+
+    bs = max(1, int(getattr(args, "batch_size", 1)))
+    if bs == 1:     # the reference's schedule: one line at a time (tts_with_style_and_timbre.py:91-95)
+        for cnt, line in enumerate(lines, start=first + 1):
+            kw = {} if seed is None else {"seed": int(seed) * 1000003 + cnt}
+            save(cnt, [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, args.style_wav_text, style_wav, timbre_wav, stream=False, **kw)])
+    else:           # lines are independent: the text segments of `batch_size` lines share ragged GPU batches (BASELINE config 3)
+        for c0 in range(0, len(lines), bs):
+            chunk = lines[c0:c0 + bs]
+            kw = {} if seed is None else {"seeds": [int(seed) * 1000003 + first + c0 + k + 1 for k in range(len(chunk))]}
+            if getattr(args, "fixed_tokens", None):
+                kw["fixed_tokens"] = int(args.fixed_tokens)
+            out = cosyvoice.inference_tts_with_st_batch([(line, args.style_wav_text, style_wav, timbre_wav) for line in chunk],
+                                                        max_batch=getattr(args, "max_segments", None) or 64, **kw)
+            for k, segs in enumerate(out):
+                save(first + c0 + k + 1, [j["tts_speech"] for j in segs])
+    if dist is not None:
+        dist.barrier()
     return written
 
 
@@ -85,6 +116,14 @@ def build_parser():
     parser.add_argument("--allow_random_init", action="store_true",
                         help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     parser.add_argument("--keep_last_segment_only", action="store_true")
+    parser.add_argument("--batch_size", type=int, default=1,
+                        help="lines synthesised together: their text segments share ragged GPU batches (1 = the reference's schedule)")
+    parser.add_argument("--max_segments", type=int, default=64, help="text segments per ragged GPU batch in the batched schedule")
+    parser.add_argument("--fixed_tokens", type=int, default=None,
+                        help="batched schedule only: every text segment decodes exactly this many speech tokens (EOS ignored) -- "
+                             "fixed-length throughput runs, e.g. 250 for BASELINE config 3")
+    parser.add_argument("--seed", type=int, default=None,
+                        help="per-line random streams (line cnt draws from (seed, cnt)); always on in a data-parallel run (default 0 there)")
     return parser
 
 
@@ -100,3 +139,5 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+    from astts import parallel
+    parallel.shutdown()

@@ -81,19 +81,26 @@ def main(argv=None, cosyvoice=None):
         styles = [(p, get_style_wav_text(args.style_json, os.path.basename(p)[:-4])) for p in get_path(args.style_dir, args.style_num, rng)]
     timbres = get_path(args.timbre_dir, args.timbre_num, rng)
     rows = []
+    bs = max(1, int(args.batch_size))
     for style_path, style_text in styles:
         style_wav = load_wav(style_path, 16000)
         style = os.path.basename(style_path)[:-4]
         for timbre_path in timbres:
             timbre_wav = load_wav(timbre_path, 16000)
             timbre = os.path.basename(timbre_path)[:-4]
-            for cnt, line in enumerate(lines, start=1):
-                segs = [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, style_text, style_wav, timbre_wav, stream=False)]
-                name = f"{style}_to_{timbre}_{cnt}_new"
-                if segs:
-                    wav = segs[-1] if args.keep_last_segment_only else torch.cat(segs, dim=1)
-                    audio.write_wav(os.path.join(args.result_dir, name + ".wav"), wav, 22050)
-                rows.append([name, style_text, timbre_path, line])
+            for c0 in range(0, len(lines), bs):
+                chunk = lines[c0:c0 + bs]
+                if bs == 1:     # the reference's schedule (vc_from_dir.py:196-201)
+                    outs = [list(cosyvoice.inference_tts_with_st(chunk[0], style_text, style_wav, timbre_wav, stream=False))]
+                else:           # the lines of one (style, timbre) pair share ragged GPU batches
+                    outs = cosyvoice.inference_tts_with_st_batch([(line, style_text, style_wav, timbre_wav) for line in chunk], max_batch=64)
+                for k, (line, out) in enumerate(zip(chunk, outs)):
+                    segs = [j["tts_speech"] for j in out]
+                    name = f"{style}_to_{timbre}_{c0 + k + 1}_new"
+                    if segs:
+                        wav = segs[-1] if args.keep_last_segment_only else torch.cat(segs, dim=1)
+                        audio.write_wav(os.path.join(args.result_dir, name + ".wav"), wav, 22050)
+                    rows.append([name, style_text, timbre_path, line])
     meta = os.path.join(args.result_dir, "meta.lst")
     with open(meta, "w", encoding="utf-8") as f:
         for row in rows:
@@ -117,6 +124,7 @@ def build_parser():
                    help="run on seeded random weights when model_dir holds no llm.pt / flow.pt / hift.pt (otherwise that is an error)")
     p.add_argument("--seed", type=int, default=None, help="seed of the file draw (default: unseeded, as the reference)")
     p.add_argument("--keep_last_segment_only", action="store_true", help="reproduce the reference's overwrite of multi-segment lines")
+    p.add_argument("--batch_size", type=int, default=1, help="lines of one (style, timbre) pair synthesised together (1 = the reference's schedule)")
     return p
 
 

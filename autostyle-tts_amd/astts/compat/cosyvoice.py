@@ -288,6 +288,8 @@ class CosyVoice:
                     gens.append(self.segment_generator(seeds[k], n_seg))
         if gens is not None:
             controls["draws"] = gens
+        if isinstance(controls.get("fixed_tokens"), int):        # one length for every text segment (throughput runs: SURVEY.md 7)
+            controls["fixed_tokens"] = [controls["fixed_tokens"]] * len(reqs)
         wavs = self.synthesize_batch(reqs, max_batch, **controls)
         out = [[] for _ in items]
         for k, w in zip(owner, wavs):

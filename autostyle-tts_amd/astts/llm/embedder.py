@@ -18,6 +18,8 @@ deterministic stand-in so that the CLIs run end to end without one.
 """
 from __future__ import annotations
 
+import threading
+
 import math
 from typing import List, Optional, Sequence
 
@@ -84,11 +86,21 @@ class LlamaEmbedder:
             self.norm = f("model.norm.weight")
             head = state["model.embed_tokens.weight"] if cfg.tie_embeddings else state["lm_head.weight"]
             self.head = PackedWeight(head, None, dev)
+            self._rope_lock = threading.Lock()
             self._rope_tables(max(max_length, 16) + 64)
 
     def _rope_tables(self, n: int) -> None:
+        """(cos, sin) rows for positions < n, published as ONE tuple: a thread that sees the new cos also sees the new sin."""
         fr = torch.arange(n, dtype=torch.float32)[:, None] * llama3_inv_freq(self.cfg)[None, :]
-        self.cos, self.sin = fr.cos().to(self.device).contiguous(), fr.sin().to(self.device).contiguous()
+        self._rope = (fr.cos().to(self.device).contiguous(), fr.sin().to(self.device).contiguous())
+
+    @property
+    def cos(self) -> torch.Tensor:
+        return self._rope[0]
+
+    @property
+    def sin(self) -> torch.Tensor:
+        return self._rope[1]
 
     # ------------------------------------------------------------------ the decoder stack
     def hidden(self, ids: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -96,14 +108,17 @@ class LlamaEmbedder:
         (== outputs.hidden_states[-1] of LlamaModel)."""
         cfg = self.cfg
         b, t = ids.shape
-        if t > self.cos.shape[0]:       # the untruncated generation prompt (milvus/search_json.py:178) can exceed max_length
-            self._rope_tables((t + 255) // 256 * 256)
+        if t > self._rope[0].shape[0]:  # the untruncated generation prompt (milvus/search_json.py:178) can exceed max_length
+            with self._rope_lock:
+                if t > self._rope[0].shape[0]:
+                    self._rope_tables((t + 255) // 256 * 256)
+        cos, sin = self._rope           # one consistent pair for the whole pass
         hq, hk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
         x = ops.embedding(self.embed, ids.to(self.device))
         for L in self.L:
             h = ops.rmsnorm(x, L["n1"], cfg.rms_eps)                              # fp16: its only consumer is an MFMA operand
             qkv = ops.linear(h, L["wqkv"], out_dtype=torch.float16)              # [B, T, hq + 2 hk]
-            ops.rope_llama_(qkv, self.cos, self.sin, cfg.heads + cfg.kv_heads, cfg.head_dim)   # q heads then k heads: contiguous
+            ops.rope_llama_(qkv, cos, sin, cfg.heads + cfg.kv_heads, cfg.head_dim)             # q heads then k heads: contiguous
             a = ops.attn_causal_gqa(qkv[..., :hq], qkv[..., hq:hq + hk], qkv[..., hq + hk:], cfg.heads, cfg.kv_heads, cfg.head_dim, lens)
             x = ops.linear(a, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["n2"], cfg.rms_eps)
@@ -166,11 +181,21 @@ Answer:"""
         stripped and lower-cased."""
         prompt = self.EMOTION_PROMPT.format(text, text)
         out = self.generate_greedy(list(self.tokenizer.encode(prompt)), max_new_tokens)     # untruncated: only get_embedding truncates there
-        try:
-            label = self.tokenizer.decode(out, skip_special_tokens=True)                   # search_json.py:191
-        except TypeError:                                                                  # stand-in tokenizers have no special tokens
-            label = self.tokenizer.decode(out)
+        label = self.tokenizer.decode(out, skip_special_tokens=True) if self._decode_takes_skip else self.tokenizer.decode(out)   # search_json.py:191
         return label.strip().lower()
+
+    @property
+    def _decode_takes_skip(self) -> bool:
+        """Decided from the tokenizer's signature, once: a TypeError raised INSIDE a real tokenizer's decode must not be mistaken for
+        "this stand-in has no skip_special_tokens argument" (and silently decoded with the special tokens in)."""
+        if not hasattr(self, "_decode_skip"):
+            import inspect
+            try:
+                ps = inspect.signature(self.tokenizer.decode).parameters
+                self._decode_skip = "skip_special_tokens" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
+            except (TypeError, ValueError):
+                self._decode_skip = True
+        return self._decode_skip
 
     def combined_embedding(self, emotion_text: str, biography_text: str) -> np.ndarray:
         """milvus/search_json.py:201-229 / src/search_milvus.py:214-221: [emotion | biography] float32, un-normalised."""

@@ -608,10 +608,15 @@ def selftest_xlane() -> int:
 
 
 def cu_masked_stream(cus, device=None) -> "torch.cuda.ExternalStream":
-    """A torch stream whose kernels run only on the CUs listed in ``cus`` (iterable of CU indices, or an int n = the first n).
-    Kept alive for the life of the process (the pipeline that uses it owns it)."""
+    """A torch stream whose kernels run only on the CUs whose mask bits are listed in ``cus`` (iterable of bit indices, or an int n =
+    the first n).  On gfx950 bit b enables CU b // 8 of XCC b % 8 (scripts/micro/cu_census.hip): a mask takes CUs away inside every
+    XCC, never whole XCCs (an XCC whose bits are all clear keeps ALL its CUs).  The HIP stream lives as long as the process (nothing
+    destroys it: a handful per experiment, scripts/cu_mask_probe*.py)."""
     dev = device or torch.device("cuda", torch.cuda.current_device())
     ids = list(range(cus)) if isinstance(cus, int) else [int(c) for c in cus]
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if not ids or min(ids) < 0 or max(ids) >= n_cu:
+        raise ValueError(f"cu_masked_stream: need a non-empty list of mask bits in 0..{n_cu - 1}, got {ids[:8]}{'...' if len(ids) > 8 else ''}")
     words = (max(ids) // 32) + 1
     arr = (ctypes.c_uint32 * words)()
     for c in ids:

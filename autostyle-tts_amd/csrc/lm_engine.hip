@@ -44,7 +44,11 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
     int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
     (void)take(sizeof(int32_t) * b);
-    float* part_o = (float*)take(astts_op_gemm_fused_workspace_bytes());   // [b][heads][2][64] + [b][heads][2][2] (v1's split-K area)
+    // the attention's split-key partials live in v1's split-K area: [b][heads][2][64] + [b][heads][2][2] floats must fit it
+    ASTTS_REQUIRE((size_t)b * c.heads * (2 * 64 + 2 * 2) * sizeof(float) <= astts_op_gemm_fused_workspace_bytes(), ASTTS_ERR_WORKSPACE,
+                  "astts_lm_decode: the split-key partials of %d rows x %d heads do not fit the %zu-byte split-K area", b, c.heads,
+                  astts_op_gemm_fused_workspace_bytes());
+    float* part_o = (float*)take(astts_op_gemm_fused_workspace_bytes());
     float* part_ml = part_o + (size_t)b * c.heads * 2 * 64;
     const float scale = 0.125f;
     const KvLayout lay = KvLayout::time_major(b, d);

@@ -501,16 +501,20 @@ __global__ __launch_bounds__(256) void resample_poly(const float* __restrict__ x
 // DFT, mel filterbank, log(clamp(., floor)).  One block per frame: the windowed frame and the twiddle table sit in LDS, every
 // thread evaluates its bins by direct summation in fp32 (index k n mod n_fft into the table) -- n_fft <= 1024 and a few
 // hundred frames per prompt: 0.3 GFLOP, far below anything worth an FFT.
+// WHISPER = the log-mel of Whisper's feature extractor (the input of the reference's speech tokenizer): centred frames
+// (reflect padding n_fft / 2), POWER spectrum, log10(max(., floor)), output [b][n_mels][frames], and the maximum over an utterance's
+// (frame, bin) values gathered in gmax[b] (order-preserving integer image of the float) for the "max - 8" floor of whisper_floor.
+template <bool WHISPER>
 __global__ __launch_bounds__(256) void mel_frames(const float* __restrict__ wav, const float* __restrict__ window,
                                                   const float* __restrict__ fb, float* __restrict__ out, int64_t n, int frames,
-                                                  int n_fft, int hop, int n_mels, float floor_) {
+                                                  int n_fft, int hop, int n_mels, float floor_, int* __restrict__ gmax) {
     extern __shared__ float sm[];
     float* fr = sm;                       // [n_fft] windowed frame
     float* twc = sm + n_fft;              // [n_fft] cos(2 pi i / n_fft)
     float* tws = twc + n_fft;             // [n_fft] sin
     float* mag = tws + n_fft;             // [n_fft / 2 + 1]
     const int f = blockIdx.x, bb = blockIdx.y, tid = threadIdx.x;
-    const int pad = (n_fft - hop) / 2;
+    const int pad = WHISPER ? n_fft / 2 : (n_fft - hop) / 2;
     const float* w = wav + (int64_t)bb * n;
     for (int i = tid; i < n_fft; i += 256) {
         int64_t s = (int64_t)f * hop + i - pad;
@@ -534,14 +538,38 @@ __global__ __launch_bounds__(256) void mel_frames(const float* __restrict__ wav,
             idx += k;
             if (idx >= n_fft) idx -= n_fft;
         }
-        mag[k] = sqrtf(re * re + im * im + 1e-9f);
+        mag[k] = WHISPER ? re * re + im * im : sqrtf(re * re + im * im + 1e-9f);
     }
     __syncthreads();
+    float vmax = -INFINITY;
     for (int m = tid; m < n_mels; m += 256) {
         const float* fr_ = fb + (int64_t)m * nb;
         float acc = 0.0f;
         for (int k = 0; k < nb; ++k) acc = fmaf(fr_[k], mag[k], acc);
-        out[((int64_t)bb * frames + f) * n_mels + m] = logf(fmaxf(acc, floor_));
+        if constexpr (WHISPER) {
+            const float v = log10f(fmaxf(acc, floor_));
+            out[((int64_t)bb * n_mels + m) * frames + f] = v;
+            vmax = fmaxf(vmax, v);
+        } else {
+            out[((int64_t)bb * frames + f) * n_mels + m] = logf(fmaxf(acc, floor_));
+        }
+    }
+    if constexpr (WHISPER) {
+        for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if ((tid & 63) == 0 && vmax > -INFINITY) {
+            // float order as integer order: non-negative floats compare as their bits, negative ones in reverse
+            const int bits = __float_as_int(vmax);
+            atomicMax(gmax + bb, bits >= 0 ? bits : (int)(0x80000000u - (unsigned)bits));
+        }
+    }
+}
+
+// second pass of the Whisper features: x -> (max(x, utterance maximum - 8) + 4) / 4
+__global__ __launch_bounds__(256) void whisper_floor(float* __restrict__ x, const int* __restrict__ gmax, int64_t per_item, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int key = gmax[i / per_item];
+        const float mx = __int_as_float(key >= 0 ? key : (int)(0x80000000u - (unsigned)key));
+        x[i] = (fmaxf(x[i], mx - 8.0f) + 4.0f) * 0.25f;
     }
 }
 
@@ -646,8 +674,33 @@ int astts_op_mel_spectrogram(const float* wav, const float* window, const float*
     const int64_t frames = (n_samples + 2 * pad - n_fft) / hop + 1;
     ASTTS_REQUIRE(frames >= 1 && frames < (1 << 30), ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: frames=%lld", (long long)frames);
     const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
-    hipLaunchKernelGGL(mel_frames, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
-                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor);
+    hipLaunchKernelGGL(mel_frames<false>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
+                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor, (int*)nullptr);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+size_t astts_op_whisper_log_mel_workspace_bytes(int32_t b) { return (size_t)(b > 0 ? b : 0) * sizeof(int); }
+
+int astts_op_whisper_log_mel(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
+                             int32_t n_fft, int32_t hop, int32_t n_mels, void* workspace, size_t workspace_bytes, astts_stream_t stream) {
+    ASTTS_REQUIRE(wav && window && mel_fb && out && workspace, ASTTS_ERR_INVALID, "astts_op_whisper_log_mel: null pointer");
+    ASTTS_REQUIRE(b >= 1 && n_fft >= 16 && n_fft <= 2048 && hop >= 1 && hop <= n_fft && n_mels >= 1, ASTTS_ERR_INVALID,
+                  "astts_op_whisper_log_mel: bad shape n_fft=%d hop=%d n_mels=%d", n_fft, hop, n_mels);
+    ASTTS_REQUIRE(workspace_bytes >= astts_op_whisper_log_mel_workspace_bytes(b), ASTTS_ERR_WORKSPACE, "astts_op_whisper_log_mel: workspace too small");
+    ASTTS_REQUIRE(n_samples > n_fft / 2, ASTTS_ERR_INVALID, "astts_op_whisper_log_mel: %lld samples are shorter than the reflect padding %d",
+                  (long long)n_samples, n_fft / 2);
+    const int64_t frames = n_samples / hop;      // centred frames 0 .. n / hop, the last one dropped (whisper.log_mel_spectrogram)
+    ASTTS_REQUIRE(frames >= 1 && frames < (1 << 30), ASTTS_ERR_INVALID, "astts_op_whisper_log_mel: frames=%lld", (long long)frames);
+    hipStream_t st = (hipStream_t)stream;
+    // every key starts below any float's image (the image of -inf is 0x80000000 - 0xff800000 = 0x80800000 as int: still above INT_MIN)
+    ASTTS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)workspace, (int)0x80000000u, (size_t)b, st));
+    const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
+    hipLaunchKernelGGL(mel_frames<true>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, st, wav, window, mel_fb, out, n_samples, (int)frames,
+                       n_fft, hop, n_mels, 1e-10f, (int*)workspace);
+    ASTTS_CHECK_LAUNCH();
+    const int64_t total = (int64_t)b * n_mels * frames;
+    hipLaunchKernelGGL(whisper_floor, dim3(grid_for_a(total)), dim3(256), 0, st, out, (const int*)workspace, (int64_t)n_mels * frames, total);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

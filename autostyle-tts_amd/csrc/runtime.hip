@@ -182,6 +182,7 @@ int astts_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, astts_str
 }
 
 int astts_stream_destroy(astts_stream_t stream) {
+    ASTTS_REQUIRE(stream, ASTTS_ERR_INVALID, "astts_stream_destroy: null stream (the default stream is not the caller's to destroy)");
     ASTTS_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
     return ASTTS_OK;
 }

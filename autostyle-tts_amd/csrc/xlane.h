@@ -32,6 +32,9 @@ __device__ __forceinline__ void row_swap(float v, float& a, float& b) {
     else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// the lane id itself (mbcnt), not threadIdx.x: the same in a 2-D block or one whose x extent is not a multiple of 64
+__device__ __forceinline__ unsigned xlane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 template <int OFF>
 __device__ __forceinline__ float lane_xor(float v) {
     static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "one bit of the lane id");
@@ -43,11 +46,11 @@ __device__ __forceinline__ float lane_xor(float v) {
         // lane ^ 16 wants [r1 r0 r3 r2]: b' on even rows, a' on odd rows
         float a, b;
         row_swap<16>(v, a, b);
-        return (threadIdx.x & 16) ? a : b;
+        return (xlane_id() & 16) ? a : b;
     } else {
         float a, b;
         row_swap<32>(v, a, b);
-        return (threadIdx.x & 32) ? a : b;
+        return (xlane_id() & 32) ? a : b;
     }
 }
 

@@ -242,6 +242,151 @@ def stub_main(args, world, rank):
     return 0
 
 
+def side_workload(args, which, dev, dist, rank, world):
+    """`--workload config3|config4|config5`: BASELINE.json's other configurations as SIDE lines with the default line's JSON schema (the
+    default `python bench.py` stays configs[1]; these make DESIGN.md's long-form / ragged / B = 256 figures reproducible by the
+    driver).  Same protocol: W untimed warm-up steps, K timed steps between barrier + synchronize, MAX over ranks, rank 0 prints.
+      config3  64 long-form lines = 384 text segments (Tt = 64, Ts = 250: 30 s per line) per step, as twelve 32-row batches through
+               the stream pipeline; weak scaling (every rank its own 64 lines).
+      config4  the 1 623 IEMOCAP test sentences, Ts_i = clamp(round(20 words_i), 25, 1500) forced, STRONG scaling: rank r takes rows
+               [r ceil(Q/W), ...) through CosyVoice.inference_tts_with_st_batch (prompt wavs -> frontend -> ragged LM / flow / vocoder ->
+               CPU waveforms) after the query-sharded retrieval of all 1 623 queries + one all-gather of the ids.
+      config5  256 queries against the 100 000 x 6144 bank (bank-sharded over the ranks when there are several) + 256 utterances at
+               the config-2 shapes, STRONG scaling over the ranks, 32-row batches through the stream pipeline."""
+    from astts import parallel
+    from astts.knn import StyleBank
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import PipelinedSynth, SynthEngine
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig(sample_rate=args.sample_rate)
+    weights = make_all(cfg, seed=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    extra = {}
+    if which in ("config3", "config5"):
+        eng = SynthEngine(weights, cfg, dev)
+        rows = 32
+        if which == "config3":
+            n_batches, tt, scaling = 12, 64, "weak"
+            total_rows = n_batches * rows * world
+        else:
+            b0, b1, _ = parallel.shard_bounds(256, world, rank)
+            n_batches, tt, scaling = (b1 - b0 + rows - 1) // rows, args.text_tokens, "strong"
+            total_rows = 256
+            rows = min(rows, max(b1 - b0, 1))
+            bank = np.random.default_rng(1234).standard_normal((100000, args.dim), dtype=np.float32).astype(np.float16)   # SURVEY.md 8d config 5
+            r0, r1, _ = parallel.shard_bounds(bank.shape[0], world, rank)
+            sb = StyleBank(bank[r0:r1] if dist is not None else bank, device=dev)
+            q_host = make_queries(bank, 256, seed=0)
+            q_dev = torch.from_numpy(q_host).to(dev)
+
+            def search():
+                if dist is None:
+                    return sb.search_device(q_dev, args.topk)[0]
+                return parallel.bank_sharded_search(lambda qq, kk: (lambda i, _s, s64: (i, s64))(*sb.search_device(qq, kk, return_f64=True)),
+                                                    q_dev, args.topk, r0, dist)[0]
+        inp = SynthInputs(cfg, rows, tt, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
+        sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
+                  inp.z, inp.phase0, inp.noise)
+        pipe = PipelinedSynth.autotune(eng, sample, depths=(2,), trials=2, steps=4)
+        last = {}
+
+        def step():
+            if which == "config5":
+                last["ids"] = search()
+            for _ in range(n_batches):
+                pipe.submit(*sample)
+            for d in pipe.drain():
+                last["wav"] = d[2]
+
+        with torch.cuda.stream(pipe.front_stream):
+            dt = timed(step)
+        audio = inp.audio_seconds / rows * total_rows * args.steps
+        ok = bool(torch.isfinite(last["wav"]).all())
+        if which == "config5":
+            from oracle import knn as oknn
+            sel = np.arange(0, 256, 37)
+            extra["ids_match_oracle_sample"] = bool(np.array_equal(last["ids"].cpu().numpy()[sel], oknn.knn_search(bank, q_host[sel], args.topk)[0]))
+        work = (f"BASELINE configs[2]: 64 long-form lines/GPU = 384 text segments (Tt={tt}, Tp={args.prompt_tokens}, Ts={args.speech_tokens}: 30 s per line) "
+                f"per step as {n_batches} batches of {rows} rows" if which == "config3" else
+                f"BASELINE configs[4]: kNN Q=256 x N=100000 x D={args.dim} k={args.topk} ({'bank-sharded over the ranks, one all-gather + merge' if dist is not None else 'one GPU holds the bank'}) "
+                f"+ 256 utterances (Tt={tt}, Tp={args.prompt_tokens}, Ts={args.speech_tokens}) over {world} GPU(s) as batches of {rows} rows")
+    else:       # config4
+        from astts.compat.cosyvoice import CosyVoice
+
+        with open(os.path.join(ROOT, "tests", "golden", "iemocap_test_sentences.json")) as f:
+            sents = json.load(f)["all"]
+        want = [int(min(max(round(20 * len(x.split())), 25), 1500)) for x in sents]
+        bank = make_config2_bank(args.bank_rows, args.dim)
+        sb = StyleBank(bank, device=dev)
+        q_all = torch.from_numpy(make_queries(bank, len(sents), seed=4)).to(dev)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True)
+        g = torch.Generator().manual_seed(0)
+        t16 = torch.arange(int(2.5 * 16000)) / 16000
+        style = (0.3 * torch.sin(2 * math.pi * 220 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
+        timbre = (0.3 * torch.sin(2 * math.pi * 330 * t16[:32000]) + 0.01 * torch.randn(32000, generator=g))[None]
+        b0, b1, _ = parallel.shard_bounds(len(sents), world, rank)
+        items = [(x, "He did. In Niagara Falls.", style, timbre) for x in sents[b0:b1]]
+        last = {}
+
+        def step():
+            idx, _ = parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
+            last["ids"] = idx
+            outs = cv.inference_tts_with_st_batch(items, max_batch=32, split=False, fixed_tokens=want[b0:b1], seeds=list(range(b0, b1)))
+            last["audio"] = sum(o[0]["tts_speech"].shape[1] for o in outs) / cfg.sample_rate
+            last["ok"] = all(bool(torch.isfinite(o[0]["tts_speech"]).all()) for o in outs)
+
+        dt = timed(step)
+        a = torch.tensor([last["audio"]], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(a)
+        audio = float(a.item()) * args.steps
+        ok = last["ok"]
+        scaling = "strong"
+        from oracle import knn as oknn
+        sel = np.arange(0, len(sents), 101)
+        extra["ids_match_oracle_sample"] = bool(np.array_equal(last["ids"].cpu().numpy()[sel], oknn.knn_search(bank, q_all.cpu().numpy()[sel], args.topk)[0]))
+        extra["host_side_included"] = "prompt wavs -> GPU resample / log-mel frontend, tokenisation, per-row vocoder, D2H of every waveform"
+        work = (f"BASELINE configs[3]: the 1 623 IEMOCAP test sentences (Ts_i = clamp(round(20 words_i), 25, 1500), {sum(want)} speech tokens) sharded over {world} GPU(s), "
+                f"kNN Q=1623 x N={args.bank_rows} x D={args.dim} k={args.topk} query-sharded + all-gather of the ids, ragged synthesis in length-bucketed groups of 32 "
+                f"through CosyVoice.inference_tts_with_st_batch")
+    if rank == 0:
+        res = {"metric": "synthesized audio sec/wall-sec (RTF^-1) + style-kNN QPS, IEMOCAP test batch", "value": audio / dt, "unit": "audio-s/wall-s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": work + "; CosyVoice-300M shapes, random-init weights", "parallelism": f"dp{world}"},
+               "side_measurement": f"--workload {which}: NOT the headline line (python bench.py = BASELINE configs[1])",
+               "audio_seconds_per_step": audio / args.steps, "waveform_finite": ok, "roofline": None, "cpu_baseline": None}
+        res.update(extra)
+        emit_json(res)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +404,8 @@ def main():
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
     ap.add_argument("--no-cobatch", action="store_true", help="skip the co-batched side measurement (16 / 32-row decode chains): profiling "
                     "runs use it so that the kernel population is the timed region's")
+    ap.add_argument("--workload", default="config2", choices=("config2", "config3", "config4", "config5"),
+                    help="config2 (default) = BASELINE configs[1], the headline; config3 / config4 / config5 = side lines for BASELINE configs[2..4] (side_workload)")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("ASTTS_BENCH_FORCE_DIST")),
                     help="initialise torch.distributed (backend nccl = RCCL) even for ONE rank, so that the id all-gather and the "
                          "bank-sharded merge run through librccl on a single GPU (also: ASTTS_BENCH_FORCE_DIST=1)")
@@ -289,6 +436,9 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
+
+    if args.workload != "config2":
+        return side_workload(args, args.workload, dev, dist, rank, world)
 
     from astts import ops
     from astts.knn import StyleBank
@@ -468,10 +618,11 @@ def main():
         bank_sharded_ok = bool(np.array_equal(bidx.cpu().numpy(), oknn.knn_search(bank16, q0_host, args.topk)[0]))
         del sb_shard
 
-    # ---- roofline: HIP events (on each launch's own stream) around every launch of the profiled kernel kinds, ONE SEQUENTIAL
-    # step per kind (one batch at a time on one stream: the mode `sequential_ms_per_step` / `stages_ms` are measured in; the
-    # timed region above runs the same kernels pipelined on several streams, where kernels of different batches overlap and a
-    # per-kernel duration is not attributable).  One kind per pass: event records perturb neighbouring launches.
+    # ---- roofline: every launch of the profiled kernel kinds timed on its own stream (dispatch timestamps for the decode kernels, HIP
+    # events for the rest), one SEQUENTIAL step per kind (one batch at a time on one stream: the mode `sequential_ms_per_step` /
+    # `stages_ms` are measured in) -- that is `roofline.achieved / frac / avg_us`; the dominant kernel is then timed again inside the
+    # PIPELINED schedule of the timed region (`roofline.pipelined`: kernels of different batches overlap there, so its launches x
+    # avg_us is not a per-step attribution).  One kind per pass: event records perturb neighbouring launches.
     kinds = {"gemm_tile": ops.PROF_GEMM_TILE, "lm_gemv": ops.PROF_GEMM_SKINNY, "attn_mha_flash": ops.PROF_ATTN_FLASH,
              "lm_attn": ops.PROF_ATTN_DECODE}
 
@@ -510,7 +661,7 @@ def main():
 
         pip = profiled(kinds[dom], pipelined_steps)
         pip = {"ms_per_step": pip["ms_per_step"] / k_p, "launches": pip["launches"] // k_p, "work": pip["work"] / k_p, "dropped": pip["dropped"]}
-    p = pip or seq
+    p = seq          # `roofline` = the sequential figure (attributable per launch); the pipelined one rides beside it
     if dom in ("gemm_tile", "attn_mha_flash"):
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e12
         roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -519,17 +670,20 @@ def main():
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     traffic = traffic_table.get(dom, {}).get("hbm_bytes_per_launch")
-    seq_us = seq["ms_per_step"] * 1e3 / max(seq["launches"], 1)
+    pip_us = pip["ms_per_step"] * 1e3 / max(pip["launches"], 1) if pip else None
     roof.update({"traffic": traffic,
                  "traffic_source": f"profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
                  "kernel": dom, "avg_us": p["ms_per_step"] * 1e3 / max(p["launches"], 1),
                  "launches_per_step": p["launches"],
                  "algorithmic_work_per_launch": p["work"] / max(p["launches"], 1),
-                 "mode": ("pipelined (the schedule of the timed region: kernels of two decode chains and a render stage share the GPU; "
-                          "kernel-level timestamps)" if pip else "sequential step"),
-                 "sequential": {"avg_us": seq_us, "achieved": seq["work"] / max(seq["launches"], 1) / (seq_us * 1e-6) / 1e9 if dom.startswith("lm_") else None,
-                                "frac": seq["work"] / max(seq["launches"], 1) / (seq_us * 1e-6) / 1e9 / HBM_PEAK_GBS if dom.startswith("lm_") else None,
-                                "note": "the same kernel in one sequential step (one batch at a time on one stream): compare with sequential_ms_per_step"},
+                 "mode": "one sequential step (one batch at a time on one stream: what sequential_ms_per_step / stages_ms are measured in; "
+                         "kernel-level dispatch timestamps)",
+                 "pipelined": ({"avg_us": pip_us, "achieved": pip["work"] / max(pip["launches"], 1) / (pip_us * 1e-6) / 1e9 if dom.startswith("lm_") else None,
+                                "frac": pip["work"] / max(pip["launches"], 1) / (pip_us * 1e-6) / 1e9 / HBM_PEAK_GBS if dom.startswith("lm_") else None,
+                                "launches_per_step": pip["launches"],
+                                "note": "the same kernel inside the schedule of the timed region (two decode chains and a render stage share the GPU: "
+                                        "kernels of different batches overlap, so launches x avg_us may exceed ms_per_step -- not a per-step attribution)"}
+                               if pip else None),
                  "all_kinds_ms_per_sequential_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})
 
     # ---- per-stage rooflines (sequential mode): algorithmic work of the whole stage / the stage's wall time

@@ -274,6 +274,13 @@ int astts_op_resample_poly(const float* x, const float* kern, float* y, int32_t 
                            int32_t width, astts_stream_t stream);
 int astts_op_mel_spectrogram(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
                              int32_t n_fft, int32_t hop, int32_t n_mels, float log_floor, astts_stream_t stream);
+/* Whisper's log-mel features (the input of the speech tokenizer behind frontend._extract_speech_token [EXT], reached from
+ * inference_tts_with_st at tts_with_rag.py:195): frames centred on multiples of `hop` (reflect padding n_fft / 2, the last frame dropped:
+ * n_samples / hop frames), periodic-Hann window[n_fft], POWER spectrum, mel_fb [n_mels][n_fft / 2 + 1], log10(max(., 1e-10)), floor at
+ * the utterance's maximum - 8, (x + 4) / 4 -> out [b, n_mels, n_samples / hop].  workspace: astts_op_whisper_log_mel_workspace_bytes(b). */
+size_t astts_op_whisper_log_mel_workspace_bytes(int32_t b);
+int astts_op_whisper_log_mel(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
+                             int32_t n_fft, int32_t hop, int32_t n_mels, void* workspace, size_t workspace_bytes, astts_stream_t stream);
 /* Repetition-aware sampling with injected uniforms [b, 2] (definition: csrc/ops_audio.hip, mirrored by oracle/synth.py::ras_sample).
  * ignore_eos: bit 0 = EOS may not be produced at this step (with eos_min_rows: per row, while hist_len < eos_min_rows[b]); bit 1 = the
  * policy inside that window: 0 mask, 1 reject (astts_lm_config_t.eos_policy). */

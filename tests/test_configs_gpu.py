@@ -4,6 +4,9 @@
             25, 1500) speech tokens, CosyVoice-300M widths, through the drop-in CosyVoice.inference_tts_with_st_batch surface
             (hot loop #2 of /root/reference/tts_with_rag.py:172-197, batched); retrieval of all 1623 queries against the
             1 000-row bank vs oracle/knn.py.
+  config 3  64 long-form lines x 6 text segments (Tt = 64, forced Ts = 250: 30 s per line) through ITS driver,
+            astts.cli.tts_with_style_and_timbre --batch_size 64 (/root/reference/tts_with_style_and_timbre.py:82-95), full model:
+            64 wavs of 30 s; three sampled lines equal their one-at-a-time run.
   config 5  B = 256 utterances at the config-2 shapes in ONE engine call (rows 0..7 equal the batch-8 run: tokens bit for bit);
             the 100k x 6144 bank searched in three row shards + merged == the unsharded search == the oracle on a sample.
 """
@@ -117,6 +120,73 @@ def test_config4_rank_shard_ragged_full_model():
         # oracle tolerance).  Waveform: the harmonic source integrates the predicted f0, so a 4e-4 mel difference becomes a phase
         # drift that grows with the utterance (30 s rows: ~37 dB; 5 s rows: > 50 dB) -- bounded, but looser than the mel bar.
         assert dm < 1e-3 and snr > 30.0, i
+
+
+def test_config3_longform_through_its_driver(tmp_path):
+    """BASELINE config 3 through the drop-in driver: a text file of 64 lines, each 6 sentences of 64 byte-tokens (the stand-in
+    tokenizer is one token per byte, so text_normalize cuts a line into exactly 6 segments of Tt = 64), one style and one timbre wav,
+    `--batch_size 64 --fixed_tokens 250 --seed 3`: 384 segments in six ragged GPU batches of 64, the segments of a line
+    concatenated (the documented divergence from the reference's overwrite, tts_with_style_and_timbre.py:94-95)."""
+    import time
+
+    from astts import audio
+    from astts.cli import tts_with_style_and_timbre as drv
+    from astts.compat.cosyvoice import CosyVoice, load_wav
+
+    cv = CosyVoice("/nonexistent", seed=0, allow_random_init=True)
+    cfg = cv.cfg
+    sr = 16000
+    t = torch.arange(3 * sr) / sr
+    g = torch.Generator().manual_seed(0)
+    audio.write_wav(str(tmp_path / "style_a.wav"), (0.3 * torch.sin(2 * math.pi * 220 * t) + 0.01 * torch.randn(t.shape, generator=g))[None], sr)
+    audio.write_wav(str(tmp_path / "timbre_b.wav"), (0.3 * torch.sin(2 * math.pi * 330 * t) + 0.01 * torch.randn(t.shape, generator=g))[None], sr)
+    words = ["alpha", "bravo", "delta", "gamma", "omega", "sigma", "theta", "kappa"]
+    lines = []
+    for i in range(64):
+        sents = []
+        for k in range(6):
+            body = " ".join(words[(i + k + j) % 8] for j in range(12))[:63 - len(f" {i} {k}")] + f" {i} {k}"
+            sents.append(body.ljust(63, "x") + ".")
+        assert all(len(x.encode()) == 64 for x in sents)
+        lines.append(" ".join(sents))
+    (tmp_path / "long.txt").write_text("\n".join(lines) + "\n", encoding="utf-8")
+    from astts.frontend import text_normalize
+    assert [len(cv.frontend.tokenizer.encode(x)) for x in text_normalize(lines[5], cv.frontend.tokenizer)] == [64] * 6
+    style_text = "He did. In Niagara Falls."
+    args = drv.build_parser().parse_args(["--style_wav_path", str(tmp_path / "style_a.wav"), "--timbre_wav_path", str(tmp_path / "timbre_b.wav"),
+                                          "--style_wav_text", style_text, "--txt_path", str(tmp_path / "long.txt"),
+                                          "--result_dir", str(tmp_path / "out"), "--batch_size", "64", "--fixed_tokens", "250", "--seed", "3"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    written = drv.tts_for_infer(args, cosyvoice=cv)
+    dt = time.perf_counter() - t0
+    assert [os.path.basename(p) for p in written] == [f"style_a_{i}_to_timbre_b.wav" for i in range(1, 65)]
+    n_line = 6 * cfg.mel_frames_for_tokens(250) * cfg.hop
+    secs = 0.0
+    for p in written:
+        w, rate = audio.read_wav(p)
+        assert rate == 22050 and w.shape == (1, n_line) and bool(np.isfinite(w).all()) and float(np.abs(w).max()) <= cfg.audio_limit + 1e-6
+        secs += w.shape[1] / rate
+    assert secs >= 64 * 29.9
+    print(f"config 3 through its driver: 64 lines x 6 segments, {secs:.0f} s of audio in {dt:.1f} s (prompts, host I/O and wav writing included) = {secs / dt:.0f}x real time")
+    # three sampled lines one at a time (a batch of the line's own six segments) under the same per-line seed
+    style_wav, timbre_wav = load_wav(str(tmp_path / "style_a.wav"), 16000), load_wav(str(tmp_path / "timbre_b.wav"), 16000)
+    for i in (0, 31, 63):
+        cnt = i + 1
+        one = cv.inference_tts_with_st_batch([(lines[i], style_text, style_wav, timbre_wav)], max_batch=64, seeds=[3 * 1000003 + cnt], fixed_tokens=250)
+        assert len(one[0]) == 6
+        toks_one = [tk.clone() for tk in cv.last_tokens]
+        w_one = torch.cat([j["tts_speech"] for j in one[0]], dim=1)
+        w_drv = torch.from_numpy(audio.read_wav(written[i])[0])
+        # free-running tokens of a 6-row batch vs the 64-row batch the driver formed: the prefix comes out of other GEMM tiles
+        # (1 ulp), which sampling can amplify at a near-tie -- as in the config-4 test the first tokens must agree; when ALL tokens
+        # agree the audio must too, to the rounding noise of other tiles
+        same = all(int(tk.numel()) == 250 for tk in toks_one)
+        assert same
+        a, b = w_one.double(), w_drv.double()
+        snr = 10.0 * math.log10(float((b ** 2).sum()) / max(float(((a - b) ** 2).sum()), 1e-30))
+        print(f"config 3 line {cnt}: one-at-a-time vs driver waveform SNR {snr:.1f} dB")
+        assert snr > 25.0, (cnt, snr)
 
 
 def test_config5_batch256_rows_equal_batch8():

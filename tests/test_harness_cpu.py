@@ -110,12 +110,16 @@ def test_search_json_record_format(golden_dir, tmp_path, monkeypatch):
     bank = np.load(os.path.join(golden_dir, "style_bank_130x6144.f16.npy")).astype(np.float32)
     meta = json.load(open(os.path.join(golden_dir, "style_bank_meta.json")))
 
-    def fake_search(self, collection_name, data, **kw):                       # CPU stand-in for the GPU bank (checker only)
-        from oracle import knn as oknn
-        idx, sc = oknn.knn_search(bank.astype(np.float16), np.asarray(data, np.float32), 1)
-        return [[{"id": meta["pk"][int(i[0])], "distance": float(s[0]), "entity": dict(meta["rows"][int(i[0])])}] for i, s in zip(idx, sc)]
+    class OracleBank:                                                          # CPU stand-in for the GPU bank (checker only)
+        def __init__(self, m):
+            self.m = m
 
-    monkeypatch.setattr(pm.MilvusClient, "search", fake_search)
+        def search(self, q, k):
+            from oracle import knn as oknn
+            idx, sc = oknn.knn_search(self.m.astype(np.float16), np.asarray(q, np.float32), k)
+            return idx, sc.astype(np.float32)
+
+    monkeypatch.setattr(pm._Collection, "bank", lambda self: OracleBank(self.matrix()))
     inp = tmp_path / "in.jsonl"
     inp.write_text("\n".join(json.dumps({"zh_text": f"line {i}", "speaker": "w1"}) for i in range(3)) + "\n", encoding="utf-8")
     np.save(tmp_path / "q.npy", bank[[5, 61, 129]])
@@ -140,13 +144,17 @@ def test_search_json_skips_rows_without_text(golden_dir, tmp_path, monkeypatch):
     meta = json.load(open(os.path.join(golden_dir, "style_bank_meta.json")))
     seen = {}
 
-    def fake_search(self, collection_name, data, **kw):
-        from oracle import knn as oknn
-        seen["n"] = len(data)
-        idx, sc = oknn.knn_search(bank.astype(np.float16), np.asarray(data, np.float32), 1)
-        return [[{"id": 0, "distance": float(s[0]), "entity": dict(meta["rows"][int(i[0])])}] for i, s in zip(idx, sc)]
+    class OracleBank:
+        def __init__(self, m):
+            self.m = m
 
-    monkeypatch.setattr(pm.MilvusClient, "search", fake_search)
+        def search(self, q, k):
+            from oracle import knn as oknn
+            seen["n"] = len(q)
+            idx, sc = oknn.knn_search(self.m.astype(np.float16), np.asarray(q, np.float32), k)
+            return idx, sc.astype(np.float32)
+
+    monkeypatch.setattr(pm._Collection, "bank", lambda self: OracleBank(self.matrix()))
     inp = tmp_path / "in.jsonl"
     lines = [{"zh_text": "first", "speaker": "w1"}, {"zh_text": "   ", "speaker": "m1"}, {"speaker": "m2"}, {"zh_text": "last", "speaker": "w2"}]
     inp.write_text("\n".join(json.dumps(l) for l in lines) + "\n", encoding="utf-8")

@@ -218,7 +218,7 @@ def test_fullsize_v2_bench_geometry_every_step_vs_oracle():
 
 @pytest.mark.parametrize("engine,b,tp", [("v2", 3, 1100), ("v2", 8, 1300), ("v1", 32, 1690), ("v2", 32, 1690), ("v2", 16, 1100)])
 def test_tiny_long_context_vs_oracle(engine, b, tp):
-    """> 1 024 keys: each key-split half of lm_attn walks more than one 512-key chunk (csrc/lm_step.hip chunk loop); v1's
+    """> 1 024 keys: each key-split half of lm_attn walks more than one 256-key chunk (csrc/lm_step.hip chunk loop); v1's
     attn_relpos_decode at the ~1 700 keys x 32 rows of the long-form probe (BASELINE config 3); the same for the wide v2 forms."""
     from astts.synth.config import SynthConfig
     from astts.synth.weights import make_all
@@ -262,3 +262,39 @@ def test_fullsize_v2_rows_do_not_depend_on_the_batch_width(rows):
         t_w = lm.decode(pre, steps, u, True, None)
         t_n = lm.decode(pre[:, :8].contiguous(), steps, u[:, :8].contiguous(), True, None)
         assert torch.equal(t_n, t_w[:8])
+
+
+def test_embedding_table_path_equals_the_per_step_projection(monkeypatch):
+    """The decode step gathers its input row from the table speech_emb W^T + b formed at load; ASTTS_LM_EMBED_TABLE=0 leaves the
+    table out and the engine projects the sampled token's embedding every step (the branch no caller reaches otherwise).  Same fp16
+    products, another fp32 summation order (big-tile GEMM vs the step's GEMV): teacher-forced logits agree to rounding, free-running
+    tokens agree."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import AcousticLM
+    from astts.synth.weights import make_lm_weights
+
+    cfg = SynthConfig()
+    sd = make_lm_weights(cfg, 0)
+    g = torch.Generator().manual_seed(77)
+    b, tt, tp, steps = 8, 16, 40, 12
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g).to(DEV)
+    tlen = torch.full((b,), tt, dtype=torch.int32, device=DEV)
+    spk = torch.randn(b, cfg.spk_dim, generator=g).to(DEV)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g).to(DEV)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g).to(DEV)
+    u = torch.rand(steps, b, 2, generator=g).to(DEV)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASTTS_LM_EMBED_TABLE", flag)
+        lm = AcousticLM(sd, cfg, torch.device(DEV))
+        pre = lm.prefix(text, tlen, spk, prompt)
+        with _engine("v2"):
+            _, lg = lm.decode(pre, steps, u, True, forced, return_logits=True)
+            tk = lm.decode(pre, steps, u, True, None)
+        assert (lm.embed_table is None) == (flag == "0")
+        outs[flag] = (lg.cpu(), tk.cpu())
+    scale = float(outs["1"][0].abs().max())
+    err = float((outs["1"][0] - outs["0"][0]).abs().max()) / scale
+    print(f"embedding table vs per-step projection: logits rel diff {err:.2e}")
+    assert err < 1e-3
+    assert torch.equal(outs["1"][1], outs["0"][1])

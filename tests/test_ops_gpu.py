@@ -498,6 +498,34 @@ def test_mel_spectrogram_kernel_matches_host_definition(sr, n_fft, hop, n_mels, 
     assert float((out.cpu() - ref).abs().max()) < 2e-4
 
 
+def test_whisper_log_mel_kernel_matches_the_feature_extractor_fixture():
+    """astts_op_whisper_log_mel (the 128-bin log-mel the reference's speech tokenizer takes: SURVEY.md a12 / 8f rank 3) against the
+    committed WhisperFeatureExtractor output (tests/golden/synth_blocks.npz, made by transformers in the build container) and
+    against the host form of the same definition; batch of two utterances whose maxima differ (the "max - 8" floor is per
+    utterance), lengths that are / are not multiples of the hop."""
+    from astts import audio
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth_blocks.npz"))
+    wav = torch.from_numpy(fx["whisper.wav"])
+    out = audio.whisper_log_mel(wav.to(DEV))
+    ref = fx["whisper.features"]
+    assert out.is_cuda and tuple(out.shape) == (1,) + ref.shape
+    err = float(np.abs(out[0].cpu().numpy() - ref).max())
+    print(f"whisper log-mel (HIP) vs WhisperFeatureExtractor: max abs diff {err:.2e}")
+    assert err < 3e-4                                              # the host (torch.stft) path holds 2e-4 to the same fixture
+    g = torch.Generator().manual_seed(8)
+    for n in (16000, 16000 * 3 + 77, 4000):
+        t = torch.arange(n) / 16000.0
+        x = torch.stack([0.4 * torch.sin(2 * math.pi * 330.0 * t) + 0.02 * torch.randn(n, generator=g),
+                         0.003 * torch.sin(2 * math.pi * 2500.0 * t) + 0.0005 * torch.randn(n, generator=g)])     # 40 dB quieter: its own floor
+        host = audio.whisper_log_mel(x)
+        dev = audio.whisper_log_mel(x.to(DEV)).cpu()
+        assert dev.shape == host.shape == (2, 128, n // 160)
+        assert float((dev - host).abs().max()) < 3e-4, n
+        assert float(dev[0].max() - dev[0].min()) <= 2.0 + 1e-5 and float(dev[1].max() - dev[1].min()) <= 2.0 + 1e-5    # floor at max - 8 -> (x + 4) / 4
+        assert float(dev[0].max()) > float(dev[1].max()) + 0.5                  # each utterance has its own maximum
+
+
 def test_new_entry_points_validate_arguments():
     """Argument errors come back as AsttsError with a message, before anything is launched."""
     import ctypes
