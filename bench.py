@@ -108,20 +108,37 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, ts=250):
     nh = cfg.nb_harmonics + 1
     ph = torch.zeros(b, nh)
     noise = torch.randn(b, tm * cfg.upsample_total, nh, generator=g)
+    with torch.no_grad():
+        # The decode loop is 250 x 14 layers of one-row GEMVs: with all 64 threads of the GPU host it ran 5x SLOWER than with 8
+        # (fork / join per small operator).  Untimed calibration: a few decode steps per thread count, the fastest one decodes.
+        pre = osyn.lm_prefix(weights["llm"], cfg, text, tlen, spk, tok_p)
+        lm_threads, best = threads, float("inf")
+        for n in sorted({min(threads, c) for c in (4, 8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            osyn.lm_decode(weights["llm"], cfg, pre, 2, u[:2], True, None)          # warm: position tables, allocator
+            tc = time.perf_counter()
+            osyn.lm_decode(weights["llm"], cfg, pre, 4, u[:4], True, None)
+            tc = time.perf_counter() - tc
+            if tc < best:
+                lm_threads, best = n, tc
+        torch.set_num_threads(threads)
     t0 = time.perf_counter()
     with torch.no_grad():
         oknn.knn_search_fast_f32(bank16.astype(np.float32),
                                  (1.0 / np.linalg.norm(bank16.astype(np.float64), axis=1)).astype(np.float32), q_host, k)
         tk = time.perf_counter()
+        torch.set_num_threads(lm_threads)
         pre = osyn.lm_prefix(weights["llm"], cfg, text, tlen, spk, tok_p)
         toks, _ = osyn.lm_decode(weights["llm"], cfg, pre, ts, u, True, None)
+        torch.set_num_threads(threads)
         t1 = time.perf_counter()
         mel = osyn.flow_decode(weights["flow"], cfg, torch.cat([tok_p, toks.long()], 1), torch.full((b,), tp + ts), mel_p, spk, z, tmp + tm)
         t2 = time.perf_counter()
         wav = osyn.hift_forward(weights["hift"], cfg, mel, ph, noise)
     t3 = time.perf_counter()
     audio = wav.shape[1] / cfg.sample_rate
-    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "cpu": cpu_model_string(), "kind": "port",
+    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "threads_by_stage": {"lm": lm_threads, "flow": threads, "vocoder": threads},
+            "cpu": cpu_model_string(), "kind": "port",
             "sample": f"one full-length utterance of the batch (B=1, Tt={tt}, {tp}-token prompt, Ts={ts} tokens = {audio:.2f} s of audio) "
                       f"+ kNN of the 8 queries; oracle/ fp32 torch-CPU",
             "stage_seconds": {"knn": round(tk - t0, 4), "lm": round(t1 - tk, 2), "flow": round(t2 - t1, 2), "vocoder": round(t3 - t2, 2)}}
@@ -571,7 +588,7 @@ def main():
     knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
     traffic_table = {}
     traffic_file = None
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
         try:                                                 # FETCH_SIZE, own pass; cannot be collected inside this run)
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_table = json.load(f)

@@ -44,7 +44,7 @@ def alone(s_r, s_c):
 base = PipelinedSynth(eng, lm_depth=2, lm_priority=0, render_priority=0, pipe_classes=classes)
 lm0, rd0 = alone(base.s_render, base.s_lm[0])
 print(f'unmasked: decode alone {lm0:.1f} ms, render alone {rd0:.1f} ms; pipelined {run(base):.1f} ms/batch, again {run(base):.1f}', flush=True)
-for n_chain, share in ((32, True), (48, True), (64, True), (64, False), (96, True), (128, True), (0, True)):
+for n_chain, share in (() if os.environ.get('PROBE2_ONLY_CHAINS') else ((32, True), (48, True), (64, True), (64, False), (96, True), (128, True), (0, True))):
     try:
         n_r = 256 - n_chain if n_chain else 192
         s_r = ops.cu_masked_stream(list(range(n_r)), dev)
@@ -61,3 +61,15 @@ for n_chain, share in ((32, True), (48, True), (64, True), (64, False), (96, Tru
               f'pipelined {run(pipe):.1f} ms/batch, again {run(pipe):.1f}', flush=True)
     except Exception as e:
         print('partition', n_chain, 'failed:', repr(e)[:300], flush=True)
+
+# chains confined to the HIGH n mask bits, render unrestricted: decode workgroups then never sit on the other CUs, so the render
+# stage's one-workgroup-per-CU kernels are only delayed on the chains' share of the chip
+for n_chain in (224, 192, 160, 128, 96):
+    try:
+        lm = [ops.cu_masked_stream(list(range(256 - n_chain, 256)), dev) for _ in range(2)]
+        pipe = PipelinedSynth(eng, lm_depth=2, lm_priority=0, render_priority=0, streams=lm + [classes[0][0]])
+        l1, r1 = alone(classes[0][0], lm[0])
+        print(f'render unmasked / chains high {n_chain} (shared): decode alone {l1:.1f} ms, render alone {r1:.1f} ms; '
+              f'pipelined {run(pipe):.1f} ms/batch, again {run(pipe):.1f}', flush=True)
+    except Exception as e:
+        print('chains-only mask', n_chain, 'failed:', repr(e)[:300], flush=True)

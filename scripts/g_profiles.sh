@@ -1,6 +1,6 @@
 # Round profiles (run on the GPU box through gpurun): kernel stats of the benchmark command, PMC passes for HBM traffic and LDS conflicts.
-# Usage: bash scripts/g_profiles.sh r03
-R=${1:-r03}
+# Usage: bash scripts/g_profiles.sh r04
+R=${1:-r04}
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
 rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o b --output-format csv -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-24khz --no-cobatch > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err
 python3 scripts/demangle_csv.py $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
@@ -9,6 +9,18 @@ rm -rf /tmp/p4 && PROBE_TS=250 PROBE_ITERS=2 rocprofv3 --kernel-trace --stats -d
 python3 scripts/demangle_csv.py $(find /tmp/p4 -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_sequential_kernel_stats.csv
 rm -rf /tmp/p2 && PROBE_TS=12 PROBE_ITERS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p2 -o p --output-format csv -- python3 scripts/fullsize_probe.py > /dev/null 2>&1
 ( echo "== rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 scripts/fullsize_probe.py (PROBE_TS=12 PROBE_ITERS=1); per kernel: (launches, mean FETCH_SIZE [KB] per launch); HBM bytes = value * 1024 * 2 on gfx950"; python scripts/pmc_summary.py /tmp/p2 gpurun_out/${R}_traffic_raw.json ) > gpurun_out/${R}_pmc_fetch_synth.txt
+# the retrieval scan at the benchmark's shape (1000 x 6144 fp16 bank, Q = 8): its own FETCH_SIZE pass -> knn_roofline.traffic of the bench line
+rm -rf /tmp/p5 && KNN_ITERS=50 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p5 -o k --output-format csv -- python3 scripts/knn_small.py > /dev/null 2>&1
+( echo "== rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 scripts/knn_small.py (config-2 retrieval: N=1000, D=6144, Q=8, k=3)"; python scripts/pmc_summary.py /tmp/p5 gpurun_out/${R}_traffic_knn_raw.json ) > gpurun_out/${R}_pmc_fetch_knn.txt
+python3 - <<PY
+import json
+t = json.load(open("gpurun_out/${R}_traffic_raw.json"))
+k = json.load(open("gpurun_out/${R}_traffic_knn_raw.json"))
+if "knn_scan" in k:
+    t["knn_scan_1000_x_6144"] = k["knn_scan"]
+json.dump(t, open("gpurun_out/${R}_traffic.json", "w"), indent=1)
+print("traffic table:", {n: v["hbm_bytes_per_launch"] for n, v in t.items()})
+PY
 rm -rf /tmp/p3 && FLOW_N=1 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES -d /tmp/p3 -o p --output-format csv -- python3 scripts/flow_only.py > /dev/null 2>&1
 ( echo "== rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/flow_only.py (FLOW_N=1: warm-up + 1 solve); per kernel: (launches, mean counter value per launch)"; python scripts/pmc_summary.py /tmp/p3 ) > gpurun_out/${R}_pmc_flow_lds.txt
 head -12 gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-150; cat gpurun_out/${R}_pmc_fetch_synth.txt | head -12; cat gpurun_out/${R}_pmc_flow_lds.txt | head -8
