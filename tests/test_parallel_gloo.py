@@ -1,4 +1,4 @@
-"""CPU test of the N>1 path: world_size-2 gloo processes run the query-sharded search + all-gather
+"""CPU test of the N>1 path: world_size-2 and world_size-8 gloo processes run the query-sharded search + all-gather
 logic of astts.parallel.  The per-rank bank search is the ORACLE here (checker only -- the product's
 search_fn is StyleBank.search_device, which needs a GPU)."""
 import os
@@ -52,14 +52,14 @@ def _worker(rank, world, port, nq, k, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nq", [8, 7, 1])
-def test_sharded_search_world2(nq):
-    world = 2
+@pytest.mark.parametrize("world,nq", [(2, 8), (2, 7), (2, 1), (8, 203), (8, 5)])
+def test_sharded_search_over_ranks(world, nq):
+    """world 8 = the node the north star names: 203 queries = 7 shards of 26 and one of 21; 5 queries leave three ranks empty."""
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
     mp.spawn(_worker, args=(world, port, nq, 3, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_shard_bounds_cover_everything():
@@ -113,13 +113,14 @@ def _worker_bank(rank, world, port, n, nq, k, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,nq,k", [(301, 9, 3), (5, 4, 3)])
-def test_bank_sharded_search_world2(n, nq, k):
-    world = 2
+@pytest.mark.parametrize("world,n,nq,k", [(2, 301, 9, 3), (2, 5, 4, 3), (8, 1000, 9, 3), (8, 13, 4, 3)])
+def test_bank_sharded_search_over_ranks(world, n, nq, k):
+    """world 8: 1 000 rows = 125 per rank (BASELINE config 5's layout at the config-2 bank size); 13 rows = 2 per rank, the last rank
+    short, every shard shorter than k."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_bank, args=(world, _free_port(), n, nq, k, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_merge_topk_total_order():
