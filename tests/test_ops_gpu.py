@@ -2,6 +2,7 @@
 the same op.  Tolerances: fp16-operand / fp32-accumulate contractions are held to a relative error
 of 2e-3 of the output scale (operand rounding 2^-11); pure fp32 kernels to 1e-5..1e-4."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -512,7 +513,7 @@ def test_whisper_log_mel_kernel_matches_the_feature_extractor_fixture():
     assert out.is_cuda and tuple(out.shape) == (1,) + ref.shape
     err = float(np.abs(out[0].cpu().numpy() - ref).max())
     print(f"whisper log-mel (HIP) vs WhisperFeatureExtractor: max abs diff {err:.2e}")
-    assert err < 3e-4                                              # the host (torch.stft) path holds 2e-4 to the same fixture
+    assert err < 1e-4                                              # observed 2.1e-5 (the host torch.stft path: 2.3e-5)
     g = torch.Generator().manual_seed(8)
     for n in (16000, 16000 * 3 + 77, 4000):
         t = torch.arange(n) / 16000.0
@@ -521,7 +522,7 @@ def test_whisper_log_mel_kernel_matches_the_feature_extractor_fixture():
         host = audio.whisper_log_mel(x)
         dev = audio.whisper_log_mel(x.to(DEV)).cpu()
         assert dev.shape == host.shape == (2, 128, n // 160)
-        assert float((dev - host).abs().max()) < 3e-4, n
+        assert float((dev - host).abs().max()) < 1e-4, n               # observed <= 3e-5
         assert float(dev[0].max() - dev[0].min()) <= 2.0 + 1e-5 and float(dev[1].max() - dev[1].min()) <= 2.0 + 1e-5    # floor at max - 8 -> (x + 4) / 4
         assert float(dev[0].max()) > float(dev[1].max()) + 0.5                  # each utterance has its own maximum
 
