@@ -54,6 +54,8 @@ _SIGNATURES = {
     "astts_knn_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     # frontend signal processing (astts/audio.py)
     "astts_op_resample_poly": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_kaldi_fbank": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
+                                       c_float, c_void_p]),
     "astts_op_whisper_log_mel_workspace_bytes": (c_size_t, [c_int32]),
     "astts_op_whisper_log_mel": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_size_t,
                                            c_void_p]),

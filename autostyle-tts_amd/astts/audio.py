@@ -224,3 +224,61 @@ def whisper_log_mel(wav16k: torch.Tensor, n_mels: int = 128) -> torch.Tensor:
     log_spec = torch.log10(torch.clamp(torch.matmul(fb, power), min=1e-10))
     log_spec = torch.maximum(log_spec, log_spec.amax(dim=(1, 2), keepdim=True) - 8.0)
     return (log_spec + 4.0) / 4.0
+
+
+# ------------------------------------------------------------------------------------------ Kaldi fbank (speaker-net input)
+def kaldi_mel_filterbank(sr: int = 16000, n_fft: int = 512, n_mels: int = 80, fmin: float = 20.0, fmax: float = 0.0) -> np.ndarray:
+    """Kaldi's mel bank (compute-fbank-feats / torchaudio.compliance.kaldi.get_mel_banks): mel(f) = 1127 ln(1 + f / 700), n_mels + 2
+    points equally spaced in mel between fmin and fmax (<= 0: Nyquist + fmax), triangles drawn IN MEL SPACE over the FFT bin centres,
+    no area normalisation -> [n_mels, n_fft // 2 + 1] float32."""
+    hi = fmax if fmax > 0 else sr / 2 + fmax
+    mel = lambda f: 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+    pts = np.linspace(mel(fmin), mel(hi), n_mels + 2)
+    bins = mel(np.arange(n_fft // 2 + 1) * (sr / n_fft))
+    slopes = pts[None, :] - bins[:, None]                       # [bins, n_mels + 2]
+    d = np.diff(pts)
+    w = np.maximum(0.0, np.minimum(-slopes[:, :-2] / d[:-1], slopes[:, 2:] / d[1:]))
+    return w.T.astype(np.float32)
+
+
+def kaldi_fbank(wav16k: torch.Tensor, n_mels: int = 80, scale: float = 1.0, subtract_mean: bool = False, sr: int = 16000) -> torch.Tensor:
+    """The input features of the reference's speaker-embedding network (SURVEY.md 8a row a12: "spk-emb ... ONNX on 80-bin Kaldi fbank";
+    upstream frontend._extract_spk_embedding calls torchaudio.compliance.kaldi.fbank(speech, num_mel_bins=80, dither=0,
+    sample_frequency=16000) and subtracts the mean over time): 25 ms frames every 10 ms without padding (snip_edges), per frame: remove the
+    DC offset, pre-emphasis 0.97 (first sample x0 (1 - 0.97)), Povey window (hann^0.85, symmetric), zero-pad to 512, POWER spectrum,
+    Kaldi mel bank (20 Hz .. Nyquist), log(max(., float32 eps)).  ``scale``: what the samples are multiplied by first (Kaldi's own
+    tools read 16-bit integers: 32768; torchaudio and upstream take the [-1, 1] floats as they are: 1).  wav [B, n] or [n] ->
+    [B, 1 + (n - 400) // 160, n_mels] (any device; CUDA input: the HIP kernel astts_op_kaldi_fbank).  Pinned against transformers'
+    SeamlessM4TFeatureExtractor (its numpy "mimic Kaldi" path; tests/test_oracle_synth_blocks.py)."""
+    w = wav16k if wav16k.dim() == 2 else wav16k[None]
+    w = w.to(torch.float32)
+    flen, hop, n_fft = int(0.025 * sr), int(0.010 * sr), 512
+    b, n = w.shape
+    if n < flen:
+        raise ValueError(f"kaldi_fbank: {n} samples are shorter than one {flen}-sample frame")
+    frames = 1 + (n - flen) // hop
+    eps = 1.1920928955078125e-07
+    if w.is_cuda:
+        from . import _lib
+        key = ("kaldi", sr, n_mels, w.device.index)
+        tabs = _KERNEL_CACHE.get(key)
+        if tabs is None:
+            win = torch.from_numpy(np.power(np.hanning(flen), 0.85).astype(np.float32))
+            tabs = _KERNEL_CACHE[key] = (win.to(w.device), torch.from_numpy(kaldi_mel_filterbank(sr, n_fft, n_mels)).contiguous().to(w.device))
+        w = w.contiguous()
+        out = torch.empty((b, frames, n_mels), dtype=torch.float32, device=w.device)
+        _lib.check(_lib.load().astts_op_kaldi_fbank(w.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), out.data_ptr(), b, n, flen, hop, n_fft,
+                                                    n_mels, float(scale), 0.97, eps, _lib.stream_ptr()))
+    else:
+        idx = torch.arange(flen)[None, :] + hop * torch.arange(frames)[:, None]
+        fr = w[:, idx].double() * scale                                             # [B, frames, flen]
+        fr = fr - fr.mean(dim=-1, keepdim=True)
+        fr = torch.cat([fr[..., :1] * (1.0 - 0.97), fr[..., 1:] - 0.97 * fr[..., :-1]], dim=-1)
+        fr = fr * torch.from_numpy(np.power(np.hanning(flen), 0.85))
+        spec = torch.fft.rfft(fr, n=n_fft)
+        power = spec.real ** 2 + spec.imag ** 2
+        fb = torch.from_numpy(kaldi_mel_filterbank(sr, n_fft, n_mels)).double()
+        out = torch.log(torch.clamp(power @ fb.T, min=eps)).float()
+    if subtract_mean:
+        out = out - out.mean(dim=1, keepdim=True)
+    return out

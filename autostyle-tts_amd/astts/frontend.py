@@ -57,7 +57,8 @@ class EnergyVQSpeechTokenizer:
 
 
 class StatsSpeakerEmbedder:
-    """Deterministic stand-in for the speaker-embedding network: mean/std of 80-bin log-mel -> 192-d."""
+    """Deterministic stand-in for the speaker-embedding network: pooled statistics of its real INPUT -- the 80-bin Kaldi fbank of the
+    16 kHz prompt (``audio.kaldi_fbank``: what upstream's frontend hands campplus.onnx, before the mean over time is removed) -> 192-d."""
 
     def __init__(self, dim: int, seed: int = 4321):
         g = torch.Generator().manual_seed(seed)
@@ -66,9 +67,8 @@ class StatsSpeakerEmbedder:
 
     def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
         w = wav16k.to(self.device) if self.device is not None else wav16k
-        mel = audio.mel_spectrogram(w, sr=16000, n_fft=400, hop=160, win=400, n_mels=80, fmin=20.0, fmax=7600.0)[0].cpu()
-        mel = mel - mel.mean(dim=0, keepdim=True)
-        stats = torch.cat([mel.mean(dim=0), mel.std(dim=0)])
+        mel = audio.kaldi_fbank(w, n_mels=80)[0].cpu()            # [frames, 80]; upstream subtracts the mean over time before the network
+        stats = torch.cat([mel.mean(dim=0) - mel.mean(), (mel - mel.mean(dim=0, keepdim=True)).std(dim=0)])
         return (stats @ self.proj)[None, :]                                                 # [1, dim]
 
 

@@ -504,10 +504,17 @@ __global__ __launch_bounds__(256) void resample_poly(const float* __restrict__ x
 // WHISPER = the log-mel of Whisper's feature extractor (the input of the reference's speech tokenizer): centred frames
 // (reflect padding n_fft / 2), POWER spectrum, log10(max(., floor)), output [b][n_mels][frames], and the maximum over an utterance's
 // (frame, bin) values gathered in gmax[b] (order-preserving integer image of the float) for the "max - 8" floor of whisper_floor.
-template <bool WHISPER>
+// KALDI = the fbank of Kaldi's compute-fbank-feats (the input of the reference's speaker-embedding net): frames of
+// frame_len samples every hop samples WITHOUT padding, each scaled, freed of its DC offset, pre-emphasised (x[i] -= c x[i-1]; x[0] *=
+// 1 - c), multiplied by window[frame_len] and zero-padded to n_fft; power spectrum, natural log, output [b][frames][n_mels].
+enum { MEL_MATCHA = 0, MEL_WHISPER = 1, MEL_KALDI = 2 };
+template <int MODE>
 __global__ __launch_bounds__(256) void mel_frames(const float* __restrict__ wav, const float* __restrict__ window,
                                                   const float* __restrict__ fb, float* __restrict__ out, int64_t n, int frames,
-                                                  int n_fft, int hop, int n_mels, float floor_, int* __restrict__ gmax) {
+                                                  int n_fft, int hop, int n_mels, float floor_, int* __restrict__ gmax, int frame_len,
+                                                  float scale, float preemph) {
+    constexpr bool WHISPER = MODE == MEL_WHISPER;
+    constexpr bool KALDI = MODE == MEL_KALDI;
     extern __shared__ float sm[];
     float* fr = sm;                       // [n_fft] windowed frame
     float* twc = sm + n_fft;              // [n_fft] cos(2 pi i / n_fft)
@@ -516,29 +523,64 @@ __global__ __launch_bounds__(256) void mel_frames(const float* __restrict__ wav,
     const int f = blockIdx.x, bb = blockIdx.y, tid = threadIdx.x;
     const int pad = WHISPER ? n_fft / 2 : (n_fft - hop) / 2;
     const float* w = wav + (int64_t)bb * n;
-    for (int i = tid; i < n_fft; i += 256) {
-        int64_t s = (int64_t)f * hop + i - pad;
-        if (s < 0) s = -s;                                     // reflect (no edge repeat)
-        if (s >= n) s = 2 * (n - 1) - s;
-        s = s < 0 ? 0 : (s >= n ? n - 1 : s);
-        fr[i] = w[s] * window[i];
-        float sv, cv;
-        sincospif(2.0f * (float)i / (float)n_fft, &sv, &cv);
-        twc[i] = cv;
-        tws[i] = sv;
+    int n_time = n_fft;                                        // samples of the frame that can be non-zero
+    if constexpr (KALDI) {
+        __shared__ float s_part[4];
+        n_time = frame_len;
+        const float* src = w + (int64_t)f * hop;               // frames never reach beyond the signal (snip_edges)
+        float part = 0.0f;
+        for (int i = tid; i < n_fft; i += 256) {
+            const float v = i < frame_len ? src[i] * scale : 0.0f;
+            fr[i] = v;
+            part += v;
+            float sv, cv;
+            sincospif(2.0f * (float)i / (float)n_fft, &sv, &cv);
+            twc[i] = cv;
+            tws[i] = sv;
+        }
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if ((tid & 63) == 0) s_part[tid >> 6] = part;
+        __syncthreads();
+        const float mean = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (float)frame_len;
+        // pre-emphasis reads the neighbour's value BEFORE anybody overwrites it: values into registers, barrier, then write back
+        float cur[2], prv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            cur[j] = i < frame_len ? fr[i] - mean : 0.0f;
+            prv[j] = (i >= 1 && i < frame_len) ? fr[i - 1] - mean : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            if (i < frame_len) fr[i] = (i == 0 ? cur[j] * (1.0f - preemph) : cur[j] - preemph * prv[j]) * window[i];
+        }
+    } else {
+        for (int i = tid; i < n_fft; i += 256) {
+            int64_t s = (int64_t)f * hop + i - pad;
+            if (s < 0) s = -s;                                     // reflect (no edge repeat)
+            if (s >= n) s = 2 * (n - 1) - s;
+            s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+            fr[i] = w[s] * window[i];
+            float sv, cv;
+            sincospif(2.0f * (float)i / (float)n_fft, &sv, &cv);
+            twc[i] = cv;
+            tws[i] = sv;
+        }
     }
     __syncthreads();
     const int nb = n_fft / 2 + 1;
     for (int k = tid; k < nb; k += 256) {
         float re = 0.0f, im = 0.0f;
         int idx = 0;
-        for (int i = 0; i < n_fft; ++i) {
+        for (int i = 0; i < n_time; ++i) {
             re = fmaf(fr[i], twc[idx], re);
             im = fmaf(fr[i], tws[idx], im);
             idx += k;
             if (idx >= n_fft) idx -= n_fft;
         }
-        mag[k] = WHISPER ? re * re + im * im : sqrtf(re * re + im * im + 1e-9f);
+        mag[k] = (WHISPER || KALDI) ? re * re + im * im : sqrtf(re * re + im * im + 1e-9f);
     }
     __syncthreads();
     float vmax = -INFINITY;
@@ -674,8 +716,25 @@ int astts_op_mel_spectrogram(const float* wav, const float* window, const float*
     const int64_t frames = (n_samples + 2 * pad - n_fft) / hop + 1;
     ASTTS_REQUIRE(frames >= 1 && frames < (1 << 30), ASTTS_ERR_INVALID, "astts_op_mel_spectrogram: frames=%lld", (long long)frames);
     const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
-    hipLaunchKernelGGL(mel_frames<false>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
-                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor, (int*)nullptr);
+    hipLaunchKernelGGL(mel_frames<MEL_MATCHA>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
+                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor, (int*)nullptr, n_fft, 1.0f, 0.0f);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_kaldi_fbank(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples, int32_t frame_len,
+                         int32_t hop, int32_t n_fft, int32_t n_mels, float scale, float preemph, float log_floor, astts_stream_t stream) {
+    ASTTS_REQUIRE(wav && window && mel_fb && out, ASTTS_ERR_INVALID, "astts_op_kaldi_fbank: null pointer");
+    ASTTS_REQUIRE(b >= 1 && frame_len >= 16 && frame_len <= n_fft && n_fft <= 512 && hop >= 1 && n_mels >= 1 && log_floor > 0.0f, ASTTS_ERR_INVALID,
+                  "astts_op_kaldi_fbank: bad shape frame_len=%d n_fft=%d hop=%d n_mels=%d (one thread holds two samples of a frame: n_fft <= 512)",
+                  frame_len, n_fft, hop, n_mels);
+    ASTTS_REQUIRE(n_samples >= frame_len, ASTTS_ERR_INVALID, "astts_op_kaldi_fbank: %lld samples are shorter than one frame of %d",
+                  (long long)n_samples, frame_len);
+    const int64_t frames = 1 + (n_samples - frame_len) / hop;
+    ASTTS_REQUIRE(frames < (1 << 30), ASTTS_ERR_INVALID, "astts_op_kaldi_fbank: frames=%lld", (long long)frames);
+    const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
+    hipLaunchKernelGGL(mel_frames<MEL_KALDI>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, (hipStream_t)stream, wav, window, mel_fb, out,
+                       n_samples, (int)frames, n_fft, hop, n_mels, log_floor, (int*)nullptr, frame_len, scale, preemph);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -696,8 +755,8 @@ int astts_op_whisper_log_mel(const float* wav, const float* window, const float*
     // every key starts below any float's image (the image of -inf is 0x80000000 - 0xff800000 = 0x80800000 as int: still above INT_MIN)
     ASTTS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)workspace, (int)0x80000000u, (size_t)b, st));
     const size_t lds = sizeof(float) * ((size_t)3 * n_fft + n_fft / 2 + 1);
-    hipLaunchKernelGGL(mel_frames<true>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, st, wav, window, mel_fb, out, n_samples, (int)frames,
-                       n_fft, hop, n_mels, 1e-10f, (int*)workspace);
+    hipLaunchKernelGGL(mel_frames<MEL_WHISPER>, dim3((unsigned)frames, (unsigned)b), dim3(256), lds, st, wav, window, mel_fb, out, n_samples, (int)frames,
+                       n_fft, hop, n_mels, 1e-10f, (int*)workspace, n_fft, 1.0f, 0.0f);
     ASTTS_CHECK_LAUNCH();
     const int64_t total = (int64_t)b * n_mels * frames;
     hipLaunchKernelGGL(whisper_floor, dim3(grid_for_a(total)), dim3(256), 0, st, out, (const int*)workspace, (int64_t)n_mels * frames, total);

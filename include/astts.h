@@ -281,6 +281,13 @@ int astts_op_mel_spectrogram(const float* wav, const float* window, const float*
 size_t astts_op_whisper_log_mel_workspace_bytes(int32_t b);
 int astts_op_whisper_log_mel(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples,
                              int32_t n_fft, int32_t hop, int32_t n_mels, void* workspace, size_t workspace_bytes, astts_stream_t stream);
+/* Kaldi's fbank (compute-fbank-feats), the input of the speaker-embedding network behind frontend._extract_spk_embedding [EXT] (reached
+ * from inference_tts_with_st at tts_with_rag.py:195): frames of frame_len samples every hop samples without padding (1 + (n - frame_len) /
+ * hop of them), each multiplied by `scale`, freed of its DC offset, pre-emphasised (x[i] -= preemph x[i-1]; x[0] *= 1 - preemph), multiplied
+ * by window[frame_len] (Povey) and zero-padded to n_fft (<= 512); power spectrum, mel_fb [n_mels][n_fft / 2 + 1], log(max(., log_floor))
+ * -> out [b, frames, n_mels]. */
+int astts_op_kaldi_fbank(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples, int32_t frame_len,
+                         int32_t hop, int32_t n_fft, int32_t n_mels, float scale, float preemph, float log_floor, astts_stream_t stream);
 /* Repetition-aware sampling with injected uniforms [b, 2] (definition: csrc/ops_audio.hip, mirrored by oracle/synth.py::ras_sample).
  * ignore_eos: bit 0 = EOS may not be produced at this step (with eos_min_rows: per row, while hist_len < eos_min_rows[b]); bit 1 = the
  * policy inside that window: 0 mask, 1 reject (astts_lm_config_t.eos_policy). */

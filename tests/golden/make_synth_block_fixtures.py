@@ -17,6 +17,8 @@ oracle/synth.py restates, produced by independent third-party implementations of
   prompt log-mel     transformers.audio_utils.mel_filter_bank / spectrogram -> astts.audio.mel_filterbank / mel_spectrogram (a12 / a14)
   transformer block  torch.nn.TransformerEncoderLayer(norm_first=True, gelu) -> oracle.synth._tfm_block (the estimator's BasicTransformerBlock) (a14)
   nucleus set        TopPLogitsWarper (generation/logits_process.py) -> oracle.synth.nucleus (the sampler's candidate set)  (a13)
+  Kaldi fbank        SeamlessM4TFeatureExtractor._extract_fbank_features (numpy "mimic Kaldi" path)
+                                                         -> astts.audio.kaldi_fbank / kaldi_mel_filterbank  (a12; own file kaldi_fbank.npz)
   CFM t-grid + CFG   Qwen2_5OmniToken2WavDiTModel.sample (sway_coefficient -1 = the cosine grid; guided + (guided - null) g)
                                                          -> oracle.synth.cfm_t_grid / cfg_combine  (a14; own file cfm_grid_cfg.npz)
 
@@ -236,6 +238,24 @@ def nucleus_sets(out):
     print("top-p sets:", {k: v_.sum(1).tolist() for k, v_ in kept.items()})
 
 
+def kaldi_fbank_fixture():
+    """80-bin Kaldi fbank of a seeded waveform by transformers' SeamlessM4TFeatureExtractor._extract_fbank_features (its numpy
+    "mimic Kaldi" path: povey window, pre-emphasis 0.97, DC removal, 512-point power spectrum, Kaldi mel bank, log with float32-eps
+    floor, samples scaled by 2^15) -> tests/golden/kaldi_fbank.npz.  Held against astts.audio.kaldi_fbank(scale=32768)."""
+    from transformers import SeamlessM4TFeatureExtractor
+
+    fe = SeamlessM4TFeatureExtractor(feature_size=80, num_mel_bins=80, sampling_rate=16000)
+    g = torch.Generator().manual_seed(31)
+    n = 16000 + 777
+    t = torch.arange(n) / 16000.0
+    wav = (0.3 * torch.sin(2 * np.pi * 180 * t) + 0.1 * torch.sin(2 * np.pi * 2310 * t + 0.5) + 0.02 * torch.randn(n, generator=g) + 0.01).numpy()
+    feats = fe._extract_fbank_features(wav.astype(np.float64))                         # [frames, 80]
+    path = os.path.join(ROOT, "tests", "golden", "kaldi_fbank.npz")
+    np.savez_compressed(path, wav=wav.astype(np.float32), features=feats.astype(np.float32), mel_filters=np.asarray(fe.mel_filters, np.float32),
+                        window=np.asarray(fe.window, np.float32))
+    print("kaldi fbank:", feats.shape, "->", path, os.path.getsize(path) // 1024, "KB")
+
+
 def cfm_grid_and_cfg():
     """The time grid and the classifier-free-guidance combination of a flow-matching sampler, as transformers'
     Qwen2_5OmniToken2WavDiTModel.sample codes them (models/qwen2_5_omni/modeling_qwen2_5_omni.py: `time_embedding += sway * (cos(pi/2 t)
@@ -305,6 +325,9 @@ def cfm_grid_and_cfg():
 if __name__ == "__main__":
     if "--cfm" in sys.argv:
         cfm_grid_and_cfg()
+        sys.exit(0)
+    if "--kaldi" in sys.argv:
+        kaldi_fbank_fixture()
         sys.exit(0)
     fx = {}
     relpos_fastspeech2(fx)

@@ -527,6 +527,32 @@ def test_whisper_log_mel_kernel_matches_the_feature_extractor_fixture():
         assert float(dev[0].max()) > float(dev[1].max()) + 0.5                  # each utterance has its own maximum
 
 
+def test_kaldi_fbank_kernel_matches_the_fixture_and_the_host_definition():
+    """astts_op_kaldi_fbank (the speaker network's input features) against the committed output of transformers'
+    Kaldi-mimicking extractor and against the host (float64 FFT) form; both sample scales, a batch, lengths around the frame grid."""
+    from astts import audio
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kaldi_fbank.npz"))
+    wav = torch.from_numpy(fx["wav"])
+    out = audio.kaldi_fbank(wav.to(DEV), scale=32768.0)
+    assert out.is_cuda and tuple(out.shape) == (1,) + fx["features"].shape
+    err = float(np.abs(out[0].cpu().numpy() - fx["features"]).max())
+    print(f"kaldi fbank (HIP) vs SeamlessM4TFeatureExtractor: max abs diff {err:.2e}")
+    assert err < 2e-4
+    g = torch.Generator().manual_seed(12)
+    for n in (400, 559, 560, 16000 * 2 + 3):
+        t = torch.arange(n) / 16000.0
+        x = torch.stack([0.4 * torch.sin(2 * math.pi * 330.0 * t) + 0.02 * torch.randn(n, generator=g) + 0.05,
+                         0.01 * torch.sin(2 * math.pi * 2500.0 * t) + 0.001 * torch.randn(n, generator=g)])
+        for scale in (1.0, 32768.0):
+            host = audio.kaldi_fbank(x, scale=scale)
+            dev = audio.kaldi_fbank(x.to(DEV), scale=scale).cpu()
+            assert dev.shape == host.shape == (2, 1 + (n - 400) // 160, 80)
+            assert float((dev - host).abs().max()) < 5e-4, (n, scale, float((dev - host).abs().max()))
+    with pytest.raises(ValueError):
+        audio.kaldi_fbank(torch.zeros(1, 300, device=DEV))
+
+
 def test_new_entry_points_validate_arguments():
     """Argument errors come back as AsttsError with a message, before anything is launched."""
     import ctypes

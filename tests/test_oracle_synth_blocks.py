@@ -302,3 +302,26 @@ def test_reject_policy_has_the_distribution_of_upstreams_redraw_loop():
     for i in range(4000):
         counts_m[int(osyn.ras_sample(logits, hist, us[i], top_k, top_p, win, tau, eos, True, "mask")[0])] += 1
     assert np.abs(counts_m / 4000 - analytic).max() > 0.02
+
+
+def test_kaldi_fbank_matches_the_kaldi_mimicking_feature_extractor():
+    """astts.audio.kaldi_fbank / kaldi_mel_filterbank (the 80-bin Kaldi fbank the reference's speaker-embedding network takes: SURVEY.md a12)
+    against transformers' SeamlessM4TFeatureExtractor (numpy path that mimics Kaldi: tests/golden/kaldi_fbank.npz, generated by
+    make_synth_block_fixtures.py --kaldi; that extractor scales the samples by 2^15 as Kaldi's own tools do: scale=32768 here)."""
+    from astts import audio
+
+    fx = np.load(os.path.join(GOLD, "kaldi_fbank.npz"))
+    fb = audio.kaldi_mel_filterbank(16000, 512, 80, 20.0, 0.0)
+    assert fb.shape == (80, 257) and float(np.abs(fb.T - fx["mel_filters"]).max()) < 1e-7
+    assert float(np.abs(np.power(np.hanning(400), 0.85) - fx["window"]).max()) < 1e-6
+    wav = torch.from_numpy(fx["wav"])
+    f = audio.kaldi_fbank(wav, scale=32768.0)[0].numpy()
+    assert f.shape == fx["features"].shape == (1 + (wav.numel() - 400) // 160, 80)
+    assert float(np.abs(f - fx["features"]).max()) < 2e-5
+    # upstream's own scale (torchaudio takes the floats as they are): the same features shifted by 2 ln(32768) wherever the floor is not hit,
+    # and the shift disappears with the mean over time that upstream subtracts
+    g = audio.kaldi_fbank(wav, scale=1.0, subtract_mean=True)[0].numpy()
+    h = f - f.mean(axis=0, keepdims=True)
+    assert float(np.abs(g - h).max()) < 1e-4
+    with pytest.raises(ValueError):
+        audio.kaldi_fbank(torch.zeros(1, 399))
