@@ -116,9 +116,12 @@ def tts_for_infer(args, cosyvoice=None, now=None):
         if dist is not None:
             dist.barrier()
         return written
-    # batched schedule: same files, same names; rows are independent so they share ragged GPU batches
-    for c0 in range(0, len(items), bs):
-        chunk = items[c0:c0 + bs]
+    # batched schedule: same files, same names; rows are independent so they share ragged GPU batches of `bs` rows.  The surface is
+    # handed up to 256 rows at a time: it sorts them by length, decodes their 32-row LM jobs on two streams and renders one group
+    # while the next ones decode (CosyVoice.synthesize_batch)
+    step = max(bs, 256)
+    for c0 in range(0, len(items), step):
+        chunk = items[c0:c0 + step]
         for item in chunk:
             print(item)
         reqs = [(it["tts_text"], it["style_wav_text"], *wavs_of(it)) for it in chunk]

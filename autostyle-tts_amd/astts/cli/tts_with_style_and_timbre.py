@@ -64,8 +64,9 @@ def tts_for_infer(args, cosyvoice=None):
             kw = {} if seed is None else {"seed": int(seed) * 1000003 + cnt}
             save(cnt, [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, args.style_wav_text, style_wav, timbre_wav, stream=False, **kw)])
     else:           # lines are independent: the text segments of `batch_size` lines share ragged GPU batches (BASELINE config 3)
-        for c0 in range(0, len(lines), bs):
-            chunk = lines[c0:c0 + bs]
+        step = max(bs, 256)     # the surface schedules up to 256 lines' segments itself (LM jobs on two streams, render overlapped)
+        for c0 in range(0, len(lines), step):
+            chunk = lines[c0:c0 + step]
             kw = {} if seed is None else {"seeds": [int(seed) * 1000003 + first + c0 + k + 1 for k in range(len(chunk))]}
             if getattr(args, "fixed_tokens", None):
                 kw["fixed_tokens"] = int(args.fixed_tokens)

@@ -169,9 +169,19 @@ class CosyVoice:
     # ------------------------------------------------------------------ ragged batches (many segments in one pass)
     def synthesize_batch(self, requests, max_batch: int = 32, bucket: bool = True, fixed_tokens=None, draws=None, forced=None):
         """``requests``: list of (text_ids [1, Tt] = prompt text + segment text, n_segment_text_tokens, lm_prompt,
-        flow_prompt).  All segments go through ONE left-padded LM batch (per-row EOS window, tokens truncated at
-        each row's EOS), one ragged flow-matching batch and the vocoder.  Returns one FloatTensor[1, n] per request,
-        each what the one-at-a-time path produces for that segment up to sampling draws.
+        flow_prompt).  The segments go through left-padded LM batches (per-row EOS window, tokens truncated at each row's EOS),
+        ragged flow-matching batches and the vocoder.  Returns one FloatTensor[1, n] per request, each what the one-at-a-time
+        path produces for that segment up to sampling draws.
+
+        Schedule (the reference loops one utterance at a time, tts_with_rag.py:172-197; rows are independent):
+          * rows are sorted by length (``bucket``) and cut into render groups of ``max_batch`` rows, each made of LM jobs of <= 32 rows;
+          * the LM jobs -- latency-bound launch chains that leave most of the chip idle -- run on TWO worker threads with their own
+            streams, longest job first (a 1 500-step job of long rows beside all the short ones), each decoding only as far as its
+            own longest row;
+          * the calling thread renders (flow matching + vocoder) every group as soon as its tokens are there, in the order the jobs
+            are expected to finish: the render stage of one group overlaps the decode chains of the next.
+        Every request draws from its OWN random stream (``draws``; by default one ``torch.Generator`` per request seeded from the
+        instance generator in request order), so the result does not depend on the schedule.
 
         Explicit control of the stochastic parts (SURVEY.md 7 "hard parts": throughput runs need fixed-length decode, parity
         needs injectable randomness), all per request, in request order:
@@ -182,20 +192,29 @@ class CosyVoice:
                                draws for the same segment under the same seed);
           ``forced[i]``        teacher forcing: int tokens [n] that replace the sampled ones.
         The tokens and mels of the last call stay in ``self.last_tokens`` / ``self.last_mels`` (CPU)."""
+        import threading
+        from concurrent.futures import Future
+
         cfg, dev, eng = self.cfg, self.device, self.engine
-        out = [None] * len(requests)
-        self.last_tokens, self.last_mels = [None] * len(requests), [None] * len(requests)
-        # length bucketing (SURVEY.md 8e): a group is padded to its longest row in every stage, so rows of similar text
-        # length go together; results return in request order
-        key = (lambda i: -fixed_tokens[i]) if fixed_tokens is not None else (lambda i: -requests[i][1])
-        order = sorted(range(len(requests)), key=key) if bucket else list(range(len(requests)))
-        for g0 in range(0, len(requests), max_batch):
-            idxs = order[g0:g0 + max_batch]
+        n_req = len(requests)
+        out = [None] * n_req
+        self.last_tokens, self.last_mels = [None] * n_req, [None] * n_req
+        if n_req == 0:
+            return out
+        if draws is None:
+            draws = [torch.Generator().manual_seed(int(torch.randint(0, 1 << 62, (1,), generator=self._gen))) for _ in range(n_req)]
+        # length bucketing (SURVEY.md 8e): a group is padded to its longest row in every stage, so rows of similar length go
+        # together; results return in request order
+        want = [int(fixed_tokens[i]) if fixed_tokens is not None else self.max_token_text_ratio * requests[i][1] for i in range(n_req)]
+        order = sorted(range(n_req), key=lambda i: -want[i]) if bucket else list(range(n_req))
+        rgroups = [order[g0:g0 + max_batch] for g0 in range(0, n_req, max_batch)]
+        jobs = [(gi, g[c0:c0 + 32]) for gi, g in enumerate(rgroups) for c0 in range(0, len(g), 32)]        # (render group, request indices)
+
+        def lm_stage(idxs):
             grp = [requests[i] for i in idxs]
             b = len(grp)
-            texts = [r[0].view(-1) for r in grp]
-            spk_lm = torch.cat([r[2].spk_embedding for r in grp], 0)
-            pre, ks = eng.lm.prefix_ragged(texts, spk_lm, [r[2].speech_tokens.view(-1) for r in grp])
+            pre, ks = eng.lm.prefix_ragged([r[0].view(-1) for r in grp], torch.cat([r[2].spk_embedding for r in grp], 0),
+                                           [r[2].speech_tokens.view(-1) for r in grp])
             if fixed_tokens is not None:
                 max_len = [self._cap_tokens(int(fixed_tokens[i]), pre.shape[0], f"request {i}") for i in idxs]   # the position tables bound prefix + tokens
                 min_len = list(max_len)
@@ -204,14 +223,10 @@ class CosyVoice:
                 max_len = [max(self._cap_tokens(self.max_token_text_ratio * r[1], pre.shape[0], f"request {i}"), m + 1)
                            for i, r, m in zip(idxs, grp, min_len)]
             n_steps = max(max_len)
-            if draws is not None:
-                u = torch.zeros(n_steps, b, 2)
-                for j, i in enumerate(idxs):
-                    d = draws[i]
-                    u[:max_len[j], j] = torch.rand(max_len[j], 2, generator=d) if isinstance(d, torch.Generator) else d["u"][:max_len[j]]
-                u = u.to(dev)
-            else:
-                u = torch.rand(n_steps, b, 2, generator=self._gen).to(dev)
+            u = torch.zeros(n_steps, b, 2)
+            for j, i in enumerate(idxs):
+                d = draws[i]
+                u[:max_len[j], j] = torch.rand(max_len[j], 2, generator=d) if isinstance(d, torch.Generator) else d["u"][:max_len[j]]
             ft = None
             if forced is not None:
                 ft = torch.zeros(b, n_steps, dtype=torch.int32)
@@ -219,37 +234,93 @@ class CosyVoice:
                     ft[j, :max_len[j]] = forced[i][:max_len[j]].to(torch.int32)
                 ft = ft.to(dev)
             eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
-            toks = eng.lm.decode(pre, n_steps, u, ignore_eos=eos_min, key_start=ks, forced_tokens=ft).cpu()       # one sync per group
-            gen_tokens = []
-            for i in range(b):
-                row = toks[i, :max_len[i]]
+            toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft).cpu()   # one sync per job (this thread's stream)
+            gen = []
+            for j in range(b):
+                row = toks[j, :max_len[j]]
                 eos = (row >= cfg.speech_vocab).nonzero() if fixed_tokens is None else torch.empty(0)
-                n = int(eos[0]) if eos.numel() else max_len[i]
-                gen_tokens.append(row[:max(n, 1)].to(torch.int32))
+                n = int(eos[0]) if eos.numel() else max_len[j]
+                gen.append(row[:max(n, 1)].to(torch.int32))
+            return gen
+
+        def render(idxs, gen_tokens):
             all_tok, pmels, zs, dr = [], [], [], []
-            for i, r in enumerate(grp):
-                fp = r[3]
+            for i in idxs:
+                fp = requests[i][3]
                 n_gen = cfg.mel_frames_for_tokens(int(gen_tokens[i].numel()))
                 tmp = int(fp.mel.shape[1])
-                if draws is not None and isinstance(draws[idxs[i]], torch.Generator):
-                    _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen, draws[idxs[i]])
-                elif draws is not None:
-                    d = draws[idxs[i]]
-                    z, phase0, noise = d["z"][:, :tmp + n_gen], d["phase0"], d["noise"][:, :n_gen * cfg.upsample_total]
+                d = draws[i]
+                if isinstance(d, torch.Generator):
+                    _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen, d)
                 else:
-                    _, z, phase0, noise = self._draws(0, tmp + n_gen, n_gen)
+                    z, phase0, noise = d["z"][:, :tmp + n_gen], d["phase0"], d["noise"][:, :n_gen * cfg.upsample_total]
                 all_tok.append(torch.cat([fp.speech_tokens.view(-1).to(torch.int32), gen_tokens[i]]))
                 pmels.append(fp.mel[0])
                 zs.append(z[0])
                 dr.append((phase0, noise))
-            spk_flow = torch.cat([r[3].spk_embedding for r in grp], 0)
-            mels = eng.flow.decode_ragged(all_tok, pmels, spk_flow, zs)
-            wavs = [eng.hift.forward(mels[i][None], dr[i][0].to(dev), dr[i][1].to(dev))      # vocoder per row: its conv stack has no length masks
-                    for i in range(b)]                                                        # (3 % of the time); every row enqueued before the
-            for i in range(b):                                                                # first copy waits for the GPU
-                out[idxs[i]] = wavs[i].cpu()
-                self.last_tokens[idxs[i]] = gen_tokens[i]
-                self.last_mels[idxs[i]] = mels[i].cpu()
+            mels = eng.flow.decode_ragged(all_tok, pmels, torch.cat([requests[i][3].spk_embedding for i in idxs], 0), zs)
+            wavs = [eng.hift.forward(mels[j][None], dr[j][0].to(dev), dr[j][1].to(dev))      # vocoder per row: its conv stack has no length masks
+                    for j in range(len(idxs))]                                                # (3 % of the time); every row enqueued before the
+            for j, i in enumerate(idxs):                                                      # first copy waits for the GPU
+                out[i] = wavs[j].cpu()
+                self.last_tokens[i] = gen_tokens[i]
+                self.last_mels[i] = mels[j].cpu()
+
+        if len(jobs) == 1:                      # one job: nothing to overlap
+            render(rgroups[0], dict(zip(jobs[0][1], lm_stage(jobs[0][1]))))
+            return out
+        # static schedule of the LM jobs over the two workers (longest first, onto the less loaded one): deterministic, and it gives
+        # the order in which the render groups can expect their tokens
+        cost = [max(want[i] for i in idxs) for _, idxs in jobs]
+        loads, assign, fin = [0, 0], [[], []], [0] * len(jobs)
+        for j in sorted(range(len(jobs)), key=lambda j: (-cost[j], j)):
+            w = loads.index(min(loads))
+            assign[w].append(j)
+            loads[w] += cost[j]
+            fin[j] = loads[w]
+        futs = [Future() for _ in jobs]
+        if getattr(self, "_lm_streams", None) is None:
+            # one stream per command-processor pipe, found by measurement (launch chains whose queues share a pipe take turns at every
+            # kernel boundary: synth/model.py, PipelinedSynth): render, then the two decode workers
+            from .. import ops
+            firsts = [c[0] for c in ops.stream_pipe_classes(device=dev)]
+            if len(firsts) >= 3:
+                self._render_stream_b, self._lm_streams = firsts[0], firsts[1:3]
+            else:
+                self._render_stream_b, self._lm_streams = torch.cuda.current_stream(dev), ops.concurrent_streams(2, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        rs = self._render_stream_b
+
+        def worker(w):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(self._lm_streams[w]):
+                    for j in assign[w]:
+                        futs[j].set_result(lm_stage(jobs[j][1]))
+            except BaseException as e:          # noqa: BLE001  (re-raised on the calling thread)
+                for j in assign[w]:
+                    if not futs[j].done():
+                        futs[j].set_exception(e)
+
+        threads = []
+        for w in range(2):
+            self._lm_streams[w].wait_stream(cur)
+            threads.append(threading.Thread(target=worker, args=(w,)))
+            threads[-1].start()
+        try:
+            gfin = [max(fin[j] for j, (gj, _) in enumerate(jobs) if gj == gi) for gi in range(len(rgroups))]
+            rs.wait_stream(cur)
+            with torch.cuda.stream(rs):
+                for gi in sorted(range(len(rgroups)), key=lambda gi: (gfin[gi], gi)):
+                    toks = {}
+                    for j, (gj, idxs) in enumerate(jobs):
+                        if gj == gi:
+                            toks.update(zip(idxs, futs[j].result()))
+                    render(rgroups[gi], toks)
+        finally:
+            for th in threads:
+                th.join()
+            for st in list(self._lm_streams) + [rs]:
+                cur.wait_stream(st)
         return out
 
     def make_draws(self, n_tokens: int, prompt_mel_frames: int, seed: int):

@@ -332,7 +332,7 @@ class AcousticLM:
 
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
                forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True,
-               key_start: Optional[torch.Tensor] = None):
+               key_start: Optional[torch.Tensor] = None, group_steps: Optional[List[int]] = None):
         """Fixed-length autoregressive decode, no host synchronisation inside the loop.
         prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1])."""
         cfg = self.cfg
@@ -347,6 +347,10 @@ class AcousticLM:
             import threading
 
             groups = [slice(b0, min(b0 + 32, b)) for b0 in range(0, b, 32)]
+            # ``group_steps``: group g decodes only group_steps[g] <= n_steps steps (ragged batches sorted by length: the rows of a
+            # later group need fewer); its tokens come back zero-padded to n_steps
+            if group_steps is not None and (len(group_steps) != len(groups) or return_logits or max(group_steps) > n_steps):
+                raise ValueError("AcousticLM.decode: group_steps needs one step count <= n_steps per 32-row group (and no return_logits)")
             if getattr(self, "_group_streams", None) is None:
                 self._group_streams = ops.concurrent_streams(2, device=self.device)
             cur = torch.cuda.current_stream(self.device)
@@ -356,10 +360,14 @@ class AcousticLM:
                 try:
                     sl = groups[gi]
                     with torch.cuda.device(self.device), torch.cuda.stream(st):
-                        outs[gi] = self.decode_engine(prefix[:, sl].contiguous(), n_steps, uniforms[:, sl].contiguous(),
-                                                      ignore_eos[sl].contiguous() if torch.is_tensor(ignore_eos) else ignore_eos,
-                                                      None if forced_tokens is None else forced_tokens[sl], return_logits,
-                                                      None if key_start is None else key_start[sl].contiguous())
+                        n_g = n_steps if group_steps is None else int(group_steps[gi])
+                        o = self.decode_engine(prefix[:, sl].contiguous(), n_g, uniforms[:n_g, sl].contiguous(),
+                                               ignore_eos[sl].contiguous() if torch.is_tensor(ignore_eos) else ignore_eos,
+                                               None if forced_tokens is None else forced_tokens[sl, :n_g].contiguous(), return_logits,
+                                               None if key_start is None else key_start[sl].contiguous())
+                        if n_g < n_steps:
+                            o = torch.nn.functional.pad(o, (0, n_steps - n_g))
+                        outs[gi] = o
                 except BaseException as e:      # noqa: BLE001  (re-raised on the calling thread)
                     errs.append(e)
 

@@ -23,7 +23,7 @@ def wrap(obj, name, key):
     setattr(obj, name, w)
 def run():
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    outs = cv.inference_tts_with_st_batch(items, max_batch=32, split=False, fixed_tokens=want, seeds=list(range(len(items))))
+    outs = cv.inference_tts_with_st_batch(items, max_batch=int(os.environ.get('MB', 32)), split=False, fixed_tokens=want, seeds=list(range(len(items))))
     torch.cuda.synchronize(); return time.perf_counter() - t0, sum(o[0]['tts_speech'].shape[1] for o in outs) / cv.cfg.sample_rate
 run()
 dt, audio = run()

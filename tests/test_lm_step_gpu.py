@@ -298,3 +298,28 @@ def test_embedding_table_path_equals_the_per_step_projection(monkeypatch):
     print(f"embedding table vs per-step projection: logits rel diff {err:.2e}")
     assert err < 1e-3
     assert torch.equal(outs["1"][1], outs["0"][1])
+
+
+def test_group_steps_stop_each_32_row_group_at_its_own_length():
+    """AcousticLM.decode(group_steps=): a batch wider than 32 rows runs as 32-row chains; group g decodes only group_steps[g] steps
+    (ragged batches sorted by length).  Its tokens equal the unrestricted decode's first group_steps[g] columns; the rest is zero."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import AcousticLM
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig.tiny()
+    lm = AcousticLM(make_all(cfg, 0)["llm"], cfg, torch.device(DEV))
+    g = torch.Generator().manual_seed(5)
+    b, tt, tp, steps = 40, 6, 9, 12
+    text = torch.randint(0, cfg.text_vocab, (b, tt), generator=g).to(DEV)
+    tlen = torch.full((b,), tt, dtype=torch.int32, device=DEV)
+    spk = torch.randn(b, cfg.spk_dim, generator=g).to(DEV)
+    prompt = torch.randint(0, cfg.speech_vocab, (b, tp), generator=g).to(DEV)
+    u = torch.rand(steps, b, 2, generator=g).to(DEV)
+    pre = lm.prefix(text, tlen, spk, prompt)
+    full = lm.decode(pre, steps, u, True, None).cpu()
+    part = lm.decode(pre, steps, u, True, None, group_steps=[steps, 5]).cpu()
+    assert torch.equal(part[:32], full[:32])
+    assert torch.equal(part[32:, :5], full[32:, :5]) and int(part[32:, 5:].abs().sum()) == 0
+    with pytest.raises(ValueError):
+        lm.decode(pre, steps, u, True, None, group_steps=[steps])
