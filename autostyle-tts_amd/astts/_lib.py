@@ -9,10 +9,14 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
-# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue never overlap.
-# The pipelined synthesis wants one queue per decode chain + render + front stream.  Read by the HIP runtime when it
-# initialises (the first HIP call), so it has to be in the environment before that; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues; streams that share a queue never overlap, and the chip's command
+# processor has FOUR pipes: queues that share a pipe take turns at every kernel boundary (two launch chains on such a pair run 2.4x slower
+# each, synth/model.py).  FOUR queues = one per pipe: the pipeline's render stream and its (up to three) decode chains then sit on pipes of
+# their own by construction and the caller's front stream shares the render queue.  Rounds 1-3 asked for 8 (two queues per pipe): with
+# that the three-chain pipeline lost to the two-chain one; with 4 it wins (batch-8 benchmark, same box, alternating: 428 -> 457x real
+# time; 5: the same; 3 and 6: no gain; 2: 292x).  Read by the HIP runtime when it initialises (the first HIP call), so it has to be in
+# the environment before that; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libastts.so")

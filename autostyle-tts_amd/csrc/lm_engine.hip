@@ -51,6 +51,8 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     float* part_o = (float*)take(astts_op_gemm_fused_workspace_bytes());
     float* part_ml = part_o + (size_t)b * c.heads * 2 * 64;
     const float scale = 0.125f;
+    // ASTTS_LM_KSPLIT=1 (experiments): the decode attention as 128 workgroups with the whole key range each instead of 256 with half of it
+    static const int ksplit = [] { const char* e = getenv("ASTTS_LM_KSPLIT"); return e && atoi(e) == 1 ? 1 : 2; }();
     const KvLayout lay = KvLayout::time_major(b, d);
     auto gemv = [&]() {
         GemvArgs a;
@@ -104,11 +106,15 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             AttnArgs t;
             memset(&t, 0, sizeof(t));
             t.q = q; t.kv = kvc; t.postab = (const _Float16*)L.pos; t.bias_u = L.bias_u; t.bias_v = L.bias_v; t.kstart = key_start;
-            t.part_o = part_o; t.part_ml = part_ml; t.ksplit = 2; t.b = b; t.h = c.heads; t.ldq = d; t.ldp = c.pos_ld; t.center = c.pos_center;
+            t.part_o = part_o; t.part_ml = part_ml; t.ksplit = ksplit; t.b = b;
+            t.h = c.heads; t.ldq = d; t.ldp = c.pos_ld; t.center = c.pos_center;
+            if (ksplit == 1) { t.out = ff; t.ldo = d; }      // one workgroup per (row, head): the fp16 FFN buffer is free until FFN-in
             t.d = d; t.scale = scale; t.pos = pos; t.kv_t = lay.t; t.kv_b = lay.b; t.kv_h = lay.h; t.kv_v = lay.v;
             if ((rc = lm_attn_launch(t, st)) != ASTTS_OK) return rc;
             a = gemv();             // out-proj on the merged attention partials + residual
-            a.x = part_o; a.x2 = part_ml; a.x_mode = 2; a.w = (const _Float16*)L.wo; a.bias = L.bo; a.res = x; a.ldr = d; a.out = y; a.ldo = d;
+            a.x = part_o; a.x2 = part_ml; a.x_mode = 2;
+            if (ksplit == 1) { a.x = ff; a.x2 = nullptr; a.x_mode = 1; a.ldx = d; }
+            a.w = (const _Float16*)L.wo; a.bias = L.bo; a.res = x; a.ldr = d; a.out = y; a.ldo = d;
             a.n = d; a.k = d; a.kpad = d;
             if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             a = gemv();             // LN2 + FFN-in + ReLU -> fp16 hidden (its only consumer is an MFMA operand)

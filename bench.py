@@ -26,8 +26,8 @@ for _p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-# one hardware queue per pipeline stream (astts/_lib.py sets the same default; it must precede the first HIP call)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# one hardware queue per command-processor pipe (astts/_lib.py sets the same default and says why; it must precede the first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -481,7 +481,8 @@ def main():
     # overlap (PipelinedSynth.autotune) -- on this rank's own inputs.
     sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
               inp.z, inp.phase0, inp.noise)
-    pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=max(2, min(args.steps, 8)), verbose=rank == 0 and bool(os.environ.get("ASTTS_BENCH_VERBOSE")),
+    depths = tuple(int(x) for x in os.environ.get("ASTTS_BENCH_DEPTHS", "2,3").split(","))      # decode chains tried by the calibration
+    pipe = PipelinedSynth.autotune(eng, sample, depths=depths, trials=2, steps=max(2, min(args.steps, 8)), verbose=rank == 0 and bool(os.environ.get("ASTTS_BENCH_VERBOSE")),
                                    front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
     n_done = [0]
 
