@@ -272,7 +272,8 @@ class CosyVoice:
         # static schedule of the LM jobs over the two workers (longest first, onto the less loaded one): deterministic, and it gives
         # the order in which the render groups can expect their tokens
         cost = [max(want[i] for i in idxs) for _, idxs in jobs]
-        loads, assign, fin = [0, 0], [[], []], [0] * len(jobs)
+        nw = max(1, min(int(os.environ.get("ASTTS_RAGGED_LM_WORKERS", "2")), 3, len(jobs)))
+        loads, assign, fin = [0] * nw, [[] for _ in range(nw)], [0] * len(jobs)
         for j in sorted(range(len(jobs)), key=lambda j: (-cost[j], j)):
             w = loads.index(min(loads))
             assign[w].append(j)
@@ -284,10 +285,13 @@ class CosyVoice:
             # kernel boundary: synth/model.py, PipelinedSynth): render, then the two decode workers
             from .. import ops
             firsts = [c[0] for c in ops.stream_pipe_classes(device=dev)]
-            if len(firsts) >= 3:
-                self._render_stream_b, self._lm_streams = firsts[0], firsts[1:3]
+            if len(firsts) >= 4:
+                self._render_stream_b, self._lm_streams = firsts[0], firsts[1:4]
+            elif len(firsts) == 3:
+                self._render_stream_b, self._lm_streams = firsts[0], firsts[1:3] + [firsts[1]]
             else:
-                self._render_stream_b, self._lm_streams = torch.cuda.current_stream(dev), ops.concurrent_streams(2, device=dev)
+                two = ops.concurrent_streams(2, device=dev)
+                self._render_stream_b, self._lm_streams = torch.cuda.current_stream(dev), two + [two[0]]
         cur = torch.cuda.current_stream(dev)
         rs = self._render_stream_b
 
@@ -302,7 +306,7 @@ class CosyVoice:
                         futs[j].set_exception(e)
 
         threads = []
-        for w in range(2):
+        for w in range(nw):
             self._lm_streams[w].wait_stream(cur)
             threads.append(threading.Thread(target=worker, args=(w,)))
             threads[-1].start()

@@ -76,8 +76,12 @@ __device__ __forceinline__ float wsum64(float v) { return wave_sum_desc(v); }
 // XM: input form -- 0 fp32 rows (optional gather / embedding pre-transform / LayerNorm), 1 fp16 rows, 2 the split-key
 // partials of lm_attn (merged while staging).  NL: weight lines a wave keeps in flight (2 for K <= 1024 at 16 columns: the
 // kernel then fits two workgroups per CU, e.g. the 257 workgroups of the output head in one wave of blocks).
-template <int MT, int FORM, int XM, int NL>
-__global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(const void* p_x, const _Float16* p_w, const float* p_x2, const int* p_gather, int p_m, int p_n, int p_k, int p_kpad, int p_ldx,
+// NCT (FORM 0, MT 1 only): column tiles of 16 per workgroup.  NCT = 2 ("wide"): 32 columns, the A fragments of the staged rows feed two
+// weight fragments each -- half the workgroups of the 16-column grid for the wide projections (QKV, FFN-in, head) at the same number of
+// memory round trips.  Inside the stream pipeline a decode kernel costs the chip (CUs it holds) x (time it holds them); the sums of a
+// column are formed exactly as with NCT = 1 (per wave: its K lines in order; then waves 0..7): bit-identical results.
+template <int MT, int FORM, int XM, int NL, int NCT = 1>
+__global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(const void* p_x, const _Float16* p_w, const float* p_x2, const int* p_gather, int p_m, int p_n, int p_k, int p_kpad, int p_ldx,
                                                                                                                 GemvArgs a_in) {
     // The first 13 dwords of the kernarg segment are what the FIRST global loads need (input rows, weight lines).  As explicit
     // leading parameters they are PRELOADED into SGPRs by the command processor (-amdgpu-kernarg-preload-count, Makefile): the
@@ -90,12 +94,13 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
     constexpr bool HALF8 = FORM != 0;                          // K halved over MFMA columns, 8 output columns per workgroup
     constexpr bool DIAG = FORM == 1;
     constexpr int RH = DIAG ? 8 : 16 * MT;                     // LDS row offset of the second K half
-    constexpr int NACC = FORM == 2 ? 2 * MT : MT;              // accumulators per wave
+    static_assert(NCT == 1 || (FORM == 0 && MT == 1), "column tiles: 16-column form, one row tile");
+    constexpr int NACC = FORM == 2 ? 2 * MT : MT * NCT;        // accumulators per wave
     extern __shared__ __attribute__((aligned(16))) char gv_smem[];
     LM_STAMP(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    constexpr int NC = HALF8 ? 8 : 16;
+    constexpr int NC = HALF8 ? 8 : 16 * NCT;
     const int n0 = blockIdx.x * NC;
     const int M = a.m;
     const int Kc = HALF8 ? (a.kpad >> 1) : a.kpad;          // K elements per MFMA row
@@ -187,15 +192,17 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
             }
         }
     }
-    half8 fb[NL][2];
+    half8 fb[NCT * NL][2];                                      // [column tile][line in flight]
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int line = wid + i * GV_WAVES;
-        if (line < lines) {
-            fb[i][0] = LM_WLOAD(wrow + line * 64);
-            fb[i][1] = LM_WLOAD(wrow + line * 64 + 8);
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int line = wid + i * GV_WAVES;
+            if (line < lines) {
+                fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64);
+                fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64 + 8);
+            }
         }
-    }
     pin_args(a);            // the remaining arguments: ONE wide scalar load + ONE wait, behind the loads issued above
     // LayerNorm parameters of the lanes' k positions (same positions for every row)
     float4 lg[MAXV], lb[MAXV];
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         }
     }
     // epilogue operands of the thread's output element
-    constexpr int NOUT = DIAG ? 64 : (FORM == 2 ? MT * 128 : MT * 256);
+    constexpr int NOUT = DIAG ? 64 : (FORM == 2 ? MT * 128 : MT * NCT * 256);
     const bool owner = tid < NOUT;
     int on, om;                                               // output column / row of this thread
     if constexpr (DIAG) {
@@ -222,9 +229,9 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         on = n0 + (tid & 7);
         om = tid >> 3;
     } else {
-        const int t = tid >> 8, e = (tid >> 6) & 3;
-        on = n0 + (lane & 15);
-        om = t * 16 + (lane >> 4) * 4 + e;
+        const int t = tid >> 8, e = (tid >> 6) & 3;              // accumulator t: row tile (NCT 1) or column tile (NCT 2)
+        on = n0 + (NCT == 2 ? t * 16 : 0) + (lane & 15);
+        om = (NCT == 2 ? 0 : t * 16) + (lane >> 4) * 4 + e;
     }
     const bool live = owner && on < a.n && om < M;
     float e_bias = 0.0f, e_res = 0.0f;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         if constexpr (FORM == 2) {
             mr = (t >> 1) * 16 + c + RH * (t & 1);            // accumulator (row tile t / 2, K half t % 2)
         } else {
-            mr = t * 16 + c;
+            mr = (NCT == 2 ? 0 : t * 16) + c;                 // NCT 2: both accumulators take the one row tile
             if constexpr (!HALF8) {
                 if (mr >= M) mr = M - 1;
             }
@@ -478,20 +485,23 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
                 for (int t = 0; t < NACC; ++t) {
                     const half8 fa0 = *reinterpret_cast<const half8*>(arow[t] + line * 64);
                     const half8 fa1 = *reinterpret_cast<const half8*>(arow[t] + line * 64 + 8);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[i][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[i][1], acc[t], 0, 0, 0);
+                    const int fi = (NCT == 2 ? t * NL : 0) + i;      // weights: shared by the row tiles, one set per column tile
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[fi][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[fi][1], acc[t], 0, 0, 0);
                 }
             }
         }
         if (wid + (pass + 1) * NL * GV_WAVES >= lines) break;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int line = wid + ((pass + 1) * NL + i) * GV_WAVES;
-            if (line < lines) {
-                fb[i][0] = LM_WLOAD(wrow + line * 64);
-                fb[i][1] = LM_WLOAD(wrow + line * 64 + 8);
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int line = wid + ((pass + 1) * NL + i) * GV_WAVES;
+                if (line < lines) {
+                    fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64);
+                    fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64 + 8);
+                }
             }
-        }
     }
     LM_STAMP(a, 4);
     // ---- (3) cross-wave reduction + epilogue
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(512, (NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 
         } else {
             const int t = tid >> 8, e = (tid >> 6) & 3;
 #pragma unroll
-            for (int w = 0; w < GV_WAVES; ++w) v += red[((w * MT + t) * 4 + e) * 64 + lane];
+            for (int w = 0; w < GV_WAVES; ++w) v += red[((w * NACC + t) * 4 + e) * 64 + lane];
         }
         v += e_bias;
         if (a.relu) v = fmaxf(v, 0.0f);
@@ -704,17 +714,35 @@ int lm_gemv_variant(const GemvArgs& a) {
     return form | (mt << 2);
 }
 
+// ASTTS_LM_WIDE=1: the wide (32-column) form for 16-column projections with K <= 1024 at <= 16 rows (same sums, half the workgroups)
+static bool lm_wide() {
+    static const bool v = [] { const char* e = getenv("ASTTS_LM_WIDE"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 #define GV_LEAD(a) (a).x, (a).w, (a).x2, (a).gather, (a).m, (a).n, (a).k, (a).kpad, (a).ldx     // the preloaded leading kernel arguments
 #define AT_LEAD(a) (a).q, (a).kv, (a).postab + (int64_t)(a).center * (a).ldp, (a).kstart, (a).kv_t, (a).kv_b, (a).kv_h, (a).kv_v, (a).ldq, (a).ldp
 
 template <int MT, int FORM, int XM>
-static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st) {
+static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st, bool wide = false) {
     static std::once_flag attr;   // first use (never inside a capture: lm_step_set_attrs() visits every variant up front)
     std::call_once(attr, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, FORM, XM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<MT, FORM, XM, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (FORM == 0 && MT == 1 && XM != 2)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_gemv<1, 0, XM, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (grid.x == 0) return;
+    if constexpr (FORM == 0 && MT == 1 && XM != 2) {
+        if (wide) {              // 32 columns per workgroup (K <= 1024: two lines per wave)
+            hipEvent_t e0, e1;
+            if (prof_events(ASTTS_PROF_GEMM_SKINNY, (double)a.n * a.kpad * 2.0, &e0, &e1))
+                hipExtLaunchKernelGGL((lm_gemv<1, 0, XM, 2, 2>), grid, dim3(512), (uint32_t)lds, st, e0, e1, 0, GV_LEAD(a), a);
+            else
+                hipLaunchKernelGGL((lm_gemv<1, 0, XM, 2, 2>), grid, dim3(512), lds, st, GV_LEAD(a), a);
+            return;
+        }
+    }
     // bench-only launch profiler: algorithmic bytes of a decode GEMV = its weight image, streamed once
     hipEvent_t e0, e1;
     if (prof_events(ASTTS_PROF_GEMM_SKINNY, (double)a.n * a.kpad * 2.0, &e0, &e1)) {
@@ -727,9 +755,9 @@ static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_p
 }
 
 template <int MT, int FORM>
-static void gemv_launch_xm(const GemvArgs& a, int xm, dim3 grid, size_t lds, int lpw, hipStream_t st) {
-    if (xm == 0) gemv_launch_nl<MT, FORM, 0>(a, grid, lds, lpw, st);
-    else if (xm == 1) gemv_launch_nl<MT, FORM, 1>(a, grid, lds, lpw, st);
+static void gemv_launch_xm(const GemvArgs& a, int xm, dim3 grid, size_t lds, int lpw, hipStream_t st, bool wide = false) {
+    if (xm == 0) gemv_launch_nl<MT, FORM, 0>(a, grid, lds, lpw, st, wide);
+    else if (xm == 1) gemv_launch_nl<MT, FORM, 1>(a, grid, lds, lpw, st, wide);
     else gemv_launch_nl<MT, FORM, 2>(a, grid, lds, lpw, st);
 }
 
@@ -797,12 +825,14 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
         }
         a.advance = a0.advance && r0 + rows >= a0.m;
         // the form of the FIRST chunk serves every chunk (a short last chunk must not change the arithmetic of its rows)
-        const dim3 grid((a.n + (form ? 7 : 15)) / (form ? 8 : 16));
         const int lpw = ((kc >> 6) + GV_WAVES - 1) / GV_WAVES;
+        const bool wide = form == 0 && mt == 1 && xm != 2 && lpw <= 2 && lm_wide();
+        const dim3 grid(wide ? (a.n + 31) / 32 : (a.n + (form ? 7 : 15)) / (form ? 8 : 16));
+        if (wide) lds = gemv_lds_bytes(a.m, kc, 2);      // two accumulators per wave in the cross-wave reduction
         if (form == 1) gemv_launch_xm<1, 1>(a, xm, grid, lds, lpw, st);
         else if (form == 2 && mt == 1) gemv_launch_xm<1, 2>(a, xm, grid, lds, lpw, st);
         else if (form == 2) gemv_launch_xm<2, 2>(a, xm, grid, lds, lpw, st);
-        else if (mt == 1) gemv_launch_xm<1, 0>(a, xm, grid, lds, lpw, st);
+        else if (mt == 1) gemv_launch_xm<1, 0>(a, xm, grid, lds, lpw, st, wide);
         else gemv_launch_xm<2, 0>(a, xm, grid, lds, lpw, st);
     }
     ASTTS_CHECK_LAUNCH();

@@ -534,7 +534,7 @@ def main():
     cob = {}
     main_pipe = pipe
     if args.steps >= 2 and not args.no_cobatch:
-        cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
+        cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (3, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
         pipe = PipelinedSynth.autotune(eng, sample, depths=cob_cfgs, trials=2, steps=max(2, min(args.steps, 8)),
                                        front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
         with torch.cuda.stream(pipe.front_stream):
@@ -796,7 +796,7 @@ def main():
                                                "decode_chains": cob["chains"], "batches_per_chain": cob["batches_per_chain"],
                                                "note": "same K steps, LM stages of consecutive batches co-batched into one 16- or 32-row decode "
                                                        "chain (a row's tokens do not depend on the chain's width: outputs bit-identical per batch); "
-                                                       "the fastest of (2 chains x 2 batches, 2 x 4, 1 x 4) by calibration; reported beside `value`, not as it"} if cob else None),
+                                                       "the fastest of (2 chains x 2 batches, 3 x 2, 2 x 4, 1 x 4) by calibration; reported beside `value`, not as it"} if cob else None),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "sequential_ms_per_step": round(sum(stages.values()), 3),
             "roofline": roof,
