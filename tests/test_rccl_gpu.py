@@ -54,3 +54,39 @@ def test_bench_under_torch_distributed_run_prints_one_json_line():
     res = json.loads(lines[0])
     assert res["rccl_world_size"] == 1 and res["rccl_backend"] == "nccl" and res["gathered_ids_match_oracle"] is True
     assert res["n_gpus"] == 1 and res["value"] > 0
+
+
+@pytest.mark.gpu
+def test_drivers_under_torch_distributed_run_through_rccl(tmp_path):
+    """The retrieval DRIVER's data-parallel form on the hardware that exists: `python -m torch.distributed.run --nproc-per-node 1 -m
+    astts.cli.search_json` with ASTTS_FORCE_DIST=1 forms a one-rank RCCL process group (backend nccl), so the all-gather of the (style
+    id, similarity) pairs and the barrier run through librccl on the GPU; the JSONL equals the plain one-process run's, byte for byte.
+    (World sizes 2 and 8, and the synthesis driver: tests/test_drivers_dist_cpu.py over gloo.)"""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    from bench import free_port
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    bank = np.load(os.path.join(gold, "style_bank_130x6144.f16.npy")).astype(np.float32)
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, 130, 37)
+    np.save(tmp_path / "q.npy", (bank[rows] + 0.3 * rng.standard_normal((37, 6144))).astype(np.float32))
+    (tmp_path / "in.jsonl").write_text("\n".join(json.dumps({"zh_text": f"line {i}", "speaker": ["w1", "m2"][i % 2]}) for i in range(37)) + "\n")
+    pkg = os.path.join(ROOT, "autostyle-tts_amd")
+    base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=pkg + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        base_env.pop(k, None)
+    args = ["--input_json", str(tmp_path / "in.jsonl"), "--query_npy", str(tmp_path / "q.npy"), "--db_path", os.path.join(gold, "milvus_demo.db")]
+    r1 = subprocess.run([sys.executable, "-m", "astts.cli.search_json"] + args + ["--output_file", str(tmp_path / "one.jsonl")], env=base_env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", str(free_port()), "-m", "astts.cli.search_json"] + args + ["--output_file", str(tmp_path / "dist.jsonl")],
+                        env=dict(base_env, ASTTS_FORCE_DIST="1"), capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    one, dist = (tmp_path / "one.jsonl").read_bytes(), (tmp_path / "dist.jsonl").read_bytes()
+    assert one == dist and one.count(b"\n") == 37
+    recs = [json.loads(l) for l in one.decode().splitlines()]
+    meta = json.load(open(os.path.join(gold, "style_bank_meta.json")))
+    assert [r["retrieved_file_id"] for r in recs] == [meta["rows"][int(i)]["file_id"] for i in rows]        # 0.3 sigma of noise: top-1 is the source row
