@@ -679,6 +679,7 @@ def main():
 
         pip = profiled(kinds[dom], pipelined_steps)
         pip = {"ms_per_step": pip["ms_per_step"] / k_p, "launches": pip["launches"] // k_p, "work": pip["work"] / k_p, "dropped": pip["dropped"]}
+    pipe_depth_now = pipe.depth
     p = seq          # `roofline` = the sequential figure (attributable per launch); the pipelined one rides beside it
     if dom in ("gemm_tile", "attn_mha_flash"):
         achieved = p["work"] / (p["ms_per_step"] / 1e3) / 1e12
@@ -696,10 +697,10 @@ def main():
                  "algorithmic_work_per_launch": p["work"] / max(p["launches"], 1),
                  "mode": "one sequential step (one batch at a time on one stream: what sequential_ms_per_step / stages_ms are measured in; "
                          "kernel-level dispatch timestamps)",
-                 "pipelined": ({"avg_us": pip_us, "achieved": pip["work"] / max(pip["launches"], 1) / (pip_us * 1e-6) / 1e9 if dom.startswith("lm_") else None,
+                 "pipelined": ({"decode_chains": pipe_depth_now, "avg_us": pip_us, "achieved": pip["work"] / max(pip["launches"], 1) / (pip_us * 1e-6) / 1e9 if dom.startswith("lm_") else None,
                                 "frac": pip["work"] / max(pip["launches"], 1) / (pip_us * 1e-6) / 1e9 / HBM_PEAK_GBS if dom.startswith("lm_") else None,
                                 "launches_per_step": pip["launches"],
-                                "note": "the same kernel inside the schedule of the timed region (two decode chains and a render stage share the GPU: "
+                                "note": "the same kernel inside the schedule of the timed region (the decode chains and a render stage share the GPU: "
                                         "kernels of different batches overlap, so launches x avg_us may exceed ms_per_step -- not a per-step attribution)"}
                                if pip else None),
                  "all_kinds_ms_per_sequential_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()}})
