@@ -45,3 +45,14 @@ def test_external_launcher_env_is_respected():
     env = dict(os.environ, ASTTS_BENCH_STUB="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_eight_ranks_the_node_the_north_star_names():
+    """`python bench.py --gpus 8` (the driver's SCALE run): eight ranks rendezvous, barrier, reduce the MAX time and print ONE line."""
+    r = _run({}, "--gpus", "8", "--steps", "3", "--warmup", "1", timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["rccl_world_size"] == 8 and res["ranks_seen"] == list(range(8))
+    assert res["ms_per_step"] >= 15.9          # the slowest rank (rank 7 sleeps 16 ms per step) sets the time

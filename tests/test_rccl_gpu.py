@@ -90,3 +90,26 @@ def test_drivers_under_torch_distributed_run_through_rccl(tmp_path):
     recs = [json.loads(l) for l in one.decode().splitlines()]
     meta = json.load(open(os.path.join(gold, "style_bank_meta.json")))
     assert [r["retrieved_file_id"] for r in recs] == [meta["rows"][int(i)]["file_id"] for i in rows]        # 0.3 sigma of noise: top-1 is the source row
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config3", "config5"])
+def test_bench_side_workloads_print_the_same_schema(workload):
+    """`python bench.py --workload config3|config5` (BASELINE configs[2] / configs[4] as side lines): one JSON line on stdout with the
+    default line's keys, `side_measurement` set, a finite waveform and -- config 5 -- retrieved ids equal to the oracle's on a sample."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "ASTTS_BENCH_STUB", "ASTTS_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in res, key
+    assert res["side_measurement"].startswith(f"--workload {workload}") and "workload" in res["config"] and res["waveform_finite"] is True
+    assert res["value"] > 50.0 and res["n_gpus"] == 1 and res["steps"] == 1
+    if workload == "config5":
+        assert res["ids_match_oracle_sample"] is True and res["scaling"] == "strong"
+    print(f"bench --workload {workload}:", round(res["value"], 1), "x real time,", round(res["ms_per_step"], 1), "ms per step")
