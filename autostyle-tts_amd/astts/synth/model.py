@@ -904,6 +904,11 @@ class SynthEngine:
         return mel, wav
 
 
+def _lib_check_spin(us: int, stream) -> None:
+    from .. import _lib
+    _lib.check(_lib.load().astts_stream_spin(int(us), int(stream.cuda_stream)))
+
+
 class PipelinedSynth:
     """Software pipeline over consecutive (independent) batches on several HIP streams of one GPU.
 
@@ -922,7 +927,8 @@ class PipelinedSynth:
     waveform are bit-identical to running it alone (tested)."""
 
     def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None,
-                 cobatch: int = 1, render_depth: int = 1, pipe_classes=None, front_prefill: Optional[bool] = None):
+                 cobatch: int = 1, render_depth: int = 1, pipe_classes=None, front_prefill: Optional[bool] = None,
+                 stagger_ms: Optional[float] = None):
         import os
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
@@ -978,6 +984,8 @@ class PipelinedSynth:
         self._pending = []                  # batches waiting for their (co-batched) LM stage to be launched
         self.cobatch = max(1, int(cobatch))
         self.front_prefill = (os.environ.get("ASTTS_PIPE_FRONT_PREFILL", "1") != "0") if front_prefill is None else bool(front_prefill)
+        self.stagger_ms = float(os.environ.get("ASTTS_PIPE_STAGGER_MS", "0")) if stagger_ms is None else float(stagger_ms)
+        self._staggered = set()
         self._i = 0
 
     @classmethod
@@ -1027,9 +1035,20 @@ class PipelinedSynth:
     def _launch_group(self):
         """Start the LM stage of the pending batches as ONE decode chain (rows of all of them side by side)."""
         group, self._pending = self._pending, []
-        stream = self.s_lm[self._i % self.depth]
+        chain = self._i % self.depth
+        stream = self.s_lm[chain]
         self._i += 1
         cur = torch.cuda.current_stream(self.eng.device)
+        # ``stagger_ms``: after an idle pipeline (construction, drain) chain c starts its first decode c * stagger_ms late (a one-wave
+        # busy-wait kernel at the head of its stream).  Chains that start together stay in phase: their batches finish together, the
+        # render stage gets them in bursts and the drain ends with `depth` renders in a row; offset by a third of a chain's period they
+        # hand the render stage one batch at a time and the drain ends with ONE render.
+        if self.stagger_ms > 0 and chain > 0 and chain not in self._staggered:
+            self._staggered.add(chain)
+            us = int(self.stagger_ms * 1000.0 * chain)
+            while us > 0:
+                _lib_check_spin(min(us, 100000), stream)
+                us -= 100000
         if len(group) == 1:
             lm_args = group[0]["lm"]
         else:   # rows are independent in every LM kernel: a row's tokens do not depend on which rows sit next to it
@@ -1113,6 +1132,8 @@ class PipelinedSynth:
     def drain(self):
         if self._pending:
             self._launch_group()
+        self._staggered = set()          # the pipeline runs empty: the next first batches are staggered again
+        self._i = 0
         out = []
         while self._fifo:
             out.append(self._render(self._fifo.popleft()))
