@@ -998,6 +998,7 @@ class PipelinedSynth:
         ``sample_args`` (the positional arguments of ``submit``) and the fastest configuration is kept.  ``front``: the
         caller's own per-batch GPU work (a callable, e.g. the style retrieval), enqueued on ``pipe.front_stream`` before
         each submit exactly as the caller will."""
+        import os
         import time
 
         best, best_dt = None, float("inf")
@@ -1007,8 +1008,9 @@ class PipelinedSynth:
             cfg_ = cfg_ if isinstance(cfg_, tuple) else (cfg_, 1)
             depth, cob, rdep = (tuple(cfg_) + (1,))[:3]
             for _ in range(trials):
-                pipe = cls(engine, lm_depth=depth, lm_priority=0, render_priority=0, cobatch=cob, render_depth=rdep,
-                           pipe_classes=classes if rdep == 1 else None)
+                lm_prio = int(os.environ.get("ASTTS_PIPE_LM_PRIORITY", "0"))      # experiments: -1 = high-priority decode streams
+                pipe = cls(engine, lm_depth=depth, lm_priority=lm_prio, render_priority=0, cobatch=cob, render_depth=rdep,
+                           pipe_classes=classes if rdep == 1 and lm_prio == 0 else None)
                 with torch.cuda.stream(pipe.front_stream):
                     for _ in range((depth + 1) * cob):
                         if front is not None:
