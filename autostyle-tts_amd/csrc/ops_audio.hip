@@ -396,27 +396,34 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
             // repeated with probability p_t / cum, in the fallback with rho = sum over the repeated entries of p_t / cum, and the
             // fallback ends off EOS with probability 1 - p_eos.  Conditioned on "not EOS": weights a_t = p_t for the direct entries and
             // F = (sum of the repeated p_t) (1 - p_eos) for the fallback -- drawn with u1 in rank order, the fallback last.
+            // Lane r holds rank r (probability, id, "repeated"): the walks below then read lanes (v_readlane with a uniform index), not LDS
+            // words behind ballots -- as dependent LDS round trips per rank this branch cost ~4 us of a 14 us kernel.
             const float p_eos = prob[a.eos];
-            float asum = 0.0f, prep = 0.0f;
-            unsigned long long direct = 0ull;               // rank r is a direct entry (wave-uniform)
+            const float pr_l = lane < cnt ? sh_s[lane] : 0.0f;
+            const int ir_l = lane < cnt ? sh_i[lane] : -1;
+            int repc = 0;
+            if (win_in_wave) {
+                const int wl = a.hist_len - h0;             // window tokens sit on lanes 0 .. wl - 1 of hwin
+                for (int j = 0; j < wl; ++j) repc += __builtin_amdgcn_readlane(hwin, j) == ir_l ? 1 : 0;
+            } else {
+                for (int i = h0; i < a.hist_len; ++i) repc += a.history[(int64_t)bb * a.hist_ld + i] == ir_l ? 1 : 0;
+            }
+            const bool rep_l = (float)repc >= (float)a.win * a.tau_r;
+            const unsigned long long direct = __ballot(lane < cnt && ir_l != a.eos && !rep_l);      // neither EOS nor repeated
+            const unsigned long long again = __ballot(lane < cnt && ir_l != a.eos && rep_l);        // repeated: their mass goes to the fallback
+            float asum = 0.0f, prep = 0.0f;                  // fp32 sums in rank order: the oracle's order
             for (int r = 0; r < cnt; ++r) {
-                const float pr = sh_s[r];
-                const int ir = sh_i[r];
-                if (ir == a.eos) continue;
-                if (repeated(ir)) {
-                    prep += pr;
-                } else {
-                    asum += pr;
-                    direct |= 1ull << r;
-                }
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr_l), r));
+                if (direct >> r & 1ull) asum += v;
+                else if (again >> r & 1ull) prep += v;
             }
             const float target = u_first * (asum + prep * (1.0f - p_eos));
             float run = 0.0f;
             tok = -1;
             for (int r = 0; r < cnt && tok < 0; ++r) {
                 if (direct >> r & 1ull) {
-                    run += sh_s[r];
-                    if (run > target) tok = sh_i[r];
+                    run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr_l), r));
+                    if (run > target) tok = __builtin_amdgcn_readlane(ir_l, r);
                 }
             }
             fallback = tok < 0;                             // also: a nucleus that holds nothing but EOS
