@@ -325,7 +325,7 @@ def side_workload(args, which, dev, dist, rank, world):
         inp = SynthInputs(cfg, rows, tt, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
         sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
                   inp.z, inp.phase0, inp.noise)
-        pipe = PipelinedSynth.autotune(eng, sample, depths=(2,), trials=2, steps=4)
+        pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=6)
         last = {}
 
         def step():
