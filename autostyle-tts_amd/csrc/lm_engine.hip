@@ -53,6 +53,11 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     const float scale = 0.125f;
     // ASTTS_LM_KSPLIT=1 (experiments): the decode attention as 128 workgroups with the whole key range each instead of 256 with half of it
     static const int ksplit = [] { const char* e = getenv("ASTTS_LM_KSPLIT"); return e && atoi(e) == 1 ? 1 : 2; }();
+    // ASTTS_LM_SKIP=<bits> (timing experiments only, results are garbage): 1 drops the out-projection launch, 2 the FFN-out launch
+    static const int skip = [] { const char* e = getenv("ASTTS_LM_SKIP"); return e ? atoi(e) : 0; }();
+    // ASTTS_LM_FFN_SPLIT=0: FFN-out as one workgroup per column block over the whole K (rounds 2-3)
+    static const bool ffn_split_env = [] { const char* e = getenv("ASTTS_LM_FFN_SPLIT"); return !e || atoi(e) != 0; }();
+    const bool ffn_split = ffn_split_env && (c.ffn & 255) == 0;
     const KvLayout lay = KvLayout::time_major(b, d);
     auto gemv = [&]() {
         GemvArgs a;
@@ -86,11 +91,17 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             a.n = d; a.k = d; a.kpad = d;
             if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
         }
-        float* x = xa;
+        // the residual stream alternates between two buffers: layer l reads X[l % 2] and its FFN-out projection leaves X[(l + 1) % 2].
+        // FFN-out runs as two K slices per column block (lm_step.h, GemvArgs::ksplit: 256 workgroups with 32 KB of weights each instead
+        // of 128 with 64 KB) that meet in the output with one fp32 atomic each, so the output must hold zeros: the FFN-in launch of the
+        // layer clears it (its last readers, QKV and the out-projection of the layer, are done by then).
+        float* X[2] = {xa, h1};          // (h1 is free once layer 0's QKV has read it)
         float* y = xb;
         for (int l = 0; l < c.layers; ++l) {
             const astts_lm_layer_t& L = h->layers[l];
             _Float16* kvc = (_Float16*)kv_cache[l];
+            float* x = X[l & 1];
+            float* xn = X[(l + 1) & 1];
             a = gemv();             // LN1 + QKV: q -> `q`, K|V -> cache row `pos`
             if (l == 0) {
                 a.x = g.embed_table ? g.embed_table : h1;
@@ -116,16 +127,19 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             if (ksplit == 1) { a.x = ff; a.x2 = nullptr; a.x_mode = 1; a.ldx = d; }
             a.w = (const _Float16*)L.wo; a.bias = L.bo; a.res = x; a.ldr = d; a.out = y; a.ldo = d;
             a.n = d; a.k = d; a.kpad = d;
-            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            if (!(skip & 1) && (rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             a = gemv();             // LN2 + FFN-in + ReLU -> fp16 hidden (its only consumer is an MFMA operand)
             a.x = y; a.ldx = d; with_ln(a, L.n2_g, L.n2_b);
             a.w = (const _Float16*)L.w1; a.bias = L.b1; a.out16 = ff; a.ldo16 = c.ffn; a.relu = 1; a.n = c.ffn; a.k = d; a.kpad = d;
+            if (ffn_split) { a.zero = xn; a.zero_n = b * d; }
             if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             a = gemv();             // FFN-out + residual
-            a.x = ff; a.x_mode = 1; a.ldx = c.ffn; a.w = (const _Float16*)L.w2; a.bias = L.b2; a.res = y; a.ldr = d; a.out = x; a.ldo = d;
+            a.x = ff; a.x_mode = 1; a.ldx = c.ffn; a.w = (const _Float16*)L.w2; a.bias = L.b2; a.res = y; a.ldr = d; a.out = xn; a.ldo = d;
             a.n = d; a.k = c.ffn; a.kpad = c.ffn;
-            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            if (ffn_split) a.ksplit = 2;
+            if (!(skip & 2) && (rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
         }
+        float* x = X[c.layers & 1];
         a = gemv();                 // after_norm + output head
         a.x = x; a.ldx = d; with_ln(a, g.after_g, g.after_b);
         a.w = (const _Float16*)g.head_w; a.bias = g.head_b; a.out = lg; a.ldo = c.vocab_out; a.n = c.vocab_out; a.k = d; a.kpad = d;

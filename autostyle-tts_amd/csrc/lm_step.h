@@ -45,6 +45,11 @@ struct GemvArgs {
     int x_mode, relu, advance, stamp_slot;
     int ln_plain;             // LayerNorm without scale / shift (folded into w / bias at load); ln_g must then be null
     int pos;                  // kv row when st is null
+    int ksplit;               // 2: the launch carries TWO workgroups per column block, each over one half of K (fp16 input only, k == kpad); both
+                              //   add their sum into `out` with ONE fp32 atomic each (slice 0 carries bias + residual).  `out` must hold zeros at
+                              //   launch; two addends on a zero commute exactly, so the result does not depend on which arrives first
+    float* zero;              // optional: the launch clears zero[0 .. zero_n) (the accumulator of a later split launch) -- no reader in between
+    int zero_n;
 };
 
 struct AttnArgs {

@@ -90,6 +90,15 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     LM_RAISE_PRIO();
     GemvArgs a = a_in;
     a.x = p_x; a.w = p_w; a.x2 = p_x2; a.gather = p_gather; a.m = p_m; a.n = p_n; a.k = p_k; a.kpad = p_kpad; a.ldx = p_ldx;
+    const int wld = p_kpad;                                   // weight row stride
+    if constexpr (XM == 1) {
+        if (gridDim.y > 1) {                                  // K slice blockIdx.y of a split projection (GemvArgs::ksplit)
+            const int kh = p_kpad >> 1;
+            a.x = reinterpret_cast<const _Float16*>(p_x) + (int)blockIdx.y * kh;
+            a.w = p_w + (int)blockIdx.y * kh;
+            a.k = kh; a.kpad = kh;
+        }
+    }
     constexpr bool XF16 = XM != 0;
     constexpr bool HALF8 = FORM != 0;                          // K halved over MFMA columns, 8 output columns per workgroup
     constexpr bool DIAG = FORM == 1;
@@ -112,8 +121,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
 
     // ---- (0) everything this block will need from memory, issued before anything waits
     // weights: lane (c, g) owns bytes [32g, 32g + 32) of its row in every 128-byte line (two 16x16x32 k-steps)
-    const _Float16* wrow = HALF8 ? a.w + (int64_t)(n0 + (c & 7)) * a.kpad + (c >> 3) * Kc + g * 16
-                                 : a.w + (int64_t)(n0 + c) * a.kpad + g * 16;
+    const _Float16* wrow = HALF8 ? a.w + (int64_t)(n0 + (c & 7)) * wld + (c >> 3) * Kc + g * 16
+                                 : a.w + (int64_t)(n0 + c) * wld + g * 16;
     // input row of this wave (fp32 path, K <= 1024: 4 float4 per lane) -- needed first, so issued first
     constexpr int MAXV = 4;
     constexpr int RPW = DIAG ? 1 : 2 * MT;                    // rows a wave stages (rows wid, wid + 8, ...): ALL prefetched up front
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         for (int i = 0; i < NL; ++i) {
             const int line = wid + i * GV_WAVES;
             if (line < lines) {
-                fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64);
-                fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64 + 8);
+                fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64);
+                fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64 + 8);
             }
         }
     pin_args(a);            // the remaining arguments: ONE wide scalar load + ONE wait, behind the loads issued above
@@ -235,9 +244,12 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     }
     const bool live = owner && on < a.n && om < M;
     float e_bias = 0.0f, e_res = 0.0f;
-    if (live) {
+    if (live && blockIdx.y == 0) {                            // (a split projection's second K slice adds neither)
         if (a.bias) e_bias = a.bias[on];
         if (a.res) e_res = a.res[(int64_t)om * a.ldr + on];
+    }
+    if (a.zero) {                                             // accumulator of a later split launch
+        for (int i = (int)blockIdx.x * 512 + tid; i < a.zero_n; i += (int)gridDim.x * 512) a.zero[i] = 0.0f;
     }
     int kv_pos = a.pos;
     if (a.kv && a.st) kv_pos = a.st->pos0 + a.st->step;
@@ -498,8 +510,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
             for (int i = 0; i < NL; ++i) {
                 const int line = wid + ((pass + 1) * NL + i) * GV_WAVES;
                 if (line < lines) {
-                    fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64);
-                    fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * a.kpad + line * 64 + 8);
+                    fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64);
+                    fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64 + 8);
                 }
             }
     }
@@ -534,6 +546,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         if (a.kv && on >= a.n_split) {
             const int dd = (a.n - a.n_split) >> 1, c = on - a.n_split, isv = c >= dd ? 1 : 0, cc = c - isv * dd;
             a.kv[(int64_t)kv_pos * a.kv_t + (int64_t)om * a.kv_b + (int64_t)(cc >> 6) * a.kv_h + (int64_t)isv * a.kv_v + (cc & 63)] = (_Float16)v;
+        } else if (XM == 1 && gridDim.y > 1) {
+            unsafeAtomicAdd(a.out + (int64_t)om * a.ldo + on, v);     // the two K slices meet on a zero: a + b == b + a
         } else {
             if (a.out) a.out[(int64_t)om * a.ldo + on] = v;
             if (a.out16) a.out16[(int64_t)om * a.ldo16 + on] = (_Float16)v;
@@ -787,14 +801,21 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
     ASTTS_REQUIRE(xm != 2 || (a0.x2 && (a0.k & 63) == 0 && a0.k == a0.kpad), ASTTS_ERR_INVALID, "lm_gemv: attention partials need x2 and k = heads * 64");
     ASTTS_REQUIRE(!a0.pre_g || (a0.k <= 1024 && (a0.k & 3) == 0 && (a0.ldx & 3) == 0 && ((uintptr_t)a0.x & 15) == 0), ASTTS_ERR_INVALID,
                   "lm_gemv: the embedding pre-transform needs k <= 1024 and aligned rows");
+    const int ksp = a0.ksplit == 2 ? 2 : 1;
+    ASTTS_REQUIRE(a0.ksplit == 0 || a0.ksplit == 1 || (a0.ksplit == 2 && xm == 1 && a0.k == a0.kpad && (a0.kpad & 255) == 0 && a0.out && !a0.out16 && !a0.kv &&
+                                                          !a0.relu && !a0.advance), ASTTS_ERR_INVALID,
+                  "lm_gemv: ksplit=%d needs fp16 input, k == kpad (a multiple of 256), a fp32 output holding zeros, no relu / out16 / kv", a0.ksplit);
+    ASTTS_REQUIRE(!a0.zero || a0.zero_n >= 0, ASTTS_ERR_INVALID, "lm_gemv: zero_n=%d", a0.zero_n);
     lm_step_set_attrs();
+    const int kslice = a0.kpad / ksp;                         // K extent of a workgroup
     auto shape_of = [&](int rows, int* form, int* mt, int* kc, size_t* lds) {
         GemvArgs t = a0;
         t.m = rows;
+        t.k = t.kpad = kslice;
         const int var = lm_gemv_variant(t);
         *form = var & 3;
         *mt = var >> 2;
-        *kc = *form ? a0.kpad / 2 : a0.kpad;
+        *kc = *form ? kslice / 2 : kslice;
         const int lrows = *form == 1 ? 16 : (*form == 2 ? 32 * *mt : rows);
         *lds = gemv_lds_bytes(lrows, *kc, *form == 2 ? 2 * *mt : *mt);
     };
@@ -827,7 +848,7 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
         // the form of the FIRST chunk serves every chunk (a short last chunk must not change the arithmetic of its rows)
         const int lpw = ((kc >> 6) + GV_WAVES - 1) / GV_WAVES;
         const bool wide = form == 0 && mt == 1 && xm != 2 && lpw <= 2 && lm_wide();
-        const dim3 grid(wide ? (a.n + 31) / 32 : (a.n + (form ? 7 : 15)) / (form ? 8 : 16));
+        const dim3 grid(wide ? (a.n + 31) / 32 : (a.n + (form ? 7 : 15)) / (form ? 8 : 16), ksp);
         if (wide) lds = gemv_lds_bytes(a.m, kc, 2);      // two accumulators per wave in the cross-wave reduction
         if (form == 1) gemv_launch_xm<1, 1>(a, xm, grid, lds, lpw, st);
         else if (form == 2 && mt == 1) gemv_launch_xm<1, 2>(a, xm, grid, lds, lpw, st);

@@ -1,0 +1,12 @@
+#!/bin/bash
+# FFN-out as two K slices per column block (GemvArgs::ksplit): parity, timing alone, pipelined A/B
+cd "$GRAFT_REPO_ROOT"
+timeout 1200 python -m pytest tests/test_lm_step_gpu.py -m gpu -x -q 2>&1 | tail -4
+echo "=== alone"
+for s in 0 1 0 1; do ASTTS_LM_FFN_SPLIT=$s LM_TIME_ENGINES=v2 timeout 300 python scripts/lm_engine_time.py 2>&1 | grep "^b=" | sed "s/^/split=$s /"; done
+echo "=== pipelined A/B"
+run() { v=$(env "$@" timeout 600 python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-24khz --no-cobatch 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stages_ms']; print(round(d['value'],1), round(d['ms_per_step'],2), 'lm', s['lm_ms'], 'flow', s['flow_ms'], d['pipelining'][:14])"); echo "$*: $v"; }
+run ASTTS_LM_FFN_SPLIT=0
+run ASTTS_LM_FFN_SPLIT=1
+run ASTTS_LM_FFN_SPLIT=0
+run ASTTS_LM_FFN_SPLIT=1
