@@ -53,7 +53,8 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     const float scale = 0.125f;
     // ASTTS_LM_KSPLIT=1 (experiments): the decode attention as 128 workgroups with the whole key range each instead of 256 with half of it
     static const int ksplit = [] { const char* e = getenv("ASTTS_LM_KSPLIT"); return e && atoi(e) == 1 ? 1 : 2; }();
-    // ASTTS_LM_SKIP=<bits> (timing experiments only, results are garbage): 1 drops the out-projection launch, 2 the FFN-out launch
+    // ASTTS_LM_SKIP=<bits> (timing experiments only, results are garbage): drops a launch of every layer -- 1 out-projection, 2 FFN-out, 4 QKV,
+    // 8 attention, 16 FFN-in
     static const int skip = [] { const char* e = getenv("ASTTS_LM_SKIP"); return e ? atoi(e) : 0; }();
     // ASTTS_LM_FFN_SPLIT=0: FFN-out as one workgroup per column block over the whole K (rounds 2-3)
     static const bool ffn_split_env = [] { const char* e = getenv("ASTTS_LM_FFN_SPLIT"); return !e || atoi(e) != 0; }();
@@ -113,7 +114,7 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             a.ldx = d; with_ln(a, L.n1_g, L.n1_b);
             a.w = (const _Float16*)L.wqkv; a.bias = L.bqkv; a.out = q; a.ldo = d; a.kv = kvc; a.n_split = d; a.kv_t = lay.t; a.kv_b = lay.b; a.kv_h = lay.h; a.kv_v = lay.v; a.pos = pos;
             a.n = 3 * d; a.k = d; a.kpad = d;
-            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            if (!(skip & 4) && (rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             AttnArgs t;
             memset(&t, 0, sizeof(t));
             t.q = q; t.kv = kvc; t.postab = (const _Float16*)L.pos; t.bias_u = L.bias_u; t.bias_v = L.bias_v; t.kstart = key_start;
@@ -121,7 +122,7 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             t.h = c.heads; t.ldq = d; t.ldp = c.pos_ld; t.center = c.pos_center;
             if (ksplit == 1) { t.out = ff; t.ldo = d; }      // one workgroup per (row, head): the fp16 FFN buffer is free until FFN-in
             t.d = d; t.scale = scale; t.pos = pos; t.kv_t = lay.t; t.kv_b = lay.b; t.kv_h = lay.h; t.kv_v = lay.v;
-            if ((rc = lm_attn_launch(t, st)) != ASTTS_OK) return rc;
+            if (!(skip & 8) && (rc = lm_attn_launch(t, st)) != ASTTS_OK) return rc;
             a = gemv();             // out-proj on the merged attention partials + residual
             a.x = part_o; a.x2 = part_ml; a.x_mode = 2;
             if (ksplit == 1) { a.x = ff; a.x2 = nullptr; a.x_mode = 1; a.ldx = d; }
@@ -132,7 +133,7 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
             a.x = y; a.ldx = d; with_ln(a, L.n2_g, L.n2_b);
             a.w = (const _Float16*)L.w1; a.bias = L.b1; a.out16 = ff; a.ldo16 = c.ffn; a.relu = 1; a.n = c.ffn; a.k = d; a.kpad = d;
             if (ffn_split) { a.zero = xn; a.zero_n = b * d; }
-            if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
+            if (!(skip & 16) && (rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
             a = gemv();             // FFN-out + residual
             a.x = ff; a.x_mode = 1; a.ldx = c.ffn; a.w = (const _Float16*)L.w2; a.bias = L.b2; a.res = y; a.ldr = d; a.out = xn; a.ldo = d;
             a.n = d; a.k = c.ffn; a.kpad = c.ffn;

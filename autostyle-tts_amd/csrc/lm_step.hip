@@ -590,7 +590,20 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
     const int head = blockIdx.x, bb = blockIdx.y;
     const int qpos = a.st ? a.st->pos0 + a.st->step : a.pos;  // absolute position of the query = index of the newest key
     const int len = qpos + 1;
-    const int ks_first = a.kstart ? min(a.kstart[bb], len - 1) : 0;
+    // Load schedule (round 4).  The kernel has THREE kinds of operands -- the row's first valid key, the query / bias vectors, the keys --
+    // and only the key addresses depend on another load (the first valid key).  Issued in that order, with every key load of a chunk
+    // UNCONDITIONAL (the index is clamped to the newest key; what lies beyond the range is masked when the scores are formed): a load
+    // inside an `if (j < kend)` block made the compiler open each block with s_waitcnt vmcnt(0), so the four 64-key groups of a chunk --
+    // meant to be one memory round trip -- were four dependent ones, behind a fifth for the query.
+    const float* qp = a.q + (int64_t)bb * a.ldq + head * 64 + sub * 8;
+    const float4 x0 = *reinterpret_cast<const float4*>(qp), x1 = *reinterpret_cast<const float4*>(qp + 4);
+    const float4 u0 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8), u1 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8 + 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8), w1 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8 + 4);
+    // (the first valid key LAST of this group: the wait for it then covers the whole group -- one round trip -- and unconditional through a
+    // selected address: a load inside `if (a.kstart)` is waited for at the end of its block)
+    int ks_raw = *(a.kstart ? a.kstart + bb : reinterpret_cast<const int*>(a.q));
+    if (!a.kstart) ks_raw = 0;
+    const int ks_first = min(ks_raw, len - 1);
     // key split (gridDim.z = 2): two workgroups per (row, head) take the two halves of the valid keys (a multiple of 64
     // keys each) and write unnormalised partials; the consumer (lm_gemv XM == 2) merges them while staging its input.
     int ks0 = ks_first, kend = len;
@@ -603,12 +616,19 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
     const _Float16* kb = a.kv + (int64_t)bb * a.kv_b + (int64_t)head * a.kv_h + sub * 8;
     const _Float16* vb = kb + a.kv_v;
     const _Float16* pb = pos_row0 + head * 64 + sub * 8;
+    half8 kk[AT_U], pp[AT_U], vv[AT_U];
+    auto load_chunk = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) {
+            const int jc = min(j0 + u * 64 + kg, qpos);      // clamped: always a row of the cache
+            kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)jc * trow);
+            pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - jc) * a.ldp);
+            vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)jc * trow);
+        }
+    };
+    load_chunk(ks0);                                          // (a workgroup with an empty key range loads the newest key and uses nothing)
     float qu[8], qv[8];
     {
-        const float* qp = a.q + (int64_t)bb * a.ldq + head * 64 + sub * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(qp), x1 = *reinterpret_cast<const float4*>(qp + 4);
-        const float4 u0 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8), u1 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8 + 4);
-        const float4 w0 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8), w1 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8 + 4);
         const float xs_[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         const float us_[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
         const float ws_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -625,16 +645,7 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.0f;
     for (int j0 = ks0; j0 < kend; j0 += 64 * AT_U) {
-        half8 kk[AT_U], pp[AT_U], vv[AT_U];
-#pragma unroll
-        for (int u = 0; u < AT_U; ++u) {
-            const int j = j0 + u * 64 + kg;
-            if (j < kend) {
-                kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)j * trow);
-                pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - j) * a.ldp);
-                vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)j * trow);
-            }
-        }
+        if (j0 != ks0) load_chunk(j0);
         LM_STAMP(a, 1);
         float s[AT_U];
         float m_new = m_run;

@@ -218,11 +218,22 @@ __global__ __launch_bounds__(RS_NT) void ras_sample(const float* p_logits, const
     if (tid == 0) s_cnt = 0;
     if (tid < 16 && ((a.v + 15) & ~15) - 16 + tid >= a.v) prob[((a.v + 15) & ~15) - 16 + tid] = 0.0f;   // tail of the last 16-chunk
     float mx = -INFINITY;
-    for (int i = tid; i < a.v; i += RS_NT) {
-        float x = lg[i];
-        if (mask_eos && i == a.eos) x = -INFINITY;
-        prob[i] = x;
-        mx = fmaxf(mx, x);
+    // eight logits per thread and round trip, unconditional (clamped index): a load inside the bounds check is waited for in its own
+    // block, which made the 4 097-entry row five dependent round trips
+    for (int base = 0; base < a.v; base += 8 * RS_NT) {
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = lg[min(base + u * RS_NT + tid, a.v - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * RS_NT + tid;
+            if (i < a.v) {
+                float x = xv[u];
+                if (mask_eos && i == a.eos) x = -INFINITY;
+                prob[i] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
     }
     mx = xmax<1>(xmax<2>(xmax<4>(xmax<8>(xmax<16>(xmax<32>(mx))))));      // xlane.h: VALU lane exchanges instead of six ds_bpermute round trips
     if (lane == 0) red_max[wid] = mx;

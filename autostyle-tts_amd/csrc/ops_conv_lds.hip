@@ -68,35 +68,46 @@ __global__ __launch_bounds__((BM / 64) * (C / 64) * 64, (BM / 64) * (C / 64) == 
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) dst[nt * 8 + ks] = *reinterpret_cast<const half8*>(p + ((int64_t)nt * (C / 16) + ks) * 512);
     };
+    // (the Snake parameters of this thread's columns first: their wait must not cover the weight loads behind them)
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.alpha) a4 = *reinterpret_cast<const float4*>(a.alpha + (tid % CV) * 4);
     load_unit(0, wf[0]);
 
     // ---- staging: Snake once per element, fp16 rows in LDS; rows outside the sequence are zero (the convolution pads the
     // ACTIVATED signal, and snake(0) = 0 anyway)
     {
         const int col = (tid % CV) * 4, r0 = tid / CV;
-        float al[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {0.f, 0.f, 0.f, 0.f};
+        float al[4] = {a4.x, a4.y, a4.z, a4.w}, inv[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.alpha) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a.alpha + col);
-            al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) inv[j] = 1.0f / (al[j] + 1e-9f);
         }
         constexpr int SU = 12;                        // rows per thread in flight (a 178-row tile in two trips)
         for (int rb = r0; rb < sr; rb += RPP * SU) {
+            // every row's load is UNCONDITIONAL (frame index clamped into the sequence, zeroed afterwards): a load inside the bounds
+            // check is waited for at the end of its block, which made the SU loads "in flight" SU dependent round trips
             float4 v[SU];
+            if (a.x_f16) {
+                half4 hv[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int t = min(max(t0 - halo + rb + u * RPP, 0), a.l - 1);
+                    hv[u] = *reinterpret_cast<const half4*>((const _Float16*)a.x + (seq + t) * C + col);
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) v[u] = make_float4((float)hv[u][0], (float)hv[u][1], (float)hv[u][2], (float)hv[u][3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int t = min(max(t0 - halo + rb + u * RPP, 0), a.l - 1);
+                    v[u] = *reinterpret_cast<const float4*>((const float*)a.x + (seq + t) * C + col);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const int r = rb + u * RPP;
                 const int t = t0 - halo + r;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < sr && t >= 0 && t < a.l) {
-                    if (a.x_f16) {
-                        const half4 h = *reinterpret_cast<const half4*>((const _Float16*)a.x + (seq + t) * C + col);
-                        v[u] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                    } else {
-                        v[u] = *reinterpret_cast<const float4*>((const float*)a.x + (seq + t) * C + col);
-                    }
-                }
+                if (!(r < sr && t >= 0 && t < a.l)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {

@@ -380,40 +380,87 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     half8 ra[A_CH];
     half8 rb[B_CH];
 
+    // Every load of a tile is UNCONDITIONAL on the usual shapes (aligned rows, channels a multiple of 8): the address of a chunk that lies
+    // in the padding / outside the sequence is replaced by the tensor's base and the chunk zeroed afterwards.  A load inside the bounds
+    // check is waited for at the end of its block, which made the A_CH + B_CH chunks of a tile as many dependent round trips.
+    const bool fast = vec_ok && (a.cin & 7) == 0;
+    // (weight rows are padded to whole tiles: a chunk index beyond the tile -- only when BN * CPR is not a multiple of 256 -- re-reads chunk 0)
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < B_CH; ++c)
+            rb[c] = *reinterpret_cast<const half8*>(a.w + (int64_t)(n0 + (b_live[c] ? b_row[c] : 0)) * ktot + k0 + (b_live[c] ? b_seg[c] : 0));
+    };
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         const int tap = k0 / a.cin_pad;
         const int c0 = k0 - tap * a.cin_pad;
-#pragma unroll
-        for (int c = 0; c < A_CH; ++c) {
-            const int ts = a_t[c] + tap * a.dil;
-            const bool ok = a_live[c] && ts >= 0 && ts < a.t_in;
-            const int ch = c0 + a_seg[c];
-            const int64_t off = (a_base[c] + ts) * (int64_t)a.lda + ch;
+        if (fast) {
+            bool okc[A_CH];
             if constexpr (A16) {
-                if (ok && vec_ok && ch + 8 <= a.cin) {
+#pragma unroll
+                for (int c = 0; c < A_CH; ++c) {
+                    const int ts = a_t[c] + tap * a.dil;
+                    const int ch = c0 + a_seg[c];
+                    okc[c] = a_live[c] && ts >= 0 && ts < a.t_in && ch < a.cin;
+                    const int64_t off = okc[c] ? (a_base[c] + ts) * (int64_t)a.lda + ch : 0;
                     ra[c] = *reinterpret_cast<const half8*>(x16 + off);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ra[c][j] = (ok && ch + j < a.cin) ? x16[off + j] : (_Float16)0.0f;
                 }
+                load_b(k0);
+#pragma unroll
+                for (int c = 0; c < A_CH; ++c)
+                    if (!okc[c]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ra[c][j] = (_Float16)0.0f;
+                    }
             } else {
-                float tmp[8];
-                if (ok && vec_ok && ch + 8 <= a.cin) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
-                    const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
-                    tmp[0] = v0.x; tmp[1] = v0.y; tmp[2] = v0.z; tmp[3] = v0.w; tmp[4] = v1.x; tmp[5] = v1.y; tmp[6] = v1.z; tmp[7] = v1.w;
-                } else {
+                float4 v0[A_CH], v1[A_CH];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) tmp[j] = (ok && ch + j < a.cin) ? a.x[off + j] : 0.0f;
+                for (int c = 0; c < A_CH; ++c) {
+                    const int ts = a_t[c] + tap * a.dil;
+                    const int ch = c0 + a_seg[c];
+                    okc[c] = a_live[c] && ts >= 0 && ts < a.t_in && ch < a.cin;
+                    const int64_t off = okc[c] ? (a_base[c] + ts) * (int64_t)a.lda + ch : 0;
+                    v0[c] = *reinterpret_cast<const float4*>(a.x + off);
+                    v1[c] = *reinterpret_cast<const float4*>(a.x + off + 4);
                 }
+                load_b(k0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ra[c][j] = (_Float16)tmp[j];
+                for (int c = 0; c < A_CH; ++c) {
+                    if (!okc[c]) v0[c] = v1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ra[c][0] = (_Float16)v0[c].x; ra[c][1] = (_Float16)v0[c].y; ra[c][2] = (_Float16)v0[c].z; ra[c][3] = (_Float16)v0[c].w;
+                    ra[c][4] = (_Float16)v1[c].x; ra[c][5] = (_Float16)v1[c].y; ra[c][6] = (_Float16)v1[c].z; ra[c][7] = (_Float16)v1[c].w;
+                }
             }
-        }
+        } else {
 #pragma unroll
-        for (int c = 0; c < B_CH; ++c)
-            if (b_live[c]) rb[c] = *reinterpret_cast<const half8*>(a.w + (int64_t)(n0 + b_row[c]) * ktot + k0 + b_seg[c]);
+            for (int c = 0; c < A_CH; ++c) {
+                const int ts = a_t[c] + tap * a.dil;
+                const bool ok = a_live[c] && ts >= 0 && ts < a.t_in;
+                const int ch = c0 + a_seg[c];
+                const int64_t off = (a_base[c] + ts) * (int64_t)a.lda + ch;
+                if constexpr (A16) {
+                    if (ok && vec_ok && ch + 8 <= a.cin) {
+                        ra[c] = *reinterpret_cast<const half8*>(x16 + off);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ra[c][j] = (ok && ch + j < a.cin) ? x16[off + j] : (_Float16)0.0f;
+                    }
+                } else {
+                    float tmp[8];
+                    if (ok && vec_ok && ch + 8 <= a.cin) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
+                        const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
+                        tmp[0] = v0.x; tmp[1] = v0.y; tmp[2] = v0.z; tmp[3] = v0.w; tmp[4] = v1.x; tmp[5] = v1.y; tmp[6] = v1.z; tmp[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tmp[j] = (ok && ch + j < a.cin) ? a.x[off + j] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ra[c][j] = (_Float16)tmp[j];
+                }
+            }
+            load_b(k0);
+        }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll

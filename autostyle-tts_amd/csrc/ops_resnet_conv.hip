@@ -19,6 +19,7 @@
 // Tried and dropped: 64 frames x 128 channels per workgroup of four waves (192 workgroups, half the weight stream each): the flow
 // solve got 1.2 ms SLOWER -- as with the split feed-forward form, the weight stream is not what a launch waits for.
 #include "common.h"
+#include "xlane.h"
 
 namespace astts {
 
@@ -76,6 +77,25 @@ __device__ __forceinline__ void rc_merge(const float* stats, int bb, int ntile, 
     *rstd_out = rsqrtf((n > 0.0f ? m2 / n : 0.0f) + eps);
 }
 
+// The same merge by one WAVE: lane i holds tile i's triple (loaded by the caller: ONE round trip instead of one per tile), the tiles are
+// folded in tile order through v_readlane -- the same operations in the same order as rc_merge, hence the same bits.  <= 64 tiles.
+__device__ __forceinline__ void rc_merge_lanes(float nb_l, float mb_l, float qb_l, int ntile, float eps, float* mean_out, float* rstd_out) {
+    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int i = 0; i < ntile; ++i) {
+        const float nb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nb_l), i));
+        const float mb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mb_l), i));
+        const float qb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qb_l), i));
+        if (nb > 0.0f) {
+            const float nn = n + nb, d = mb - mean;
+            mean += d * (nb / nn);
+            m2 += qb + d * d * (n * nb / nn);
+            n = nn;
+        }
+    }
+    *mean_out = mean;
+    *rstd_out = rsqrtf((n > 0.0f ? m2 / n : 0.0f) + eps);
+}
+
 template <int CIN>
 // Leading parameters = what the first loads need: preloaded into SGPRs by the command processor (-amdgpu-kernarg-preload-count,
 // csrc/Makefile; a by-value struct is not), the struct carries the rest.
@@ -99,7 +119,42 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Flo
     const int len = a.lens ? min(a.lens[bb], a.t) : a.t;
     const int64_t seq = (int64_t)bb * a.t;
 
-    // ---- weights of the first unit (tap 0, slice 0) first, then the rows
+    // ---- Prologue loads, in the order their consumers run and with nothing conditional between them (a load inside an `if` block is
+    // waited for at the end of the block: the bounds-checked rows were NPASS dependent round trips, the tile-by-tile statistics merge
+    // one per tile, and the L2 prefetch loop held everything behind an HBM miss).  (1) GroupNorm partials: wave w owns group w, lane i
+    // tile i (through a selected pointer when absent); (2) the rows, frame index clamped into the sequence and zeroed afterwards;
+    // (3) the per-channel parameters of the staging transform; (4) two units of weights; (5) the prefetch lines, nobody waits for.
+    const bool in_gn = CIN == RC_C && a.in_stats != nullptr;      // the staging transform exists for 256-channel inputs only
+    const bool lanes_ok = ntile <= 64;
+    float st_in[3] = {0.f, 0.f, 0.f}, st_res[3] = {0.f, 0.f, 0.f};
+    {
+        const int ti = min(lane, ntile - 1);
+        const float* pi = a.in_stats ? a.in_stats + (((int64_t)bb * ntile + ti) * 8 + wid) * 3 : a.x;
+        const float* pr = a.res_stats ? a.res_stats + (((int64_t)bb * ntile + ti) * 8 + wid) * 3 : a.x;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {     // (the compiler sinks these into the blocks that use them: a second, short round trip)
+            st_in[j] = pi[j];
+            st_res[j] = pr[j];
+        }
+    }
+    // TPR threads per row (one float4 each), RPP rows per pass; a thread keeps one column group (4 channels)
+    const int col = (tid % TPR) * 4, r0 = tid / TPR;
+    float4 v[NPASS];
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u) {
+        const int t = min(max(t0 - halo + r0 + RPP * u, 0), a.t - 1);
+        v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * CIN + col);
+    }
+    float4 ga, be, ad;
+    {
+        const float* pg = in_gn ? a.in_gamma + col : a.x;
+        const float* pb = in_gn ? a.in_beta + col : a.x;
+        const float* pa = in_gn && a.in_add ? a.in_add + (int64_t)bb * RC_C + col : a.x;
+        ga = *reinterpret_cast<const float4*>(pg);
+        be = *reinterpret_cast<const float4*>(pb);
+        ad = *reinterpret_cast<const float4*>(pa);
+        if (!(in_gn && a.in_add)) ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     half8 wf[2][16];
     const _Float16* wbase = a.w + ((int64_t)wid * (CIN / 16) * 64 + lane) * 8;
     auto load_unit = [&](int u, half8 (&dst)[16]) {   // unit = tap * KC + slice
@@ -110,38 +165,43 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Flo
     };
     const int nunits = a.taps * KC;
     load_unit(0, wf[0]);
-    unsigned pf_sink = 0;
-    if (a.pf) {   // workgroups of one XCD (linear ids congruent mod 8) split the range, one 128-byte line per thread
+    load_unit(nunits > 1 ? 1 : 0, wf[1]);
+    unsigned pf_keep[2];
+    {   // workgroups of one XCD (linear ids congruent mod 8) split the range, one 128-byte line per thread; the first two lines of a
+        // thread, as straight-line loads behind everything above (a counted wait never reaches them; a range beyond 1 024 lines per slot --
+        // none today -- is left to the next launch itself: the prefetch is a hint)
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
         const unsigned slot = lin >> 3, nslots = max((nwg + 7) >> 3, 1u);
-        const unsigned lines = (a.pf_bytes + 127) >> 7;
+        const unsigned lines = a.pf ? (a.pf_bytes + 127) >> 7 : 0u;
         const unsigned per = (lines + nslots - 1) / nslots;
-        for (unsigned i = tid; i < per; i += 512) {
-            const unsigned ln = slot * per + i;
-            if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf + ((size_t)ln << 7));
+        const char* pfb = a.pf ? a.pf : reinterpret_cast<const char*>(a.x);
+#pragma unroll
+        for (unsigned k = 0; k < 2; ++k) {
+            const unsigned i = tid + k * 512, ln = slot * per + i;
+            prefetch_line(pfb + (i < per && ln < lines ? (size_t)ln << 7 : (size_t)0), pf_keep[k]);      // (xlane.h)
         }
     }
-    // TPR threads per row (one float4 each), RPP rows per pass; a thread keeps one column group (4 channels)
-    const int col = (tid % TPR) * 4, r0 = tid / TPR;
-    float4 v[NPASS];
 #pragma unroll
     for (int u = 0; u < NPASS; ++u) {
         const int r = r0 + RPP * u;
         const int t = t0 - halo + r;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < sr && t >= 0 && t < a.t) v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * CIN + col);
+        if (!(r < sr && t >= 0 && t < a.t)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (nunits > 1) load_unit(1, wf[1]);
-    if (a.in_stats && tid < 8) rc_merge(a.in_stats, bb, ntile, tid, a.eps, &s_in[tid][0], &s_in[tid][1]);
-    if (a.res_stats && tid >= 64 && tid < 72) rc_merge(a.res_stats, bb, ntile, tid - 64, a.eps, &s_res[tid - 64][0], &s_res[tid - 64][1]);
-    float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f), ad = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool in_gn = CIN == RC_C && a.in_stats != nullptr;      // the staging transform exists for 256-channel inputs only
-    if (in_gn) {
-        ga = *reinterpret_cast<const float4*>(a.in_gamma + col);
-        be = *reinterpret_cast<const float4*>(a.in_beta + col);
-        if (a.in_add) ad = *reinterpret_cast<const float4*>(a.in_add + (int64_t)bb * RC_C + col);
-        __syncthreads();                              // the merged statistics are in LDS
+    if (lanes_ok) {
+        float mo, ro;
+        if (a.in_stats) {
+            rc_merge_lanes(st_in[0], st_in[1], st_in[2], ntile, a.eps, &mo, &ro);
+            if (lane == 0) { s_in[wid][0] = mo; s_in[wid][1] = ro; }
+        }
+        if (a.res_stats) {
+            rc_merge_lanes(st_res[0], st_res[1], st_res[2], ntile, a.eps, &mo, &ro);
+            if (lane == 0) { s_res[wid][0] = mo; s_res[wid][1] = ro; }
+        }
+    } else {
+        if (a.in_stats && tid < 8) rc_merge(a.in_stats, bb, ntile, tid, a.eps, &s_in[tid][0], &s_in[tid][1]);
+        if (a.res_stats && tid >= 64 && tid < 72) rc_merge(a.res_stats, bb, ntile, tid - 64, a.eps, &s_res[tid - 64][0], &s_res[tid - 64][1]);
     }
+    if (in_gn) __syncthreads();                       // the merged statistics are in LDS
     {
         const float mean = in_gn ? s_in[(col >> 5) & 7][0] : 0.0f, rstd = in_gn ? s_in[(col >> 5) & 7][1] : 1.0f;
 #pragma unroll
@@ -245,7 +305,8 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Flo
             a.out[(seq + t) * RC_C + f] = o;
         }
     }
-    if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = 0.0f;               // never true: keeps the prefetch loads alive
+    prefetch_keep(pf_keep[0]);
+    prefetch_keep(pf_keep[1]);
 }
 
 }  // namespace astts

@@ -20,6 +20,7 @@
 //            barrier, no global load in the key loop.
 // LDS: K [TKP][72] + V^T [64][TKP + 4] + A [2][32][264] + Q [192][64] halfs = 151 KB at T = 344 (TKP = 352), 159.5 KB at TKP = 384: T <= 384.
 #include "common.h"
+#include "xlane.h"
 
 namespace astts {
 
@@ -247,18 +248,19 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     } else if (ntile == 6) {
         tile = 4 + (wid & 1); part = (wid - 4) >> 1; parts = 2;
     }
-    unsigned pf_sink = 0;
-    {   // the workgroups of one XCD (ids congruent mod 8) split each range between them; the loaded words are only "used" by a
-        // never-true test at the very end (so that the wait lands there)
+    unsigned pf_keep[3];
+    {   // L2 prefetch of the next launches' weights: the workgroups of one XCD (ids congruent mod 8) split each range between them, one
+        // 128-byte line per thread and range (a range beyond 512 lines per slot -- none today -- is left to its own launch).  Untracked asm
+        // loads (xlane.h prefetch_line): the volatile loads used before compiled to system-scope flat loads with an immediate
+        // s_waitcnt vmcnt(0) each -- the waves owning query tiles 0 and 1 sat out three HBM misses in a row before their first score
         const unsigned slot = blockIdx.x >> 3, nslots = max(gridDim.x >> 3, 1u);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const unsigned lines = (a.pf_bytes[r] + 127) >> 7;
+            const unsigned lines = a.pf[r] ? (a.pf_bytes[r] + 127) >> 7 : 0u;
             const unsigned per = (lines + nslots - 1) / nslots;
-            for (unsigned i = tid; i < per; i += 512) {
-                const unsigned ln = slot * per + i;
-                if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf[r] + ((size_t)ln << 7));
-            }
+            const unsigned ln = slot * per + tid;
+            const char* base = a.pf[r] ? a.pf[r] : reinterpret_cast<const char*>(a.x);
+            prefetch_line(base + (tid < per && ln < lines ? (size_t)ln << 7 : (size_t)0), pf_keep[r]);
         }
     }
     const int nkt = (len + 31) >> 5;                    // key tiles with at least one valid key
@@ -396,7 +398,9 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
             *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + tf_q(r, seg));
     }
     }
-    if (pf_sink == 0x9e3779b9u && a.t < 0) a.out[0] = (_Float16)0.0f;     // never true: keeps the prefetch loads alive
+    prefetch_keep(pf_keep[0]);                         // the prefetch destinations stay reserved to the end
+    prefetch_keep(pf_keep[1]);
+    prefetch_keep(pf_keep[2]);
 }
 
 // Leading parameters = what the first loads (weight fragments, the sequence's rows) need: preloaded into SGPRs by the command
@@ -601,15 +605,14 @@ __device__ __forceinline__ void tfm_ffn_body(const TfmFfnArgs& a, const int64_t 
     }
     __syncthreads();
 
-    unsigned pf_sink = 0;
+    unsigned pf_keep;
     {   // workgroups of one XCD (ids congruent mod 8) split the range; see tfm_attn_fused
         const unsigned slot = blockIdx.x >> 3, nslots = max((gridDim.x + 7) >> 3, 1u);
-        const unsigned lines = (a.pf_bytes + 127) >> 7;
+        const unsigned lines = a.pf ? (a.pf_bytes + 127) >> 7 : 0u;
         const unsigned per = (lines + nslots - 1) / nslots;
-        for (unsigned i = tid; i < per; i += 512) {
-            const unsigned ln = slot * per + i;
-            if (ln < lines) pf_sink ^= *reinterpret_cast<const volatile unsigned*>(a.pf + ((size_t)ln << 7));
-        }
+        const unsigned ln = slot * per + tid;
+        const char* base = a.pf ? a.pf : reinterpret_cast<const char*>(a.x);
+        prefetch_line(base + (tid < per && ln < lines ? (size_t)ln << 7 : (size_t)0), pf_keep);
     }
     float16v acc2;
 #pragma unroll
@@ -709,7 +712,7 @@ __device__ __forceinline__ void tfm_ffn_body(const TfmFfnArgs& a, const int64_t 
         const int64_t row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (row < mend) a.out[row * TF_C + f] = (xr[e] + b2) + acc2[e];
     }
-    if (pf_sink == 0x9e3779b9u && a.m < 0) a.out[0] = 0.0f;               // never true: keeps the prefetch loads alive
+    prefetch_keep(pf_keep);
 }
 
 template <bool WO>

@@ -102,4 +102,13 @@ __device__ __forceinline__ float wave_sum_desc(float v) {
     return v;
 }
 
+
+// L2 prefetch of a 128-byte line nobody waits for.  A normal load whose value is unused is deleted; one whose value is "used" (volatile, or
+// consumed at the end of the kernel) is waited for -- volatile loads at once, the others by the first s_waitcnt vmcnt(0) the compiler
+// places, and that stalls a kernel prologue on an HBM miss.  An asm load is invisible to the compiler's vmcnt bookkeeping: its waits for
+// loads issued EARLIER never include this one (the counter is in order; an untracked younger load only makes vmcnt(N) wait for more of the
+// older ones).  The destination register must stay reserved until the data has landed: pass it to prefetch_keep() at the end of the kernel.
+__device__ __forceinline__ void prefetch_line(const void* p, unsigned& keep) { asm volatile("global_load_dword %0, %1, off" : "=v"(keep) : "v"(p)); }
+__device__ __forceinline__ void prefetch_keep(unsigned keep) { asm volatile("" ::"v"(keep)); }
+
 }  // namespace astts
