@@ -131,19 +131,29 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     float4 v0[XF16 ? 1 : RPW][MAXV];
     if constexpr (!XF16) {
         if (vec_ok) {
+            // Every load of every row of this wave is UNCONDITIONAL (row index clamped to the last row, K position clamped into the row,
+            // zeroed afterwards): loads inside `if (row < m)` / `if (k < K)` blocks, or behind the wait for a gathered row index, are
+            // waited for block by block -- the RPW rows of a wave (2 at 16 rows, 4 at 32) were as many dependent round trips.
+            auto load_rows = [&](const int64_t (&srcs)[RPW]) {
 #pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) {
-                const int mr = wid + rr * GV_WAVES;
-                if (mr < M) {
-                    const int64_t src = a.gather ? (int64_t)a.gather[mr] : (int64_t)mr;
-                    const float* xr = reinterpret_cast<const float*>(a.x) + src * a.ldx;
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const float* xr = reinterpret_cast<const float*>(a.x) + srcs[rr] * a.ldx;
 #pragma unroll
-                    for (int i = 0; i < MAXV; ++i) {
-                        const int k = lane * 4 + i * 256;
-                        v0[rr][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (i < nv && k < a.k) v0[rr][i] = *reinterpret_cast<const float4*>(xr + k);
-                    }
+                    for (int i = 0; i < MAXV; ++i) v0[rr][i] = *reinterpret_cast<const float4*>(xr + min(lane * 4 + i * 256, a.k - 4));
                 }
+            };
+            int64_t srcs[RPW];
+            if (a.gather) {
+                int gi[RPW];
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) gi[rr] = a.gather[min(wid + rr * GV_WAVES, M - 1)];
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) srcs[rr] = gi[rr];
+                load_rows(srcs);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) srcs[rr] = min(wid + rr * GV_WAVES, M - 1);
+                load_rows(srcs);
             }
         }
     }
@@ -187,17 +197,17 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         const float* pob = reinterpret_cast<const float*>(a.x);
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int q = tid + i * 512;
-            if (q < npieces) {
-                const int row = q / kp8, kk = (q - row * kp8) << 3;
-                const int hd = kk >> 6, dd = kk & 63;
-                const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+            // (unconditional, piece index clamped: guarded, the compiler merges this block with the guarded merge + LDS store below and
+            // drains every piece before the next one's loads -- and before the weight loads, which it moves behind them)
+            const int q = min(tid + i * 512, npieces - 1);
+            const int row = q / kp8, kk = (q - row * kp8) << 3;
+            const int hd = kk >> 6, dd = kk & 63;
+            const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
-                    po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
-                    pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
-                }
+            for (int sp = 0; sp < 2; ++sp) {
+                po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
+                po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
+                pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
             }
         }
     }
@@ -313,13 +323,16 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         auto merge = [&](const float4 (&o)[2][2], const float2 (&ml)[2]) {
             const float mx = fmaxf(ml[0].x, ml[1].x);
             const float w0 = ml[0].x == -INFINITY ? 0.0f : __expf(ml[0].x - mx), w1 = ml[1].x == -INFINITY ? 0.0f : __expf(ml[1].x - mx);
-            const float l = ml[0].y * w0 + ml[1].y * w1;
+            // a w0 + b w1 with the contraction PINNED (fma(a, w0, b w1)): left to the compiler, which of the two products is fused depends on
+            // the surrounding code, i.e. on the kernel variant -- and a row's bits must not depend on the variant (8- vs 16- vs 32-row forms)
+            auto mix = [&](float p0, float p1) { return __builtin_fmaf(p0, w0, p1 * w1); };
+            const float l = mix(ml[0].y, ml[1].y);
             const float inv = l > 0.0f ? 1.0f / l : 0.0f;
             half8 hv;
-            hv[0] = (_Float16)((o[0][0].x * w0 + o[1][0].x * w1) * inv); hv[1] = (_Float16)((o[0][0].y * w0 + o[1][0].y * w1) * inv);
-            hv[2] = (_Float16)((o[0][0].z * w0 + o[1][0].z * w1) * inv); hv[3] = (_Float16)((o[0][0].w * w0 + o[1][0].w * w1) * inv);
-            hv[4] = (_Float16)((o[0][1].x * w0 + o[1][1].x * w1) * inv); hv[5] = (_Float16)((o[0][1].y * w0 + o[1][1].y * w1) * inv);
-            hv[6] = (_Float16)((o[0][1].z * w0 + o[1][1].z * w1) * inv); hv[7] = (_Float16)((o[0][1].w * w0 + o[1][1].w * w1) * inv);
+            hv[0] = (_Float16)(mix(o[0][0].x, o[1][0].x) * inv); hv[1] = (_Float16)(mix(o[0][0].y, o[1][0].y) * inv);
+            hv[2] = (_Float16)(mix(o[0][0].z, o[1][0].z) * inv); hv[3] = (_Float16)(mix(o[0][0].w, o[1][0].w) * inv);
+            hv[4] = (_Float16)(mix(o[0][1].x, o[1][1].x) * inv); hv[5] = (_Float16)(mix(o[0][1].y, o[1][1].y) * inv);
+            hv[6] = (_Float16)(mix(o[0][1].z, o[1][1].z) * inv); hv[7] = (_Float16)(mix(o[0][1].w, o[1][1].w) * inv);
             return hv;
         };
 #pragma unroll
@@ -334,17 +347,15 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
             const float* pob = reinterpret_cast<const float*>(a.x);
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                const int q = q0 + tid + i * 512;
-                if (q < npieces) {
-                    const int row = q / kp8, kk = (q - row * kp8) << 3;
-                    const int hd = kk >> 6, dd = kk & 63;
-                    const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
+                const int q = min(q0 + tid + i * 512, npieces - 1);      // unconditional, clamped (see the first batch)
+                const int row = q / kp8, kk = (q - row * kp8) << 3;
+                const int hd = kk >> 6, dd = kk & 63;
+                const int64_t base = ((int64_t)row * (a.k >> 6) + hd) * 2;
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
-                        po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
-                        pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
-                    }
+                for (int sp = 0; sp < 2; ++sp) {
+                    po[i][sp][0] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd);
+                    po[i][sp][1] = *reinterpret_cast<const float4*>(pob + (base + sp) * 64 + dd + 4);
+                    pml[i][sp] = *reinterpret_cast<const float2*>(a.x2 + (base + sp) * 2);
                 }
             }
 #pragma unroll
@@ -360,6 +371,9 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         // register path: wave w owns rows w, w + 8, ... (the first one was prefetched above)
         auto stage_row = [&](float4 (&v)[MAXV], int mr) {
             const float inv_k = 1.0f / (float)a.k;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i)                    // positions beyond K were loaded from a clamped address: zero them
+                if (!(i < nv && lane * 4 + i * 256 < a.k)) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.pre_g) {
                 // embedding stage: two-pass LayerNorm (as layernorm_rows) -> ReLU -> * pre_scale
                 float s = 0.0f;
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
                     const int k = lane * 4 + i * 256;
                     if (i < nv && k < a.k) {
                         const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-                        qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                        qq += __builtin_fmaf(dx, dx, dy * dy) + __builtin_fmaf(dz, dz, dw * dw);
                     }
                 }
                 const float rstd = rsqrtf(wsum64(qq) * inv_k + a.ln_eps);
@@ -400,7 +414,9 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                    s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                    // (a a + b b with the contraction pinned: which product the compiler fuses may differ between kernel variants, and a
+                    // row's bits must not depend on the variant)
+                    s2 += __builtin_fmaf(v[i].x, v[i].x, v[i].y * v[i].y) + __builtin_fmaf(v[i].z, v[i].z, v[i].w * v[i].w);
                 }
                 s1 = wsum64(s1);
                 s2 = wsum64(s2);
