@@ -81,9 +81,9 @@ __device__ __forceinline__ float wsum64(float v) { return wave_sum_desc(v); }
 // memory round trips.  Inside the stream pipeline a decode kernel costs the chip (CUs it holds) x (time it holds them); the sums of a
 // column are formed exactly as with NCT = 1 (per wave: its K lines in order; then waves 0..7): bit-identical results.
 template <int MT, int FORM, int XM, int NL, int NCT = 1>
-__global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(const void* p_x, const _Float16* p_w, const float* p_x2, const int* p_gather, int p_m, int p_n, int p_k, int p_kpad, int p_ldx,
+__global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM == 0 && MT == 1 && XM != 2))) ? 4 : 2) void lm_gemv(const void* p_x, const _Float16* p_w, const float* p_x2, const int* p_gather, int p_m, int p_n, int p_k, int p_kpad, int p_ldx, int p_ks,
                                                                                                                 GemvArgs a_in) {
-    // The first 13 dwords of the kernarg segment are what the FIRST global loads need (input rows, weight lines).  As explicit
+    // The first 14 dwords of the kernarg segment (the most the hardware preloads) are what the FIRST global loads need (input rows, weight lines).  As explicit
     // leading parameters they are PRELOADED into SGPRs by the command processor (-amdgpu-kernarg-preload-count, Makefile): the
     // wave issues those loads without waiting for an s_load of its arguments (a cold scalar-cache miss, ~0.5-1 us in a kernel
     // that lasts 3-5).  The struct behind them carries the same fields again (ignored) and everything else.
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     a.x = p_x; a.w = p_w; a.x2 = p_x2; a.gather = p_gather; a.m = p_m; a.n = p_n; a.k = p_k; a.kpad = p_kpad; a.ldx = p_ldx;
     const int wld = p_kpad;                                   // weight row stride
     if constexpr (XM == 1) {
-        if (gridDim.y > 1) {                                  // K slice blockIdx.y of a split projection (GemvArgs::ksplit)
+        if (p_ks > 1) {                                       // K slice blockIdx.y of a split projection (GemvArgs::ksplit; preloaded: gridDim.y
+                                                              // is an implicit argument = a scalar load + wait in front of the first loads)
             const int kh = p_kpad >> 1;
             a.x = reinterpret_cast<const _Float16*>(p_x) + (int)blockIdx.y * kh;
             a.w = p_w + (int)blockIdx.y * kh;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         if (a.kv && on >= a.n_split) {
             const int dd = (a.n - a.n_split) >> 1, c = on - a.n_split, isv = c >= dd ? 1 : 0, cc = c - isv * dd;
             a.kv[(int64_t)kv_pos * a.kv_t + (int64_t)om * a.kv_b + (int64_t)(cc >> 6) * a.kv_h + (int64_t)isv * a.kv_v + (cc & 63)] = (_Float16)v;
-        } else if (XM == 1 && gridDim.y > 1) {
+        } else if (XM == 1 && p_ks > 1) {
             unsafeAtomicAdd(a.out + (int64_t)om * a.ldo + on, v);     // the two K slices meet on a zero: a + b == b + a
         } else {
             if (a.out) a.out[(int64_t)om * a.ldo + on] = v;
@@ -591,46 +592,51 @@ __device__ __forceinline__ float dot8(const float (&q)[8], half8 k) {
 }
 
 __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float16* p_kv, const _Float16* p_pos0, const int* p_kstart, int p_kv_t, int p_kv_b,
-                                                  int p_kv_h, int p_kv_v, int p_ldq, int p_ldp, AttnArgs a_in) {
+                                                  int p_kv_h, int p_kv_v, int p_ld, int p_pos, AttnArgs a_in) {
     __shared__ float s_m[8];
     __shared__ float s_l[8];
     __shared__ __attribute__((aligned(16))) float s_o[8][64];
     LM_RAISE_PRIO();
-    AttnArgs a = a_in;      // leading parameters: preloaded into SGPRs (see lm_gemv; 14 dwords is the most the hardware preloads)
-    a.q = p_q; a.kv = p_kv; a.kstart = p_kstart; a.kv_t = p_kv_t; a.kv_b = p_kv_b; a.kv_h = p_kv_h; a.kv_v = p_kv_v; a.ldq = p_ldq; a.ldp = p_ldp;
+    // Leading parameters: preloaded into SGPRs by the command processor (see lm_gemv; 14 dwords is the most the hardware preloads).  They
+    // are everything the QUERY and KEY loads need -- p_ld = ldq | ldp << 16, p_pos = the query's position (-1: device-side step state)
+    // -- so those loads go out before the by-value struct (a cold scalar-cache miss, ~1 us: bias vectors, scale, outputs) has arrived.
     const _Float16* pos_row0 = p_pos0;                       // the position table's row of relative position 0 (postab + center * ldp)
-    pin_args(a);
-    LM_STAMP(a, 0);
+    const int ldq = p_ld & 0xffff, ldp = (int)((unsigned)p_ld >> 16);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = tid & 7, kg = tid >> 3;                   // key group 0..63
     const int head = blockIdx.x, bb = blockIdx.y;
-    const int qpos = a.st ? a.st->pos0 + a.st->step : a.pos;  // absolute position of the query = index of the newest key
+    // p_pos >= 0: bits 0-27 the query's absolute position (= index of the newest key), bits 28-29 the key split - 1 (gridDim.z is an
+    // implicit kernel argument: reading it is a scalar load whose wait covers the whole struct); < 0: device-side step state, -key split
+    int qpos = p_pos & 0x0fffffff;
+    int nsplit = ((p_pos >> 28) & 3) + 1;
+    if (p_pos < 0) {
+        qpos = a_in.st->pos0 + a_in.st->step;
+        nsplit = -p_pos;
+    }
     const int len = qpos + 1;
     // Load schedule (round 4).  The kernel has THREE kinds of operands -- the row's first valid key, the query / bias vectors, the keys --
     // and only the key addresses depend on another load (the first valid key).  Issued in that order, with every key load of a chunk
     // UNCONDITIONAL (the index is clamped to the newest key; what lies beyond the range is masked when the scores are formed): a load
     // inside an `if (j < kend)` block made the compiler open each block with s_waitcnt vmcnt(0), so the four 64-key groups of a chunk --
     // meant to be one memory round trip -- were four dependent ones, behind a fifth for the query.
-    const float* qp = a.q + (int64_t)bb * a.ldq + head * 64 + sub * 8;
+    const float* qp = p_q + (int64_t)bb * ldq + head * 64 + sub * 8;
     const float4 x0 = *reinterpret_cast<const float4*>(qp), x1 = *reinterpret_cast<const float4*>(qp + 4);
-    const float4 u0 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8), u1 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8 + 4);
-    const float4 w0 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8), w1 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8 + 4);
-    // (the first valid key LAST of this group: the wait for it then covers the whole group -- one round trip -- and unconditional through a
-    // selected address: a load inside `if (a.kstart)` is waited for at the end of its block)
-    int ks_raw = *(a.kstart ? a.kstart + bb : reinterpret_cast<const int*>(a.q));
-    if (!a.kstart) ks_raw = 0;
+    // (the first valid key in a uniform branch: batches without left padding pass no table and must not wait for a load here -- the key
+    // addresses depend on this value)
+    int ks_raw = 0;
+    if (p_kstart) ks_raw = p_kstart[bb];
     const int ks_first = min(ks_raw, len - 1);
     // key split (gridDim.z = 2): two workgroups per (row, head) take the two halves of the valid keys (a multiple of 64
     // keys each) and write unnormalised partials; the consumer (lm_gemv XM == 2) merges them while staging its input.
     int ks0 = ks_first, kend = len;
-    if (gridDim.z > 1) {
+    if (nsplit > 1) {
         const int half = (((len - ks_first + 1) >> 1) + 63) & ~63;
         ks0 = ks_first + (int)blockIdx.z * half;
         kend = min(len, ks0 + half);
     }
-    const int64_t trow = a.kv_t;                              // one time step of the cache (KvLayout)
-    const _Float16* kb = a.kv + (int64_t)bb * a.kv_b + (int64_t)head * a.kv_h + sub * 8;
-    const _Float16* vb = kb + a.kv_v;
+    const int64_t trow = p_kv_t;                              // one time step of the cache (KvLayout)
+    const _Float16* kb = p_kv + (int64_t)bb * p_kv_b + (int64_t)head * p_kv_h + sub * 8;
+    const _Float16* vb = kb + p_kv_v;
     const _Float16* pb = pos_row0 + head * 64 + sub * 8;
     half8 kk[AT_U], pp[AT_U], vv[AT_U];
     auto load_chunk = [&](int j0) {
@@ -638,11 +644,18 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
         for (int u = 0; u < AT_U; ++u) {
             const int jc = min(j0 + u * 64 + kg, qpos);      // clamped: always a row of the cache
             kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)jc * trow);
-            pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - jc) * a.ldp);
+            pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(qpos - jc) * ldp);
             vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)jc * trow);
         }
     };
     load_chunk(ks0);                                          // (a workgroup with an empty key range loads the newest key and uses nothing)
+    // ---- now the struct: bias vectors, scale, outputs
+    AttnArgs a = a_in;
+    a.q = p_q; a.kv = p_kv; a.kstart = p_kstart; a.kv_t = p_kv_t; a.kv_b = p_kv_b; a.kv_h = p_kv_h; a.kv_v = p_kv_v; a.ldq = ldq; a.ldp = ldp;
+    pin_args(a);
+    LM_STAMP(a, 0);
+    const float4 u0 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8), u1 = *reinterpret_cast<const float4*>(a.bias_u + head * 64 + sub * 8 + 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8), w1 = *reinterpret_cast<const float4*>(a.bias_v + head * 64 + sub * 8 + 4);
     float qu[8], qv[8];
     {
         const float xs_[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -721,7 +734,7 @@ __global__ __launch_bounds__(512, 4) void lm_attn(const float* p_q, const _Float
             l += s_l[w] * sc;
         }
         const float m_run = mx;
-        if (gridDim.z > 1) {
+        if (nsplit > 1) {
             const int64_t slot = ((int64_t)bb * a.h + head) * 2 + blockIdx.z;
             a.part_o[slot * 64 + tid] = tot;
             if (tid == 0) *reinterpret_cast<float2*>(a.part_ml + slot * 2) = make_float2(m_run, l);
@@ -761,8 +774,8 @@ static bool lm_wide() {
     return v;
 }
 
-#define GV_LEAD(a) (a).x, (a).w, (a).x2, (a).gather, (a).m, (a).n, (a).k, (a).kpad, (a).ldx     // the preloaded leading kernel arguments
-#define AT_LEAD(a) (a).q, (a).kv, (a).postab + (int64_t)(a).center * (a).ldp, (a).kstart, (a).kv_t, (a).kv_b, (a).kv_h, (a).kv_v, (a).ldq, (a).ldp
+#define GV_LEAD(a) (a).x, (a).w, (a).x2, (a).gather, (a).m, (a).n, (a).k, (a).kpad, (a).ldx, ((a).ksplit == 2 ? 2 : 1)     // the preloaded leading kernel arguments (14 dwords)
+#define AT_LEAD(a) (a).q, (a).kv, (a).postab + (int64_t)(a).center * (a).ldp, (a).kstart, (a).kv_t, (a).kv_b, (a).kv_h, (a).kv_v, (int)((unsigned)(a).ldq | (unsigned)(a).ldp << 16), ((a).st ? -(a).ksplit : (int)((unsigned)(a).pos | (unsigned)((a).ksplit - 1) << 28))
 
 template <int MT, int FORM, int XM>
 static void gemv_launch_nl(const GemvArgs& a, dim3 grid, size_t lds, int lines_per_wave, hipStream_t st, bool wide = false) {
@@ -889,6 +902,8 @@ int lm_gemv_launch(const GemvArgs& a0, hipStream_t st) {
 
 int lm_attn_launch(const AttnArgs& a, hipStream_t st) {
     ASTTS_REQUIRE(a.q && a.kv && a.postab && a.bias_u && a.bias_v, ASTTS_ERR_INVALID, "lm_attn: null pointer");
+    ASTTS_REQUIRE(a.ldq > 0 && a.ldq < 65536 && a.ldp > 0 && a.ldp < 65536 && (a.st || (a.pos >= 0 && a.pos < (1 << 28))), ASTTS_ERR_INVALID,
+                  "lm_attn: ldq=%d ldp=%d (< 65536: they share one preloaded kernel argument) pos=%d", a.ldq, a.ldp, a.pos);
     ASTTS_REQUIRE(a.b >= 1 && a.h >= 1 && a.d == a.h * 64 && (a.ldq & 3) == 0 && (a.ldp & 7) == 0, ASTTS_ERR_INVALID,
                   "lm_attn: bad shape b=%d h=%d d=%d", a.b, a.h, a.d);
     ASTTS_REQUIRE(a.kv_t > 0 && ((a.kv_t | a.kv_b | a.kv_h | a.kv_v) & 7) == 0, ASTTS_ERR_INVALID,
