@@ -43,7 +43,11 @@ namespace astts {
 __device__ __forceinline__ void pin_args(const GemvArgs& a) {
     asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.gather), "s"(a.pre_g), "s"(a.pre_b), "s"(a.pre_out), "s"(a.ln_g), "s"(a.ln_b), "s"(a.w),
                  "s"(a.bias), "s"(a.res), "s"(a.out), "s"(a.out16), "s"(a.kv), "s"(a.st), "s"(a.m), "s"(a.n), "s"(a.k), "s"(a.kpad), "s"(a.ldx),
-                 "s"(a.ldr), "s"(a.ldo), "s"(a.ldo16), "s"(a.n_split), "s"(a.kv_t), "s"(a.kv_b), "s"(a.kv_h), "s"(a.kv_v), "s"(a.x_mode), "s"(a.relu), "s"(a.pos), "s"(a.ln_plain));
+                 "s"(a.ldr), "s"(a.ldo), "s"(a.ldo16), "s"(a.n_split), "s"(a.kv_t), "s"(a.kv_b), "s"(a.kv_h), "s"(a.kv_v), "s"(a.x_mode), "s"(a.relu), "s"(a.pos), "s"(a.ln_plain),
+                 "s"(a.zero), "s"(a.zero_n), "s"(a.advance), "s"(a.stamp_slot), "s"(a.ksplit), "s"(a.stamps), "s"(a.ln_eps), "s"(a.pre_scale)
+                 : "memory");     // EVERY field is listed: a field left out is dead on arrival, its SGPR is reused at once, and a write to a register
+                                  // whose scalar load is still in flight costs an s_waitcnt lgkmcnt(0) on this cold miss -- it sat in front of the
+                                  // weight loads.  The clobber keeps the loads issued before the pin (input rows, weight lines) before it.
 }
 __device__ __forceinline__ void pin_args(const AttnArgs& a) {
     asm volatile("" ::"s"(a.q), "s"(a.kv), "s"(a.bias_u), "s"(a.bias_v), "s"(a.kstart), "s"(a.out), "s"(a.part_o), "s"(a.part_ml),
@@ -88,7 +92,15 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     // wave issues those loads without waiting for an s_load of its arguments (a cold scalar-cache miss, ~0.5-1 us in a kernel
     // that lasts 3-5).  The struct behind them carries the same fields again (ignored) and everything else.
     LM_RAISE_PRIO();
+    // Until the up-front loads are out, `a` holds the leading parameters only (the rest zero).  The struct itself is read through a pointer the
+    // compiler cannot see through before that point (LM_LATE_ARGS below): read at the top -- where the scheduler hoists independent scalar
+    // loads -- its ~60 destination SGPRs are in flight while the kernel computes its load addresses, the kernel uses every SGPR there is,
+    // and the first temporary that lands in one of them costs an s_waitcnt lgkmcnt(0) on a cold scalar miss: in front of the weight loads.
+#if !defined(LM_LATE_ARGS) || defined(LM_STAMPS) || !defined(__HIP_DEVICE_COMPILE__)
     GemvArgs a = a_in;
+#else
+    GemvArgs a{};
+#endif
     a.x = p_x; a.w = p_w; a.x2 = p_x2; a.gather = p_gather; a.m = p_m; a.n = p_n; a.k = p_k; a.kpad = p_kpad; a.ldx = p_ldx;
     const int wld = p_kpad;                                   // weight row stride
     if constexpr (XM == 1) {
@@ -217,12 +229,22 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int line = wid + i * GV_WAVES;
-            if (line < lines) {
-                fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64);
-                fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64 + 8);
-            }
+            // (unconditional, line clamped: guarded, these loads sit in blocks of their own and the compiler moves them BELOW the argument
+            // pin that follows -- whose scalar-load wait, a cold miss, then delays the whole weight stream; a line beyond K is never used)
+            const int line = min(wid + i * GV_WAVES, lines - 1);
+            fb[ct * NL + i][0] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64);
+            fb[ct * NL + i][1] = LM_WLOAD(wrow + (int64_t)ct * 16 * wld + line * 64 + 8);
         }
+#if defined(LM_LATE_ARGS) && !defined(LM_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    {   // LM_LATE_ARGS: the struct sits behind the 14 leading dwords (4 pointers + 6 ints = 56 bytes) of the kernarg segment
+        const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const GemvArgs full = *(const __attribute__((address_space(4))) GemvArgs*)(kp + 56);
+        const GemvArgs lead = a;
+        a = full;
+        a.x = lead.x; a.w = lead.w; a.x2 = lead.x2; a.gather = lead.gather; a.m = lead.m; a.n = lead.n; a.k = lead.k; a.kpad = lead.kpad; a.ldx = lead.ldx;
+    }
+#endif
     pin_args(a);            // the remaining arguments: ONE wide scalar load + ONE wait, behind the loads issued above
     // LayerNorm parameters of the lanes' k positions (same positions for every row)
     float4 lg[MAXV], lb[MAXV];
@@ -260,7 +282,8 @@ __global__ __launch_bounds__(512, (NCT == 1 && NL <= 2 && (FORM == 1 || (FORM ==
         if (a.res) e_res = a.res[(int64_t)om * a.ldr + on];
     }
     if (a.zero) {                                             // accumulator of a later split launch
-        for (int i = (int)blockIdx.x * 512 + tid; i < a.zero_n; i += (int)gridDim.x * 512) a.zero[i] = 0.0f;
+        const int nblk = (a.n + NC - 1) / NC;                 // = gridDim.x, without the scalar load + wait an implicit argument costs
+        for (int i = (int)blockIdx.x * 512 + tid; i < a.zero_n; i += nblk * 512) a.zero[i] = 0.0f;
     }
     int kv_pos = a.pos;
     if (a.kv && a.st) kv_pos = a.st->pos0 + a.st->step;
