@@ -57,7 +57,9 @@ struct TfmAttnArgs {
     float eps, scale;
     int balance;             // split the key range of the tiles owned by waves 4 / 5 with the otherwise idle waves
     const char* pf[3];       // L2 prefetch of the NEXT launch's weights (cold otherwise: every block has its own): up to three ranges,
-    unsigned pf_bytes[3];    // touched one 128-byte line per thread by the workgroups of each XCD at the start of phase 2
+    unsigned pf_bytes[4];    // touched one 128-byte line per thread by the workgroups of each XCD at the start of phase 2.  ([3] is unused but
+                             // READ: the compiler fetches the four dwords with one wide scalar load at kernel entry; a dead fourth dword's SGPR
+                             // is reused at once, and writing it under the in-flight load costs an s_waitcnt lgkmcnt(0) in front of the first loads)
 };
 
 // The kernel body: workgroup L of 2 * heads * b.  Every wave returns from it (no early exit, so that a caller can continue in the
@@ -98,7 +100,6 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     _Float16* sVt = sK + (size_t)tkp * TF_KS;        // [64][vs]
     _Float16* sA = sVt + (size_t)TF_DH * vs;         // [2][32][264]
     _Float16* sQ = sA + 2 * 32 * TF_AS;              // [192][64], swizzled (tf_q)
-    const int len = a.lens ? min(a.lens[b], T) : T;
     const float* xb = a.x + (int64_t)b * T * TF_C;
     const int hd = a.heads * TF_DH;
 
@@ -254,6 +255,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
         // loads (xlane.h prefetch_line): the volatile loads used before compiled to system-scope flat loads with an immediate
         // s_waitcnt vmcnt(0) each -- the waves owning query tiles 0 and 1 sat out three HBM misses in a row before their first score
         const unsigned slot = blockIdx.x >> 3, nslots = max(gridDim.x >> 3, 1u);
+        asm volatile("" ::"s"(a.pf_bytes[3]));
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const unsigned lines = a.pf[r] ? (a.pf_bytes[r] + 127) >> 7 : 0u;
@@ -263,6 +265,8 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
             prefetch_line(base + (tid < per && ln < lines ? (size_t)ln << 7 : (size_t)0), pf_keep[r]);
         }
     }
+    const int len = a.lens ? min(a.lens[b], T) : T;     // (here, where it is first needed: at the top its scalar load's wait stood in front of
+                                                        // the weight and row loads -- an s_waitcnt lgkmcnt covers every scalar load in flight)
     const int nkt = (len + 31) >> 5;                    // key tiles with at least one valid key
     const int jb0 = tile >= 0 ? (nkt * part / parts) * 32 : 0;
     const int jb1 = tile >= 0 ? min((nkt * (part + 1) / parts) * 32, len) : 0;
