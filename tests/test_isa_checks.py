@@ -54,7 +54,7 @@ def test_splitk_partials_are_drained_before_the_arrival_barrier(tmp_path):
 
 def test_decode_step_kernels_get_their_leading_arguments_preloaded(tmp_path):
     """lm_gemv / lm_attn (lm_step.hip) pass what their first global loads need as explicit leading parameters so that the command
-    processor preloads them into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile): 13 / 14 dwords (14 is the hardware's limit).  A by-value struct
+    processor preloads them into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile): 14 dwords each, the hardware's limit.  A by-value struct
     parameter is NOT preloaded (length 0), so a refactor back to `lm_gemv(GemvArgs)` would silently lose 5 % of the decode step."""
     with open(os.path.join(CSRC, "Makefile")) as f:
         assert "-amdgpu-kernarg-preload-count=16" in f.read()
@@ -65,5 +65,51 @@ def test_decode_step_kernels_get_their_leading_arguments_preloaded(tmp_path):
         found[m.group(1)] = int(n.group(1)) if n else 0
     gemv = {k: v for k, v in found.items() if "lm_gemv" in k}
     attn = {k: v for k, v in found.items() if "lm_attn" in k}
-    assert len(gemv) >= 10 and all(v == 13 for v in gemv.values()), gemv
+    assert len(gemv) >= 10 and all(v == 14 for v in gemv.values()), gemv
     assert len(attn) == 1 and all(v == 14 for v in attn.values()), attn
+
+
+def _longest_load_batch(body):
+    """Longest run of global loads in the kernel's text that no FULL wait interrupts: s_waitcnt vmcnt(0) or any s_waitcnt lgkmcnt (a scalar
+    wait covers every scalar load in flight, i.e. a cold kernarg miss).  Counted vector waits (vmcnt(N > 0)) leave loads in flight and do
+    not end a run.  The kernarg-preload compatibility prologue in front of the first numbered block is skipped."""
+    lines = body.splitlines()
+    start = next((i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_0:", l.strip())), 0)
+    best = run = 0
+    for l in lines[start:]:
+        t = l.strip()
+        if t.startswith("global_load"):
+            run += 1
+            best = max(best, run)
+        elif t.startswith("s_waitcnt") and ("lgkmcnt" in t or "vmcnt(0)" in t):
+            run = 0
+    return best
+
+
+def test_decode_step_kernels_issue_their_loads_in_one_batch(tmp_path):
+    """What round 4's ISA audit established (EXPERIMENTS.md G), as an assertion on the emitted code of the lm_gemv variants of a decode step
+    and of lm_attn: the up-front loads -- input rows / pieces AND the weight lines -- form one batch that no full wait interrupts.  Each of
+    these once broke it: loads inside bounds checks (one dependent round trip per block), a guarded load block merged with its guarded
+    consumer, the wait for a gathered row index between the rows of a wave, a struct field missing from the argument pin (its SGPR reused
+    under the in-flight scalar load), an implicit argument (gridDim) read in front of the loads."""
+    asm = _asm(os.path.join(CSRC, "lm_step.hip"), tmp_path)
+    want = {
+        r"lm_gemvILi1ELi0ELi0ELi2ELi1E": 8 + 4,      # QKV / FFN-in / head at <= 16 rows: 2 rows x 4 float4 + 2 weight lines x 2 fragments
+        r"lm_gemvILi2ELi0ELi0ELi2ELi1E": 16 + 4,     # the same at 32 rows: the 4 rows of a wave
+        r"lm_gemvILi1ELi1ELi2ELi2ELi1E": 10 + 4,     # out-projection at <= 8 rows: 2 pieces x 5 partial loads + weights
+        r"lm_gemvILi1ELi1ELi1ELi2ELi1E": 8 + 4,      # FFN-out (one K slice) at <= 8 rows: 8 fp16 pieces + weights
+        r"lm_attn": 12,                              # one chunk of K / position / V rows (the query loads sit in front of an optional path)
+    }
+    for pat, batch in want.items():
+        ks = _kernels(asm, pat)
+        assert len(ks) == 1, (pat, sorted(ks))
+        name, body = next(iter(ks.items()))
+        assert _longest_load_batch(body) >= batch, (name, _longest_load_batch(body), batch)
+
+
+def test_no_volatile_system_scope_loads_in_the_hot_kernels(tmp_path):
+    """A `volatile` global load compiles to a system-scope `flat_load ... sc0 sc1` followed at once by s_waitcnt vmcnt(0) lgkmcnt(0): the L2
+    prefetches of the flow kernels stalled their issuing waves on an HBM miss that way.  They are untracked asm loads now (xlane.h)."""
+    for src in ("ops_tfm_fused.hip", "ops_resnet_conv.hip", "lm_step.hip", "ops_conv_lds.hip"):
+        asm = _asm(os.path.join(CSRC, src), tmp_path)
+        assert not re.search(r"(flat|global)_load_\w+ [^\n]*sc0 sc1", asm), src
