@@ -107,6 +107,23 @@ def test_decode_step_kernels_issue_their_loads_in_one_batch(tmp_path):
         assert _longest_load_batch(body) >= batch, (name, _longest_load_batch(body), batch)
 
 
+def test_render_kernels_issue_their_prologue_loads_in_one_batch(tmp_path):
+    """The same property for the flow / vocoder kernels whose prologues were chains of guarded loads (EXPERIMENTS.md G): the frame rows of
+    rconv_lds (+ its two units of weights) and of conv_lds' staging pass, the weight fragments + first row chunks of tfm_attn_fused, the A / B
+    chunks of a gemm_tile K tile."""
+    cases = [("ops_resnet_conv.hip", r"rconv_ldsILi256E", 5 + 32), ("ops_resnet_conv.hip", r"rconv_ldsILi512E", 9 + 32),
+             ("ops_conv_lds.hip", r"conv_ldsILi128ELi128E", 12), ("ops_tfm_fused.hip", r"tfm_attn_fused", 16 + 4),
+             ("ops_gemm.hip", r"gemm_tileILi2ELi2ELi1ELi1ELb0ELi128E", 8 + 4)]
+    cache = {}
+    for src, pat, batch in cases:
+        if src not in cache:
+            cache[src] = _asm(os.path.join(CSRC, src), tmp_path)
+        ks = _kernels(cache[src], pat)
+        assert len(ks) == 1, (pat, sorted(ks))
+        name, body = next(iter(ks.items()))
+        assert _longest_load_batch(body) >= batch, (name, _longest_load_batch(body), batch)
+
+
 def test_no_volatile_system_scope_loads_in_the_hot_kernels(tmp_path):
     """A `volatile` global load compiles to a system-scope `flat_load ... sc0 sc1` followed at once by s_waitcnt vmcnt(0) lgkmcnt(0): the L2
     prefetches of the flow kernels stalled their issuing waves on an HBM miss that way.  They are untracked asm loads now (xlane.h)."""
