@@ -49,13 +49,16 @@ class CosyVoice:
         from ..synth.model import SynthEngine
         from ..synth.weights import load_state_dicts, make_all
 
+        engine = _kw.pop("engine", None)          # an existing SynthEngine (benchmarks: one engine for several surfaces)
         self.model_dir = model_dir
         if config is None:
             config = SynthConfig.tiny() if os.environ.get("ASTTS_TINY_MODEL") == "1" else SynthConfig()
         self.cfg = config
         self.sample_rate = config.sample_rate
         have = all(os.path.exists(os.path.join(model_dir, f"{n}.pt")) for n in ("llm", "flow", "hift"))
-        if have:
+        if engine is not None:
+            state, self.random_init = None, bool(getattr(engine, "random_init", not have))
+        elif have:
             state = load_state_dicts(model_dir)
             self.random_init = False
         else:
@@ -68,7 +71,7 @@ class CosyVoice:
                           f"at the configured shapes (explicitly allowed)", stacklevel=2)
             state = make_all(config, seed)
             self.random_init = True
-        self.engine = SynthEngine(state, config, device)          # raises without a GPU: no CPU fallback
+        self.engine = engine if engine is not None else SynthEngine(state, config, device)    # raises without a GPU: no CPU fallback
         self.device = self.engine.device
         self.frontend = frontend or Frontend(config, device=self.device)
         self._gen = torch.Generator().manual_seed(seed)
@@ -103,9 +106,11 @@ class CosyVoice:
         tlen = torch.tensor([text_ids.shape[1]], dtype=torch.int32, device=dev)
         pre = lm.prefix(text_ids.to(dev), tlen, lm_prompt.spk_embedding.to(dev), lm_prompt.speech_tokens.to(dev))
         min_len = self.min_token_text_ratio * n_tts_text
-        max_len = self._cap_tokens(self.max_token_text_ratio * n_tts_text, pre.shape[0])
-        max_len = max(max_len, min_len + 1)
-        u = torch.rand(max_len, 1, 2, generator=gen or self._gen).to(dev)
+        want = self.max_token_text_ratio * n_tts_text
+        max_len = max(self._cap_tokens(want, pre.shape[0]), min_len + 1)
+        # a FIXED count of uniforms per segment (upstream's 20x window), whatever the position-table cap: the later draws of the
+        # segment's stream (CFM noise, phases, source noise) then do not shift when a cap applies
+        u = torch.rand(max(want, max_len), 1, 2, generator=gen or self._gen)[:max_len].to(dev)
         toks = lm.decode(pre, max_len, u, ignore_eos=min_len)[0].cpu()       # one sync per segment
         eos = (toks >= cfg.speech_vocab).nonzero()
         n = int(eos[0]) if eos.numel() else max_len
@@ -226,7 +231,10 @@ class CosyVoice:
             u = torch.zeros(n_steps, b, 2)
             for j, i in enumerate(idxs):
                 d = draws[i]
-                u[:max_len[j], j] = torch.rand(max_len[j], 2, generator=d) if isinstance(d, torch.Generator) else d["u"][:max_len[j]]
+                # a generator hands out a FIXED count per request (its uncapped window): `_cap_tokens` sees the padded prefix of the
+                # whole LM job, so a capped row's length depends on its job (warned) -- but the rest of its random stream must not
+                n_draw = max(want[i], max_len[j])
+                u[:max_len[j], j] = torch.rand(n_draw, 2, generator=d)[:max_len[j]] if isinstance(d, torch.Generator) else d["u"][:max_len[j]]
             ft = None
             if forced is not None:
                 ft = torch.zeros(b, n_steps, dtype=torch.int32)

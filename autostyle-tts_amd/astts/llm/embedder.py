@@ -70,6 +70,8 @@ class LlamaEmbedder:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.tokenizer = tokenizer or HashTokenizer(cfg)
         self.max_length = max_length                                  # truncation=True, max_length=512: src/search_milvus.py:92
+        import os
+        self.mfma_attention = os.environ.get("ASTTS_LLM_ATTN", "mfma") != "valu"
         dev = self.device
         with torch.cuda.device(dev):
             f = lambda k: state[k].to(device=dev, dtype=torch.float32).contiguous()
@@ -119,7 +121,10 @@ class LlamaEmbedder:
             h = ops.rmsnorm(x, L["n1"], cfg.rms_eps)                              # fp16: its only consumer is an MFMA operand
             qkv = ops.linear(h, L["wqkv"], out_dtype=torch.float16)              # [B, T, hq + 2 hk]
             ops.rope_llama_(qkv, cos, sin, cfg.heads + cfg.kv_heads, cfg.head_dim)             # q heads then k heads: contiguous
-            a = ops.attn_causal_gqa(qkv[..., :hq], qkv[..., hq:hq + hk], qkv[..., hq + hk:], cfg.heads, cfg.kv_heads, cfg.head_dim, lens)
+            if self.mfma_attention:                                                # v_mfma_f32_32x32x16_f16 (csrc/ops_llm.hip attn_gqa_mfma)
+                a = ops.attn_gqa(qkv[..., :hq], qkv[..., hq:hq + hk], qkv[..., hq + hk:], cfg.heads, cfg.kv_heads, cfg.head_dim, lens=lens)
+            else:                                                                  # the VALU kernel: the second implementation (tests)
+                a = ops.attn_causal_gqa(qkv[..., :hq], qkv[..., hq:hq + hk], qkv[..., hq + hk:], cfg.heads, cfg.kv_heads, cfg.head_dim, lens)
             x = ops.linear(a, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["n2"], cfg.rms_eps)
             gu = ops.linear(h, L["wgu"], out_dtype=torch.float16)
@@ -136,9 +141,9 @@ class LlamaEmbedder:
         h = self.hidden(ids)[:, -1]
         return ops.linear(h.contiguous(), self.head)
 
-    def generate_greedy(self, ids: Sequence[int], max_new_tokens: int = 10) -> List[int]:
-        """do_sample=False continuation (milvus/search_json.py:178-188).  The prompt is re-run for every new token: the
-        label is <= 10 tokens behind a ~60-token prompt, and the embedding passes -- not this -- are the volume."""
+    def generate_greedy_recompute(self, ids: Sequence[int], max_new_tokens: int = 10) -> List[int]:
+        """do_sample=False continuation with the prompt re-run for every new token (rounds 3-4; kept as the second implementation
+        the tests hold the cached path to)."""
         out = list(int(i) for i in ids)
         for _ in range(max_new_tokens):
             lg = self.logits_last(torch.tensor([out], dtype=torch.int64, device=self.device))
@@ -147,6 +152,71 @@ class LlamaEmbedder:
             if nxt == self.cfg.eos_token_id:
                 break
         return out
+
+    def generate_greedy_batch(self, prompts: Sequence[Sequence[int]], max_new_tokens: int = 10) -> List[List[int]]:
+        """do_sample=False continuation (milvus/search_json.py:178-188: model.generate(max_new_tokens=10)) of several prompts at once,
+        with a KV cache and no host synchronisation inside the loop: ONE pass over the prompts, then ``max_new_tokens - 1`` one-token
+        steps; the argmax runs on the device (``astts_op_argmax_rows``) and feeds the next step's embedding lookup; the tokens come
+        back in one copy at the end and are cut at each row's first EOS on the host (transformers stops a row there).
+        Layout: prompts are LEFT-padded to a common length, time-major ``[T, B]`` (the rows of a step are contiguous in the cache
+        ``[T_max, B, 2 * kv_heads * 128]`` per layer); ``key_start[b]`` masks a row's pad keys and shifts its RoPE positions so that its
+        first token has position 0, as in the one-at-a-time reference run."""
+        cfg, dev = self.cfg, self.device
+        prompts = [[int(i) for i in p] for p in prompts]
+        b, lens = len(prompts), [len(p) for p in prompts]
+        t, n_new = max(lens), int(max_new_tokens)
+        if n_new <= 0:
+            return [list(p) for p in prompts]
+        t_max = t + n_new
+        if t_max > self._rope[0].shape[0]:
+            with self._rope_lock:
+                if t_max > self._rope[0].shape[0]:
+                    self._rope_tables((t_max + 255) // 256 * 256)
+        cos, sin = self._rope
+        hq, hk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+        ids = torch.zeros((t, b), dtype=torch.int32)
+        for j, p in enumerate(prompts):
+            ids[t - lens[j]:, j] = torch.tensor(p, dtype=torch.int32)
+        start = torch.tensor([t - n for n in lens], dtype=torch.int32, device=dev)
+        cache = [torch.empty((t_max, b, 2 * hk), dtype=torch.float16, device=dev) for _ in self.L]
+        toks = torch.zeros((n_new, b), dtype=torch.int32, device=dev)
+
+        def stack(x: torch.Tensor, pos0: int) -> torch.Tensor:
+            """x fp32 [T', B, hidden] = the new positions pos0 .. pos0 + T' - 1 -> final-norm hidden of the LAST of them [B, hidden]."""
+            tn = x.shape[0]
+            for L, kv in zip(self.L, cache):
+                h = ops.rmsnorm(x, L["n1"], cfg.rms_eps)
+                qkv = ops.linear(h, L["wqkv"], out_dtype=torch.float16)                       # [T', B, hq + 2 hk]
+                ops.rope_llama_ex_(qkv, cos, sin, cfg.heads + cfg.kv_heads, cfg.head_dim, pos0=pos0, shift=start, time_major=True)
+                kv[pos0:pos0 + tn].copy_(qkv[..., hq:])                                        # K (rotated) | V into the cache rows
+                a = ops.attn_gqa(qkv[..., :hq], kv[:pos0 + tn, :, :hk], kv[:pos0 + tn, :, hk:], cfg.heads, cfg.kv_heads, cfg.head_dim,
+                                 key_start=start, pos0=pos0, time_major=True)
+                x = ops.linear(a, L["wo"], residual=x)
+                h = ops.rmsnorm(x, L["n2"], cfg.rms_eps)
+                gu = ops.linear(h, L["wgu"], out_dtype=torch.float16)
+                x = ops.linear(ops.swiglu(gu), L["wd"], residual=x)
+            return ops.rmsnorm(x[-1].contiguous(), self.norm, cfg.rms_eps, out_dtype=torch.float32)
+
+        x = ops.embedding(self.embed, ids.to(dev))
+        for s in range(n_new):
+            h_last = stack(x, 0 if s == 0 else t + s - 1)
+            ops.argmax_rows(ops.linear(h_last, self.head), out=toks[s])
+            if s + 1 < n_new:
+                x = ops.embedding(self.embed, toks[s])[None]
+        got = toks.cpu().numpy()                                                               # the one synchronisation
+        out = []
+        for j, p in enumerate(prompts):
+            row = list(p)
+            for s in range(n_new):
+                row.append(int(got[s, j]))
+                if row[-1] == cfg.eos_token_id:
+                    break
+            out.append(row)
+        return out
+
+    def generate_greedy(self, ids: Sequence[int], max_new_tokens: int = 10) -> List[int]:
+        """do_sample=False continuation of one prompt (milvus/search_json.py:178-188): the cached path with one row."""
+        return self.generate_greedy_batch([ids], max_new_tokens)[0]
 
     # ------------------------------------------------------------------ the reference's call surface
     def _encode(self, text: str) -> List[int]:
@@ -179,10 +249,14 @@ Answer:"""
     def generate_emotion_label(self, text: str, max_new_tokens: int = 10) -> str:
         """milvus/search_json.py:154-198: greedy continuation of the few-shot prompt, decoded (prompt included, as there),
         stripped and lower-cased."""
-        prompt = self.EMOTION_PROMPT.format(text, text)
-        out = self.generate_greedy(list(self.tokenizer.encode(prompt)), max_new_tokens)     # untruncated: only get_embedding truncates there
-        label = self.tokenizer.decode(out, skip_special_tokens=True) if self._decode_takes_skip else self.tokenizer.decode(out)   # search_json.py:191
-        return label.strip().lower()
+        return self.generate_emotion_labels([text], max_new_tokens)[0]
+
+    def generate_emotion_labels(self, texts: Sequence[str], max_new_tokens: int = 10) -> List[str]:
+        """The labels of several utterances in one batched greedy decode (each equals generate_emotion_label of its text)."""
+        prompts = [list(self.tokenizer.encode(self.EMOTION_PROMPT.format(t, t))) for t in texts]    # untruncated: only get_embedding truncates there
+        outs = self.generate_greedy_batch(prompts, max_new_tokens)
+        dec = (lambda o: self.tokenizer.decode(o, skip_special_tokens=True)) if self._decode_takes_skip else self.tokenizer.decode   # search_json.py:191
+        return [dec(o).strip().lower() for o in outs]
 
     @property
     def _decode_takes_skip(self) -> bool:

@@ -155,6 +155,9 @@ _SIGS.update({   # query-embedder operators (csrc/ops_llm.hip)
     "astts_op_attn_causal_gqa": (c_int32, [c_void_p] * 5 + [c_int32] * 8 + [c_float, c_void_p]),
     "astts_op_swiglu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_mean_pool": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_attn_gqa": (c_int32, [c_void_p] * 6 + [c_int32] * 7 + [c_int64] * 6 + [c_float, c_void_p]),
+    "astts_op_rope_llama_ex": (c_int32, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p]),
+    "astts_op_argmax_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
 })
 _lib.register_signatures(_SIGS)
 
@@ -746,6 +749,44 @@ def attn_causal_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     out = torch.empty((b, t, heads * head_dim), dtype=torch.float16, device=q.device)
     _lib.check(_L().astts_op_attn_causal_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(lens), out.data_ptr(), b, t, heads, kv_heads,
                                              head_dim, q.stride(1), k.stride(1), heads * head_dim, 1.0 / math.sqrt(head_dim), _st()))
+    return out
+
+
+def attn_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, kv_heads: int, head_dim: int, lens: Optional[torch.Tensor] = None,
+             key_start: Optional[torch.Tensor] = None, pos0: int = 0, time_major: bool = False) -> torch.Tensor:
+    """Causal grouped-query attention on the matrix cores (astts_op_attn_gqa).  q ``[B, Tq, heads*hd]``, k / v ``[B, Tk, kv_heads*hd]``
+    fp16 strided views (``time_major``: ``[T, B, ...]``, e.g. the first rows of a time-major KV cache); query i has key index
+    ``pos0 + i``; ``lens`` masks keys at or beyond (right padding), ``key_start`` keys before (left padding).  -> fp16, laid out as q."""
+    assert q.dtype == k.dtype == v.dtype == torch.float16 and q.dim() == k.dim() == v.dim() == 3
+    assert q.stride(2) == k.stride(2) == v.stride(2) == 1 and k.stride() == v.stride()
+    bd, td = (1, 0) if time_major else (0, 1)
+    b, tq, tk = q.shape[bd], q.shape[td], k.shape[td]
+    out = torch.empty(q.shape[:2] + (heads * head_dim,), dtype=torch.float16, device=q.device)
+    _lib.check(_L().astts_op_attn_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(lens), _p(key_start), out.data_ptr(), b, tq, tk, pos0, heads,
+                                      kv_heads, head_dim, q.stride(bd), q.stride(td), k.stride(bd), k.stride(td), out.stride(bd), out.stride(td),
+                                      1.0 / math.sqrt(head_dim), _st()))
+    return out
+
+
+def rope_llama_ex_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, head_dim: int, pos0: int = 0,
+                   shift: Optional[torch.Tensor] = None, time_major: bool = False) -> torch.Tensor:
+    """rope_llama_ with the row order stated (``time_major``: x is ``[T, B, ld]``) and a per-row position shift (int32 ``[B]``: the time
+    step of row b's first real token -- left-padded prompts keep the positions transformers gives them).  In place."""
+    assert x.dtype == torch.float16 and x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+    t, b = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
+    assert cos.shape[0] >= pos0 + t and cos.shape[1] == head_dim // 2 and cos.is_contiguous() and sin.is_contiguous()
+    _lib.check(_L().astts_op_rope_llama_ex(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), _p(shift), b, t, 1 if time_major else 0, heads,
+                                           x.stride(1), head_dim, pos0, _st()))
+    return x
+
+
+def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 ``[rows, n]`` -> int32 ``[rows]`` (ties: the lowest index), on the device: the greedy step's token."""
+    x = _f32(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
+    _lib.check(_L().astts_op_argmax_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), _st()))
     return out
 
 

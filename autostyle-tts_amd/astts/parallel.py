@@ -121,7 +121,14 @@ def init_from_env(backend: Optional[str] = None):
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:              # a one-rank group (ASTTS_FORCE_DIST=1): any free port -- two such jobs on one host must not collide
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            else:                       # several ranks without a launcher-provided port have to agree on one
+                os.environ["MASTER_PORT"] = "29533"
         be = backend or os.environ.get("ASTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if be == "nccl":
             torch.cuda.set_device(local)

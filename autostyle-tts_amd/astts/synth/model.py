@@ -990,18 +990,21 @@ class PipelinedSynth:
 
     @classmethod
     def autotune(cls, engine: "SynthEngine", sample_args, depths=(3, 2), trials: int = 3, steps: int = 4, verbose: bool = False,
-                 front=None):
+                 front=None, dist=None):
         """Build the pipeline by measurement.  How well the chains overlap depends on which hardware queues HIP hands the
         streams (it multiplexes streams onto a few queues in an order the caller cannot see; a chain that shares a queue
         with another busy stream, or with the stream the caller enqueues its own work on, stalls the hand-over events).
         Each trial draws a fresh set of mutually concurrent streams (ops.concurrent_streams), runs ``steps`` batches of
         ``sample_args`` (the positional arguments of ``submit``) and the fastest configuration is kept.  ``front``: the
         caller's own per-batch GPU work (a callable, e.g. the style retrieval), enqueued on ``pipe.front_stream`` before
-        each submit exactly as the caller will."""
+        each submit exactly as the caller will.  ``dist`` (an initialised torch.distributed module): every rank runs the same
+        trials and ALL ranks keep the configuration whose slowest rank is fastest (one all-reduce MAX of the per-configuration
+        times) -- ranks that picked different chain counts would straggle at the per-step all-gather of the style ids."""
         import os
         import time
 
         best, best_dt = None, float("inf")
+        per_cfg = []                        # (best pipe, best time) per configuration, in the order of `depths`
         with torch.cuda.device(engine.device):
             classes = ops.stream_pipe_classes(device=engine.device, verbose=verbose)      # one probe for all trials
         for cfg_ in depths:
@@ -1030,7 +1033,18 @@ class PipelinedSynth:
                     print(f"PipelinedSynth.autotune: depth {depth} cobatch {cob} render streams {rdep}: {dt * 1e3:.1f} ms/batch", flush=True)
                 if dt < best_dt:
                     best, best_dt = pipe, dt
+                if not per_cfg or per_cfg[-1][2] != cfg_:
+                    per_cfg.append([pipe, dt, cfg_])
+                elif dt < per_cfg[-1][1]:
+                    per_cfg[-1][0], per_cfg[-1][1] = pipe, dt
+        if dist is not None and len(per_cfg) > 1:
+            t = torch.tensor([c[1] for c in per_cfg], dtype=torch.float64, device=engine.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            k = int(torch.argmin(t).item())
+            best, best_dt = per_cfg[k][0], per_cfg[k][1]
+            best.tuned_agreed_over_ranks = True
         best.tuned_ms_per_batch = best_dt * 1e3
+        best.tuned_table_ms = {str(c[2]): round(c[1] * 1e3, 2) for c in per_cfg}
         return best
 
     # ---- stages

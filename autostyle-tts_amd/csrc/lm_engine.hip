@@ -23,8 +23,8 @@ using namespace astts;
 // ---- v2: one decode step = sampler + 14 x (QKV, attention, out-proj, FFN-in, FFN-out) + head = 72 launches (73 without
 // the projected embedding table)
 static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max, int32_t b,
-                     int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
-                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, hipStream_t st) {
+                     int32_t pos0, int32_t n_steps, int32_t s_begin, int32_t s_end, const float* uniforms, const int32_t* forced_tokens,
+                     int32_t eos_min_steps, const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, hipStream_t st) {
     const astts_lm_config_t& c = h->cfg;
     const astts_lm_globals_t& g = h->g;
     const int d = c.d;
@@ -71,8 +71,10 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
         if (c.ln_folded) a.ln_plain = 1;
         else { a.ln_g = gam; a.ln_b = bet; }
     };
-    const float* cur = logits0;
-    for (int s = 0; s < n_steps; ++s) {
+    // steps [s_begin, s_end) of an n_steps decode: a range that does not start at 0 samples from the logits the previous range left in
+    // the workspace (`lg`: the caller passes the SAME workspace, token buffer and cache to every range of one decode)
+    const float* cur = s_begin == 0 ? logits0 : lg;
+    for (int s = s_begin; s < s_end; ++s) {
         if (logits_out)
             ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
                                              cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
@@ -150,100 +152,6 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     return ASTTS_OK;
 }
 
-// ---- v3: one decode step = sampler + 14 x (attention block, feed-forward block) + convert + head = 31 launches (lm_fused.hip).  The
-// residual stream lives in three rotating 64-bit fixed-point buffers: launch k accumulates into buffer k % 3 (cleared by launch k - 1),
-// reads buffer (k - 1) % 3 and clears buffer (k + 1) % 3; k runs on across the steps of the call.
-static int decode_v3(astts_lm* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max, int32_t b,
-                     int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
-                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, hipStream_t st) {
-    const astts_lm_config_t& c = h->cfg;
-    const astts_lm_globals_t& g = h->g;
-    const int d = c.d;
-    char* ws = (char*)workspace;
-    size_t o = 0;
-    auto take = [&](size_t bytes) {
-        void* p = ws + o;
-        o = align_up(o + bytes, 256);
-        return p;
-    };
-    (void)take(sizeof(float) * b * d);
-    float* xf = (float*)take(sizeof(float) * b * d);                 // fp32 copy of the final residual stream (the head's input)
-    (void)take(sizeof(float) * b * d);
-    (void)take(sizeof(float) * b * d);
-    (void)take(sizeof(float) * b * c.ffn);
-    float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
-    int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
-    (void)take(sizeof(int32_t) * b);
-    const size_t ring_bytes = align_up(sizeof(long long) * (size_t)b * d, 256);
-    ASTTS_REQUIRE(3 * ring_bytes <= astts_op_gemm_fused_workspace_bytes(), ASTTS_ERR_WORKSPACE,
-                  "astts_lm_decode: three %zu-byte accumulator buffers do not fit the %zu-byte split-K area", ring_bytes,
-                  astts_op_gemm_fused_workspace_bytes());
-    char* ring0 = (char*)take(astts_op_gemm_fused_workspace_bytes());
-    auto ring = [&](long k) { return (long long*)(ring0 + ((k % 3 + 3) % 3) * ring_bytes); };
-    const KvLayout lay = KvLayout::time_major(b, d);
-    if (n_steps > 1) ASTTS_CHECK_HIP(hipMemsetAsync(ring0, 0, ring_bytes, st));      // launch 0's accumulator
-    long k = 0;
-    const char* dbg_env = getenv("ASTTS_LM_FUSED_DBG");
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
-    const float* cur = logits0;
-    for (int s = 0; s < n_steps; ++s) {
-        if (logits_out)
-            ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
-                                             cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
-                                             hipMemcpyDeviceToDevice, st));
-        int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
-                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, (s < eos_min_steps ? 1 : 0) | (c.eos_policy ? 2 : 0), eos_min_rows, forced_tokens,
-                                        st);
-        if (rc != ASTTS_OK) return rc;
-        if (s + 1 == n_steps) break;
-        const int pos = pos0 + s;
-        for (int l = 0; l < c.layers; ++l) {
-            const astts_lm_layer_t& L = h->layers[l];
-            FAttnArgs a;
-            memset(&a, 0, sizeof(a));
-            if (l == 0) {
-                a.table = g.embed_table; a.tok = tok; a.pre_g = g.embed_ln_g; a.pre_b = g.embed_ln_b; a.pre_scale = sqrtf((float)d);
-            } else {
-                a.xin = ring(k - 1);
-            }
-            if (c.ln_folded) a.ln_plain = 1;
-            else { a.ln_g = L.n1_g; a.ln_b = L.n1_b; }
-            a.eps = c.eps;
-            a.wqkv = (const _Float16*)L.wqkv; a.bqkv = L.bqkv;
-            a.kv = (_Float16*)kv_cache[l]; a.kv_t = lay.t; a.kv_b = lay.b; a.kv_h = lay.h; a.kv_v = lay.v;
-            a.postab = (const _Float16*)L.pos; a.ldp = c.pos_ld; a.center = c.pos_center;
-            a.bias_u = L.bias_u; a.bias_v = L.bias_v; a.kstart = key_start;
-            a.wo = (const _Float16*)L.wo; a.bo = L.bo;
-            a.xout = ring(k); a.xzero = ring(k + 1);
-            a.b = b; a.d = d; a.heads = c.heads; a.pos = pos; a.scale = 0.125f; a.dbg = dbg;
-            if ((rc = lm_attn_block_launch(a, st)) != ASTTS_OK) return rc;
-            ++k;
-            FFfnArgs f;
-            memset(&f, 0, sizeof(f));
-            f.xin = ring(k - 1);
-            if (c.ln_folded) f.ln_plain = 1;
-            else { f.ln_g = L.n2_g; f.ln_b = L.n2_b; }
-            f.eps = c.eps;
-            f.w1 = (const _Float16*)L.w1; f.b1 = L.b1; f.w2 = (const _Float16*)L.w2; f.b2 = L.b2;
-            f.xout = ring(k); f.xzero = ring(k + 1);
-            f.b = b; f.d = d; f.ffn = c.ffn; f.dbg = dbg;
-            if ((rc = lm_ffn_block_launch(f, st)) != ASTTS_OK) return rc;
-            ++k;
-        }
-        if ((rc = lm_fx_to_f32_launch(ring(k - 1), xf, b * d, st)) != ASTTS_OK) return rc;
-        GemvArgs a;                 // after_norm + output head
-        memset(&a, 0, sizeof(a));
-        a.m = b; a.ln_eps = c.eps;
-        a.x = xf; a.ldx = d;
-        if (c.ln_folded) a.ln_plain = 1;
-        else { a.ln_g = g.after_g; a.ln_b = g.after_b; }
-        a.w = (const _Float16*)g.head_w; a.bias = g.head_b; a.out = lg; a.ldo = c.vocab_out; a.n = c.vocab_out; a.k = d; a.kpad = d;
-        if ((rc = lm_gemv_launch(a, st)) != ASTTS_OK) return rc;
-        cur = lg;
-    }
-    return ASTTS_OK;
-}
-
 extern "C" {
 
 int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* globals, const astts_lm_layer_t* layers,
@@ -289,8 +197,21 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                     int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream) {
+    return astts_lm_decode_range(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, 0, n_steps, uniforms, forced_tokens, eos_min_steps,
+                                 eos_min_rows, tokens_out, logits_out, workspace, workspace_bytes, stream);
+}
+
+// Steps [s_begin, s_end) of an n_steps decode (streaming synthesis: the chain is issued hop by hop, a chunk is rendered while the next
+// hop decodes).  The ranges of one decode are issued in order on ONE stream with the same cache, token buffer and workspace: the
+// workspace carries the logits from one range to the next, tokens_out the sampler's history.  Range (0, n_steps) = astts_lm_decode.
+int astts_lm_decode_range(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
+                          int32_t b, int32_t pos0, int32_t n_steps, int32_t s_begin, int32_t s_end, const float* uniforms,
+                          const int32_t* forced_tokens, int32_t eos_min_steps, const int32_t* eos_min_rows, int32_t* tokens_out,
+                          float* logits_out, void* workspace, size_t workspace_bytes, astts_stream_t stream) {
     ASTTS_REQUIRE(h && logits0 && kv_cache && uniforms && tokens_out && workspace, ASTTS_ERR_INVALID,
                   "astts_lm_decode: null argument");
+    ASTTS_REQUIRE(s_begin >= 0 && s_begin < s_end && s_end <= n_steps, ASTTS_ERR_INVALID, "astts_lm_decode_range: steps [%d, %d) of %d", s_begin,
+                  s_end, n_steps);
     ASTTS_REQUIRE(b >= 1 && b <= 32, ASTTS_ERR_INVALID, "astts_lm_decode: b=%d (1..32 per call)", b);
     ASTTS_REQUIRE(n_steps >= 1 && pos0 >= 1 && pos0 + n_steps - 1 <= t_max, ASTTS_ERR_INVALID,
                   "astts_lm_decode: pos0=%d n_steps=%d t_max=%d", pos0, n_steps, t_max);
@@ -305,17 +226,14 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     // kernel, 8-column workgroups, key-split attention merged by its consumer) for every batch of <= 32 rows: a row's arithmetic
     // there does not depend on the number of rows (lm_step.hip, FORM 2), so 8-, 16- and 32-row chains agree bit for bit.
     // "v1" = the operator chain below (round 1), kept as the second implementation the tests compare with.
-    // "v3" = two fused launches per layer with a fixed-point residual stream (lm_fused.hip): parity-green, 2.4x slower alone (EXPERIMENTS.md
-    // F); only on request.  ASTTS_LM_ENGINE=v1|v2|v3 forces one.
+    // (A "v3" -- two fused launches per layer with a fixed-point residual stream -- was built in round 4, parity-green and 2.4x slower:
+    // EXPERIMENTS.md F holds the log; the code is gone.)  ASTTS_LM_ENGINE=v1|v2 forces one.
     const char* env = getenv("ASTTS_LM_ENGINE");           // read per call: tests switch engines inside one process
-    const int forced = !env ? 0 : (!strcmp(env, "v1") ? 1 : (!strcmp(env, "v2") ? 2 : (!strcmp(env, "v3") ? 3 : 0)));
+    const int forced = !env ? 0 : (!strcmp(env, "v1") ? 1 : (!strcmp(env, "v2") ? 2 : 0));
     const bool v2_ok = c.kv_f16 && c.pos_f16 && (d % 64) == 0 && (c.ffn % 64) == 0 && d <= 1024;
-    if (v2_ok && forced == 3 && g.embed_table)
-        return decode_v3(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, uniforms, forced_tokens, eos_min_steps, eos_min_rows,
-                         tokens_out, logits_out, workspace, st);
     if (v2_ok && forced != 1)
-        return decode_v2(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, uniforms, forced_tokens, eos_min_steps, eos_min_rows,
-                         tokens_out, logits_out, workspace, st);
+        return decode_v2(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, s_begin, s_end, uniforms, forced_tokens, eos_min_steps,
+                         eos_min_rows, tokens_out, logits_out, workspace, st);
     char* ws = (char*)workspace;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -337,8 +255,8 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
     const float scale = 0.125f;  // 1/sqrt(64)
     const int64_t kv_row = (int64_t)b * 2 * d;  // one time step of the time-major cache
 
-    const float* cur = logits0;
-    for (int s = 0; s < n_steps; ++s) {
+    const float* cur = s_begin == 0 ? logits0 : lg;
+    for (int s = s_begin; s < s_end; ++s) {
         if (logits_out)
             ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
                                              cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,

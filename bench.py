@@ -259,37 +259,149 @@ def stub_main(args, world, rank):
     return 0
 
 
-def side_workload(args, which, dev, dist, rank, world):
-    """`--workload config3|config4|config5`: BASELINE.json's other configurations as SIDE lines with the default line's JSON schema (the
-    default `python bench.py` stays configs[1]; these make DESIGN.md's long-form / ragged / B = 256 figures reproducible by the
-    driver).  Same protocol: W untimed warm-up steps, K timed steps between barrier + synchronize, MAX over ranks, rank 0 prints.
+def _profiled(ops, kind, fn, max_launches=40000):
+    ops.prof_enable(kind, True, max_launches)
+    fn()
+    torch.cuda.synchronize()
+    ms, n, work, dropped = ops.prof_read(kind)
+    ops.prof_enable(kind, False)
+    return {"ms": ms, "launches": n, "work": work, "dropped": dropped}
+
+
+PROF_KINDS = {"gemm_tile": (0, "mfma"), "lm_gemv": (1, "hbm"), "attn_mha_flash": (2, "mfma"), "lm_attn": (3, "hbm")}
+
+
+def kind_rooflines(ops, fn, dist=None, dev=None, traffic_table=None, max_launches=40000):
+    """One pass of `fn` (ONE sequential unit of the workload: one batch on one stream) per profiled kernel kind, every launch of the kind
+    timed on its own stream.  Returns (dominant single kernel's roofline, {kind: roofline}).  `gemm_tile` is a FAMILY (ring / tile GEMMs,
+    the fused transformer-block, ResNet and vocoder convolution kernels: work = flops); the dominant KERNEL is the decode GEMV whenever
+    it takes more than half of that family's time (the rule of the headline line)."""
+    out = {}
+    for name, (kind, bound) in PROF_KINDS.items():
+        p = _profiled(ops, kind, fn, max_launches)
+        ms = torch.tensor([p["ms"]], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        n = max(p["launches"], 1)
+        us = p["ms"] * 1e3 / n
+        per = p["work"] / n
+        if bound == "mfma":
+            ach, peak, unit = (per / (us * 1e-6) / 1e12 if us > 0 else 0.0), MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = (per / (us * 1e-6) / 1e9 if us > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
+        out[name] = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "kernel": name, "avg_us": us,
+                     "launches": p["launches"], "algorithmic_work_per_launch": per, "ms_total": p["ms"], "ms_total_max_over_ranks": float(ms.item()),
+                     "dropped": p["dropped"],
+                     "traffic": (traffic_table or {}).get(name, {}).get("hbm_bytes_per_launch")}
+    tot = {k: v["ms_total_max_over_ranks"] for k, v in out.items()}
+    dom = max(tot, key=tot.get)
+    if dom == "gemm_tile" and tot["lm_gemv"] > 0.5 * tot["gemm_tile"]:
+        dom = "lm_gemv"
+    return dict(out[dom]), out
+
+
+def load_traffic_table():
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f), name
+        except OSError:
+            pass
+    return {}, None
+
+
+_BANK100K = {}
+
+
+def config5_bank(dim):
+    """N = 100 000 rows ~ N(0, 1) rounded to fp16, seed 1234 (generated once per process: 2.4 GB of fp32 on the host)."""
+    if dim not in _BANK100K:
+        _BANK100K[dim] = np.random.default_rng(1234).standard_normal((100000, dim), dtype=np.float32).astype(np.float16)
+    return _BANK100K[dim]
+
+
+def knn_stress(args, dev, traffic_table):
+    """BASELINE configs[4]'s retrieval leg on ONE GPU, each shape against ITS roofline: 100k x 6144 with Q = 8 (HBM: the bank
+    is read once per search), Q = 256 (the GEMM scan: MFMA; the bank bytes per scan launch come from the committed FETCH_SIZE pass) and
+    100k x 768 with Q = 256.  `scan_us` = HIP events around the scan launch(es) of a search (astts_knn_profile_*), `search_us` = wall time per
+    whole search (prep + scan + select + fp64 re-score, back to back on one stream).  ids checked against oracle/knn.py on a sample."""
+    from astts.knn import StyleBank
+    from oracle import knn as oknn
+
+    out = {}
+    for dim, qs in ((6144, (8, 256)), (768, (256,))):
+        bank = config5_bank(dim)
+        sb = StyleBank(bank, device=dev)
+        for nq in qs:
+            q_host = make_queries(bank, nq, seed=0)
+            q_dev = torch.from_numpy(q_host).to(dev)
+            oi = torch.empty((nq, args.topk), dtype=torch.int64, device=dev)
+            osc = torch.empty((nq, args.topk), dtype=torch.float32, device=dev)
+            for _ in range(5):
+                sb.search_device(q_dev, args.topk, out_idx=oi, out_score=osc)
+            torch.cuda.synchronize()
+            n_it = 30
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                sb.search_device(q_dev, args.topk, out_idx=oi, out_score=osc)
+            torch.cuda.synchronize()
+            search_us = (time.perf_counter() - t0) / n_it * 1e6
+            sb.profile_enable(True)
+            for _ in range(n_it):
+                sb.search_device(q_dev, args.topk, out_idx=oi, out_score=osc)
+            torch.cuda.synchronize()
+            ms, n_launch = sb.profile_read()
+            sb.profile_enable(False)
+            scan_us = ms * 1e3 / n_it                      # all scan launches of one search (two 128-query groups at Q = 256 before round 5)
+            nbytes = bank.shape[0] * dim * 2 + nq * dim * 4 + nq * args.topk * 12      # SURVEY.md 8(d): bank read ONCE per search
+            flops = 2.0 * nq * bank.shape[0] * dim
+            sel = np.arange(0, nq, max(1, nq // 7))
+            ok = bool(np.array_equal(oi.cpu().numpy()[sel], oknn.knn_search(bank, q_host[sel], args.topk)[0]))
+            key = f"knn_scan_100000_x_{dim}_q{nq}"
+            traffic = traffic_table.get(key, {}).get("hbm_bytes_per_launch")
+            launches = max(n_launch // n_it, 1)
+            hbm = {"bound": "hbm", "achieved": nbytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": nbytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            mfma = {"bound": "mfma", "achieved": flops / (scan_us * 1e-6) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / (scan_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS}
+            roof = dict(hbm if nq < 64 else mfma)
+            roof.update({"kernel": "knn_scan" if nq < 64 else "gemm_ring (the scan as one GEMM)", "avg_us": scan_us / launches, "scan_launches_per_search": launches,
+                         "algorithmic_bytes_per_search": nbytes, "algorithmic_flops_per_search": flops,
+                         "traffic": traffic * launches if traffic else None, "traffic_per_launch": traffic,
+                         "other_bound": mfma if nq < 64 else hbm})
+            out[f"N100000_D{dim}_Q{nq}"] = {"qps": nq / (search_us * 1e-6), "search_us": search_us, "scan_us": scan_us, "k": args.topk,
+                                           "ids_match_oracle_sample": ok, "roofline": roof}
+        del sb
+    return out
+
+
+def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=1, warmup=1, traffic_table=None):
+    """BASELINE.json's other configurations, measured with the default line's protocol (W untimed warm-up steps, K timed steps between
+    barrier + synchronize, MAX over ranks).  Returns the record on rank 0 (None elsewhere).
       config3  64 long-form lines = 384 text segments (Tt = 64, Ts = 250: 30 s per line) per step, as twelve 32-row batches through
-               the stream pipeline; weak scaling (every rank its own 64 lines).
+               the stream pipeline; weak scaling (every rank its own 64 lines).  tts_with_style_and_timbre.py:91-95.
       config4  the 1 623 IEMOCAP test sentences, Ts_i = clamp(round(20 words_i), 25, 1500) forced, STRONG scaling: rank r takes rows
                [r ceil(Q/W), ...) through CosyVoice.inference_tts_with_st_batch (prompt wavs -> frontend -> ragged LM / flow / vocoder ->
-               CPU waveforms) after the query-sharded retrieval of all 1 623 queries + one all-gather of the ids.
+               CPU waveforms) after the query-sharded retrieval of all 1 623 queries + one all-gather of the ids.  tts_with_rag.py:172-197.
       config5  256 queries against the 100 000 x 6144 bank (bank-sharded over the ranks when there are several) + 256 utterances at
-               the config-2 shapes, STRONG scaling over the ranks, 32-row batches through the stream pipeline."""
-    from astts import parallel
+               the config-2 shapes, STRONG scaling over the ranks, 32-row batches through the stream pipeline.  milvus/search_json.py:382-411."""
+    from astts import ops, parallel
     from astts.knn import StyleBank
-    from astts.synth.config import SynthConfig
     from astts.synth.model import PipelinedSynth, SynthEngine
-    from astts.synth.weights import make_all
 
-    cfg = SynthConfig(sample_rate=args.sample_rate)
-    weights = make_all(cfg, seed=0)
+    traffic_table = traffic_table or {}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn):
-        for _ in range(args.warmup):
-            step_fn()
+    def timed(step_fn, warm_fn=None):
+        for _ in range(warmup):
+            (warm_fn or step_fn)()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step_fn()
         barrier()
         dt = time.perf_counter() - t0
@@ -299,9 +411,14 @@ def side_workload(args, which, dev, dist, rank, world):
             dt = float(t.item())
         return dt
 
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
     extra = {}
     if which in ("config3", "config5"):
-        eng = SynthEngine(weights, cfg, dev)
+        eng = eng if eng is not None else SynthEngine(weights, cfg, dev)
         rows = 32
         if which == "config3":
             n_batches, tt, scaling = 12, 64, "weak"
@@ -311,7 +428,7 @@ def side_workload(args, which, dev, dist, rank, world):
             n_batches, tt, scaling = (b1 - b0 + rows - 1) // rows, args.text_tokens, "strong"
             total_rows = 256
             rows = min(rows, max(b1 - b0, 1))
-            bank = np.random.default_rng(1234).standard_normal((100000, args.dim), dtype=np.float32).astype(np.float16)
+            bank = config5_bank(args.dim)
             r0, r1, _ = parallel.shard_bounds(bank.shape[0], world, rank)
             sb = StyleBank(bank[r0:r1] if dist is not None else bank, device=dev)
             q_host = make_queries(bank, 256, seed=0)
@@ -325,7 +442,7 @@ def side_workload(args, which, dev, dist, rank, world):
         inp = SynthInputs(cfg, rows, tt, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
         sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
                   inp.z, inp.phase0, inp.noise)
-        pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=2, steps=6)
+        pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=1 if steps <= 2 else 2, steps=4 if steps <= 2 else 6, dist=dist)
         last = {}
 
         def step():
@@ -338,12 +455,30 @@ def side_workload(args, which, dev, dist, rank, world):
 
         with torch.cuda.stream(pipe.front_stream):
             dt = timed(step)
-        audio = inp.audio_seconds / rows * total_rows * args.steps
+        audio = inp.audio_seconds / rows * total_rows * steps
         ok = bool(torch.isfinite(last["wav"]).all())
+        extra["decode_chains"] = pipe.depth
+        del pipe
+        # one sequential 32-row batch: stage times, then the kernel kinds against their rooflines
+        e0 = ev()
+        toks = eng.tts_tokens(*sample[:6])
+        e1 = ev()
+        all_tok = torch.cat([inp.timbre_tok.to(torch.int32), toks], 1)
+        tl = torch.full((inp.b,), all_tok.shape[1], dtype=torch.int32, device=dev)
+        mel = eng.flow.decode(all_tok, tl, inp.timbre_mel, inp.spk_timbre, inp.z, inp.tmp + inp.tm)
+        e2 = ev()
+        eng.hift.forward(mel, inp.phase0, inp.noise)
+        e3 = ev()
+        torch.cuda.synchronize()
+        extra["stages_ms_one_sequential_batch"] = {"rows": rows, "lm_ms": round(e0.elapsed_time(e1), 3), "flow_ms": round(e1.elapsed_time(e2), 3),
+                                                    "vocoder_ms": round(e2.elapsed_time(e3), 3)}
+        roof, by_kind = kind_rooflines(ops, lambda: eng.tts(*sample), dist, dev, traffic_table)
+        roof["mode"] = f"one sequential {rows}-row batch on one stream (kernel-level dispatch timestamps for the decode kernels, HIP events for the rest)"
         if which == "config5":
             from oracle import knn as oknn
             sel = np.arange(0, 256, 37)
             extra["ids_match_oracle_sample"] = bool(np.array_equal(last["ids"].cpu().numpy()[sel], oknn.knn_search(bank, q_host[sel], args.topk)[0]))
+            del sb
         work = (f"BASELINE configs[2]: 64 long-form lines/GPU = 384 text segments (Tt={tt}, Tp={args.prompt_tokens}, Ts={args.speech_tokens}: 30 s per line) "
                 f"per step as {n_batches} batches of {rows} rows" if which == "config3" else
                 f"BASELINE configs[4]: kNN Q=256 x N=100000 x D={args.dim} k={args.topk} ({'bank-sharded over the ranks, one all-gather + merge' if dist is not None else 'one GPU holds the bank'}) "
@@ -360,7 +495,7 @@ def side_workload(args, which, dev, dist, rank, world):
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True)
+            cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
         g = torch.Generator().manual_seed(0)
         t16 = torch.arange(int(2.5 * 16000)) / 16000
         style = (0.3 * torch.sin(2 * math.pi * 220 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
@@ -369,38 +504,141 @@ def side_workload(args, which, dev, dist, rank, world):
         items = [(x, "He did. In Niagara Falls.", style, timbre) for x in sents[b0:b1]]
         last = {}
 
-        def step():
-            idx, _ = parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
-            last["ids"] = idx
-            outs = cv.inference_tts_with_st_batch(items, max_batch=32, split=False, fixed_tokens=want[b0:b1], seeds=list(range(b0, b1)))
+        def run_rows(sel_rows):
+            outs = cv.inference_tts_with_st_batch([items[i] for i in sel_rows], max_batch=32, split=False,
+                                                  fixed_tokens=[want[b0 + i] for i in sel_rows], seeds=[b0 + i for i in sel_rows])
             last["audio"] = sum(o[0]["tts_speech"].shape[1] for o in outs) / cfg.sample_rate
             last["ok"] = all(bool(torch.isfinite(o[0]["tts_speech"]).all()) for o in outs)
 
-        dt = timed(step)
+        def step():
+            idx, _ = parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
+            last["ids"] = idx
+            run_rows(range(len(items)))
+
+        def warm():          # bounded warm-up: every 8th row of the shard (allocator, position tables, every kernel variant)
+            parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
+            run_rows(range(0, len(items), 8))
+
+        dt = timed(step, warm if steps <= 1 else None)
         a = torch.tensor([last["audio"]], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(a)
-        audio = float(a.item()) * args.steps
+        audio = float(a.item()) * steps
         ok = last["ok"]
         scaling = "strong"
         from oracle import knn as oknn
         sel = np.arange(0, len(sents), 101)
         extra["ids_match_oracle_sample"] = bool(np.array_equal(last["ids"].cpu().numpy()[sel], oknn.knn_search(bank, q_all.cpu().numpy()[sel], args.topk)[0]))
-        extra["host_side_included"] = "prompt wavs -> GPU resample / log-mel frontend, tokenisation, per-row vocoder, D2H of every waveform"
+        extra["host_side_included"] = "prompt wavs -> GPU resample / log-mel frontend, tokenisation, ragged vocoder, D2H of every waveform"
+        # rooflines: one ragged render group (32 rows of the shard, every 8th row: lengths 25 ... several hundred tokens) through the same surface
+        prof_rows = list(range(0, len(items), max(1, len(items) // 32)))[:32]
+        roof, by_kind = kind_rooflines(ops, lambda: run_rows(prof_rows), dist, dev, traffic_table, max_launches=120000)
+        roof["mode"] = "one ragged group of 32 sentences of the shard through CosyVoice.inference_tts_with_st_batch (LM jobs on two streams, render overlapped)"
         work = (f"BASELINE configs[3]: the 1 623 IEMOCAP test sentences (Ts_i = clamp(round(20 words_i), 25, 1500), {sum(want)} speech tokens) sharded over {world} GPU(s), "
                 f"kNN Q=1623 x N={args.bank_rows} x D={args.dim} k={args.topk} query-sharded + all-gather of the ids, ragged synthesis in length-bucketed groups of 32 "
                 f"through CosyVoice.inference_tts_with_st_batch")
-    if rank == 0:
-        res = {"metric": "synthesized audio sec/wall-sec (RTF^-1) + style-kNN QPS, IEMOCAP test batch", "value": audio / dt, "unit": "audio-s/wall-s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": work + "; CosyVoice-300M shapes, random-init weights", "parallelism": f"dp{world}"},
-               "side_measurement": f"--workload {which}: NOT the headline line (python bench.py = BASELINE configs[1])",
-               "audio_seconds_per_step": audio / args.steps, "waveform_finite": ok, "roofline": None, "cpu_baseline": None}
-        res.update(extra)
-        emit_json(res)
+        del cv, sb
+    if rank != 0:
+        return None
+    res = {"value": audio / dt, "unit": "audio-s/wall-s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+           "scaling": scaling, "dtype": "f16", "data": "synthetic", "workload": work + "; CosyVoice-300M shapes, random-init weights",
+           "audio_seconds_per_step": audio / steps, "waveform_finite": ok, "roofline": roof,
+           "roofline_by_kind": {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "launches", "algorithmic_work_per_launch", "ms_total", "dropped", "traffic")}
+                                for k, v in by_kind.items()}}
+    res.update(extra)
+    return res
+
+
+def side_extras(args, dev, cfg, eng):
+    """Measurements of the rows next to the path that ride in the default line: filled in by the functions below as
+    those rows are measured (rank 0 only, bounded to a few seconds each)."""
+    out = {}
+    for name, fn in (("embedder", bench_embedder), ("streaming", bench_streaming)):
+        try:
+            out[name] = fn(args, dev, cfg, eng)
+        except Exception as e:      # noqa: BLE001  a side probe must never take the headline line down; the failure is reported in its place
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def bench_embedder(args, dev, cfg, eng):
+    """SURVEY.md 8f rank 2, the step before the retrieval (milvus/search_json.py:154-229, src/search_milvus.py:75-108): the Llama query
+    embedder at Llama-3.2-3B's WIDTHS (hidden 3072, 24 / 8 heads of 128, FFN 8192) with the test fixture's layer count (3 of 28: the
+    weights regenerate from a seed in seconds; per-layer work is what the kernels see, the 28-layer figure is the per-layer one x 28 / 3),
+    32 texts of 60 tokens per pass: mean-pooled embeddings per second, and the 10-token greedy label decode with the KV cache."""
+    from astts.llm.config import LlamaShape
+    from astts.llm.embedder import LlamaEmbedder
+    from astts.llm.weights import make_llama_weights
+
+    shape = LlamaShape.wide()
+    emb = LlamaEmbedder(make_llama_weights(shape, 0), shape, dev)
+    b, t, n_new = 32, 60, 10
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, shape.vocab, (b, t), generator=g)
+    lens = torch.full((b,), t, dtype=torch.int32)
+    for _ in range(3):
+        emb.embed_ids(ids, lens)
+    torch.cuda.synchronize()
+    n_it = 20
+    t0 = time.perf_counter()
+    for _ in range(n_it):
+        e = emb.embed_ids(ids, lens)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_it
+    hq, hk = shape.heads * shape.head_dim, shape.kv_heads * shape.head_dim
+    per_tok_layer = 2.0 * (shape.hidden * (hq + 2 * hk) + hq * shape.hidden + 3 * shape.hidden * shape.ffn)
+    flops = b * t * shape.layers * per_tok_layer + b * shape.layers * 4.0 * shape.heads * shape.head_dim * t * (t + 1) / 2
+    prompts = [ids[i].tolist() for i in range(b)]
+    emb.generate_greedy_batch(prompts, n_new)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        emb.generate_greedy_batch(prompts, n_new)
+    dg = (time.perf_counter() - t1) / 5
+    t2 = time.perf_counter()
+    emb.generate_greedy_recompute(prompts[0], n_new)
+    d1 = time.perf_counter() - t2
+    return {"texts_per_s": b / dt, "ms_per_pass": dt * 1e3, "texts": b, "tokens_per_text": t, "layers": shape.layers, "hidden": shape.hidden,
+            "finite": bool(torch.isfinite(e).all()),
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_pass": flops,
+                         "note": "whole embedding pass (embedding lookup, 3 x [RMSNorm, q|k|v GEMM, RoPE, MFMA causal GQA attention, out GEMM, RMSNorm, "
+                                 "gate|up GEMM, SwiGLU, down GEMM], final norm, mean-pool) over the pass's wall time; 1 920 rows per GEMM: launch- and "
+                                 "ingest-bound, not MFMA-bound"},
+            "greedy_label": {"texts": b, "prompt_tokens": t, "new_tokens": n_new, "ms_per_batch": dg * 1e3, "labels_per_s": b / dg,
+                             "ms_one_text_prompt_rerun_per_token": d1 * 1e3,
+                             "note": "KV cache + argmax on the device, one host synchronisation per batch (rounds 3-4 re-ran the prompt per token "
+                                     "with a host sync each: the last figure, ONE text)"},
+            "extrapolated_28_layers_texts_per_s": b / (dt * 28.0 / shape.layers)}
+
+
+def bench_streaming(args, dev, cfg, eng):
+    return None
+
+
+def side_workload(args, which, dev, dist, rank, world):
+    """`--workload config3|config4|config5`: one side configuration as a line of its own, with the default line's JSON schema (the default
+    `python bench.py` = BASELINE configs[1] carries bounded passes of all three under `side_workloads`)."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig(sample_rate=args.sample_rate)
+    weights = make_all(cfg, seed=0)
+    table, _ = load_traffic_table()
+    r = run_side(args, which, dev, dist, rank, world, cfg, weights, None, steps=args.steps, warmup=args.warmup, traffic_table=table)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        res = {"metric": "synthesized audio sec/wall-sec (RTF^-1) + style-kNN QPS, IEMOCAP test batch", "value": r["value"], "unit": r["unit"],
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+               "scaling": r["scaling"], "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": r["workload"], "parallelism": f"dp{world}"},
+               "side_measurement": f"--workload {which}: NOT the headline line (python bench.py = BASELINE configs[1])"}
+        res.update({k: v for k, v in r.items() if k not in res and k != "workload"})
+        if not args.no_cpu_baseline:
+            bank16 = make_config2_bank(args.bank_rows, args.dim)
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, make_queries(bank16, 8, seed=0), args.topk)
+        emit_json(res)
     return 0
 
 
@@ -421,6 +659,8 @@ def main():
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
     ap.add_argument("--no-cobatch", action="store_true", help="skip the co-batched side measurement (16 / 32-row decode chains): profiling "
                     "runs use it so that the kernel population is the timed region's")
+    ap.add_argument("--no-side", action="store_true", help="skip the bounded passes of BASELINE configs[2..4] (side_workloads), the 100k-bank "
+                    "retrieval stress (knn_stress), the query embedder and the streaming latency probe that the default line carries")
     ap.add_argument("--workload", default="config2", choices=("config2", "config3", "config4", "config5"),
                     help="config2 (default) = BASELINE configs[1], the headline; config3 / config4 / config5 = side lines for BASELINE configs[2..4] (side_workload)")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("ASTTS_BENCH_FORCE_DIST")),
@@ -483,7 +723,7 @@ def main():
               inp.z, inp.phase0, inp.noise)
     depths = tuple(int(x) for x in os.environ.get("ASTTS_BENCH_DEPTHS", "2,3").split(","))      # decode chains tried by the calibration
     pipe = PipelinedSynth.autotune(eng, sample, depths=depths, trials=2, steps=max(2, min(args.steps, 8)), verbose=rank == 0 and bool(os.environ.get("ASTTS_BENCH_VERBOSE")),
-                                   front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
+                                   front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc), dist=dist)
     n_done = [0]
 
     def take(done):
@@ -536,7 +776,7 @@ def main():
     if args.steps >= 2 and not args.no_cobatch:
         cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (3, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
         pipe = PipelinedSynth.autotune(eng, sample, depths=cob_cfgs, trials=2, steps=max(2, min(args.steps, 8)),
-                                       front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc))
+                                       front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc), dist=dist)
         with torch.cuda.stream(pipe.front_stream):
             for _ in range(args.warmup):
                 step()
@@ -587,16 +827,8 @@ def main():
         sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc)
     torch.cuda.synchronize()
     knn_qps = nsearch * args.batch / (time.perf_counter() - tq)
-    traffic_table = {}
-    traffic_file = None
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc
-        try:                                                 # FETCH_SIZE, own pass; cannot be collected inside this run)
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic_table = json.load(f)
-            traffic_file = name
-            break
-        except OSError:
-            pass
+    traffic_table, traffic_file = load_traffic_table()      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, own
+                                                            # pass; cannot be collected inside this run)
     # retrieval kernel against ITS roofline (HBM: the bank is read once per search): HIP events around the scan launch
     sb.profile_enable(True)
     for _ in range(100):
@@ -731,7 +963,7 @@ def main():
     v24 = None
     pipe_depth, pipe_tuned_ms = pipe.depth, pipe.tuned_ms_per_batch
     if not args.no_24khz and args.sample_rate != 24000 and args.steps >= 2:
-        del pipe
+        pipe = None
         cfg24 = SynthConfig(sample_rate=24000)
         eng24 = SynthEngine(weights, cfg24, dev)
         inp24 = SynthInputs(cfg24, args.batch, args.text_tokens, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
@@ -762,8 +994,23 @@ def main():
                "note": "same workload with SynthConfig(sample_rate=24000): 468 mel frames per 250 tokens instead of 430"}
         del pipe24, eng24
 
+    # ---- BASELINE's other configurations, bounded, with the same protocol (every rank takes part: configs[3] / [4] are sharded jobs)
+    side, stress, extras = {}, None, {}
+    if not args.no_side:
+        pipe = main_pipe = None
+        torch.cuda.empty_cache()
+        for which, (k_s, w_s) in (("config3", (1, 1)), ("config5", (2, 1)), ("config4", (1, 1))):
+            r = run_side(args, which, dev, dist, rank, world, cfg, weights, eng, steps=k_s, warmup=w_s, traffic_table=traffic_table)
+            if rank == 0:
+                side[which] = r
+            torch.cuda.empty_cache()
+        if rank == 0:
+            stress = knn_stress(args, dev, traffic_table)
+            extras = side_extras(args, dev, cfg, eng)
+
+    total_audio = inp.audio_seconds * args.steps * world
+    res = None
     if rank == 0:
-        total_audio = inp.audio_seconds * args.steps * world
         res = {
             "metric": "synthesized audio sec/wall-sec (RTF^-1) + style-kNN QPS, IEMOCAP test batch",
             "value": total_audio / dt,
@@ -792,7 +1039,7 @@ def main():
             "knn_roofline": knn_roof,
             "ids_match_oracle": ids_ok,
             "waveform_finite_and_clamped": wav_ok,
-            "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + LM prefix / prefill + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration); every one of the K batches completes inside the timed region",
+            "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + LM prefix / prefill + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration; with several ranks all keep the configuration whose slowest rank is fastest); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
                                                "decode_chains": cob["chains"], "batches_per_chain": cob["batches_per_chain"],
                                                "note": "same K steps, LM stages of consecutive batches co-batched into one 16- or 32-row decode "
@@ -803,12 +1050,17 @@ def main():
             "roofline": roof,
             "roofline_by_stage": by_stage,
             "value_24khz": v24,
+            "side_workloads": side or None,
+            "knn_stress": stress,
         }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)
-        emit_json(res)
+        res.update(extras)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU baseline at every N (rank 0, after the process group is gone: the other ranks have left, the host cores are free)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)
+        emit_json(res)
 
 
 if __name__ == "__main__":

@@ -374,6 +374,19 @@ int astts_op_rope_llama(void* x_f16, const float* cos_tab, const float* sin_tab,
 int astts_op_attn_causal_gqa(const void* q_f16, const void* k_f16, const void* v_f16, const int32_t* lens, void* out_f16, int32_t b,
                              int32_t t, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
                              astts_stream_t stream);
+/* the same attention on the matrix cores (v_mfma_f32_32x32x16_f16; round 5), generalised for the generation path of
+ * /root/reference/milvus/search_json.py:178-188 (model.generate, greedy): explicit element strides of batch row / time step
+ * (sqb, sqt: q; skb, skt: k and v; sob, sot: out) so that a time-major KV cache is read in place; query i has key index
+ * pos0 + i and attends keys [key_start[b], min(pos0 + i + 1, lens[b])) (either mask array may be NULL); head_dim 128 */
+int astts_op_attn_gqa(const void* q_f16, const void* k_f16, const void* v_f16, const int32_t* lens, const int32_t* key_start, void* out_f16,
+                      int32_t b, int32_t tq, int32_t tk, int32_t pos0, int32_t heads, int32_t kv_heads, int32_t head_dim, int64_t sqb, int64_t sqt,
+                      int64_t skb, int64_t skt, int64_t sob, int64_t sot, float scale, astts_stream_t stream);
+/* astts_op_rope_llama with the row order stated (time_major: row = t * b_count + b, else b * t_count + t) and a per-row position
+ * shift (int32 [b] or NULL): position = max(pos0 + t - shift[b], 0) -- left-padded prompts keep transformers' positions */
+int astts_op_rope_llama_ex(void* x_f16, const float* cos_tab, const float* sin_tab, const int32_t* shift, int32_t b, int32_t t, int32_t time_major,
+                           int32_t heads, int32_t ld, int32_t head_dim, int32_t pos0, astts_stream_t stream);
+/* out[row] = argmax over x[row, 0 .. n) (ties: the lowest index, as torch.argmax): the greedy step's token, on the device */
+int astts_op_argmax_rows(const float* x, int32_t* out, int32_t rows, int32_t n, int64_t ld, astts_stream_t stream);
 /* out = silu(gate) * up on a fused projection gate_up fp16 [rows, ldg] = gate[f] | up[f] */
 int astts_op_swiglu(const void* gate_up_f16, void* out_f16, int64_t rows, int32_t f, int32_t ldg, int32_t ldo, astts_stream_t stream);
 /* out[b, c] = mean over the first lens[b] (NULL: t) tokens of x fp32 [b, t, c] */

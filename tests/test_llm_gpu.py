@@ -48,12 +48,26 @@ def test_embedder_matches_transformers_fixtures(name):
     e_l = _rel(lg, fx["logits_last_row0"])
     print(f"[parity] llama {name}: last-token logits rel err {e_l:.2e}")
     assert e_l < 1e-2
-    gen = emb.generate_greedy(row0[0].tolist(), len(fx["greedy"]) - int(lens[0]))
+    n_new = len(fx["greedy"]) - int(lens[0])
+    gen = emb.generate_greedy(row0[0].tolist(), n_new)                  # KV cache, argmax on the device, one synchronisation
     ref = fx["greedy"].tolist()
     # greedy tokens: equal unless the fp32 reference itself has a near-tie at a step (top-2 logit gap below the fp16 error)
     if gen != ref:
         first = next(i for i, (a, b) in enumerate(zip(gen, ref)) if a != b)
         pytest.fail(f"greedy continuation differs from transformers at position {first}: {gen} vs {ref}")
+    assert emb.generate_greedy_recompute(row0[0].tolist(), n_new) == ref          # the prompt-per-token form (second implementation)
+    # a BATCH of prompts of different lengths (left-padded, per-row RoPE shift + key_start mask): every row equals its own run
+    prompts = [ids[i, :int(n)].tolist() for i, n in enumerate(lens)]
+    batch = emb.generate_greedy_batch(prompts, n_new)
+    assert batch[0] == ref
+    for p_, got in zip(prompts, batch):
+        assert got == emb.generate_greedy_recompute(p_, n_new), (len(p_), got)
+    # the VALU attention (rounds 3-4) and the MFMA attention give the same embedding to fp16 rounding
+    emb.mfma_attention = False
+    e_v = _rel(emb.embed_ids(ids, torch.from_numpy(lens)).cpu().numpy(), fx["embedding"])
+    emb.mfma_attention = True
+    print(f"[parity] llama {name}: padded-batch embedding rel err with the VALU attention {e_v:.2e} (MFMA {e_b:.2e})")
+    assert e_v < 5e-3
 
 
 def test_llm_operators_against_definitions():
@@ -90,10 +104,46 @@ def test_llm_operators_against_definitions():
     ref = (torch.softmax(s, -1) @ v.repeat_interleave(rep, 1)).transpose(1, 2).reshape(b, t, heads * hd)
     a = ops.attn_causal_gqa(d[..., :heads * hd], d[..., heads * hd:(heads + kvh) * hd], d[..., (heads + kvh) * hd:], heads, kvh, hd,
                             lens.to(DEV, torch.int32)).float().cpu()
+    am = ops.attn_gqa(d[..., :heads * hd], d[..., heads * hd:(heads + kvh) * hd], d[..., (heads + kvh) * hd:], heads, kvh, hd,
+                      lens=lens.to(DEV, torch.int32)).float().cpu()                # the same on the matrix cores (attn_gqa_mfma)
     for i in range(b):
         n = int(lens[i])
         assert _rel(a[i, :n], ref[i, :n]) < 2e-3, i
+        assert _rel(am[i, :n], ref[i, :n]) < 2e-3, i
         assert float(a[i, n:].abs().max()) == 0.0 if n < t else True              # padded queries produce zeros
+        assert float(am[i, n:].abs().max()) == 0.0 if n < t else True
+    # generation-path form: time-major cache views, left padding (key_start), a block of new queries at key index pos0 (tq < tk),
+    # more than one 128-query block and more than one 64-key tile
+    for (tq, tk) in ((1, 201), (3, 77), (150, 333)):
+        pos0 = tk - tq
+        gq = torch.randn(tq, b, heads * hd, generator=g).half()
+        gkv = torch.randn(tk, b, 2 * kvh * hd, generator=g).half()
+        ks = torch.tensor([0, min(37, tk - tq)], dtype=torch.int32)
+        qh = gq.float().view(tq, b, heads, hd).permute(1, 2, 0, 3)
+        kh = gkv[..., :kvh * hd].float().view(tk, b, kvh, hd).permute(1, 2, 0, 3).repeat_interleave(rep, 1)
+        vh = gkv[..., kvh * hd:].float().view(tk, b, kvh, hd).permute(1, 2, 0, 3).repeat_interleave(rep, 1)
+        kidx, qidx = torch.arange(tk)[None, None, None, :], (pos0 + torch.arange(tq))[None, None, :, None]
+        bad = (kidx > qidx) | (kidx < ks[:, None, None, None])
+        sc = (qh @ kh.transpose(-1, -2) / hd ** 0.5).masked_fill(bad, float("-inf"))
+        want = (torch.softmax(sc, -1) @ vh).permute(2, 0, 1, 3).reshape(tq, b, heads * hd)
+        dkv = gkv.to(DEV)
+        got = ops.attn_gqa(gq.to(DEV), dkv[..., :kvh * hd], dkv[..., kvh * hd:], heads, kvh, hd, key_start=ks.to(DEV), pos0=pos0,
+                           time_major=True).float().cpu()
+        valid = (pos0 + torch.arange(tq))[:, None] >= ks[None, :]                  # a pad query (before its row's first token) has no key: zeros
+        assert _rel(got[valid], want[valid]) < 2e-3, (tq, tk)
+        assert float(got[~valid].abs().max()) == 0.0 if bool((~valid).any()) else True
+    # rope with a per-row shift on a time-major buffer == the plain kernel on each row's own (unpadded) sequence
+    tmx = torch.randn(t, b, (heads + kvh) * hd, generator=g).half()
+    sh = torch.tensor([0, 9], dtype=torch.int32)
+    r_tm = ops.rope_llama_ex_(tmx.to(DEV).clone(), cos[:, :hd // 2].contiguous().to(DEV), sin[:, :hd // 2].contiguous().to(DEV), heads + kvh, hd,
+                              pos0=0, shift=sh.to(DEV), time_major=True).cpu()
+    for i in range(b):
+        own = tmx[int(sh[i]):, i][None].contiguous().to(DEV)
+        ops.rope_llama_(own, cos[:, :hd // 2].contiguous().to(DEV), sin[:, :hd // 2].contiguous().to(DEV), heads + kvh, hd)
+        assert torch.equal(r_tm[int(sh[i]):, i], own.cpu()[0]), i
+    lg = torch.randn(5, 4099, generator=g)
+    lg[2, 17] = lg[2, 4000] = 9.0                                                  # a tie: the lowest index wins, as torch.argmax
+    assert ops.argmax_rows(lg.to(DEV)).cpu().tolist() == [int(x) for x in torch.argmax(lg, 1)] and int(torch.argmax(lg, 1)[2]) == 17
     gu = torch.randn(5, 33, 2 * 1024, generator=g).half()
     sw = ops.swiglu(gu.to(DEV)).float().cpu()
     assert _rel(sw, torch.nn.functional.silu(gu[..., :1024].float()) * gu[..., 1024:].float()) < 2e-3
@@ -192,3 +242,48 @@ def test_emotion_label_decodes_without_special_tokens_and_with_the_untruncated_p
     assert skipped is True
     assert len(ids) >= len(tok.encode(emb.EMOTION_PROMPT.format(text, text)))     # nothing was cut off the prompt
     assert emb.get_embedding(text).shape == (cfg.hidden,)                          # the embedding path still truncates and works
+
+
+def test_search_json_text_to_style_ids_in_one_command(tmp_path, capsys):
+    """milvus/search_json.py:372-461 restated with its LLM half (astts.cli.search_json --model_path ...): per row emotion label (batched
+    KV-cached greedy decode) -> [label | biography] embedding -> top-1 COSINE search -> JSONL.  The JSONL must equal what the same
+    driver writes from the precomputed query vectors (--query_npy: the form rounds 1-4 had), the labels must equal the one-at-a-time
+    labels, and speakers without a biography get the reference's placeholder text."""
+    import json
+
+    from astts.cli import search_json as drv
+    from astts.llm.config import LlamaShape
+    from astts.llm.embedder import LlamaEmbedder
+    from astts.llm.weights import make_llama_weights
+
+    cfg = LlamaShape.wide()
+    emb = LlamaEmbedder(make_llama_weights(cfg, 8), cfg, DEV)
+    rows = [{"zh_text": "I did it, I asked her to marry me.", "speaker": "m1"}, {"zh_text": "Yeah.", "speaker": "w1"},
+            {"zh_text": "", "speaker": "w1"},                                            # skipped, as the reference skips it
+            {"zh_text": "Oh my god, that is wonderful news, congratulations to both of you!", "speaker": "w2"},
+            {"zh_text": "I don't know. I just feel like nothing is ever going to change.", "speaker": "m1"}]
+    inp = tmp_path / "in.jsonl"
+    inp.write_text("\n".join(json.dumps(r) for r in rows) + "\n")
+    bios = tmp_path / "bios.json"
+    bios.write_text(json.dumps({"m1": "A pragmatic and thoughtful person who values honesty.", "w1": "Cheerful and optimistic, always looking for the silver lining."}))
+    db = os.path.join(GOLD, "milvus_demo.db")
+    out1, out2 = tmp_path / "a.jsonl", tmp_path / "b.jsonl"
+    args = drv.build_parser().parse_args(["--input_json", str(inp), "--db_path", db, "--output_file", str(out1), "--biography_json", str(bios),
+                                          "--file_prefix_path", "/data/seg_wav", "--llm_batch", "3"])
+    res = drv.main(args, embedder=emb)
+    assert len(res) == 4 and all(r["retrieved_file_id"].startswith("/data/seg_wav/") for r in res)
+    kept = [r for r in rows if r["zh_text"].strip()]
+    q, labels = drv.embed_rows(kept, emb, drv.load_biographies(str(bios)), batch=3)
+    assert labels == [emb.generate_emotion_label(r["zh_text"]) for r in kept]            # batched labels == one at a time
+    h = cfg.hidden
+    assert _rel(q[2, h:], emb.get_embedding(drv.PLACEHOLDER_BIOGRAPHY)) < 2e-3           # w2 has no biography: the reference's fallback text
+    assert _rel(q[0, h:], emb.get_embedding("A pragmatic and thoughtful person who values honesty.")) < 2e-3
+    assert _rel(q[0, :h], emb.get_embedding(labels[0])) < 2e-3
+    full = np.zeros((len(rows), 2 * h), np.float32)
+    full[[0, 1, 3, 4]] = q
+    np.save(tmp_path / "q.npy", full)
+    args2 = drv.build_parser().parse_args(["--input_json", str(inp), "--db_path", db, "--output_file", str(out2), "--query_npy", str(tmp_path / "q.npy"),
+                                           "--file_prefix_path", "/data/seg_wav"])
+    drv.main(args2)
+    assert out1.read_text() == out2.read_text()
+    capsys.readouterr()

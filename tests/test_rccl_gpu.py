@@ -19,7 +19,7 @@ def test_bench_one_rank_through_rccl():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ASTTS_BENCH_STUB"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-24khz"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-24khz", "--no-side"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     # stdout is the ONE JSON line and nothing else: RCCL prints a version banner to C stdout (flushed at exit, i.e. after the
     # line) -- bench.py hands file descriptor 1 to stderr for everything but its own line (json_only_stdout)
@@ -47,7 +47,7 @@ def test_bench_under_torch_distributed_run_prints_one_json_line():
 
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-24khz", "--no-cobatch"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-24khz", "--no-cobatch", "--no-side"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
@@ -92,24 +92,65 @@ def test_drivers_under_torch_distributed_run_through_rccl(tmp_path):
     assert [r["retrieved_file_id"] for r in recs] == [meta["rows"][int(i)]["file_id"] for i in rows]        # 0.3 sigma of noise: top-1 is the source row
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["config3", "config5"])
-def test_bench_side_workloads_print_the_same_schema(workload):
-    """`python bench.py --workload config3|config5` (BASELINE configs[2] / configs[4] as side lines): one JSON line on stdout with the
-    default line's keys, `side_measurement` set, a finite waveform and -- config 5 -- retrieved ids equal to the oracle's on a sample."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _clean_env(**extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "ASTTS_BENCH_STUB", "ASTTS_BENCH_FORCE_DIST"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1"], env=env,
-                       capture_output=True, text=True, timeout=900)
+        if k not in extra:
+            env.pop(k, None)
+    return env
+
+
+def _roofline_ok(r):
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0.0 < r["frac"] < 1.0, r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_us"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_side_workload_as_a_line_of_its_own():
+    """`python bench.py --workload config3` (BASELINE configs[2] as a line of its own): one JSON line on stdout with the default line's
+    keys, `side_measurement` set, a finite waveform, its own dominant-kernel roofline and the per-kind rooflines."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
     res = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in res, key
-    assert res["side_measurement"].startswith(f"--workload {workload}") and "workload" in res["config"] and res["waveform_finite"] is True
+    assert res["side_measurement"].startswith("--workload config3") and "workload" in res["config"] and res["waveform_finite"] is True
     assert res["value"] > 50.0 and res["n_gpus"] == 1 and res["steps"] == 1
-    if workload == "config5":
-        assert res["ids_match_oracle_sample"] is True and res["scaling"] == "strong"
-    print(f"bench --workload {workload}:", round(res["value"], 1), "x real time,", round(res["ms_per_step"], 1), "ms per step")
+    _roofline_ok(res["roofline"])
+    assert set(res["roofline_by_kind"]) == {"gemm_tile", "lm_gemv", "attn_mha_flash", "lm_attn"}
+    print("bench --workload config3:", round(res["value"], 1), "x real time,", round(res["ms_per_step"], 1), "ms per step;",
+          res["roofline"]["kernel"], round(res["roofline"]["frac"], 3))
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_every_baseline_config():
+    """The DEFAULT line (`python bench.py --gpus 1`, what the driver times) carries bounded passes of BASELINE configs[2..4] under
+    `side_workloads` -- each with value, ms_per_step, its dominant kernel's roofline and per-kind rooflines -- and the 100k-bank
+    retrieval stress under `knn_stress` (Q = 8 against the HBM roofline, Q = 256 against the MFMA roofline, ids checked on a sample)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-24khz",
+                        "--no-cobatch"], env=_clean_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["ids_match_oracle"] is True and res["waveform_finite_and_clamped"] is True and res["value"] > 50.0
+    _roofline_ok(res["roofline"])
+    side = res["side_workloads"]
+    assert set(side) == {"config3", "config4", "config5"}
+    for name, s in side.items():
+        assert s["value"] > 50.0 and s["ms_per_step"] > 0 and s["waveform_finite"] is True, (name, s)
+        _roofline_ok(s["roofline"])
+        assert set(s["roofline_by_kind"]) == {"gemm_tile", "lm_gemv", "attn_mha_flash", "lm_attn"}
+    assert side["config4"]["ids_match_oracle_sample"] is True and side["config5"]["ids_match_oracle_sample"] is True
+    assert side["config3"]["scaling"] == "weak" and side["config4"]["scaling"] == "strong" and side["config5"]["scaling"] == "strong"
+    ks = res["knn_stress"]
+    assert set(ks) == {"N100000_D6144_Q8", "N100000_D6144_Q256", "N100000_D768_Q256"}
+    for name, k in ks.items():
+        assert k["ids_match_oracle_sample"] is True and k["qps"] > 0, (name, k)
+        _roofline_ok(k["roofline"])
+    assert ks["N100000_D6144_Q8"]["roofline"]["bound"] == "hbm" and ks["N100000_D6144_Q256"]["roofline"]["bound"] == "mfma"
+    print("default line:", round(res["value"], 1), "x;", {n: round(s["value"], 1) for n, s in side.items()},
+          {n: (round(k["qps"]), round(k["roofline"]["frac"], 3)) for n, k in ks.items()})
