@@ -16,6 +16,23 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 # that the three-chain pipeline lost to the two-chain one; with 4 it wins (batch-8 benchmark, same box, alternating: 428 -> 457x real
 # time; 5: the same; 3 and 6: no gain; 2: 292x).  Read by the HIP runtime when it initialises (the first HIP call), so it has to be in
 # the environment before that; an explicit setting wins.
+def _hip_already_initialised() -> bool:
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:      # noqa: BLE001
+        return False
+
+
+if "GPU_MAX_HW_QUEUES" not in os.environ and _hip_already_initialised():
+    # too late: the runtime read its own default (8 queues = two per pipe) at its first call.  Everything still works; the stream
+    # pipeline then calibrates to two decode chains instead of three.
+    import warnings
+    warnings.warn("astts: HIP was initialised before astts was imported, so GPU_MAX_HW_QUEUES=4 (one hardware queue per command-processor "
+                  "pipe) cannot take effect any more; PipelinedSynth then runs two decode chains instead of three (measured: 428x instead "
+                  "of 457x real time on the batch-8 benchmark).  Import astts -- or export GPU_MAX_HW_QUEUES=4 -- before the first "
+                  "torch.cuda call.", RuntimeWarning, stacklevel=2)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

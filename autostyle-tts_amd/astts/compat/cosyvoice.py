@@ -39,6 +39,77 @@ def load_wav(path: str, target_sr: int) -> torch.Tensor:
     return audio.load_wav(path, target_sr)
 
 
+class _LmTokenStream:
+    """The speech tokens of one segment WHILE the LM decodes them (``stream=True``).  Upstream runs ``llm.inference`` on a thread that
+    appends to a list and lets ``tts()`` cut a chunk as soon as hop + look-ahead tokens are there; here the decode chain is issued in
+    ranges of steps (``AcousticLM.decode_range`` -> astts_lm_decode_range) by a worker thread on its OWN HIP stream, each range
+    followed by an event and an asynchronous copy of its tokens to pinned memory, so that chunk k is rendered on the caller's stream
+    while the chain decodes the tokens of chunk k + 1.  ``wait(n)`` returns the tokens so far once n exist (or all there will be):
+    the interface ``synth.stream.stream_render`` takes in place of a finished token tensor."""
+
+    def __init__(self, lm, state, uniforms, min_len: int, max_len: int, eos_id: int, ranges, stream: "torch.cuda.Stream", fixed: bool):
+        import threading
+
+        self.lm, self.eos, self.max_len, self.fixed = lm, eos_id, max_len, fixed
+        self.stream = stream
+        dev = lm.device
+        stream.wait_stream(torch.cuda.current_stream(dev))          # the prefill ran on the caller's stream
+        for t in lm.prefill_tensors(state) + [uniforms]:
+            t.record_stream(stream)
+        with torch.cuda.stream(stream):
+            self.ctx = lm.decode_begin(state, uniforms, ignore_eos=max_len if fixed else min_len)
+        self.host = torch.empty((max_len,), dtype=torch.int32).pin_memory()
+        self.ranges = list(ranges)                                   # [(s_begin, s_end)] covering [0, max_len)
+        self.events = [torch.cuda.Event() for _ in self.ranges]
+        self.issued = [threading.Event() for _ in self.ranges]
+        self.have, self.finished, self.cancel, self.error = 0, False, False, None
+        self._done_ranges = 0
+        self.thread = threading.Thread(target=self._issue, daemon=True)
+        self.thread.start()
+
+    def _issue(self):
+        try:
+            with torch.cuda.device(self.lm.device), torch.cuda.stream(self.stream):
+                for k, (b, e) in enumerate(self.ranges):
+                    if self.cancel:
+                        break
+                    self.lm.decode_range(self.ctx, e)
+                    self.host[b:e].copy_(self.ctx["toks"][0, b:e], non_blocking=True)
+                    self.events[k].record(self.stream)
+                    self.issued[k].set()
+        except BaseException as e:      # noqa: BLE001  (re-raised in wait())
+            self.error = e
+        finally:
+            for ev in self.issued:
+                ev.set()
+
+    def wait(self, n: int):
+        n = min(int(n), self.max_len)
+        while self.have < n and not self.finished:
+            k = self._done_ranges
+            self.issued[k].wait()
+            if self.error is not None:
+                raise self.error
+            self.events[k].synchronize()                             # this range's tokens are in pinned memory
+            b, e = self.ranges[k]
+            self._done_ranges += 1
+            row = self.host[b:e]
+            eos = (row >= self.eos).nonzero() if not self.fixed else torch.empty(0)
+            if eos.numel():                                          # the segment ends here: later ranges are not needed
+                self.have = max(b + int(eos[0]), 1)
+                self.finished, self.cancel = True, True
+            else:
+                self.have = e
+                if self._done_ranges == len(self.ranges):
+                    self.finished = True
+        return self.host[:self.have].clone(), self.finished
+
+    def close(self):
+        self.cancel = True
+        self.thread.join()
+        torch.cuda.current_stream(self.lm.device).wait_stream(self.stream)
+
+
 class CosyVoice:
     def __init__(self, model_dir: str, config: Optional[SynthConfig] = None, seed: int = 0, device=None,
                  frontend: Optional[Frontend] = None, allow_random_init: Optional[bool] = None, **_kw):
@@ -52,14 +123,18 @@ class CosyVoice:
         engine = _kw.pop("engine", None)          # an existing SynthEngine (benchmarks: one engine for several surfaces)
         self.model_dir = model_dir
         if config is None:
-            config = SynthConfig.tiny() if os.environ.get("ASTTS_TINY_MODEL") == "1" else SynthConfig()
+            cfg_file = os.path.join(model_dir, "astts.json")          # this build's plain-JSON model config (sample rate, max_positions,
+            if os.path.exists(cfg_file):                              # up-rates, vocabulary sizes ...: SynthConfig.from_json)
+                config = SynthConfig.from_json(cfg_file)
+            else:
+                config = SynthConfig.tiny() if os.environ.get("ASTTS_TINY_MODEL") == "1" else SynthConfig()
         self.cfg = config
         self.sample_rate = config.sample_rate
         have = all(os.path.exists(os.path.join(model_dir, f"{n}.pt")) for n in ("llm", "flow", "hift"))
         if engine is not None:
             state, self.random_init = None, bool(getattr(engine, "random_init", not have))
         elif have:
-            state = load_state_dicts(model_dir)
+            state = load_state_dicts(model_dir, config)               # held to the config's key / shape manifest: one readable error
             self.random_init = False
         else:
             if allow_random_init is None:
@@ -76,6 +151,9 @@ class CosyVoice:
         self.frontend = frontend or Frontend(config, device=self.device)
         self._gen = torch.Generator().manual_seed(seed)
         self.min_token_text_ratio, self.max_token_text_ratio = 2, 20
+        # stream=True: render chunk k while the LM decodes the tokens of chunk k + 1 (False: one decode pass, then the chunks -- rounds 3-4,
+        # kept as the second implementation the tests compare the chunks with)
+        self.stream_lm_live = os.environ.get("ASTTS_STREAM_LM_LIVE", "1") != "0"
 
     # ------------------------------------------------------------------ one text segment
     @staticmethod
@@ -100,21 +178,57 @@ class CosyVoice:
         noise = torch.randn(1, n_mel_gen * cfg.upsample_total, nh, generator=gd, device=self.device)
         return u, z, phase0, noise
 
-    def _lm_tokens(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures, gen: Optional[torch.Generator] = None) -> torch.Tensor:
-        """LM decode with EOS: masked for the first 2x text tokens, capped at 20x (upstream ratios)."""
-        cfg, dev, lm = self.cfg, self.device, self.engine.lm
+    def _lm_setup(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures, gen: Optional[torch.Generator], fixed_tokens: Optional[int]):
+        """Prefix, decode window and sampling uniforms of one segment: EOS masked for the first 2x text tokens, capped at 20x (upstream
+        ratios); ``fixed_tokens``: exactly that many tokens, EOS ignored (throughput / latency runs: SURVEY.md 7)."""
+        dev, lm = self.device, self.engine.lm
         tlen = torch.tensor([text_ids.shape[1]], dtype=torch.int32, device=dev)
         pre = lm.prefix(text_ids.to(dev), tlen, lm_prompt.spk_embedding.to(dev), lm_prompt.speech_tokens.to(dev))
-        min_len = self.min_token_text_ratio * n_tts_text
-        want = self.max_token_text_ratio * n_tts_text
-        max_len = max(self._cap_tokens(want, pre.shape[0]), min_len + 1)
+        if fixed_tokens is not None:
+            want = int(fixed_tokens)
+            max_len = self._cap_tokens(want, pre.shape[0])
+            min_len = max_len
+        else:
+            min_len = self.min_token_text_ratio * n_tts_text
+            want = self.max_token_text_ratio * n_tts_text
+            max_len = max(self._cap_tokens(want, pre.shape[0]), min_len + 1)
         # a FIXED count of uniforms per segment (upstream's 20x window), whatever the position-table cap: the later draws of the
         # segment's stream (CFM noise, phases, source noise) then do not shift when a cap applies
         u = torch.rand(max(want, max_len), 1, 2, generator=gen or self._gen)[:max_len].to(dev)
-        toks = lm.decode(pre, max_len, u, ignore_eos=min_len)[0].cpu()       # one sync per segment
-        eos = (toks >= cfg.speech_vocab).nonzero()
+        return pre, min_len, max_len, u
+
+    def _lm_tokens(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures, gen: Optional[torch.Generator] = None,
+                   fixed_tokens: Optional[int] = None) -> torch.Tensor:
+        """The segment's speech tokens from ONE on-device decode pass (one synchronisation per segment)."""
+        cfg, lm = self.cfg, self.engine.lm
+        pre, min_len, max_len, u = self._lm_setup(text_ids, n_tts_text, lm_prompt, gen, fixed_tokens)
+        toks = lm.decode(pre, max_len, u, ignore_eos=True if fixed_tokens is not None else min_len)[0].cpu()
+        eos = (toks >= cfg.speech_vocab).nonzero() if fixed_tokens is None else torch.empty(0)
         n = int(eos[0]) if eos.numel() else max_len
         return toks[:max(n, 1)][None, :].to(torch.int32)
+
+    def _lm_token_stream(self, text_ids: torch.Tensor, n_tts_text: int, lm_prompt: PromptFeatures, gen: Optional[torch.Generator] = None,
+                         fixed_tokens: Optional[int] = None) -> _LmTokenStream:
+        """The same tokens as ``_lm_tokens`` (same prefix, window, uniforms: bit-identical), handed over WHILE they are decoded: the
+        decode chain runs hop by hop on a stream of its own (first range = hop + look-ahead = 120 tokens, then 100 at a time: the
+        chunk boundaries of ``synth.stream``), so the first chunk can be rendered after ~120 decode steps instead of after EOS."""
+        from ..synth.stream import StreamConsts
+        cfg, lm = self.cfg, self.engine.lm
+        pre, min_len, max_len, u = self._lm_setup(text_ids, n_tts_text, lm_prompt, gen, fixed_tokens)
+        c = StreamConsts.for_config(cfg)
+        state = lm.prefill(pre, max_len)
+        edges, e, hop = [0], c.token_min_hop + c.token_overlap, c.token_min_hop
+        while e < max_len:
+            edges.append(e)
+            hop = min(c.token_max_hop, int(hop * c.scale))
+            e += hop
+        edges.append(max_len)
+        if getattr(self, "_stream_lm_stream", None) is None:
+            from .. import ops
+            firsts = [cl[0] for cl in ops.stream_pipe_classes(device=self.device)]      # a hardware queue of its own (another pipe)
+            self._stream_lm_stream = firsts[1] if len(firsts) > 1 else torch.cuda.Stream(device=self.device)
+        return _LmTokenStream(lm, state, u, min_len, max_len, cfg.speech_vocab, list(zip(edges[:-1], edges[1:])), self._stream_lm_stream,
+                              fixed_tokens is not None)
 
     def _cap_tokens(self, want: int, prefix_len: int, what: str = "this segment") -> int:
         """The relative-position tables bound prefix + generated tokens (SynthConfig.max_positions).  Upstream's tables extend, so a
@@ -138,35 +252,42 @@ class CosyVoice:
         wav = eng.hift.forward(mel, phase0.to(dev), noise.to(dev))
         return wav.cpu()
 
-    def _render_stream(self, tokens: torch.Tensor, flow_prompt: PromptFeatures) -> Iterator[torch.Tensor]:
-        """``stream=True``: the segment's tokens (generated in one on-device decode pass: the chunks differ from upstream's in
-        first-chunk latency only) rendered hop by hop with upstream's overlaps and cross-fades (``astts.synth.stream``)."""
+    def _render_stream(self, tokens, flow_prompt: PromptFeatures, gen: Optional[torch.Generator] = None) -> Iterator[torch.Tensor]:
+        """``stream=True``: the segment's tokens -- a finished tensor (``inference_vc``: the source's tokens) or the live
+        ``_LmTokenStream`` of a decode still running on its own stream -- rendered hop by hop with upstream's overlaps and cross-fades
+        (``astts.synth.stream``).  With the live source the first chunk is yielded after ~120 decode steps, not after EOS."""
         from ..synth.stream import StreamConsts, stream_render
         cfg, dev, eng = self.cfg, self.device, self.engine
         nh = cfg.nb_harmonics + 1
         ptok = flow_prompt.speech_tokens.to(torch.int32)
         pmel, spk = flow_prompt.mel.to(dev), flow_prompt.spk_embedding.to(dev)
         tmp = pmel.shape[1]
+        g = gen or self._gen            # the item's own random stream when it has one (seed=): chunks then do not depend on what ran before
 
         def flow_mel(tok: torch.Tensor) -> torch.Tensor:
             n_gen = cfg.mel_frames_for_tokens(int(tok.numel()))
-            z = torch.randn(1, tmp + n_gen, cfg.mel, generator=self._gen)
+            z = torch.randn(1, tmp + n_gen, cfg.mel, generator=g)
             all_tok = torch.cat([ptok, tok.view(1, -1).to(torch.int32)], dim=1).to(dev)
             tl = torch.tensor([all_tok.shape[1]], dtype=torch.int32, device=dev)
             return eng.flow.decode(all_tok, tl, pmel, spk, z.to(dev), tmp + n_gen)
 
         def source(f0: torch.Tensor) -> torch.Tensor:
-            phase0 = (torch.rand(1, nh, generator=self._gen) * 2 - 1) * math.pi
+            phase0 = (torch.rand(1, nh, generator=g) * 2 - 1) * math.pi
             phase0[:, 0] = 0
-            noise = torch.randn(1, f0.shape[1] * cfg.upsample_total, nh, generator=self._gen)
+            noise = torch.randn(1, f0.shape[1] * cfg.upsample_total, nh, generator=g)
             return eng.hift.source(f0, phase0.to(dev), noise.to(dev))
 
-        for wav in stream_render(tokens.view(-1), StreamConsts.for_config(cfg), flow_mel, eng.hift.f0, source, eng.hift.decode):
-            yield wav.cpu()
+        toks_in = tokens if hasattr(tokens, "wait") else tokens.view(-1)
+        try:
+            for wav in stream_render(toks_in, StreamConsts.for_config(cfg), flow_mel, eng.hift.f0, source, eng.hift.decode):
+                yield wav.cpu()
+        finally:
+            if hasattr(tokens, "close"):
+                tokens.close()
 
     def _emit(self, tokens: torch.Tensor, flow_prompt: PromptFeatures, stream: bool, gen: Optional[torch.Generator] = None) -> Iterator[Dict[str, torch.Tensor]]:
         if stream:
-            for wav in self._render_stream(tokens, flow_prompt):
+            for wav in self._render_stream(tokens, flow_prompt, gen):
                 yield {"tts_speech": wav}
         else:
             yield {"tts_speech": self._render(tokens, flow_prompt, gen)}
@@ -388,9 +509,10 @@ class CosyVoice:
 
     # ------------------------------------------------------------------ public generators
     def inference_tts_with_st(self, tts_text: str, style_text: str, style_wav_16k: torch.Tensor,
-                              timbre_wav_16k: torch.Tensor, stream: bool = False, seed: Optional[int] = None) -> Iterator[Dict[str, torch.Tensor]]:
+                              timbre_wav_16k: torch.Tensor, stream: bool = False, seed: Optional[int] = None,
+                              fixed_tokens: Optional[int] = None) -> Iterator[Dict[str, torch.Tensor]]:
         """``seed`` (an addition to the reference's signature): the item's own random stream (``segment_generator``) instead of
-        the instance generator."""
+        the instance generator.  ``fixed_tokens`` (likewise): every segment decodes exactly that many speech tokens, EOS ignored."""
         fe = self.frontend
         style = fe.prompt(style_wav_16k)
         timbre = fe.prompt(timbre_wav_16k)
@@ -399,7 +521,10 @@ class CosyVoice:
             seg_ids = fe.text_ids(seg)
             text_ids = torch.cat([style_ids, seg_ids], dim=1)
             gen = None if seed is None else self.segment_generator(seed, n_seg)
-            toks = self._lm_tokens(text_ids, seg_ids.shape[1], style, gen)  # step 1: style tokens
+            if stream and self.stream_lm_live:      # step 1 WHILE step 2 renders the chunks it has the tokens for
+                toks = self._lm_token_stream(text_ids, seg_ids.shape[1], style, gen, fixed_tokens)
+            else:
+                toks = self._lm_tokens(text_ids, seg_ids.shape[1], style, gen, fixed_tokens)  # step 1: style tokens
             yield from self._emit(toks, timbre, stream, gen)                 # step 2: render with the timbre
 
     def inference_zero_shot(self, tts_text: str, prompt_text: str, prompt_wav_16k: torch.Tensor,
@@ -409,7 +534,8 @@ class CosyVoice:
         prompt_ids = fe.text_ids(prompt_text)
         for seg in text_normalize(tts_text, fe.tokenizer, split=True):
             seg_ids = fe.text_ids(seg)
-            toks = self._lm_tokens(torch.cat([prompt_ids, seg_ids], dim=1), seg_ids.shape[1], prompt)
+            lm_in = (torch.cat([prompt_ids, seg_ids], dim=1), seg_ids.shape[1], prompt)
+            toks = self._lm_token_stream(*lm_in) if stream and self.stream_lm_live else self._lm_tokens(*lm_in)
             yield from self._emit(toks, prompt, stream)
 
     def inference_vc(self, source_wav_16k: torch.Tensor, prompt_wav_16k: torch.Tensor,

@@ -84,6 +84,8 @@ _SIGS.update({
     "astts_lm_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "astts_lm_decode": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                   c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "astts_lm_decode_range": (c_int32, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                        c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 })
 
 

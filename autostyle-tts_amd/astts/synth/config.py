@@ -99,3 +99,29 @@ class SynthConfig:
 
     def with_(self, **kw) -> "SynthConfig":
         return replace(self, **kw)
+
+    # ---- model_dir/astts.json: the plain-JSON model config of this build (upstream keeps its hyper-parameters in
+    # model_dir/cosyvoice.yaml, a hyperpyyaml file that instantiates Python classes -- not readable here and not a data format)
+    def to_json(self) -> str:
+        import dataclasses
+        import json
+        return json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in dataclasses.asdict(self).items()}, indent=1)
+
+    @staticmethod
+    def from_json(text_or_path: str) -> "SynthConfig":
+        """A JSON object whose keys are SynthConfig fields (any subset: the rest keep the CosyVoice-300M defaults), given as text or
+        as a file path.  Unknown keys are an error (a typo must not silently fall back to a default)."""
+        import dataclasses
+        import json
+        import os
+        text = text_or_path
+        if not text_or_path.lstrip().startswith("{") and os.path.exists(text_or_path):
+            with open(text_or_path, "r", encoding="utf-8") as f:
+                text = f.read()
+        data = json.loads(text)
+        fields = {f.name: f for f in dataclasses.fields(SynthConfig)}
+        unknown = sorted(set(data) - set(fields))
+        if unknown:
+            raise ValueError(f"astts.json: unknown SynthConfig field(s) {unknown}; known: {sorted(fields)}")
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in data.items()}
+        return SynthConfig(**kw)

@@ -298,32 +298,52 @@ class AcousticLM:
     def prefill_tensors(state):
         return list(state["cache"]) + [state["logits0"]] + ([state["key_start"]] if state["key_start"] is not None else [])
 
-    def decode_prefilled(self, state, uniforms: torch.Tensor, ignore_eos: bool = True, forced_tokens: Optional[torch.Tensor] = None,
-                         return_logits: bool = False):
-        """The decode steps of `prefill`'s state (b <= 32 rows) on the current stream: one C++ call, no host synchronisation."""
+    def decode_begin(self, state, uniforms: torch.Tensor, ignore_eos=True, forced_tokens: Optional[torch.Tensor] = None,
+                     return_logits: bool = False):
+        """The buffers of one decode of `prefill`'s state (b <= 32 rows): token history, workspace (it carries the logits from one
+        range of steps to the next), uniforms.  -> context for `decode_range`."""
+        from .. import _lib
+        lib = _lib.load()
+        eng = self._engine()
+        b, n_steps = state["b"], state["n_steps"]
+        need = int(lib.astts_lm_workspace_bytes(eng, b))
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        ctx = dict(state)
+        ctx.update({"ws": ws, "ws_aligned": (ws.data_ptr() + 255) // 256 * 256, "ws_bytes": need,
+                    "toks": torch.zeros((b, n_steps), dtype=torch.int32, device=self.device),
+                    "logits": torch.empty((b, n_steps, self.cfg.speech_vocab + 1), dtype=torch.float32, device=self.device) if return_logits else None,
+                    "forced": None if forced_tokens is None else forced_tokens.to(torch.int32).contiguous(),
+                    "u": uniforms.to(torch.float32).contiguous(), "ignore_eos": ignore_eos, "next": 0})
+        return ctx
+
+    def decode_range(self, ctx, s_end: Optional[int] = None) -> None:
+        """Enqueue decode steps [ctx["next"], s_end) on the CURRENT stream (one C++ call, no host synchronisation).  The ranges of
+        one decode must be issued in order on one stream (astts_lm_decode_range)."""
         import ctypes
 
         from .. import _lib
         lib = _lib.load()
-        eng = self._engine()
-        cache, logits0, s0, b, n_steps, key_start = (state[k] for k in ("cache", "logits0", "s0", "b", "n_steps", "key_start"))
-        t_max = s0 + n_steps
-        need = int(lib.astts_lm_workspace_bytes(eng, b))
-        ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
-        base = ws.data_ptr()
-        aligned = (base + 255) // 256 * 256
-        toks = torch.zeros((b, n_steps), dtype=torch.int32, device=self.device)
-        lg_out = torch.empty((b, n_steps, self.cfg.speech_vocab + 1), dtype=torch.float32, device=self.device) if return_logits else None
+        n_steps, s0, b, cache, key_start, ignore_eos = (ctx[k] for k in ("n_steps", "s0", "b", "cache", "key_start", "ignore_eos"))
+        s_begin = ctx["next"]
+        s_end = n_steps if s_end is None else min(int(s_end), n_steps)
+        if s_end <= s_begin:
+            return
         ptrs = (ctypes.c_void_p * len(cache))(*[c.data_ptr() for c in cache])
-        forced = None if forced_tokens is None else forced_tokens.to(torch.int32).contiguous()
-        u = uniforms.to(torch.float32).contiguous()
-        _lib.check(lib.astts_lm_decode(eng, logits0.data_ptr(), ptrs, None if key_start is None else key_start.data_ptr(), t_max, b,
-                                       s0, n_steps, u.data_ptr(),
-                                       None if forced is None else forced.data_ptr(), self._eos_min(ignore_eos, n_steps),
-                                       ignore_eos.data_ptr() if torch.is_tensor(ignore_eos) else None, toks.data_ptr(),
-                                       None if lg_out is None else lg_out.data_ptr(), aligned, need, _lib.stream_ptr()))
-        self._keepalive = (cache, ws, logits0, forced, u, key_start, ignore_eos)   # buffers referenced by kernels still in flight
-        return (toks, lg_out) if return_logits else toks
+        _lib.check(lib.astts_lm_decode_range(self._engine(), ctx["logits0"].data_ptr(), ptrs, None if key_start is None else key_start.data_ptr(),
+                                             s0 + n_steps, b, s0, n_steps, s_begin, s_end, ctx["u"].data_ptr(),
+                                             None if ctx["forced"] is None else ctx["forced"].data_ptr(), self._eos_min(ignore_eos, n_steps),
+                                             ignore_eos.data_ptr() if torch.is_tensor(ignore_eos) else None, ctx["toks"].data_ptr(),
+                                             None if ctx["logits"] is None else ctx["logits"].data_ptr(), ctx["ws_aligned"], ctx["ws_bytes"],
+                                             _lib.stream_ptr()))
+        ctx["next"] = s_end
+
+    def decode_prefilled(self, state, uniforms: torch.Tensor, ignore_eos: bool = True, forced_tokens: Optional[torch.Tensor] = None,
+                         return_logits: bool = False):
+        """The decode steps of `prefill`'s state (b <= 32 rows) on the current stream: one C++ call, no host synchronisation."""
+        ctx = self.decode_begin(state, uniforms, ignore_eos, forced_tokens, return_logits)
+        self.decode_range(ctx)
+        self._keepalive = ctx            # buffers referenced by kernels still in flight
+        return (ctx["toks"], ctx["logits"]) if return_logits else ctx["toks"]
 
     def decode_engine(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
                       forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False,

@@ -95,10 +95,26 @@ def stream_render(tokens: torch.Tensor, consts: StreamConsts, flow_mel: Callable
             wav = wav[:, :-c.source_cache]
         return wav
 
-    toks = tokens.reshape(-1)
-    hop = c.token_min_hop
-    while toks.numel() >= hop + c.token_overlap:
-        yield token2wav(toks[:hop + c.token_overlap], False)
-        toks = toks[hop:]
-        hop = min(c.token_max_hop, int(hop * c.scale))
-    yield token2wav(toks, True)
+    # ``tokens`` is the finished token sequence (a tensor), or a token SOURCE with ``wait(n) -> (tokens so far [>= n, or all there will
+    # be], finished)`` -- the LM still decoding on its own stream (upstream: the LM thread appends to a list that tts() polls).  The
+    # schedule is the same either way: a non-final chunk is cut as soon as hop + overlap tokens exist beyond the current offset.
+    src = tokens if hasattr(tokens, "wait") else _FixedTokens(tokens)
+    off, hop = 0, c.token_min_hop
+    while True:
+        have, finished = src.wait(off + hop + c.token_overlap)
+        if have.numel() - off >= hop + c.token_overlap:
+            yield token2wav(have[off:off + hop + c.token_overlap], False)
+            off += hop
+            hop = min(c.token_max_hop, int(hop * c.scale))
+            continue
+        assert finished, "a token source returned fewer tokens than asked for without being finished"
+        yield token2wav(have[off:], True)
+        return
+
+
+class _FixedTokens:
+    def __init__(self, tokens: torch.Tensor):
+        self.tokens = tokens.reshape(-1)
+
+    def wait(self, n: int):
+        return self.tokens, True

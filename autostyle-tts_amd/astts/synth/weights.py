@@ -46,6 +46,37 @@ class _Init:
         self.sd[name] = torch.randn(*shape, generator=self.g) * scale + offset
 
 
+class _Shapes(_Init):
+    """The same walk over the architecture with shapes instead of tensors: the expected-key manifest of a checkpoint."""
+
+    def __init__(self):
+        self.sd = {}
+
+    def linear(self, name, n_out, n_in, bias=True, gain=1.0):
+        self.sd[name + ".weight"] = (n_out, n_in)
+        if bias:
+            self.sd[name + ".bias"] = (n_out,)
+
+    def conv(self, name, c_out, c_in, k, bias=True, gain=1.0):
+        self.sd[name + ".weight"] = (c_out, c_in, k)
+        if bias:
+            self.sd[name + ".bias"] = (c_out,)
+
+    def convT(self, name, c_in, c_out, k, stride):
+        self.sd[name + ".weight"] = (c_in, c_out, k)
+        self.sd[name + ".bias"] = (c_out,)
+
+    def norm(self, name, c):
+        self.sd[name + ".weight"] = (c,)
+        self.sd[name + ".bias"] = (c,)
+
+    def emb(self, name, n, c, scale=1.0):
+        self.sd[name + ".weight"] = (n, c)
+
+    def tensor(self, name, *shape, scale=1.0, offset=0.0):
+        self.sd[name] = tuple(shape)
+
+
 def _relpos_encoder(I: _Init, p: str, in_dim: int, d: int, heads: int, ffn: int, layers: int, conformer: bool):
     I.linear(f"{p}.embed.out.0", d, in_dim)
     I.norm(f"{p}.embed.out.1", d)
@@ -64,8 +95,8 @@ def _relpos_encoder(I: _Init, p: str, in_dim: int, d: int, heads: int, ffn: int,
     I.norm(f"{p}.after_norm", d)
 
 
-def make_lm_weights(cfg: SynthConfig, seed: int = 0) -> StateDict:
-    I = _Init(seed)
+def make_lm_weights(cfg: SynthConfig, seed: int = 0, I: "_Init" = None) -> StateDict:
+    I = I or _Init(seed)
     I.emb("text_embedding", cfg.text_vocab, cfg.text_dim)
     _relpos_encoder(I, "text_encoder", cfg.text_dim, cfg.lm_dim, cfg.lm_heads, cfg.lm_ffn, cfg.lm_text_layers, True)
     I.linear("text_encoder_affine_layer", cfg.lm_dim, cfg.lm_dim)
@@ -97,8 +128,8 @@ def _tfm(I: _Init, p: str, c: int, heads: int):
     I.linear(f"{p}.ff.net.2", c, 4 * c)
 
 
-def make_flow_weights(cfg: SynthConfig, seed: int = 1) -> StateDict:
-    I = _Init(seed)
+def make_flow_weights(cfg: SynthConfig, seed: int = 1, I: "_Init" = None) -> StateDict:
+    I = I or _Init(seed)
     I.emb("input_embedding", cfg.speech_vocab, cfg.flow_dim)
     I.linear("spk_embed_affine_layer", cfg.mel, cfg.spk_dim)
     _relpos_encoder(I, "encoder", cfg.flow_dim, cfg.flow_dim, cfg.flow_heads, cfg.flow_ffn, cfg.flow_layers, True)
@@ -140,14 +171,15 @@ def make_flow_weights(cfg: SynthConfig, seed: int = 1) -> StateDict:
     return I.sd
 
 
-def make_hift_weights(cfg: SynthConfig, seed: int = 2) -> StateDict:
-    I = _Init(seed)
+def make_hift_weights(cfg: SynthConfig, seed: int = 2, I: "_Init" = None) -> StateDict:
+    I = I or _Init(seed)
     c_prev = cfg.mel
     for j in range(5):
         I.conv(f"f0_predictor.condnet.{2 * j}", cfg.f0_channels, c_prev, 3)
         c_prev = cfg.f0_channels
     I.linear("f0_predictor.classifier", 1, cfg.f0_channels, gain=4.0)
-    I.sd["f0_predictor.classifier.bias"] = torch.tensor([120.0])  # voiced-range f0 with random weights
+    if not isinstance(I, _Shapes):
+        I.sd["f0_predictor.classifier.bias"] = torch.tensor([120.0])  # voiced-range f0 with random weights
     I.linear("m_source.l_linear", 1, cfg.nb_harmonics + 1, gain=3.0)
     base = cfg.hift_base
     I.conv("conv_pre", base, cfg.mel, 7)
@@ -202,8 +234,52 @@ def _fold_weight_norm(sd: StateDict) -> StateDict:
     return out
 
 
-def load_state_dicts(model_dir: str) -> Dict[str, StateDict]:
-    """Real checkpoints, when a CosyVoice-300M directory is supplied at run time (none exists here)."""
+def expected_shapes(cfg: SynthConfig) -> Dict[str, Dict[str, tuple]]:
+    """{"llm" | "flow" | "hift": {state-dict key: shape}} -- every tensor the engine reads, derived from ``cfg`` by the same walk over
+    the architecture that builds the synthetic weights (so the two cannot drift apart)."""
+    return {"llm": make_lm_weights(cfg, I=_Shapes()), "flow": make_flow_weights(cfg, I=_Shapes()), "hift": make_hift_weights(cfg, I=_Shapes())}
+
+
+# non-parameter entries real checkpoints are known to carry ([EXT]-recalled: registered buffers of upstream modules); never read here
+IGNORABLE_KEY_PATTERNS = (r"\.num_batches_tracked$", r"(^|\.)stft_window$", r"\.pos_enc\.pe$", r"^m_source\.l_sin_gen\.", r"^f0_upsamp\.")
+
+
+def check_state_dicts(state: Dict[str, StateDict], cfg: SynthConfig, strict: bool = False) -> None:
+    """Hold loaded state dicts (weight norm already folded) to the manifest of ``cfg``: missing and mis-shaped tensors are reported
+    TOGETHER in one ValueError (a wrong checkpoint / config pair otherwise surfaces as a KeyError deep inside engine construction);
+    unexpected keys are listed in a warning (``strict``: in the error) unless they match ``IGNORABLE_KEY_PATTERNS``."""
+    import re
+    import warnings
+
+    want = expected_shapes(cfg)
+    problems, extra = [], []
+    for part in ("llm", "flow", "hift"):
+        sd = state.get(part)
+        if sd is None:
+            problems.append(f"{part}: no state dict")
+            continue
+        missing = sorted(k for k in want[part] if k not in sd)
+        wrong = sorted((k, tuple(sd[k].shape), want[part][k]) for k in want[part] if k in sd and tuple(sd[k].shape) != tuple(want[part][k]))
+        unexpected = sorted(k for k in sd if k not in want[part] and not any(re.search(p, k) for p in IGNORABLE_KEY_PATTERNS))
+        if missing:
+            problems.append(f"{part}.pt: {len(missing)} missing key(s): " + ", ".join(missing[:12]) + (" ..." if len(missing) > 12 else ""))
+        if wrong:
+            problems.append(f"{part}.pt: {len(wrong)} mis-shaped tensor(s): " +
+                            ", ".join(f"{k} is {got}, expected {exp}" for k, got, exp in wrong[:12]) + (" ..." if len(wrong) > 12 else ""))
+        if unexpected:
+            extra.append(f"{part}.pt: {len(unexpected)} unexpected key(s): " + ", ".join(unexpected[:12]) + (" ..." if len(unexpected) > 12 else ""))
+    if strict:
+        problems += extra
+    if problems:
+        raise ValueError("checkpoint does not match the model config (SynthConfig / model_dir/astts.json):\n  " + "\n  ".join(problems + ([] if strict else extra)))
+    if extra:
+        warnings.warn("checkpoint carries tensors the engine does not read:\n  " + "\n  ".join(extra), RuntimeWarning, stacklevel=2)
+
+
+def load_state_dicts(model_dir: str, cfg: SynthConfig = None, strict: bool = False) -> Dict[str, StateDict]:
+    """Real checkpoints, when a CosyVoice-300M directory is supplied at run time (none exists here): ``llm.pt`` / ``flow.pt`` /
+    ``hift.pt`` as upstream saves them (weight_norm in either of torch's two forms is folded).  With ``cfg`` the result is held to
+    the config's key / shape manifest (``check_state_dicts``)."""
     out = {}
     for name in ("llm", "flow", "hift"):
         path = os.path.join(model_dir, f"{name}.pt")
@@ -211,4 +287,6 @@ def load_state_dicts(model_dir: str) -> Dict[str, StateDict]:
             raise FileNotFoundError(path)
         sd = torch.load(path, map_location="cpu", weights_only=True)
         out[name] = _fold_weight_norm({k: v.float() for k, v in sd.items() if torch.is_tensor(v)})
+    if cfg is not None:
+        check_state_dicts(out, cfg, strict)
     return out

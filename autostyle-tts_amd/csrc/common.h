@@ -49,6 +49,10 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1);
         }                                                                                  \
     } while (0)
 
+// an integer experiment switch from the environment (`dflt` when unset).  A set variable is reported once on stderr: these switches
+// change which kernel form runs (same results), and a stray one in a user's environment should not go unnoticed (runtime.hip)
+int exp_env_int(const char* name, int dflt);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -52,12 +52,17 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     float* part_ml = part_o + (size_t)b * c.heads * 2 * 64;
     const float scale = 0.125f;
     // ASTTS_LM_KSPLIT=1 (experiments): the decode attention as 128 workgroups with the whole key range each instead of 256 with half of it
-    static const int ksplit = [] { const char* e = getenv("ASTTS_LM_KSPLIT"); return e && atoi(e) == 1 ? 1 : 2; }();
-    // ASTTS_LM_SKIP=<bits> (timing experiments only, results are garbage): drops a launch of every layer -- 1 out-projection, 2 FFN-out, 4 QKV,
-    // 8 attention, 16 FFN-in
-    static const int skip = [] { const char* e = getenv("ASTTS_LM_SKIP"); return e ? atoi(e) : 0; }();
+    static const int ksplit = exp_env_int("ASTTS_LM_KSPLIT", 2) == 1 ? 1 : 2;
+    // ASTTS_LM_SKIP=<bits> (timing experiments only, results are GARBAGE): drops a launch of every layer -- 1 out-projection, 2 FFN-out,
+    // 4 QKV, 8 attention, 16 FFN-in.  Compiled in only with -DASTTS_EXPERIMENTS (make EXTRA=-DASTTS_EXPERIMENTS): the product library
+    // cannot be talked into wrong tokens by an environment variable.
+#ifdef ASTTS_EXPERIMENTS
+    static const int skip = exp_env_int("ASTTS_LM_SKIP", 0);
+#else
+    constexpr int skip = 0;
+#endif
     // ASTTS_LM_FFN_SPLIT=0: FFN-out as one workgroup per column block over the whole K (rounds 2-3)
-    static const bool ffn_split_env = [] { const char* e = getenv("ASTTS_LM_FFN_SPLIT"); return !e || atoi(e) != 0; }();
+    static const bool ffn_split_env = exp_env_int("ASTTS_LM_FFN_SPLIT", 1) != 0;
     const bool ffn_split = ffn_split_env && (c.ffn & 255) == 0;
     const KvLayout lay = KvLayout::time_major(b, d);
     auto gemv = [&]() {

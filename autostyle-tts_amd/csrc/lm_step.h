@@ -90,37 +90,4 @@ void lm_step_set_attrs();   // one-off hipFuncSetAttribute calls (outside any ca
 int lm_gemv_variant(const GemvArgs& a);
 
 
-// ---- engine v3 (lm_fused.hip): two launches per layer, residual stream in 64-bit fixed point (2^-32) accumulated with integer atomics
-struct FAttnArgs {
-    const long long* xin;      // [b][d] fixed-point residual stream, or null: layer 0 takes rows of `table` (+ the embedding's pre-transform)
-    const float* table;        // [vocab][d] fp32 (speech_emb W^T + b) gathered by tok
-    const int* tok;            // [b]
-    const float* pre_g; const float* pre_b; float pre_scale;     // layer 0: x = pre_scale * relu(LayerNorm(row; pre_g, pre_b))
-    const float* ln_g; const float* ln_b; int ln_plain; float eps;   // norm1 (ln_plain: scale / shift folded into wqkv / bqkv)
-    const _Float16* wqkv; const float* bqkv;                      // [3d][d] fp16 (q | k | v), K contiguous
-    _Float16* kv; int kv_t, kv_b, kv_h, kv_v;                     // KV cache of this layer (KvLayout strides, halfs)
-    const _Float16* postab; int ldp, center;                      // [2 center + 1][ldp] position projections
-    const float* bias_u; const float* bias_v; const int* kstart;
-    const _Float16* wo; const float* bo;                          // [d][d] fp16
-    long long* xout;           // accumulate x + attn Wo^T + bo here (all zero at kernel entry)
-    long long* xzero;          // cleared by this kernel (the next kernel accumulates into it)
-    int b, d, heads, pos;
-    float scale;
-    int dbg;                   // timing experiments only (ASTTS_LM_FUSED_DBG): 1 no atomics, 2 no key loop, 4 no clearing, 8 no fence
-};
-
-struct FFfnArgs {
-    const long long* xin;      // [b][d] fixed-point x' (complete)
-    const float* ln_g; const float* ln_b; int ln_plain; float eps;   // norm2
-    const _Float16* w1; const float* b1;                          // [ffn][d]
-    const _Float16* w2; const float* b2;                          // [d][ffn]
-    long long* xout; long long* xzero;
-    int b, d, ffn;
-    int dbg;
-};
-
-int lm_attn_block_launch(const FAttnArgs& a, hipStream_t st);
-int lm_ffn_block_launch(const FFfnArgs& a, hipStream_t st);
-int lm_fx_to_f32_launch(const long long* x, float* y, int n, hipStream_t st);
-
 }  // namespace astts

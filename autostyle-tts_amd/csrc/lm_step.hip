@@ -779,7 +779,7 @@ static size_t gemv_lds_bytes(int lrows, int kc, int nacc) {
 // workgroup stages the whole input and a CU then ingests 96 KB instead of 64).  The choice depends on the projection's shape
 // only, never on the row count: a row's arithmetic is then the same in 8-, 16- and 32-row batches.
 static int half8_max_blocks() {
-    static const int v = [] { const char* e = getenv("ASTTS_LM_HALF8_MAX_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int v = exp_env_int("ASTTS_LM_HALF8_MAX_BLOCKS", 256);
     return v;
 }
 
@@ -793,7 +793,7 @@ int lm_gemv_variant(const GemvArgs& a) {
 
 // ASTTS_LM_WIDE=1: the wide (32-column) form for 16-column projections with K <= 1024 at <= 16 rows (same sums, half the workgroups)
 static bool lm_wide() {
-    static const bool v = [] { const char* e = getenv("ASTTS_LM_WIDE"); return e && atoi(e) != 0; }();
+    static const bool v = exp_env_int("ASTTS_LM_WIDE", 0) != 0;
     return v;
 }
 

@@ -688,6 +688,8 @@ int astts_op_ras_sample(const float* logits, const int32_t* history, const float
     ASTTS_REQUIRE(logits && uniforms && out_tokens && (history || hist_len == 0), ASTTS_ERR_INVALID, "astts_op_ras_sample: null pointer");
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0, ASTTS_ERR_INVALID,
                   "astts_op_ras_sample: bad shape b=%d vocab=%d top_k=%d", b, vocab, top_k);
+    // the reject policy (bit 1) reads and clears prob[eos_id] in LDS: the id must be a vocabulary entry (the mask policy only compares with it)
+    ASTTS_REQUIRE(!(ignore_eos & 2) || (eos_id >= 0 && eos_id < vocab), ASTTS_ERR_RANGE, "astts_op_ras_sample: eos_id=%d outside [0, %d) with the reject policy", eos_id, vocab);
     SampleArgs a{logits, history, uniforms, out_tokens, nullptr, nullptr, -1, nullptr, b, vocab, hist_len, hist_ld, top_k, win_size, eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a.logits, a.eos_min_rows, a.v,
                        a.hist_len, a.eos, a.ignore_eos, a);
@@ -703,6 +705,7 @@ int astts_op_ras_sample_ex(const float* logits, int32_t* history, const float* u
     ASTTS_REQUIRE(logits && uniforms && out_tokens && history, ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: null pointer");
     ASTTS_REQUIRE(b >= 1 && vocab >= 2 && vocab <= 15000 && top_k >= 1 && top_k <= 64 && hist_len >= 0 && hist_len < hist_ld,
                   ASTTS_ERR_INVALID, "astts_op_ras_sample_ex: bad shape b=%d vocab=%d top_k=%d hist_len=%d", b, vocab, top_k, hist_len);
+    ASTTS_REQUIRE(!(ignore_eos & 2) || (eos_id >= 0 && eos_id < vocab), ASTTS_ERR_RANGE, "astts_op_ras_sample_ex: eos_id=%d outside [0, %d) with the reject policy", eos_id, vocab);
     SampleArgs a{logits, history, uniforms, out_tokens, history, forced, eos_id - 1, eos_min_rows, b, vocab, hist_len, hist_ld, top_k, win_size,
                  eos_id, ignore_eos, top_p, tau_r};
     hipLaunchKernelGGL(ras_sample, dim3(b), dim3(RS_NT), (size_t)((vocab + 15) & ~15) * sizeof(float), (hipStream_t)stream, a.logits, a.eos_min_rows, a.v,

@@ -2,7 +2,9 @@
 #include "common.h"
 #include "xlane.h"
 
+#include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace astts {
@@ -70,6 +72,23 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1) {
     p.used += 2;
     p.work += work;
     return true;
+}
+
+int exp_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    static std::mutex mu;
+    static std::vector<std::string> seen;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        bool known = false;
+        for (const auto& s : seen) known = known || s == name;
+        if (!known) {
+            seen.emplace_back(name);
+            fprintf(stderr, "astts: experiment switch %s=%s is set in the environment (default %d)\n", name, e, dflt);
+        }
+    }
+    return atoi(e);
 }
 
 void prof_end(int kind, hipStream_t st) {

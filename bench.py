@@ -613,7 +613,47 @@ def bench_embedder(args, dev, cfg, eng):
 
 
 def bench_streaming(args, dev, cfg, eng):
-    return None
+    """stream=True (tts_for_dialog.py:188, vc_from_dir.py:18 pass the flag): time to the FIRST yielded chunk of a 250-token segment through
+    CosyVoice.inference_tts_with_st(stream=True), with the LM decoding hop by hop on its own stream while the chunks render (round 5),
+    against the one-pass form (decode everything, then chunk: rounds 3-4).  Upstream's schedule needs hop + look-ahead = 120 tokens
+    before the first chunk, so 120 / 250 of the decode is the floor of the ratio for this segment length."""
+    import warnings
+
+    from astts.compat.cosyvoice import CosyVoice
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
+    g = torch.Generator().manual_seed(0)
+    t16 = torch.arange(int(3.0 * 16000)) / 16000
+    style = (0.3 * torch.sin(2 * math.pi * 220 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
+    timbre = (0.3 * torch.sin(2 * math.pi * 330 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
+    text, style_text = "I did it, I asked her to marry me.", "He did. In Niagara Falls."
+
+    def run(live, n_tok):
+        cv.stream_lm_live = live
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first, n, samples = None, 0, 0
+        for out in cv.inference_tts_with_st(text, style_text, style, timbre, stream=True, seed=1, fixed_tokens=n_tok):
+            if first is None:
+                first = time.perf_counter() - t0
+            n += 1
+            samples += out["tts_speech"].shape[1]
+        return first * 1e3, (time.perf_counter() - t0) * 1e3, n, samples
+
+    res = {}
+    for n_tok in (250, 500):
+        run(True, n_tok), run(False, n_tok)          # warm both paths (allocator, frontend cache)
+        live = min((run(True, n_tok) for _ in range(3)), key=lambda r: r[0])
+        once = min((run(False, n_tok) for _ in range(3)), key=lambda r: r[0])
+        res[f"tokens_{n_tok}"] = {"first_chunk_ms": live[0], "segment_ms": live[1], "chunks": live[2], "audio_s": live[3] / cfg.sample_rate,
+                                  "first_chunk_over_segment": live[0] / live[1],
+                                  "one_pass_first_chunk_ms": once[0], "one_pass_segment_ms": once[1],
+                                  "floor_note": f"120 of {n_tok} decode steps precede the first chunk by upstream's schedule"}
+    res["first_chunk_ms"] = res["tokens_250"]["first_chunk_ms"]
+    res["includes"] = "prompt featurisation (resample, log-mel, stand-in tokenizer / speaker net), LM prefill, decode, flow + vocoder of the chunk, D2H copy"
+    return res
 
 
 def side_workload(args, which, dev, dist, rank, world):

@@ -356,6 +356,13 @@ int astts_lm_decode(astts_lm_t* h, const float* logits0, void* const* kv_cache, 
                     int32_t b, int32_t pos0, int32_t n_steps, const float* uniforms, const int32_t* forced_tokens, int32_t eos_min_steps,
                     const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace, size_t workspace_bytes,
                     astts_stream_t stream);
+/* Steps [s_begin, s_end) of that n_steps decode (stream=True of /root/reference/tts_for_dialog.py:188, vc_from_dir.py:18: upstream's
+ * LM thread hands tokens to token2wav hop by hop).  The ranges of one decode are issued in order on ONE stream with the same
+ * kv_cache, tokens_out (the sampler's history) and workspace (it carries the logits from one range to the next). */
+int astts_lm_decode_range(astts_lm_t* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max,
+                          int32_t b, int32_t pos0, int32_t n_steps, int32_t s_begin, int32_t s_end, const float* uniforms,
+                          const int32_t* forced_tokens, int32_t eos_min_steps, const int32_t* eos_min_rows, int32_t* tokens_out,
+                          float* logits_out, void* workspace, size_t workspace_bytes, astts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Query-embedder operators: what a Llama-3.2 decoder block needs besides the GEMM family.

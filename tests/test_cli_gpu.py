@@ -264,3 +264,103 @@ def test_batch_surface_does_not_depend_on_its_schedule(cosy, tmp_path):
     o2 = cosy.inference_tts_with_st_batch(items[:36], max_batch=32, split=False, fixed_tokens=fixed[:36])
     assert all(torch.equal(x, y) for x, y in zip(t1, cosy.last_tokens))
     assert all(torch.equal(x[0]["tts_speech"], y[0]["tts_speech"]) for x, y in zip(o1, o2))
+
+
+def _stream_inputs():
+    g = torch.Generator().manual_seed(3)
+    t16 = torch.arange(int(1.5 * 16000)) / 16000
+    style = (0.3 * torch.sin(2 * np.pi * 220 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
+    timbre = (0.3 * torch.sin(2 * np.pi * 330 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]
+    return style, timbre
+
+
+def test_stream_true_live_decode_yields_the_chunks_of_the_one_pass_form(cosy):
+    """stream=True with the LM decoding hop by hop on its own stream while the chunks render (astts_lm_decode_range, _LmTokenStream)
+    yields BIT-IDENTICAL chunks to decoding the whole segment first and chunking afterwards (rounds 3-4): same prefix, same uniforms,
+    same sampler history across the ranges, same render draws -- fixed-length segments (3 chunks) and EOS-terminated ones."""
+    import warnings
+
+    style, timbre = _stream_inputs()
+    args = ("I did it, I asked her to marry me.", "He did. In Niagara Falls.", style, timbre)
+    for kw in ({"fixed_tokens": 230}, {}):
+        outs = {}
+        for live in (True, False):
+            cosy.stream_lm_live = live
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)          # the tiny model's 512-position tables cap the 20x window
+                outs[live] = [o["tts_speech"] for o in cosy.inference_tts_with_st(*args, stream=True, seed=11, **kw)]
+        cosy.stream_lm_live = True
+        assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 1
+        if kw:
+            assert len(outs[True]) == 3                                   # 230 tokens: hops at 0 and 100 + 30 left over
+        for a, b in zip(outs[True], outs[False]):
+            assert a.shape == b.shape and torch.equal(a, b)
+    # ... and a generator abandoned after its first chunk shuts its decode worker down (no thread, no stream left waiting)
+    it = cosy.inference_tts_with_st(*args, stream=True, seed=11, fixed_tokens=230)
+    first = next(it)
+    it.close()
+    assert first["tts_speech"].shape[1] > 0
+    again = [o["tts_speech"] for o in cosy.inference_tts_with_st(*args, stream=True, seed=11, fixed_tokens=230)]
+    assert torch.equal(again[0], first["tts_speech"])
+
+
+def test_stream_true_first_chunk_arrives_while_the_lm_still_decodes():
+    """Time to the first yielded chunk at the CosyVoice-300M widths: upstream's schedule needs hop + look-ahead = 120 tokens before
+    chunk 0, so 120 / n of the decode is the floor; the one-pass form (decode to the end, then chunk) pays the whole decode first.
+    250-token segment: first chunk before 65 % of the segment's wall time AND earlier than the one-pass form's; 500 tokens: before 40 %."""
+    import time
+    import warnings
+
+    from astts.compat.cosyvoice import CosyVoice
+    from astts.synth.config import SynthConfig
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cv = CosyVoice("/nonexistent", config=SynthConfig(), seed=0, allow_random_init=True)
+    style, timbre = _stream_inputs()
+    args = ("I did it, I asked her to marry me.", "He did. In Niagara Falls.", style, timbre)
+
+    def run(live, n_tok):
+        cv.stream_lm_live = live
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first = None
+        for _ in cv.inference_tts_with_st(*args, stream=True, seed=2, fixed_tokens=n_tok):
+            first = first if first is not None else time.perf_counter() - t0
+        return first, time.perf_counter() - t0
+
+    for n_tok, bar in ((250, 0.65), (500, 0.40)):
+        run(True, n_tok), run(False, n_tok)                                # warm-up
+        live = min((run(True, n_tok) for _ in range(3)), key=lambda r: r[0])
+        once = min((run(False, n_tok) for _ in range(3)), key=lambda r: r[0])
+        print(f"[stream] {n_tok} tokens: first chunk {live[0] * 1e3:.1f} ms of {live[1] * 1e3:.1f} ms ({live[0] / live[1]:.2f}); "
+              f"one-pass form {once[0] * 1e3:.1f} of {once[1] * 1e3:.1f} ms")
+        assert live[0] / live[1] <= bar, (n_tok, live)
+        assert live[0] < 0.8 * once[0], (n_tok, live, once)
+
+
+def test_cosyvoice_from_a_checkpoint_directory_with_its_json_config(tmp_path):
+    """CosyVoice(model_dir) as the reference calls it (tts_with_rag.py:159) on a directory that holds llm.pt / flow.pt / hift.pt in
+    upstream's saved form (weight_norm pairs, extra buffers) + this build's astts.json: config from the file (24 kHz here), weights
+    checked against its manifest and loaded, audio equal to the same weights handed over in memory."""
+    from test_checkpoint_cpu import _write_model_dir
+
+    from astts.compat.cosyvoice import CosyVoice
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import SynthEngine
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig.tiny().with_(sample_rate=24000)
+    state = make_all(cfg, 9)
+    d = str(tmp_path / "CosyVoice-300M")
+    _write_model_dir(d, cfg, state)
+    cv = CosyVoice(d, seed=4)
+    assert cv.random_init is False and cv.sample_rate == 24000 and cv.cfg == cfg
+    ref = CosyVoice("/nonexistent", config=cfg, seed=4, allow_random_init=True, engine=SynthEngine(state, cfg))
+    style, timbre = _stream_inputs()
+    a = list(cv.inference_tts_with_st("Guess what?", "I do. Yeah.", style, timbre, seed=3))
+    b = list(ref.inference_tts_with_st("Guess what?", "I do. Yeah.", style, timbre, seed=3))
+    assert len(a) == len(b) == 1 and a[0]["tts_speech"].shape == b[0]["tts_speech"].shape
+    err = float((a[0]["tts_speech"] - b[0]["tts_speech"]).abs().max())
+    print(f"[checkpoint dir] max waveform difference vs the in-memory weights {err:.2e}")
+    assert err < 5e-2, err            # the folded weights differ from the originals by fp32 rounding of v * (g / |v|) (f0 -> phase amplifies it)

@@ -130,3 +130,61 @@ def test_no_volatile_system_scope_loads_in_the_hot_kernels(tmp_path):
     for src in ("ops_tfm_fused.hip", "ops_resnet_conv.hip", "lm_step.hip", "ops_conv_lds.hip"):
         asm = _asm(os.path.join(CSRC, src), tmp_path)
         assert not re.search(r"(flat|global)_load_\w+ [^\n]*sc0 sc1", asm), src
+
+
+def test_untracked_prefetch_loads_keep_their_destination_register_to_themselves(tmp_path):
+    """csrc/xlane.h prefetch_line(): an L2 prefetch issued from inline asm (`global_load_dword vN, ...` between ;;#ASMSTART / ;;#ASMEND)
+    that the compiler's vmcnt bookkeeping cannot see -- nothing ever waits for it, and its write-back lands whenever the memory system
+    answers.  That is only safe while vN holds nothing else from the load to the end of the kernel: prefetch_keep() asks the register
+    allocator for exactly that, but a copy, split or spill under pressure would hand vN to another value that the late write-back then
+    corrupts, with every functional test still green on most runs.  Held here on the emitted code of every kernel that uses
+    it: NO instruction reachable from the asm load (control-flow graph over fall-through and branch targets, so loops and out-of-line
+    blocks count) names vN, alone or inside a register range, and the kernel uses no scratch (a spill could park vN's owner there)."""
+    total = 0
+    for src, pattern in (("ops_tfm_fused.hip", r"tfm_attn_fused|tfm_ffn_fused"), ("ops_resnet_conv.hip", r"rconv_lds")):
+        ks = _kernels(_asm(os.path.join(CSRC, src), tmp_path), pattern)
+        assert ks, src
+        for name, body in ks.items():
+            raw = body.splitlines()
+            code = [l.split(";")[0].strip() for l in raw]
+            labels = {m.group(1): i for i, l in enumerate(code) for m in [re.match(r"^(\.LBB\w+):", l)] if m}
+
+            def successors(i):
+                ins = code[i]
+                if ins.startswith("s_endpgm"):
+                    return []
+                b = re.match(r"s_(c?)branch\w*\s+(\.LBB\w+)", ins)
+                out = []
+                if b:
+                    out.append(labels[b.group(2)])
+                    if not b.group(1):          # s_branch: unconditional, no fall-through
+                        return out
+                if i + 1 < len(code):
+                    out.append(i + 1)
+                return out
+
+            for i, l in enumerate(raw):
+                if "ASMSTART" not in l or i + 1 >= len(raw):
+                    continue
+                m = re.match(r"\s*global_load_dword v(\d+),", raw[i + 1])
+                if not m:
+                    continue
+                total += 1
+                r = int(m.group(1))
+                seen, todo = set(), [i + 2]
+                while todo:
+                    j = todo.pop()
+                    if j in seen or j >= len(code):
+                        continue
+                    seen.add(j)
+                    todo.extend(successors(j))
+                assert any(code[j].startswith("s_endpgm") for j in seen), name
+                for j in sorted(seen):
+                    if j == i + 1:
+                        continue                # (the load itself, when a loop leads back to it: it only rewrites its own register)
+                    ins = code[j]
+                    named = any(int(a.group(1)) == r for a in re.finditer(r"\bv(\d+)\b", ins)) or \
+                        any(int(a.group(1)) <= r <= int(a.group(2)) for a in re.finditer(r"\bv\[(\d+):(\d+)\]", ins))
+                    assert not named, f"{name}: v{r} (destination of the untracked prefetch at line {i + 1}) is used again at line {j}: {ins}"
+            assert "scratch_" not in body, f"{name}: uses scratch"
+    assert total >= 6, total          # 3 in tfm_attn_fused, 1 in each tfm_ffn_fused variant, 2 per rconv_lds variant
