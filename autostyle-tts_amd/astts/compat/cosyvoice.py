@@ -154,6 +154,8 @@ class CosyVoice:
         # stream=True: render chunk k while the LM decodes the tokens of chunk k + 1 (False: one decode pass, then the chunks -- rounds 3-4,
         # kept as the second implementation the tests compare the chunks with)
         self.stream_lm_live = os.environ.get("ASTTS_STREAM_LM_LIVE", "1") != "0"
+        # ragged batches: the whole render group in one vocoder pass (False: one pass per row)
+        self.vocoder_batched = os.environ.get("ASTTS_VOCODER_BATCHED", "1") != "0"
 
     # ------------------------------------------------------------------ one text segment
     @staticmethod
@@ -388,9 +390,13 @@ class CosyVoice:
                 zs.append(z[0])
                 dr.append((phase0, noise))
             mels = eng.flow.decode_ragged(all_tok, pmels, torch.cat([requests[i][3].spk_embedding for i in idxs], 0), zs)
-            wavs = [eng.hift.forward(mels[j][None], dr[j][0].to(dev), dr[j][1].to(dev))      # vocoder per row: its conv stack has no length masks
-                    for j in range(len(idxs))]                                                # (3 % of the time); every row enqueued before the
-            for j, i in enumerate(idxs):                                                      # first copy waits for the GPU
+            if self.vocoder_batched and len(idxs) > 1:
+                # ONE vocoder pass over the ragged group: every convolution / STFT / iSTFT reads a row as a sequence of its own length
+                # (HiftVocoder.forward_ragged); each waveform equals the row vocoded alone (tests/test_synth_gpu.py)
+                wavs = eng.hift.forward_ragged(mels, [dr[j][0] for j in range(len(idxs))], [dr[j][1].to(dev) for j in range(len(idxs))])
+            else:                       # one pass per row (rounds 1-4: ~250 launches each; kept as the second implementation)
+                wavs = [eng.hift.forward(mels[j][None], dr[j][0].to(dev), dr[j][1].to(dev)) for j in range(len(idxs))]
+            for j, i in enumerate(idxs):                                                      # every row enqueued before the first copy waits for the GPU
                 out[i] = wavs[j].cpu()
                 self.last_tokens[i] = gen_tokens[i]
                 self.last_mels[i] = mels[j].cpu()

@@ -57,6 +57,11 @@ _SIGS = {
     "astts_op_nsf_source": (c_int32, [c_void_p] * 6 + [c_int32] * 4 + [c_float] * 4 + [c_void_p, c_size_t, c_void_p]),
     "astts_op_stft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "astts_op_istft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p]),
+    "astts_op_stft16_lens": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "astts_op_istft16_lens": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    "astts_op_gemm_lens": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                     c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "astts_op_ras_sample": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_float, c_int32, c_float, c_int32, c_int32, c_void_p]),
 }
 
@@ -147,6 +152,8 @@ _SIGS.update({   # fused transformer-block front half of the flow estimator (csr
     "astts_op_conv1d_snake_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "astts_op_conv1d_snake": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
                                         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "astts_op_conv1d_snake_lens": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float,
+                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "astts_op_tfm_ffn_fused_supported": (c_int32, [c_int32, c_int32]),
     "astts_op_tfm_ffn_fused": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "astts_op_tfm_attn_fused": (c_int32, [c_void_p] * 5 + [c_int32] * 4 + [c_float, c_float, c_void_p]),
@@ -237,9 +244,11 @@ def _act_in(t: torch.Tensor) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional[torch.Tensor] = None,
          row_scale: Optional[torch.Tensor] = None, alpha: float = 1.0, slope: float = 0.1,
          t_in: Optional[int] = None, t_out: Optional[int] = None, stride: int = 1, dil: int = 1, pad: int = 0,
-         out: Optional[torch.Tensor] = None, use_bias: bool = True, out_dtype=torch.float32) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, use_bias: bool = True, out_dtype=torch.float32,
+         in_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x``: ``[..., cin]`` fp32 or fp16 (rows = batch*time); conv geometry via t_in/t_out/stride/dil/pad.
-    ``out_dtype=torch.float16`` when the result only feeds MFMA consumers (another GEMM / attention)."""
+    ``out_dtype=torch.float16`` when the result only feeds MFMA consumers (another GEMM / attention).
+    ``in_lens`` (int32 ``[batches]``, ragged batches): input steps at or beyond a row's length read as zero (astts_op_gemm_lens)."""
     x = _act_in(x)
     cin = x.shape[-1]
     assert cin == w.cin, (cin, w.cin)
@@ -258,6 +267,13 @@ def gemm(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional
     if residual is not None:
         residual = _f32(residual)
         ldr = residual.shape[-1]
+    if in_lens is not None:
+        assert in_lens.dtype == torch.int32 and in_lens.numel() == batches and in_lens.is_cuda
+        _lib.check(_L().astts_op_gemm_lens(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, w.data.data_ptr(),
+                                           _p(w.bias) if use_bias else None, _p(residual), _p(row_scale), out.data_ptr(),
+                                           1 if out.dtype == torch.float16 else 0, m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
+                                           t_in, t_out, stride, dil, pad, ACT[act], alpha, slope, in_lens.data_ptr(), _st()))
+        return out
     _lib.check(_L().astts_op_gemm_ex(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, w.data.data_ptr(),
                                      _p(w.bias) if use_bias else None, _p(residual), _p(row_scale), out.data_ptr(),
                                      1 if out.dtype == torch.float16 else 0, m, w.n, w.cin, w.cin_pad, w.taps, cin, ldc, ldr,
@@ -335,23 +351,24 @@ def linear_ln(x: torch.Tensor, w: PackedWeight, residual: torch.Tensor, ln, eps:
 
 
 def conv1d(x: torch.Tensor, w: PackedWeight, stride: int = 1, dil: int = 1, pad: int = 0, act: str = "none",
-           residual=None, alpha: float = 1.0, slope: float = 0.1, out_dtype=torch.float32) -> torch.Tensor:
-    """``x``: ``[B, T, Cin]`` -> ``[B, T_out, Cout]`` (nn.Conv1d semantics on the time axis)."""
+           residual=None, alpha: float = 1.0, slope: float = 0.1, out_dtype=torch.float32, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x``: ``[B, T, Cin]`` -> ``[B, T_out, Cout]`` (nn.Conv1d semantics on the time axis).  ``lens`` (int32 ``[B]``): each row convolves
+    as a sequence of its own length (zero padding behind it); outputs behind a row's own output length are unspecified."""
     b, t, _ = x.shape
     k = w.taps
     t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
     y = gemm(x, w, act=act, residual=residual, alpha=alpha, slope=slope, t_in=t, t_out=t_out, stride=stride, dil=dil, pad=pad,
-             out_dtype=out_dtype)
+             out_dtype=out_dtype, in_lens=lens)
     return y.view(b, t_out, w.n)
 
 
-def conv_transpose1d(x: torch.Tensor, w: PackedWeight, padding: int) -> torch.Tensor:
+def conv_transpose1d(x: torch.Tensor, w: PackedWeight, padding: int, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose1d(kernel = 2*stride, stride, padding) on ``[B, T, Cin]`` -> ``[B, stride*T, Cout]``
     (for padding == stride//2).  Phase decomposition: one GEMM over T+1 steps with two taps producing
     ``stride`` output phases per step, then a shifted view."""
     b, t, _ = x.shape
     s, cout = w.ct_stride, w.ct_cout
-    y = gemm(x, w, t_in=t, t_out=t + 1, stride=1, dil=1, pad=1)  # [B*(T+1), s*cout]
+    y = gemm(x, w, t_in=t, t_out=t + 1, stride=1, dil=1, pad=1, in_lens=lens)  # [B*(T+1), s*cout]; ``lens``: input steps of each row
     y = y.view(b, (t + 1) * s, cout)
     t_full = (t - 1) * s - 2 * padding + 2 * s
     return y[:, padding:padding + t_full, :].contiguous()
@@ -496,7 +513,7 @@ def conv1d_snake_supported(c: int, taps: int, dil: int) -> bool:
 
 def conv1d_snake(x: torch.Tensor, w: PackedWeight, w_frag: torch.Tensor, dil: int = 1, alpha: Optional[torch.Tensor] = None,
                  residual: Optional[torch.Tensor] = None, out_dtype=torch.float32, want_y: bool = True,
-                 acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False):
+                 acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False, lens: Optional[torch.Tensor] = None):
     """``conv1d_same(snake_alpha(x)) + bias + residual`` on channels-last ``[B, L, C]`` (C -> C, LDS-staged kernel).  Returns ``y``
     (``out_dtype``) unless ``want_y`` is False; ``acc`` (fp32, same shape) receives ``(acc if acc_add else 0) + acc_scale * y``."""
     assert x.dtype in (torch.float32, torch.float16) and x.is_contiguous() and x.dim() == 3
@@ -508,9 +525,9 @@ def conv1d_snake(x: torch.Tensor, w: PackedWeight, w_frag: torch.Tensor, dil: in
         assert residual.shape == x.shape
     if acc is not None:
         assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.shape == x.shape
-    _lib.check(_L().astts_op_conv1d_snake(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, _p(alpha), w_frag.data_ptr(), _p(w.bias),
-                                          _p(residual), _p(y), 1 if out_dtype == torch.float16 else 0, _p(acc), acc_scale,
-                                          1 if acc_add else 0, b, l, c, w.taps, dil, _st()))
+    _lib.check(_L().astts_op_conv1d_snake_lens(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, _p(alpha), w_frag.data_ptr(), _p(w.bias),
+                                               _p(residual), _p(y), 1 if out_dtype == torch.float16 else 0, _p(acc), acc_scale,
+                                               1 if acc_add else 0, b, l, c, w.taps, dil, _p(lens), _st()))
     return y
 
 
@@ -573,19 +590,21 @@ def nsf_source(f0, phase0, noise, lin_w, lin_b, upsample: int, sample_rate: floa
     return out
 
 
-def stft16(x: torch.Tensor) -> torch.Tensor:
+def stft16(x: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``lens`` (int32 ``[B]``, samples of each row, multiples of 4): every row is transformed as a signal of its own length."""
     x = _f32(x)
     b, n = x.shape
     y = torch.empty((b, n // 4 + 1, 18), dtype=torch.float32, device=x.device)
-    _lib.check(_L().astts_op_stft16(x.data_ptr(), y.data_ptr(), b, n, _st()))
+    _lib.check(_L().astts_op_stft16_lens(x.data_ptr(), y.data_ptr(), b, n, _p(lens), _st()))
     return y
 
 
-def istft16(y: torch.Tensor, mag_clip: float = 100.0, audio_limit: float = 0.99) -> torch.Tensor:
+def istft16(y: torch.Tensor, mag_clip: float = 100.0, audio_limit: float = 0.99, frame_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``frame_lens`` (int32 ``[B]``): frames of each row; a row's overlap-add sees its own frames only."""
     y = _f32(y)
     b, f, _ = y.shape
     wav = torch.empty((b, 4 * (f - 1)), dtype=torch.float32, device=y.device)
-    _lib.check(_L().astts_op_istft16(y.data_ptr(), wav.data_ptr(), b, f, mag_clip, audio_limit, _st()))
+    _lib.check(_L().astts_op_istft16_lens(y.data_ptr(), wav.data_ptr(), b, f, mag_clip, audio_limit, _p(frame_lens), _st()))
     return wav
 
 

@@ -791,7 +791,8 @@ class _ResBlock:
         self.f1 = [ops.conv_pack_frag(w) for w in self.c1] if self.lds else None
         self.f2 = [ops.conv_pack_frag(w) for w in self.c2] if self.lds else None
 
-    def forward(self, x: torch.Tensor, acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False) -> Optional[torch.Tensor]:
+    def forward(self, x: torch.Tensor, acc: Optional[torch.Tensor] = None, acc_scale: float = 1.0, acc_add: bool = False,
+                lens: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """x + the branches, iteration by iteration: x <- x + conv2(snake(conv1(snake(x)))).  With ``acc`` the last iteration writes
         ``acc = (acc if acc_add else 0) + acc_scale * x_final`` instead of returning ``x_final`` (the mean over the parallel
         resblocks / the sum with the up-sampled stream without a launch of their own)."""
@@ -800,17 +801,17 @@ class _ResBlock:
         for j, d in enumerate(self.dils):
             last = j == n - 1
             if self.lds:
-                h = ops.conv1d_snake(x.contiguous(), self.c1[j], self.f1[j], dil=d, alpha=self.a1[j], out_dtype=torch.float16)
+                h = ops.conv1d_snake(x.contiguous(), self.c1[j], self.f1[j], dil=d, alpha=self.a1[j], out_dtype=torch.float16, lens=lens)
                 if last and acc is not None:
                     ops.conv1d_snake(h, self.c2[j], self.f2[j], dil=1, alpha=self.a2[j], residual=x, want_y=False, acc=acc,
-                                     acc_scale=acc_scale, acc_add=acc_add)
+                                     acc_scale=acc_scale, acc_add=acc_add, lens=lens)
                     return None
-                x = ops.conv1d_snake(h, self.c2[j], self.f2[j], dil=1, alpha=self.a2[j], residual=x)
+                x = ops.conv1d_snake(h, self.c2[j], self.f2[j], dil=1, alpha=self.a2[j], residual=x, lens=lens)
             else:
                 xt = ops.elementwise(ops.EL_SNAKE, x, p0=self.a1[j])
-                xt = ops.conv1d(xt, self.c1[j], dil=d, pad=d * (k - 1) // 2)
+                xt = ops.conv1d(xt, self.c1[j], dil=d, pad=d * (k - 1) // 2, lens=lens)
                 xt = ops.elementwise(ops.EL_SNAKE, xt, p0=self.a2[j])
-                x = ops.conv1d(xt, self.c2[j], pad=(k - 1) // 2, residual=x)
+                x = ops.conv1d(xt, self.c2[j], pad=(k - 1) // 2, residual=x, lens=lens)
         if acc is not None:
             if acc_add:
                 acc.copy_(ops.elementwise(ops.EL_ADD, acc, z=x, s=acc_scale))
@@ -840,10 +841,10 @@ class HiftVocoder:
             self.res.append([_ResBlock(sd, f"resblocks.{i * nk + kk}", k, cfg.res_dils, device) for kk, k in enumerate(cfg.res_kernels)])
         self.conv_post = PackedWeight.from_conv1d(sd["conv_post.weight"], sd["conv_post.bias"], device)
 
-    def f0(self, mel: torch.Tensor) -> torch.Tensor:
+    def f0(self, mel: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
         h = mel
         for w in self.f0_convs:
-            h = ops.conv1d(h, w, pad=1, act="elu")
+            h = ops.conv1d(h, w, pad=1, act="elu", lens=lens)
         f = ops.linear(h, self.f0_cls)
         return torch.abs(f.squeeze(-1))  # |.| of a [B, Tm] vector: plumbing
 
@@ -852,31 +853,59 @@ class HiftVocoder:
         return ops.nsf_source(f0.contiguous(), phase0, noise, self.src_w, self.src_b, cfg.upsample_total,
                               float(cfg.sample_rate), cfg.nsf_alpha, cfg.nsf_sigma, cfg.nsf_voiced_threshold)
 
-    def decode(self, mel: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+    def decode(self, mel: torch.Tensor, source: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``lens`` (int32 ``[B]``, mel frames of each row): a RAGGED batch in one pass.  Every convolution reads a row as a sequence of
+        its own length (zero padding behind it), the STFT mirrors a row's own last samples and the iSTFT overlap-adds its own frames
+        only, so the first ``lens[b] * upsample_total`` samples of row b equal the row run alone (the reference runs every utterance
+        alone: tts_with_rag.py:172-197); what lies behind them is unspecified."""
         cfg = self.cfg
-        s_stft = ops.stft16(source)                                           # [B, F, 18]
-        x = ops.conv1d(mel, self.conv_pre, pad=3)
+        up = cfg.upsample_total
+        ln = (lambda scale, add=0: None) if lens is None else (lambda scale, add=0: (lens * scale + add).to(torch.int32))
+        s_stft = ops.stft16(source, lens=ln(up))                             # [B, F, 18]
+        x = ops.conv1d(mel, self.conv_pre, pad=3, lens=ln(1))
         n_up = len(cfg.up_rates)
         nk = len(cfg.res_kernels)
+        rate = 1
         for i, r in enumerate(cfg.up_rates):
             x = ops.elementwise(ops.EL_LEAKY, x, s=cfg.lrelu_slope)
-            x = ops.conv_transpose1d(x, self.ups[i], padding=r // 2)
+            x = ops.conv_transpose1d(x, self.ups[i], padding=r // 2, lens=ln(rate))
+            rate *= r
+            extra = 0
             if i == n_up - 1:
                 x = torch.cat([x[:, 1:2], x], dim=1)                           # ReflectionPad1d((1, 0)): plumbing
+                extra = 1
             wd, kd = self.sdowns[i]
-            si = ops.conv1d(s_stft, wd, stride=kd // 2, pad=kd // 4) if kd > 1 else ops.conv1d(s_stft, wd)
+            f_lens = ln(up // 4, 1)                                            # STFT frames of each row
+            si = ops.conv1d(s_stft, wd, stride=kd // 2, pad=kd // 4, lens=f_lens) if kd > 1 else ops.conv1d(s_stft, wd, lens=f_lens)
             x = x.contiguous()
-            self.sres[i].forward(si, acc=x, acc_scale=1.0, acc_add=True)      # x += source resblock(si): the last conv's epilogue
-            xs = torch.empty_like(x)
+            cur = ln(rate, extra)
+            self.sres[i].forward(si, acc=x, acc_scale=1.0, acc_add=True, lens=cur)      # x += source resblock(si): the last conv's epilogue
+            xs = torch.empty_like(x) if lens is None else torch.zeros_like(x)   # (tiles behind a short row's end are skipped: keep them finite)
             for kk, rb in enumerate(self.res[i]):                            # mean of the parallel resblocks, same way
-                rb.forward(x, acc=xs, acc_scale=1.0 / nk, acc_add=kk > 0)
+                rb.forward(x, acc=xs, acc_scale=1.0 / nk, acc_add=kk > 0, lens=cur)
             x = xs
         x = ops.elementwise(ops.EL_LEAKY, x, s=0.01)
-        x = ops.conv1d(x, self.conv_post, pad=3)
-        return ops.istft16(x, 100.0, cfg.audio_limit)
+        x = ops.conv1d(x, self.conv_post, pad=3, lens=ln(up // 4, 1))
+        return ops.istft16(x, 100.0, cfg.audio_limit, frame_lens=ln(up // 4, 1))
 
-    def forward(self, mel, phase0, noise) -> torch.Tensor:
-        return self.decode(mel, self.source(self.f0(mel), phase0, noise))
+    def forward(self, mel, phase0, noise, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.decode(mel, self.source(self.f0(mel, lens), phase0, noise), lens)
+
+    def forward_ragged(self, mels: List[torch.Tensor], phase0s: List[torch.Tensor], noises: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Utterances of different lengths in ONE vocoder pass (``mels[j]``: ``[Tm_j, 80]``, ``phase0s[j]``: ``[1, H+1]``, ``noises[j]``:
+        ``[1, Tm_j * upsample_total, H+1]``) -> waveforms ``[1, Tm_j * upsample_total]``, each equal to ``forward`` of the row alone."""
+        cfg, dev = self.cfg, self.device
+        b, up = len(mels), cfg.upsample_total
+        tl = [int(m.shape[0]) for m in mels]
+        tmax = max(tl)
+        mel = torch.zeros((b, tmax, cfg.mel), dtype=torch.float32, device=dev)
+        noise = torch.zeros((b, tmax * up, cfg.nb_harmonics + 1), dtype=torch.float32, device=dev)
+        for j in range(b):
+            mel[j, :tl[j]] = mels[j]
+            noise[j, :tl[j] * up] = noises[j].reshape(tl[j] * up, -1)
+        lens = torch.tensor(tl, dtype=torch.int32, device=dev)
+        wav = self.forward(mel, torch.cat([p.reshape(1, -1) for p in phase0s], 0).to(dev), noise, lens)
+        return [wav[j:j + 1, :tl[j] * up] for j in range(b)]
 
 
 class SynthEngine:

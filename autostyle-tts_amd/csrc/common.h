@@ -49,6 +49,9 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1);
         }                                                                                  \
     } while (0)
 
+// the kNN scan as one GEMM on the LDS-DMA ring kernel (ops_gemm.hip), row panels of one bank tile first
+int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st);
+
 // an integer experiment switch from the environment (`dflt` when unset).  A set variable is reported once on stderr: these switches
 // change which kernel form runs (same results), and a stray one in a user's environment should not go unnoticed (runtime.hip)
 int exp_env_int(const char* name, int dflt);

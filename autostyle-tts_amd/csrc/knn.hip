@@ -943,8 +943,12 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
             // row-major fp16 plane [n][dp]; the LDS-DMA ring kernel runs it at 400+ TFLOP/s where the register-streaming scan
             // (built for the HBM-bound small-Q regime) re-reads the query tile from L2 per bank tile.  1 / |b_n| is applied
             // by the selection kernel.
-            rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
-                                  h->dp, h->dp, 1, h->dp, h->nld, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f, stream);
+            static const bool n_first = exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0) != 0;     // A/B: the projections' tile order (bank read once per panel)
+            if (n_first)
+                rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
+                                      h->dp, h->dp, 1, h->dp, h->nld, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f, stream);
+            else
+                rc = gemm_scan(qrow + (size_t)q0 * h->dp, h->plane16, spart, qg, h->n, h->dp, h->nld, st);
         } else
         switch (p.qt * 10 + p.rt) {
             case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, st); break;

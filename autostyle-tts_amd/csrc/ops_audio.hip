@@ -84,12 +84,22 @@ __device__ __forceinline__ float hann16(int n) {  // periodic Hann, N = 16
 }
 
 // x [B, L] -> y [B, F, 18], F = L/4 + 1, frame f covers reflect-padded samples 4f-8 .. 4f+7
-__global__ __launch_bounds__(256) void stft16(const float* __restrict__ x, float* __restrict__ y, int b, int64_t L, int64_t F) {
+// lens (ragged batches): samples of each row (a multiple of 4, >= 16; null: L).  A row is transformed as a signal of ITS length -- the
+// reflection at its end mirrors its own last samples -- into its first lens[b] / 4 + 1 frames; the frames behind them are zero.
+__global__ __launch_bounds__(256) void stft16(const float* __restrict__ x, float* __restrict__ y, int b, int64_t Lmax, int64_t F,
+                                              const int* __restrict__ lens) {
     const int64_t total = (int64_t)b * F;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int bb = (int)(i / F);
         const int64_t f = i - (int64_t)bb * F;
-        const float* xb = x + (int64_t)bb * L;
+        const float* xb = x + (int64_t)bb * Lmax;
+        const int64_t L = lens ? min((int64_t)lens[bb], Lmax) : Lmax;
+        float* o = y + i * 18;
+        if (f > L / 4) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) o[k] = 0.0f;
+            continue;
+        }
         float w[16];
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
@@ -98,7 +108,6 @@ __global__ __launch_bounds__(256) void stft16(const float* __restrict__ x, float
             if (s >= L) s = 2 * (L - 1) - s;
             w[n] = hann16(n) * xb[s];
         }
-        float* o = y + i * 18;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             float re = 0.0f, im = 0.0f;
@@ -117,13 +126,20 @@ __global__ __launch_bounds__(256) void stft16(const float* __restrict__ x, float
 }
 
 // y [B, F, 18] (log-magnitude, phase pre-activation) -> wav [B, 4(F-1)], clamped
-__global__ __launch_bounds__(256) void istft16(const float* __restrict__ y, float* __restrict__ wav, int b, int64_t F,
-                                               float mag_clip, float audio_limit) {
-    const int64_t L = 4 * (F - 1);
+// frame_lens (ragged batches): frames of each row (null: F).  A row is synthesised from ITS frames only -- the overlap-add at its end sees
+// no frame of the padding -- into its first 4 (frame_lens[b] - 1) samples; the samples behind them are zero.
+__global__ __launch_bounds__(256) void istft16(const float* __restrict__ y, float* __restrict__ wav, int b, int64_t Fmax,
+                                               float mag_clip, float audio_limit, const int* __restrict__ frame_lens) {
+    const int64_t L = 4 * (Fmax - 1);
     const int64_t total = (int64_t)b * L;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int bb = (int)(i / L);
         const int64_t t = i - (int64_t)bb * L;
+        const int64_t F = frame_lens ? min((int64_t)frame_lens[bb], Fmax) : Fmax;
+        if (t >= 4 * (F - 1)) {
+            wav[i] = 0.0f;
+            continue;
+        }
         const int64_t tp = t + 8;  // position in the centre-padded signal
         float num = 0.0f, den = 0.0f;
         const int64_t f_hi = tp / 4;
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256) void istft16(const float* __restrict__ y, floa
             const int64_t f = f_hi - q;
             const int n = (int)(tp - 4 * f);  // 0..15
             if (f < 0 || f >= F) continue;
-            const float* fr = y + ((int64_t)bb * F + f) * 18;
+            const float* fr = y + ((int64_t)bb * Fmax + f) * 18;
             float xs = 0.0f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -666,18 +682,27 @@ int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise
 }
 
 int astts_op_stft16(const float* x, float* y, int32_t b, int64_t n_samples, astts_stream_t stream) {
+    return astts_op_stft16_lens(x, y, b, n_samples, nullptr, stream);
+}
+
+int astts_op_stft16_lens(const float* x, float* y, int32_t b, int64_t n_samples, const int32_t* lens, astts_stream_t stream) {
     ASTTS_REQUIRE(x && y && b >= 1 && n_samples >= 16 && n_samples % 4 == 0, ASTTS_ERR_INVALID, "astts_op_stft16: bad argument");
     const int64_t F = n_samples / 4 + 1;
-    hipLaunchKernelGGL(stft16, dim3(grid_for_a((int64_t)b * F)), dim3(256), 0, (hipStream_t)stream, x, y, b, n_samples, F);
+    hipLaunchKernelGGL(stft16, dim3(grid_for_a((int64_t)b * F)), dim3(256), 0, (hipStream_t)stream, x, y, b, n_samples, F, lens);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
 
 int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit,
                      astts_stream_t stream) {
+    return astts_op_istft16_lens(y, wav, b, frames, mag_clip, audio_limit, nullptr, stream);
+}
+
+int astts_op_istft16_lens(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit, const int32_t* frame_lens,
+                          astts_stream_t stream) {
     ASTTS_REQUIRE(y && wav && b >= 1 && frames >= 2, ASTTS_ERR_INVALID, "astts_op_istft16: bad argument");
     hipLaunchKernelGGL(istft16, dim3(grid_for_a((int64_t)b * 4 * (frames - 1))), dim3(256), 0, (hipStream_t)stream, y,
-                       wav, b, frames, mag_clip, audio_limit);
+                       wav, b, frames, mag_clip, audio_limit, frame_lens);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

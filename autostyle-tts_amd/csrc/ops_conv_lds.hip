@@ -32,6 +32,8 @@ struct ConvLdsArgs {
     int l, taps, dil;
     int x_f16, y_f16, acc_add;
     float acc_scale;
+    const int* lens;          // [b] frames of each sequence (ragged batches; null: l).  Frames at or beyond read as zero -- every sequence
+                              // convolves as if it were alone with the zero padding behind it -- and are not written.
 };
 
 __device__ __forceinline__ float snakef(float x, float al, float inv) {
@@ -56,6 +58,8 @@ __global__ __launch_bounds__((BM / 64) * (C / 64) * 64, (BM / 64) * (C / 64) == 
     const int halo = a.dil * (a.taps - 1) / 2;
     const int sr = BM + 2 * halo;                     // staged rows: frames t0 - halo .. t0 + BM + halo - 1
     const int64_t seq = (int64_t)bb * a.l;
+    const int lim = a.lens ? min(a.lens[bb], a.l) : a.l;      // this sequence's own length
+    if (t0 >= lim) return;                            // a tile wholly behind the end of its (short) sequence: nothing to compute
 
     // ---- this wave's first weight unit (tap 0, slice 0) goes out before the staging
     half8 wf[2][16];                                  // [buffer][n-tile * 8 + k-step]
@@ -107,7 +111,7 @@ __global__ __launch_bounds__((BM / 64) * (C / 64) * 64, (BM / 64) * (C / 64) == 
             for (int u = 0; u < SU; ++u) {
                 const int r = rb + u * RPP;
                 const int t = t0 - halo + r;
-                if (!(r < sr && t >= 0 && t < a.l)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(r < sr && t >= 0 && t < lim)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__((BM / 64) * (C / 64) * 64, (BM / 64) * (C / 64) == 
         for (int i = 0; i < 8; ++i) {
             const int t = tb + er + 4 * i;
             const float4 v4 = *reinterpret_cast<const float4*>(tr + (er + 4 * i) * 68 + ec);
-            if (t < a.l) {
+            if (t < lim) {
                 const int64_t o = (seq + t) * C + wn * 64 + ec;
                 const float4 v = make_float4(v4.x + bias4.x + rv[i].x, v4.y + bias4.y + rv[i].y, v4.z + bias4.z + rv[i].z, v4.w + bias4.w + rv[i].w);
                 if (a.y) {
@@ -252,6 +256,12 @@ int astts_op_conv1d_snake_supported(int32_t c, int32_t taps, int32_t dil) {
 int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, const void* w_frag_f16, const float* bias, const float* res,
                           void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
                           int32_t taps, int32_t dil, astts_stream_t stream) {
+    return astts_op_conv1d_snake_lens(x, x_f16, alpha, w_frag_f16, bias, res, y, y_f16, acc, acc_scale, acc_add, b, l, c, taps, dil, nullptr, stream);
+}
+
+int astts_op_conv1d_snake_lens(const void* x, int32_t x_f16, const float* alpha, const void* w_frag_f16, const float* bias, const float* res,
+                               void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
+                               int32_t taps, int32_t dil, const int32_t* lens, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w_frag_f16 && (y || acc), ASTTS_ERR_INVALID, "astts_op_conv1d_snake: null pointer");
     ASTTS_REQUIRE(astts_op_conv1d_snake_supported(c, taps, dil), ASTTS_ERR_UNSUPPORTED,
                   "astts_op_conv1d_snake: c=%d taps=%d dil=%d (c 128 or 256, odd taps, halo <= 25)", c, taps, dil);
@@ -264,7 +274,7 @@ int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     });
-    ConvLdsArgs a{x, alpha, (const _Float16*)w_frag_f16, bias, res, y, acc, l, taps, dil, x_f16, y_f16, acc_add, acc_scale};
+    ConvLdsArgs a{x, alpha, (const _Float16*)w_frag_f16, bias, res, y, acc, l, taps, dil, x_f16, y_f16, acc_add, acc_scale, lens};
     hipStream_t st = (hipStream_t)stream;
     const int halo = dil * (taps - 1) / 2;
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * l * c * c * taps);

@@ -72,6 +72,13 @@ struct GemmArgs {
     float* sk_part;
     unsigned* sk_cnt;
     int ksplit;
+    // ragged batches (gemm_tile only): input time steps at or beyond in_lens[batch row] read as zero, as if each row were a sequence of
+    // its own length with the convolution's zero padding behind it (null: every row has t_in steps)
+    const int* in_lens;
+    // gemm_ring tile order: 0 = the N tiles of one row panel first (blocks that share an ACTIVATION panel sit on one XCD: the flow's
+    // projections), 1 = the row panels of one N tile first (blocks that share a WEIGHT tile are neighbours on one XCD and ask its L2 for
+    // the same lines at the same time: the kNN scan, where the "weights" are the 1.2 GB bank and the activations 256 queries)
+    int m_first;
 };
 
 #ifdef EPI_DBG_LOCAL
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
     const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
     const bool vec_ok = A16 ? ((a.lda & 7) == 0 && ((uintptr_t)a.x & 15) == 0) : ((a.lda & 3) == 0 && ((uintptr_t)a.x & 15) == 0);
 
-    int a_row[A_CH], a_seg[A_CH], a_t[A_CH];
+    int a_row[A_CH], a_seg[A_CH], a_t[A_CH], a_lim[A_CH];
     int64_t a_base[A_CH];
     bool a_live[A_CH];
 #pragma unroll
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
         const int t = a_live[c] ? (int)(m - b * a.t_out) : 0;
         a_t[c] = t * a.stride - a.pad;
         a_base[c] = b * a.t_in;
+        a_lim[c] = (a.in_lens && a_live[c]) ? min(a.in_lens[b], a.t_in) : a.t_in;
     }
     int b_row[B_CH], b_seg[B_CH];
     bool b_live[B_CH];
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
                 for (int c = 0; c < A_CH; ++c) {
                     const int ts = a_t[c] + tap * a.dil;
                     const int ch = c0 + a_seg[c];
-                    okc[c] = a_live[c] && ts >= 0 && ts < a.t_in && ch < a.cin;
+                    okc[c] = a_live[c] && ts >= 0 && ts < a_lim[c] && ch < a.cin;
                     const int64_t off = okc[c] ? (a_base[c] + ts) * (int64_t)a.lda + ch : 0;
                     ra[c] = *reinterpret_cast<const half8*>(x16 + off);
                 }
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
                 for (int c = 0; c < A_CH; ++c) {
                     const int ts = a_t[c] + tap * a.dil;
                     const int ch = c0 + a_seg[c];
-                    okc[c] = a_live[c] && ts >= 0 && ts < a.t_in && ch < a.cin;
+                    okc[c] = a_live[c] && ts >= 0 && ts < a_lim[c] && ch < a.cin;
                     const int64_t off = okc[c] ? (a_base[c] + ts) * (int64_t)a.lda + ch : 0;
                     v0[c] = *reinterpret_cast<const float4*>(a.x + off);
                     v1[c] = *reinterpret_cast<const float4*>(a.x + off + 4);
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void gemm_tile(GemmArgs a) {
 #pragma unroll
             for (int c = 0; c < A_CH; ++c) {
                 const int ts = a_t[c] + tap * a.dil;
-                const bool ok = a_live[c] && ts >= 0 && ts < a.t_in;
+                const bool ok = a_live[c] && ts >= 0 && ts < a_lim[c];
                 const int ch = c0 + a_seg[c];
                 const int64_t off = (a_base[c] + ts) * (int64_t)a.lda + ch;
                 if constexpr (A16) {
@@ -559,8 +567,14 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
         const int nwg = gridDim.x, w = blockIdx.x;
         const int xcd = w & 7, q = nwg >> 3, r = nwg & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-        bx = L / gy;
-        by = L - bx * gy;
+        if (a.m_first) {
+            const int gx = (int)((a.m + BM - 1) / BM);
+            by = L / gx;
+            bx = L - by * gx;
+        } else {
+            bx = L / gy;
+            by = L - bx * gy;
+        }
     }
     const int64_t m0 = (int64_t)bx * BM;
     const int n0 = by * BN;
@@ -964,7 +978,7 @@ static void launch_tile(const GemmArgs& a, hipStream_t st) {
 static int g_ring_mode_override = -1;   // -1: rule below / ASTTS_GEMM_RING; 0: ring kernel off; 1..3: force that tile
 
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out;
+    const bool plain = a.taps == 1 && a.stride == 1 && a.pad == 0 && a.t_in == a.t_out && !a.in_lens;   // (row lengths: the tile kernel masks them)
     if (a.m <= 32 && plain && !a.x_f16 && !a.out_f16) {
         // the block keeps its m rows of x as an fp16 image in LDS: rows are taken in chunks that fit 160 KB
         // (only m > 16 with K > 2048 needs two passes, e.g. the FFN-out projection of a 32-row decode group)
@@ -1072,6 +1086,16 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     return ASTTS_OK;
 }
 
+// the kNN scan as one GEMM (knn.hip): scores[q][n] = <query q, bank row n>, fp16 operands, fp32 out [qg][ldc]; row panels of one bank
+// tile first (GemmArgs::m_first), so that the bank is fetched from HBM once however many 128-query panels there are
+int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st) {
+    GemmArgs a{(const float*)queries, bank, nullptr, nullptr, nullptr, out, qg, (int)n, dp, dp, 1,
+               dp, ldc, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f,
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, 1, 0, 0};
+    a.m_first = 1;
+    return launch_gemm(a, st);
+}
+
 }  // namespace astts
 
 using namespace astts;
@@ -1136,6 +1160,20 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
     GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, row_scale, (float*)out, m, n, cin, cin_pad, taps,
                lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
                nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_lens(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual,
+                       const float* row_scale, void* out, int32_t out_f16, int64_t m, int32_t n, int32_t cin, int32_t cin_pad,
+                       int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
+                       int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope, const int32_t* in_lens,
+                       astts_stream_t stream) {
+    const int rc = check_gemm_args("astts_op_gemm_lens", (const float*)x, w_f16, (float*)out, m, n, cin, cin_pad, taps, t_in, t_out, stride, dil, act);
+    if (rc != ASTTS_OK) return rc;
+    GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, row_scale, (float*)out, m, n, cin, cin_pad, taps,
+               lda, ldc, ldr, t_in, t_out, stride, dil, pad, act, alpha, slope,
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
+    a.in_lens = in_lens;
     return launch_gemm(a, (hipStream_t)stream);
 }
 

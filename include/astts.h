@@ -162,6 +162,15 @@ int astts_op_gemm_ex(const void* x, int32_t x_f16, const void* w_f16, const floa
                      int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
                      int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope,
                      astts_stream_t stream);
+/* astts_op_gemm_ex for RAGGED batches (one vocoder pass over utterances of different lengths: HiFTGenerator.inference behind
+ * /root/reference/tts_with_rag.py:195, which the reference runs one utterance at a time): input time steps at or beyond
+ * in_lens[batch row] (int32 [m / t_out]) are read as zero -- each row convolves as a sequence of its own length with the
+ * convolution's zero padding behind it.  Output rows beyond a row's own length hold unspecified values. */
+int astts_op_gemm_lens(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual,
+                       const float* row_scale, void* out, int32_t out_f16, int64_t m, int32_t n, int32_t cin, int32_t cin_pad,
+                       int32_t taps, int32_t lda, int32_t ldc, int32_t ldr, int32_t t_in, int32_t t_out,
+                       int32_t stride, int32_t dil, int32_t pad, int32_t act, float alpha, float slope, const int32_t* in_lens,
+                       astts_stream_t stream);
 /* Decode-sized GEMM (m <= 32, weight-bandwidth bound) with the fusions that take whole launches out of
  * an LM decode step: optional row gather (x row of output row i = x[gather[i]], i.e. an embedding lookup),
  * optional LayerNorm(gamma, beta, eps) over the cin inputs of every row applied while loading, and an
@@ -262,8 +271,15 @@ int astts_op_nsf_source(const float* f0, const float* phase0, const float* noise
                         float sine_amp, float noise_std, float voiced_threshold, void* workspace, size_t workspace_bytes,
                         astts_stream_t stream);
 int astts_op_stft16(const float* x, float* y, int32_t b, int64_t n_samples, astts_stream_t stream);
+/* ragged batches: lens int32 [b] = samples of each row (a multiple of 4, >= 16; NULL: n_samples).  A row is transformed as a signal of
+ * its own length (the reflection at its end mirrors its own last samples); frames behind lens[b] / 4 are zero. */
+int astts_op_stft16_lens(const float* x, float* y, int32_t b, int64_t n_samples, const int32_t* lens, astts_stream_t stream);
 int astts_op_istft16(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit,
                      astts_stream_t stream);
+/* ragged batches: frame_lens int32 [b] = frames of each row (NULL: frames); a row's overlap-add sees its own frames only, samples behind
+ * 4 (frame_lens[b] - 1) are zero. */
+int astts_op_istft16_lens(const float* y, float* wav, int32_t b, int64_t frames, float mag_clip, float audio_limit, const int32_t* frame_lens,
+                          astts_stream_t stream);
 /* Frontend signal processing on the GPU (the reference does both on the host inside CosyVoice's frontend
  * [EXT], reached from load_wav / inference_* at tts_with_rag.py:180-195):
  * polyphase resampler  y[f * up + p] = sum_j kern[p][j] * x[f * down + j - width]  (kern [up][2 width + down]: the Hann-windowed
@@ -444,6 +460,11 @@ int astts_op_conv1d_snake_supported(int32_t c, int32_t taps, int32_t dil);
 int astts_op_conv1d_snake(const void* x, int32_t x_f16, const float* alpha, const void* w_frag_f16, const float* bias, const float* res,
                           void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
                           int32_t taps, int32_t dil, astts_stream_t stream);
+/* the same over a RAGGED batch: lens int32 [b] = frames of each sequence (NULL: l).  Frames at or beyond a sequence's length are read as
+ * zero (it convolves as if alone, zero padding behind it) and are not written; tiles wholly behind the end are skipped. */
+int astts_op_conv1d_snake_lens(const void* x, int32_t x_f16, const float* alpha, const void* w_frag_f16, const float* bias, const float* res,
+                               void* y, int32_t y_f16, float* acc, float acc_scale, int32_t acc_add, int32_t b, int32_t l, int32_t c,
+                               int32_t taps, int32_t dil, const int32_t* lens, astts_stream_t stream);
 
 /* ---- ResnetBlock1D convolutions with the GroupNorm + Mish passes folded in (csrc/ops_resnet_conv.hip): out = conv1d_same(x') +
  * bias [+ res'] on channels-last fp32 x [b, t, cin] -> out [b, t, 256], 1 or 3 taps, cin = 256 or 512 (the staging transform: 256 only).

@@ -107,6 +107,73 @@ def test_search_json_sharded_over_ranks_writes_the_one_process_file(search_work,
     assert set(rec) == {"zh_text", "speaker", "retrieved_file_id", "retrieved_text", "distance"} and rec["retrieved_file_id"].startswith("/data/seg/")
 
 
+class _StubEmbedder:
+    """CPU stand-in for astts.llm.embedder.LlamaEmbedder (the GPU one is held to transformers in tests/test_llm_gpu.py): labels and
+    3072-d vectors are pure functions of the text, and every call is logged so that the test can see WHICH rows a rank worked on."""
+
+    class cfg:
+        hidden = 3072
+
+    def __init__(self, log):
+        self.log = log
+
+    @staticmethod
+    def _vec(text):
+        h = int.from_bytes(hashlib.sha256(text.encode("utf-8")).digest()[:8], "little")
+        return np.random.default_rng(h).standard_normal(3072).astype(np.float32)
+
+    def generate_emotion_labels(self, texts, max_new_tokens=10):
+        with open(self.log, "a") as f:
+            f.write(f"label {len(texts)}\n")
+        return [["happy", "sad", "neutral", "angry", "excited", "frustrated"][len(t) % 6] for t in texts]
+
+    def get_embeddings(self, texts):
+        with open(self.log, "a") as f:
+            f.write(f"embed {len(texts)}\n")
+        return np.stack([self._vec(t) for t in texts])
+
+
+def _search_llm_worker(rank, world, port, work):
+    _env(rank, world, port)
+    from astts import parallel
+    from astts.cli import search_json
+    from astts.compat import pymilvus as pm
+
+    pm._Collection.bank = lambda self: _OracleBank(self.matrix(), os.path.join(work, f"llm_calls_w{world}_r{rank}.txt"))
+    args = search_json.build_parser().parse_args(["--input_json", os.path.join(work, "in200.jsonl"), "--biography_json", os.path.join(work, "bios.json"),
+                                                  "--db_path", os.path.join(GOLD, "milvus_demo.db"), "--llm_batch", "16",
+                                                  "--output_file", os.path.join(work, f"llm_out_w{world}.jsonl")])
+    res = search_json.main(args, embedder=_StubEmbedder(os.path.join(work, f"llm_embedder_w{world}_r{rank}.txt")))
+    assert len(res) == 200
+    parallel.shutdown()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_search_json_llm_half_is_sharded_too(search_work, world):
+    """milvus/search_json.py:372-411 (label -> embed -> search per row) under the data-parallel launch: a rank labels and embeds ITS rows
+    only (no query vector crosses ranks: the all-gather carries ids and similarities), speakers without a biography get the reference's
+    placeholder, and the JSONL equals the one-process run's."""
+    work = search_work
+    rows = [json.loads(l) for l in open(os.path.join(work, "in.jsonl"), encoding="utf-8")][:200]
+    with open(os.path.join(work, "in200.jsonl"), "w", encoding="utf-8") as f:
+        for r in rows:
+            f.write(json.dumps(r, ensure_ascii=False) + "\n")
+    with open(os.path.join(work, "bios.json"), "w") as f:
+        json.dump({"w1": "Cheerful and optimistic.", "m1": "Pragmatic and thoughtful."}, f)       # w2 / m2: the placeholder biography
+    mp.spawn(_search_llm_worker, args=(1, _free_port(), work), nprocs=1, join=True)
+    mp.spawn(_search_llm_worker, args=(world, _free_port(), work), nprocs=world, join=True)
+    one = open(os.path.join(work, "llm_out_w1.jsonl"), "rb").read()
+    many = open(os.path.join(work, f"llm_out_w{world}.jsonl"), "rb").read()
+    assert one == many and one.count(b"\n") == 200
+    for r in range(world):
+        calls = open(os.path.join(work, f"llm_embedder_w{world}_r{r}.txt")).read().split("\n")
+        labelled = sum(int(c.split()[1]) for c in calls if c.startswith("label"))
+        assert labelled == 100                                                                    # its own shard, in batches of 16
+        assert all(int(c.split()[1]) <= 16 for c in calls if c)
+        embedded = sum(int(c.split()[1]) for c in calls if c.startswith("embed"))
+        assert embedded <= 6 + 3                                                                  # distinct labels + distinct biographies, once each
+
+
 class _StubVoice:
     """Audio = a pure function of (text, style text, per-row seed, segment): what the drivers may rely on across ranks."""
     sample_rate = 22050

@@ -349,6 +349,52 @@ def test_ragged_flow_batch_equals_one_at_a_time():
         _close(mels[i].cpu(), ref, TOL_MEL, float(ref.abs().max()), tag=i)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_ragged_vocoder_batch_equals_one_at_a_time(wide):
+    """HiftVocoder.forward_ragged: utterances of different lengths in ONE vocoder pass (length masks in the implicit-GEMM convolutions,
+    the LDS-staged Snake convolutions, the STFT's reflection and the iSTFT's overlap-add) == every utterance vocoded alone, BIT FOR
+    BIT, at the toy widths (gemm_tile path everywhere) and at the production widths (conv_lds resblocks; rows shorter and longer than
+    one 128-frame tile, so tiles behind a short row's end are skipped beside full ones).  The reference vocodes one utterance at a time
+    (tts_with_rag.py:172-197); the one-at-a-time form is held to the oracle by the tests above."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import HiftVocoder
+    from astts.synth.weights import make_hift_weights
+
+    cfg = SynthConfig() if wide else SynthConfig.tiny()
+    voc = HiftVocoder(make_hift_weights(cfg, 2), cfg, torch.device(DEV))
+    g = torch.Generator().manual_seed(77)
+    nh, up = cfg.nb_harmonics + 1, cfg.upsample_total
+    # rows of MORE than 32 mel frames (every real utterance: 25 tokens = 43 frames is the shortest the drivers ever render) go through
+    # the same kernels alone and in a batch: bit-identical.  A row of <= 32 frames run ALONE takes the decode-sized GEMV kernel for its
+    # plain (1-tap) products (m <= 32: K split over 8 waves, another summation order), so there the comparison is to rounding -- and the
+    # f0 -> phase map turns one ulp of f0 into ~1e-4 of waveform.
+    for lens, exact in (([43, 35, 61, 50, 33] if wide else [39, 60, 33, 47], True), ([23, 3, 41, 16, 1] if wide else [9, 30, 2, 17], False)):
+        mels = [torch.randn(t, cfg.mel, generator=g).to(DEV) for t in lens]
+        ph = []
+        for _ in lens:
+            p = (torch.rand(1, nh, generator=g) * 2 - 1) * math.pi
+            p[:, 0] = 0
+            ph.append(p.to(DEV))
+        nz = [torch.randn(1, t * up, nh, generator=g).to(DEV) for t in lens]
+        got = voc.forward_ragged(mels, ph, nz)
+        worst = 0.0
+        for j, t in enumerate(lens):
+            alone = voc.forward(mels[j][None], ph[j], nz[j])
+            assert got[j].shape == alone.shape == (1, t * up)
+            assert bool(torch.isfinite(got[j]).all())
+            d = float((got[j] - alone).abs().max())
+            worst = max(worst, d)
+            if exact:
+                assert torch.equal(got[j], alone), (j, t, d)
+            else:
+                assert d < 1e-3, (j, t, d)
+        print(f"[parity] ragged vocoder batch vs one at a time ({'wide' if wide else 'tiny'}, lens {lens}): max |d| {worst:.2e}")
+    # f0 / source / decode separately with lens == the same calls without lens on a batch of equal lengths (lens is a no-op there)
+    same = torch.stack([mels[0], mels[0].flip(0)])
+    ll = torch.tensor([lens[0], lens[0]], dtype=torch.int32, device=DEV)
+    assert torch.equal(voc.f0(same, ll), voc.f0(same))
+
+
 @pytest.mark.parametrize("b,t,ragged,wide", [(2, 57, False, False), (3, 64, True, False), (1, 33, True, False), (2, 70, True, True),
                                              (2, 64, False, True)])
 def test_flow_solver_engine_is_bit_identical_to_operator_path(b, t, ragged, wide):
