@@ -332,30 +332,48 @@ __global__ __launch_bounds__(256) void attn_mha_flash(MhaArgs a) {
     // staging coordinates.  K: key row skey (0..63), 16 dims from sd0.  V: key PAIR vkp (keys 2 vkp, 2 vkp + 1), 8 dims from
     // vd0 -- the transposed image V^T[dim][key] is written as whole dwords (two keys of one dim; a 2-byte scatter of one key
     // per thread was 8-way conflicted).  Row stride FA_VS = 68 halfs: see its definition.
-    const int skey = tid >> 2, sd0 = (tid & 3) * 16;
-    const int vkp = tid >> 3, vd0 = (tid & 7) * 8;
+    // Round 5: the staging WRITES were the kernel's bank conflicts (24.6 % of its LDS cycles, profiles/r04_pmc_flow_lds.txt; the fragment
+    // reads are conflict-free by the strides above).  K: a thread owned 16 consecutive dims of one key -- the 16 lanes of a ds_write_b128
+    // cycle then wrote rows 0..3, and 36 r mod 64 puts rows 0 and 2 on the same banks.  Now a thread writes ONE 16-byte chunk (tid & 7) of
+    // rows kr and kr + 32, and consecutive 8-lane groups take rows 0, 8, 1, 9, ...: 36 * 8 = 32 (mod 64), so the two rows of a cycle
+    // cover banks 0..31 and 32..63.  V^T: a thread owned dims 8 j .. 8 j + 7 of a key pair; the eight j of a wave landed on banks
+    // 16 j (mod 64): j and j + 4 collided.  Now it owns dims 4 j .. 4 j + 3 and 32 + 4 j .. 32 + 4 j + 3: 34 * 4 j = 8 j (mod 64), the
+    // key pairs vkp = 0..7 of a wave fill the eight banks between -- all 64 banks once per ds_write_b32.
+    const int kc8 = (tid & 7) * 8, kg = tid >> 3;
+    const int kr = (kg & 1) * 8 + ((kg >> 1) & 7) + (kg >> 4) * 16;       // 0..31, lane groups alternate between rows r and r + 8
+    const int vkp = tid >> 3, vd0 = (tid & 7) * 4;
     // Two register sets: the loads of tile j + 2 are issued while tile j is computed, so a tile's K / V rows have two tiles of
     // compute (and four barriers) to arrive -- one tile of compute (~0.5 us at T = 344) did not cover an L2 round trip, and
     // the kernel ran at the pace of its global loads (18 us for 6 tiles).
     half8 rkA[2], rvA[2], rkB[2], rvB[2];
+    auto load4h = [&](const void* base, int64_t off, half8& dst, int at) {      // 4 consecutive values -> dst[at .. at + 3]
+        if constexpr (IN16) {
+            const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const _Float16*>(base) + off);
+            dst[at] = h[0]; dst[at + 1] = h[1]; dst[at + 2] = h[2]; dst[at + 3] = h[3];
+        } else {
+            const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+            dst[at] = (_Float16)f.x; dst[at + 1] = (_Float16)f.y; dst[at + 2] = (_Float16)f.z; dst[at + 3] = (_Float16)f.w;
+        }
+    };
     auto prefetch = [&](int j0, half8 (&rk)[2], half8 (&rv)[2]) {
-        const int j = min(j0 + skey, len - 1);         // clamped; keys >= len are masked in the scores
-        const int64_t off = kb + (int64_t)j * a.ldk + sd0;
-        rk[0] = load8h<IN16>(a.k, off);
-        rk[1] = load8h<IN16>(a.k, off + 8);
+        const int ja = min(j0 + kr, len - 1), jb = min(j0 + kr + 32, len - 1);         // clamped; keys >= len are masked in the scores
+        rk[0] = load8h<IN16>(a.k, kb + (int64_t)ja * a.ldk + kc8);
+        rk[1] = load8h<IN16>(a.k, kb + (int64_t)jb * a.ldk + kc8);
         const int jv0 = min(j0 + 2 * vkp, len - 1), jv1 = min(j0 + 2 * vkp + 1, len - 1);
-        rv[0] = load8h<IN16>(a.v, kb + (int64_t)jv0 * a.ldk + vd0);
-        rv[1] = load8h<IN16>(a.v, kb + (int64_t)jv1 * a.ldk + vd0);
+        load4h(a.v, kb + (int64_t)jv0 * a.ldk + vd0, rv[0], 0);
+        load4h(a.v, kb + (int64_t)jv0 * a.ldk + 32 + vd0, rv[0], 4);
+        load4h(a.v, kb + (int64_t)jv1 * a.ldk + vd0, rv[1], 0);
+        load4h(a.v, kb + (int64_t)jv1 * a.ldk + 32 + vd0, rv[1], 4);
     };
     auto stage = [&](const half8 (&rk)[2], const half8 (&rv)[2]) {
-        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0]) = rk[0];
-        *reinterpret_cast<half8*>(&ks[skey * FA_KS + sd0 + 8]) = rk[1];
+        *reinterpret_cast<half8*>(&ks[kr * FA_KS + kc8]) = rk[0];
+        *reinterpret_cast<half8*>(&ks[(kr + 32) * FA_KS + kc8]) = rk[1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             half2v pr;
             pr[0] = rv[0][i];
             pr[1] = rv[1][i];
-            *reinterpret_cast<half2v*>(&vt[(vd0 + i) * FA_VS + 2 * vkp]) = pr;
+            *reinterpret_cast<half2v*>(&vt[((i >> 2) * 32 + vd0 + (i & 3)) * FA_VS + 2 * vkp]) = pr;
         }
     };
     auto compute_tile = [&](int j0) {

@@ -1052,7 +1052,9 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         //   1: 128x128 x2 (once there are >= 4-8 tiles per CU)   2: 128x64 x2 (wide outputs)   3: 64x64 x4 (n <= 256)
         const int64_t b128 = blocks(128, 128);
         int mode;
-        if (b128 >= (a.n >= 512 ? 2048 : 1024)) mode = 1;
+        // (deep K with enough tiles -- the kNN scan as a GEMM, K = 6144: 128 x 128 measured 727 us per 256-query search against 797 for
+        // 128 x 64 and 906 for 64 x 64, profiles/r05_knn_gemm_ab.log)
+        if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512)) mode = 1;
         else if (a.n >= 512 && blocks(128, 64) >= 160) mode = 2;
         else mode = 3;
         if (ring_env > 0) mode = ring_env;

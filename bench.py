@@ -1035,7 +1035,7 @@ def main():
         del pipe24, eng24
 
     # ---- BASELINE's other configurations, bounded, with the same protocol (every rank takes part: configs[3] / [4] are sharded jobs)
-    side, stress, extras = {}, None, {}
+    side = {}
     if not args.no_side:
         pipe = main_pipe = None
         torch.cuda.empty_cache()
@@ -1044,9 +1044,6 @@ def main():
             if rank == 0:
                 side[which] = r
             torch.cuda.empty_cache()
-        if rank == 0:
-            stress = knn_stress(args, dev, traffic_table)
-            extras = side_extras(args, dev, cfg, eng)
 
     total_audio = inp.audio_seconds * args.steps * world
     res = None
@@ -1091,13 +1088,15 @@ def main():
             "roofline_by_stage": by_stage,
             "value_24khz": v24,
             "side_workloads": side or None,
-            "knn_stress": stress,
         }
-        res.update(extras)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        # the CPU baseline at every N (rank 0, after the process group is gone: the other ranks have left, the host cores are free)
+        # rank 0 alone, after the process group is gone (no collective, the other ranks have left): the one-GPU retrieval stress, the
+        # rows next to the path (query embedder, streaming latency) and the CPU baseline -- at every N
+        if not args.no_side:
+            res["knn_stress"] = knn_stress(args, dev, traffic_table)
+            res.update(side_extras(args, dev, cfg, eng))
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, bank16, q_host, args.topk)
         emit_json(res)
