@@ -32,7 +32,6 @@ namespace astts {
 static constexpr int kWave = 64;
 static constexpr int kScanThreads = 256;
 static constexpr int kMaxQPerPass = 256;
-static constexpr int kSelTile = 2048;  // scores staged in LDS per selection tile
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -391,7 +390,7 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
     __shared__ float sh_s[kSelThreads];
     __shared__ int sh_i[kSelThreads];
     __shared__ unsigned hist[2048];
-    __shared__ int s_sel_bin, s_sel_rem, s_cnt;
+    __shared__ int s_sel_bin, s_cnt;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t plane = (size_t)qpad * nld;
     const float* base = s_part + (size_t)q * nld;
@@ -399,6 +398,23 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
     const int64_t seg0 = (int64_t)segy * seg_len;
     const int64_t n = (seg0 + seg_len < n_all) ? seg0 + seg_len : n_all;
     const int nl = (int)(n - seg0);
+    if (ksplit == 1) {
+        // one score plane (large banks, the GEMM scan): the segment's <= 8 scores of this thread (and their 1 / |b|) in ONE batch of
+        // unconditional loads (clamped index) -- as a rolled loop every score was a dependent global round trip in front of its LDS store
+        static_assert(kSelSeg == 8 * kSelThreads, "staging batch");
+        float v[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t at = seg0 + min(tid + u * kSelThreads, nl - 1);
+            v[u] = base[at];
+            w[u] = inv_norm ? inv_norm[at] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * kSelThreads;
+            if (i < nl) seg[i] = inv_norm ? v[u] * w[u] : v[u];
+        }
+    } else
     for (int i = tid; i < nl; i += kSelThreads) {
         // K-split partial planes (up to ~100 for a small bank): eight independent loads in flight per thread
         const float* pp = base + seg0 + i;
@@ -418,51 +434,74 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
     tl.init();
     bool fast = true;
     if (nl > 64) {
-        unsigned prefix = 0u, known = 0u;
-        int remaining = c < nl ? c : nl;
-#pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-            const int bins = pass == 2 ? 1024 : 2048;
-            for (int i = tid; i < bins; i += kSelThreads) hist[i] = 0u;
-            __syncthreads();
-            for (int i = tid; i < nl; i += kSelThreads) {
-                const unsigned key = sel_key(seg[i]);
-                if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
-            }
-            __syncthreads();
-            if (wid == 0) {
-                const int per = bins >> 6;
-                unsigned local = 0u;
-                for (int j = 0; j < per; ++j) local += hist[lane * per + j];
-                unsigned incl = local;                       // sum over lanes >= lane
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const unsigned tv = __shfl_down(incl, off, 64);
-                    if (lane + off < 64) incl += tv;
-                }
-                const unsigned above = incl - local;
-                if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
-                    unsigned acc = above;
-                    for (int j = per - 1; j >= 0; --j) {
-                        const unsigned hcount = hist[lane * per + j];
-                        if (acc + hcount >= (unsigned)remaining) {
-                            s_sel_bin = lane * per + j;
-                            s_sel_rem = remaining - (int)acc;
-                            break;
-                        }
-                        acc += hcount;
-                    }
-                }
-            }
-            __syncthreads();
-            prefix |= (unsigned)s_sel_bin << shift;
-            known |= (unsigned)(bins - 1) << shift;
-            remaining = s_sel_rem;
-            __syncthreads();
-        }
+        // ONE histogram pass over 2048 LINEAR bins of [min, max] of the segment (round 5).  The 3-pass radix select on the float bits
+        // that stood here put cosine scores -- a narrow band around zero on a large bank -- into a handful of bins per pass: up to 8 192
+        // LDS atomics on the same few addresses, serialised (225 us of a 740 us 256-query search against a 100k bank went into this
+        // kernel, profiles/r05_knn_q256_kernel_stats.csv).  Linear bins spread the band (a Gaussian's densest bin of 2048 over +-4 sigma
+        // holds ~13 of 8 192 scores), and only the TOP of the histogram is walked: the bin b* in which the c-th largest score falls;
+        // everything in bins >= b* is gathered (a superset of the top c: the map score -> bin is monotone) and sorted by one wave.
+        __shared__ float s_mn[kSelThreads / 64], s_mx[kSelThreads / 64];
+        float mn = INFINITY, mx = -INFINITY;
         for (int i = tid; i < nl; i += kSelThreads) {
-            if (sel_key(seg[i]) >= prefix) {
+            const float v = seg[i];
+            if (v > -INFINITY && v < INFINITY) {
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        if (lane == 0) {
+            s_mn[wid] = mn;
+            s_mx[wid] = mx;
+        }
+        for (int i = tid; i < 2048; i += kSelThreads) hist[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kSelThreads / 64; ++w) {
+            mn = fminf(mn, s_mn[w]);
+            mx = fmaxf(mx, s_mx[w]);
+        }
+        const float bscale = mx > mn ? 2047.0f / (mx - mn) : 0.0f;
+        auto bin_of = [&](float v) -> int {
+            if (!(v > -INFINITY)) return 0;
+            if (!(v < INFINITY)) return 2047;
+            const int bq = (int)((v - mn) * bscale);                      // monotone in v (fp subtraction, product, truncation all are)
+            return bq < 0 ? 0 : (bq > 2047 ? 2047 : bq);
+        };
+        const int remaining = c < nl ? c : nl;
+        for (int i = tid; i < nl; i += kSelThreads) atomicAdd(&hist[bin_of(seg[i])], 1u);
+        __syncthreads();
+        if (wid == 0) {
+            constexpr int per = 32;                          // 2048 bins / 64 lanes
+            unsigned local = 0u;
+            for (int j = 0; j < per; ++j) local += hist[lane * per + j];
+            unsigned incl = local;                           // sum over lanes >= lane
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned tv = __shfl_down(incl, off, 64);
+                if (lane + off < 64) incl += tv;
+            }
+            const unsigned above = incl - local;
+            if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
+                unsigned acc = above;
+                for (int j = per - 1; j >= 0; --j) {
+                    const unsigned hcount = hist[lane * per + j];
+                    if (acc + hcount >= (unsigned)remaining) {
+                        s_sel_bin = lane * per + j;
+                        break;
+                    }
+                    acc += hcount;
+                }
+            }
+        }
+        __syncthreads();
+        const int bstar = s_sel_bin;
+        for (int i = tid; i < nl; i += kSelThreads) {
+            if (bin_of(seg[i]) >= bstar) {
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < 64) {
                     sh_s[pos] = seg[i];

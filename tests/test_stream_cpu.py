@@ -81,3 +81,42 @@ def test_mel_crossfade_arithmetic():
     assert torch.equal(seen[1][:, :c.mel_cache], m0[:, :-L][:, -c.mel_cache:])
     assert torch.allclose(seen[1][:, c.mel_cache:c.mel_cache + L], head, atol=1e-6)
     assert torch.equal(seen[1][:, c.mel_cache + L:], m1[:, L:-L])
+
+
+class _GrowingTokens:
+    """A token source as `stream_render` takes it in place of a finished tensor (the LM still decoding: compat.cosyvoice._LmTokenStream):
+    tokens become available `grow` at a time; `wait(n)` returns what exists once at least n do (or everything, finished)."""
+
+    def __init__(self, tokens, grow):
+        self.tokens, self.grow, self.have, self.calls = tokens, grow, 0, []
+
+    def wait(self, n):
+        while self.have < min(n, self.tokens.numel()):
+            self.have = min(self.have + self.grow, self.tokens.numel())
+        self.calls.append((n, self.have))
+        return self.tokens[:self.have].clone(), self.have == self.tokens.numel()
+
+
+def test_live_token_source_yields_the_chunks_of_the_finished_sequence():
+    """Whatever the pace at which tokens arrive (1, 7, 100, 120, 1000 at a time), the chunks equal those cut from the finished sequence,
+    for lengths around every boundary of the schedule (hop + overlap = 120, 220, 320 ...), and the first chunk is cut as soon as
+    120 tokens exist -- not when the sequence is complete."""
+    cfg = SynthConfig()
+    c = StreamConsts.for_config(cfg)
+    for n in (1, 80, 119, 120, 121, 219, 220, 221, 330, 600):
+        toks = torch.arange(n)
+        log = []
+        fm, f0, src, voc = _stages(cfg, log)
+        ref = list(stream_render(toks, c, fm, f0, src, voc))
+        ref_log = list(log)
+        for grow in (1, 7, 100, 120, 1000):
+            log.clear()
+            s = _GrowingTokens(toks, grow)
+            it = stream_render(s, c, fm, f0, src, voc)
+            first = next(it)
+            if n >= 120:
+                assert s.have < n or n <= 120 + grow, (n, grow, s.have)         # the first chunk did not wait for the end
+                assert s.calls[0][0] == 120
+            got = [first] + list(it)
+            assert log == ref_log, (n, grow)
+            assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref)), (n, grow)
