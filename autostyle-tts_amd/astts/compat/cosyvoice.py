@@ -156,6 +156,9 @@ class CosyVoice:
         self.stream_lm_live = os.environ.get("ASTTS_STREAM_LM_LIVE", "1") != "0"
         # ragged batches: the whole render group in one vocoder pass (False: one pass per row)
         self.vocoder_batched = os.environ.get("ASTTS_VOCODER_BATCHED", "1") != "0"
+        # measurement only (bench.py): HIP events around the LM decode of every job and the flow / vocoder passes of every render group
+        self.collect_stage_times = False
+        self._stage_events = []
 
     # ------------------------------------------------------------------ one text segment
     @staticmethod
@@ -365,7 +368,10 @@ class CosyVoice:
                     ft[j, :max_len[j]] = forced[i][:max_len[j]].to(torch.int32)
                 ft = ft.to(dev)
             eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
-            toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft).cpu()   # one sync per job (this thread's stream)
+            ev0 = self._stage_mark()
+            toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft)
+            self._stage_mark("lm", ev0)
+            toks = toks.cpu()                                                      # one sync per job (this thread's stream)
             gen = []
             for j in range(b):
                 row = toks[j, :max_len[j]]
@@ -389,13 +395,16 @@ class CosyVoice:
                 pmels.append(fp.mel[0])
                 zs.append(z[0])
                 dr.append((phase0, noise))
+            ev0 = self._stage_mark()
             mels = eng.flow.decode_ragged(all_tok, pmels, torch.cat([requests[i][3].spk_embedding for i in idxs], 0), zs)
+            ev0 = self._stage_mark("flow", ev0)
             if self.vocoder_batched and len(idxs) > 1:
                 # ONE vocoder pass over the ragged group: every convolution / STFT / iSTFT reads a row as a sequence of its own length
                 # (HiftVocoder.forward_ragged); each waveform equals the row vocoded alone (tests/test_synth_gpu.py)
                 wavs = eng.hift.forward_ragged(mels, [dr[j][0] for j in range(len(idxs))], [dr[j][1].to(dev) for j in range(len(idxs))])
             else:                       # one pass per row (rounds 1-4: ~250 launches each; kept as the second implementation)
                 wavs = [eng.hift.forward(mels[j][None], dr[j][0].to(dev), dr[j][1].to(dev)) for j in range(len(idxs))]
+            self._stage_mark("vocoder", ev0)
             for j, i in enumerate(idxs):                                                      # every row enqueued before the first copy waits for the GPU
                 out[i] = wavs[j].cpu()
                 self.last_tokens[i] = gen_tokens[i]
@@ -460,6 +469,26 @@ class CosyVoice:
                 th.join()
             for st in list(self._lm_streams) + [rs]:
                 cur.wait_stream(st)
+        return out
+
+    def _stage_mark(self, name: Optional[str] = None, since=None):
+        """``collect_stage_times``: an event on the current stream; with ``name`` the span since ``since`` is booked under it."""
+        if not self.collect_stage_times:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if name is not None and since is not None:
+            self._stage_events.append((name, since, ev))          # list.append is atomic: LM workers and the render thread share it
+        return ev
+
+    def stage_seconds(self) -> Dict[str, float]:
+        """Stream-seconds per stage since the last call (``collect_stage_times``): the LM jobs run on two streams beside the render
+        stream, so the three figures overlap in wall time and may sum to more than it."""
+        torch.cuda.synchronize(self.device)
+        out: Dict[str, float] = {}
+        for name, a, b in self._stage_events:
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b) / 1e3
+        self._stage_events = []
         return out
 
     def make_draws(self, n_tokens: int, prompt_mel_frames: int, seed: int):

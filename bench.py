@@ -511,6 +511,7 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
             last["ok"] = all(bool(torch.isfinite(o[0]["tts_speech"]).all()) for o in outs)
 
         def step():
+            cv._stage_events = []              # keep the LAST timed pass's stage events only
             idx, _ = parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
             last["ids"] = idx
             run_rows(range(len(items)))
@@ -519,7 +520,13 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
             parallel.sharded_search(lambda qq, kk: sb.search_device(qq, kk)[:2], q_all, args.topk, dist)
             run_rows(range(0, len(items), 8))
 
+        cv.collect_stage_times = True
         dt = timed(step, warm if steps <= 1 else None)
+        st_s = cv.stage_seconds()          # the last timed pass; booked per stream
+        cv.collect_stage_times = False
+        extra["stage_stream_seconds"] = {k: round(v, 3) for k, v in st_s.items()}
+        extra["stage_note"] = ("HIP events around every LM job's decode (two worker streams) and every render group's flow / vocoder pass (render stream), "
+                               "summed per stage over the last timed pass: the streams overlap in wall time, the sums exceed it")
         a = torch.tensor([last["audio"]], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(a)
