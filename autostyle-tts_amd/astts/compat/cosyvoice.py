@@ -306,11 +306,13 @@ class CosyVoice:
 
         Schedule (the reference loops one utterance at a time, tts_with_rag.py:172-197; rows are independent):
           * rows are sorted by length (``bucket``) and cut into render groups of ``max_batch`` rows, each made of LM jobs of <= 32 rows;
-          * the LM jobs -- latency-bound launch chains that leave most of the chip idle -- run on TWO worker threads with their own
-            streams, longest job first (a 1 500-step job of long rows beside all the short ones), each decoding only as far as its
-            own longest row;
-          * the calling thread renders (flow matching + vocoder) every group as soon as its tokens are there, in the order the jobs
-            are expected to finish: the render stage of one group overlaps the decode chains of the next.
+          * the LM jobs -- latency-bound launch chains that leave most of the chip idle -- run on up to THREE worker threads with
+            their own streams (one per command-processor pipe), each decoding only as far as its own longest row; the workers take
+            jobs from one list sorted by length: all but the last the LONGEST remaining one, the last the SHORTEST (the render stage
+            then has work from the first moments, and all streams run dry together);
+          * the calling thread renders (flow matching + ONE vocoder pass per group) every group as soon as its tokens are there, in
+            the order the jobs complete, and copies the results to the host asynchronously: the render stage of one group overlaps
+            the decode chains of the next.
         Every request draws from its OWN random stream (``draws``; by default one ``torch.Generator`` per request seeded from the
         instance generator in request order), so the result does not depend on the schedule.
 
@@ -324,7 +326,6 @@ class CosyVoice:
           ``forced[i]``        teacher forcing: int tokens [n] that replace the sampled ones.
         The tokens and mels of the last call stay in ``self.last_tokens`` / ``self.last_mels`` (CPU)."""
         import threading
-        from concurrent.futures import Future
 
         cfg, dev, eng = self.cfg, self.device, self.engine
         n_req = len(requests)
@@ -380,6 +381,8 @@ class CosyVoice:
                 gen.append(row[:max(n, 1)].to(torch.int32))
             return gen
 
+        copies_done = []
+
         def render(idxs, gen_tokens):
             all_tok, pmels, zs, dr = [], [], [], []
             for i in idxs:
@@ -405,28 +408,49 @@ class CosyVoice:
             else:                       # one pass per row (rounds 1-4: ~250 launches each; kept as the second implementation)
                 wavs = [eng.hift.forward(mels[j][None], dr[j][0].to(dev), dr[j][1].to(dev)) for j in range(len(idxs))]
             self._stage_mark("vocoder", ev0)
-            for j, i in enumerate(idxs):                                                      # every row enqueued before the first copy waits for the GPU
-                out[i] = wavs[j].cpu()
+            # results go to the host ASYNCHRONOUSLY (one pinned staging buffer per group, views handed out; one event per group, waited
+            # for at the end of the call): a blocking copy per row kept this thread from preparing the next group while the GPU worked
+            # on this one -- the render stream idled for the host between groups
+            n_w = [int(w.numel()) for w in wavs]
+            n_m = [int(m.numel()) for m in mels]
+            stage_w = torch.empty(sum(n_w), dtype=torch.float32, pin_memory=True)
+            stage_m = torch.empty(sum(n_m), dtype=torch.float32, pin_memory=True)
+            ow = om = 0
+            for j, i in enumerate(idxs):
+                stage_w[ow:ow + n_w[j]].copy_(wavs[j].reshape(-1), non_blocking=True)
+                stage_m[om:om + n_m[j]].copy_(mels[j].reshape(-1), non_blocking=True)
+                out[i] = stage_w[ow:ow + n_w[j]].view(1, -1)
                 self.last_tokens[i] = gen_tokens[i]
-                self.last_mels[i] = mels[j].cpu()
+                self.last_mels[i] = stage_m[om:om + n_m[j]].view(mels[j].shape)
+                ow += n_w[j]
+                om += n_m[j]
+            ev = torch.cuda.Event()
+            ev.record()
+            copies_done.append((ev, wavs, mels))          # (the device tensors stay alive until their copies have landed)
 
         if len(jobs) == 1:                      # one job: nothing to overlap
             render(rgroups[0], dict(zip(jobs[0][1], lm_stage(jobs[0][1]))))
+            for ev, _, _ in copies_done:
+                ev.synchronize()
             return out
-        # static schedule of the LM jobs over the two workers (longest first, onto the less loaded one): deterministic, and it gives
-        # the order in which the render groups can expect their tokens
+        # Schedule of the LM jobs (round 5).  The jobs are taken from ONE list sorted by cost (decode steps of the job's longest row): all
+        # workers but the last take the LONGEST remaining job, the last worker the SHORTEST.  Rounds 3-4 ran every worker longest-first
+        # on a static assignment: the first tokens then arrive when the first 1 500-step job ends -- the render stream idled for the
+        # first ~3 s of a config-4 pass and the decode streams idled at the end while it caught up (LM 12.9 s per stream, render 12 s,
+        # wall 17.1 s).  With a short-first worker the render stage has groups to work on from the first 0.1 s, the long groups arrive
+        # in between, and the two ends of the list meet in the middle: every stream runs out of work at about the same time.  Render
+        # groups are rendered in the order they COMPLETE.  (A request's randomness is its own, so the schedule does not show in the
+        # results: tests/test_cli_gpu.py::test_batch_surface_does_not_depend_on_its_schedule.)
+        import queue
         cost = [max(want[i] for i in idxs) for _, idxs in jobs]
-        nw = max(1, min(int(os.environ.get("ASTTS_RAGGED_LM_WORKERS", "2")), 3, len(jobs)))
-        loads, assign, fin = [0] * nw, [[] for _ in range(nw)], [0] * len(jobs)
-        for j in sorted(range(len(jobs)), key=lambda j: (-cost[j], j)):
-            w = loads.index(min(loads))
-            assign[w].append(j)
-            loads[w] += cost[j]
-            fin[j] = loads[w]
-        futs = [Future() for _ in jobs]
+        nw = max(1, min(int(os.environ.get("ASTTS_RAGGED_LM_WORKERS", "3")), 3, len(jobs)))
+        pool = sorted(range(len(jobs)), key=lambda j: (-cost[j], j))          # longest first
+        pool_lock = threading.Lock()
+        short_first = os.environ.get("ASTTS_RAGGED_SHORT_WORKER", "1") != "0"
+        done_q: "queue.Queue" = queue.Queue()
         if getattr(self, "_lm_streams", None) is None:
             # one stream per command-processor pipe, found by measurement (launch chains whose queues share a pipe take turns at every
-            # kernel boundary: synth/model.py, PipelinedSynth): render, then the two decode workers
+            # kernel boundary: synth/model.py, PipelinedSynth): render, then the decode workers
             from .. import ops
             firsts = [c[0] for c in ops.stream_pipe_classes(device=dev)]
             if len(firsts) >= 4:
@@ -439,15 +463,24 @@ class CosyVoice:
         cur = torch.cuda.current_stream(dev)
         rs = self._render_stream_b
 
+        def take(w):
+            with pool_lock:
+                if not pool:
+                    return None
+                return pool.pop() if (short_first and nw > 1 and w == nw - 1) else pool.pop(0)
+
         def worker(w):
             try:
                 with torch.cuda.device(dev), torch.cuda.stream(self._lm_streams[w]):
-                    for j in assign[w]:
-                        futs[j].set_result(lm_stage(jobs[j][1]))
+                    while True:
+                        j = take(w)
+                        if j is None:
+                            break
+                        done_q.put((j, lm_stage(jobs[j][1]), None))
             except BaseException as e:          # noqa: BLE001  (re-raised on the calling thread)
-                for j in assign[w]:
-                    if not futs[j].done():
-                        futs[j].set_exception(e)
+                with pool_lock:
+                    pool.clear()
+                done_q.put((-1, None, e))
 
         threads = []
         for w in range(nw):
@@ -455,20 +488,33 @@ class CosyVoice:
             threads.append(threading.Thread(target=worker, args=(w,)))
             threads[-1].start()
         try:
-            gfin = [max(fin[j] for j, (gj, _) in enumerate(jobs) if gj == gi) for gi in range(len(rgroups))]
             rs.wait_stream(cur)
+            if os.environ.get("ASTTS_RAGGED_EXCLUSIVE") == "1":       # experiment: every LM job first, then every render group
+                for th in threads:
+                    th.join()
+            need = [sum(1 for gj, _ in jobs if gj == gi) for gi in range(len(rgroups))]      # LM jobs per render group
+            toks_of = [dict() for _ in rgroups]
+            left = len(jobs)
             with torch.cuda.stream(rs):
-                for gi in sorted(range(len(rgroups)), key=lambda gi: (gfin[gi], gi)):
-                    toks = {}
-                    for j, (gj, idxs) in enumerate(jobs):
-                        if gj == gi:
-                            toks.update(zip(idxs, futs[j].result()))
-                    render(rgroups[gi], toks)
+                while left:
+                    j, gen, err = done_q.get()
+                    if err is not None:
+                        raise err
+                    left -= 1
+                    gi = jobs[j][0]
+                    toks_of[gi].update(zip(jobs[j][1], gen))
+                    need[gi] -= 1
+                    if need[gi] == 0:
+                        render(rgroups[gi], toks_of[gi])
         finally:
+            with pool_lock:
+                pool.clear()                    # (an error on this thread: the workers stop after their current job)
             for th in threads:
                 th.join()
             for st in list(self._lm_streams) + [rs]:
                 cur.wait_stream(st)
+        for ev, _, _ in copies_done:            # every waveform / mel has landed in its host buffer
+            ev.synchronize()
         return out
 
     def _stage_mark(self, name: Optional[str] = None, since=None):

@@ -307,7 +307,8 @@ def test_stream_true_live_decode_yields_the_chunks_of_the_one_pass_form(cosy):
 def test_stream_true_first_chunk_arrives_while_the_lm_still_decodes():
     """Time to the first yielded chunk at the CosyVoice-300M widths: upstream's schedule needs hop + look-ahead = 120 tokens before
     chunk 0, so 120 / n of the decode is the floor; the one-pass form (decode to the end, then chunk) pays the whole decode first.
-    250-token segment: first chunk before 65 % of the segment's wall time AND earlier than the one-pass form's; 500 tokens: before 40 %."""
+    250-token segment: first chunk before 70 % of the segment's wall time (observed 0.55-0.57) AND earlier than the one-pass form's; 500
+    tokens: before 45 % (observed 0.36)."""
     import time
     import warnings
 
@@ -329,14 +330,14 @@ def test_stream_true_first_chunk_arrives_while_the_lm_still_decodes():
             first = first if first is not None else time.perf_counter() - t0
         return first, time.perf_counter() - t0
 
-    for n_tok, bar in ((250, 0.65), (500, 0.40)):
+    for n_tok, bar in ((250, 0.70), (500, 0.45)):
         run(True, n_tok), run(False, n_tok)                                # warm-up
         live = min((run(True, n_tok) for _ in range(3)), key=lambda r: r[0])
         once = min((run(False, n_tok) for _ in range(3)), key=lambda r: r[0])
         print(f"[stream] {n_tok} tokens: first chunk {live[0] * 1e3:.1f} ms of {live[1] * 1e3:.1f} ms ({live[0] / live[1]:.2f}); "
               f"one-pass form {once[0] * 1e3:.1f} of {once[1] * 1e3:.1f} ms")
-        assert live[0] / live[1] <= bar, (n_tok, live)
-        assert live[0] < 0.8 * once[0], (n_tok, live, once)
+        assert live[0] / live[1] <= bar, (n_tok, live, once)
+        assert live[0] < 0.9 * once[0], (n_tok, live, once)
 
 
 def test_cosyvoice_from_a_checkpoint_directory_with_its_json_config(tmp_path):
