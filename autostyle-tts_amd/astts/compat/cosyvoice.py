@@ -159,6 +159,7 @@ class CosyVoice:
         # measurement only (bench.py): HIP events around the LM decode of every job and the flow / vocoder passes of every render group
         self.collect_stage_times = False
         self._stage_events = []
+        self._host_times = []
 
     # ------------------------------------------------------------------ one text segment
     @staticmethod
@@ -326,8 +327,10 @@ class CosyVoice:
           ``forced[i]``        teacher forcing: int tokens [n] that replace the sampled ones.
         The tokens and mels of the last call stay in ``self.last_tokens`` / ``self.last_mels`` (CPU)."""
         import threading
+        import time
 
         cfg, dev, eng = self.cfg, self.device, self.engine
+        t_entry = time.perf_counter()
         n_req = len(requests)
         out = [None] * n_req
         self.last_tokens, self.last_mels = [None] * n_req, [None] * n_req
@@ -343,6 +346,7 @@ class CosyVoice:
         jobs = [(gi, g[c0:c0 + 32]) for gi, g in enumerate(rgroups) for c0 in range(0, len(g), 32)]        # (render group, request indices)
 
         def lm_stage(idxs):
+            tj0 = time.perf_counter()
             grp = [requests[i] for i in idxs]
             b = len(grp)
             pre, ks = eng.lm.prefix_ragged([r[0].view(-1) for r in grp], torch.cat([r[2].spk_embedding for r in grp], 0),
@@ -370,9 +374,15 @@ class CosyVoice:
                 ft = ft.to(dev)
             eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
             ev0 = self._stage_mark()
+            th0 = time.perf_counter()
             toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft)
             self._stage_mark("lm", ev0)
+            th1 = time.perf_counter()
             toks = toks.cpu()                                                      # one sync per job (this thread's stream)
+            if self.collect_stage_times:
+                self._host_times.append(("lm_job_prepare", th0 - tj0))
+                self._host_times.append(("lm_job_enqueue", th1 - th0))
+                self._host_times.append(("lm_job_wait", time.perf_counter() - th1))
             gen = []
             for j in range(b):
                 row = toks[j, :max_len[j]]
@@ -384,6 +394,7 @@ class CosyVoice:
         copies_done = []
 
         def render(idxs, gen_tokens):
+            tr0 = time.perf_counter()
             all_tok, pmels, zs, dr = [], [], [], []
             for i in idxs:
                 fp = requests[i][3]
@@ -427,6 +438,8 @@ class CosyVoice:
             ev = torch.cuda.Event()
             ev.record()
             copies_done.append((ev, wavs, mels))          # (the device tensors stay alive until their copies have landed)
+            if self.collect_stage_times:
+                self._host_times.append(("render_group_host", time.perf_counter() - tr0))
 
         if len(jobs) == 1:                      # one job: nothing to overlap
             render(rgroups[0], dict(zip(jobs[0][1], lm_stage(jobs[0][1]))))
@@ -513,8 +526,12 @@ class CosyVoice:
                 th.join()
             for st in list(self._lm_streams) + [rs]:
                 cur.wait_stream(st)
+        t_sync = time.perf_counter()
         for ev, _, _ in copies_done:            # every waveform / mel has landed in its host buffer
             ev.synchronize()
+        if self.collect_stage_times:
+            self._host_times.append(("final_copy_wait", time.perf_counter() - t_sync))
+            self._host_times.append(("synthesize_batch_wall", time.perf_counter() - t_entry))
         return out
 
     def _stage_mark(self, name: Optional[str] = None, since=None):
@@ -534,7 +551,9 @@ class CosyVoice:
         out: Dict[str, float] = {}
         for name, a, b in self._stage_events:
             out[name] = out.get(name, 0.0) + a.elapsed_time(b) / 1e3
-        self._stage_events = []
+        for name, dt in self._host_times:                      # host-side wall seconds (thread-seconds for the per-job items)
+            out["host_" + name] = out.get("host_" + name, 0.0) + dt
+        self._stage_events, self._host_times = [], []
         return out
 
     def make_draws(self, n_tokens: int, prompt_mel_frames: int, seed: int):
@@ -556,6 +575,8 @@ class CosyVoice:
         line up with the items) go to ``synthesize_batch``; the prompts of an item are featurised once per distinct tensor.
         ``seeds``: one integer per item -- segment k of item i then draws from ``segment_generator(seeds[i], k)``, exactly what
         ``inference_tts_with_st(..., seed=seeds[i])`` draws for it: an item's randomness is its own, whatever batch or rank it is in."""
+        import time
+        t_build = time.perf_counter()
         fe = self.frontend
         reqs, owner = [], []
         gens = [] if seeds is not None else None
@@ -582,6 +603,9 @@ class CosyVoice:
             controls["draws"] = gens
         if isinstance(controls.get("fixed_tokens"), int):        # one length for every text segment (throughput runs: SURVEY.md 7)
             controls["fixed_tokens"] = [controls["fixed_tokens"]] * len(reqs)
+        if self.collect_stage_times:
+            import time
+            self._host_times.append(("build_requests", time.perf_counter() - t_build))
         wavs = self.synthesize_batch(reqs, max_batch, **controls)
         out = [[] for _ in items]
         for k, w in zip(owner, wavs):
