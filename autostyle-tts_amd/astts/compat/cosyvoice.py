@@ -156,6 +156,12 @@ class CosyVoice:
         self.stream_lm_live = os.environ.get("ASTTS_STREAM_LM_LIVE", "1") != "0"
         # ragged batches: the whole render group in one vocoder pass (False: one pass per row)
         self.vocoder_batched = os.environ.get("ASTTS_VOCODER_BATCHED", "1") != "0"
+        # ragged batches: rows per LM job.  32 = the decode-step kernels, whose rows do not depend on the batch width (a row's audio is then
+        # the same in every batch, rank and schedule).  Throughput runs may set ``wide_lm`` and up to 256 rows: one chain of plain GEMMs
+        # per job (the weights are read once per token for all rows) -- the same arithmetic in another summation order, so a row's tokens
+        # may differ from its 32-row run at near-ties of the sampler.
+        self.wide_lm = os.environ.get("ASTTS_WIDE_LM", "0") == "1"
+        self.lm_rows = int(os.environ.get("ASTTS_LM_ROWS", "128" if self.wide_lm else "32"))
         # measurement only (bench.py): HIP events around the LM decode of every job and the flow / vocoder passes of every render group
         self.collect_stage_times = False
         self._stage_events = []
@@ -306,7 +312,8 @@ class CosyVoice:
         path produces for that segment up to sampling draws.
 
         Schedule (the reference loops one utterance at a time, tts_with_rag.py:172-197; rows are independent):
-          * rows are sorted by length (``bucket``) and cut into render groups of ``max_batch`` rows, each made of LM jobs of <= 32 rows;
+          * rows are sorted by length (``bucket``) and cut into render groups of ``max_batch`` rows and into LM jobs of ``self.lm_rows``
+            rows (32; up to 256 with ``self.wide_lm``);
           * the LM jobs -- latency-bound launch chains that leave most of the chip idle -- run on up to THREE worker threads with
             their own streams (one per command-processor pipe), each decoding only as far as its own longest row; the workers take
             jobs from one list sorted by length: all but the last the LONGEST remaining one, the last the SHORTEST (the render stage
@@ -343,7 +350,12 @@ class CosyVoice:
         want = [int(fixed_tokens[i]) if fixed_tokens is not None else self.max_token_text_ratio * requests[i][1] for i in range(n_req)]
         order = sorted(range(n_req), key=lambda i: -want[i]) if bucket else list(range(n_req))
         rgroups = [order[g0:g0 + max_batch] for g0 in range(0, n_req, max_batch)]
-        jobs = [(gi, g[c0:c0 + 32]) for gi, g in enumerate(rgroups) for c0 in range(0, len(g), 32)]        # (render group, request indices)
+        # LM jobs: consecutive rows of the sorted order, ``self.lm_rows`` at a time (32: the decode-step kernels; up to 256 with
+        # ``wide_lm``: ONE chain of plain GEMMs for all rows, AcousticLM.decode(wide=True)).  A job may span several render groups and a
+        # render group several jobs: a group is rendered once every job that holds one of its rows is done.
+        lm_rows = max(1, min(int(self.lm_rows), 256 if self.wide_lm else 32))
+        jobs = [(None, order[c0:c0 + lm_rows]) for c0 in range(0, n_req, lm_rows)]                # (unused, request indices)
+        group_of = {i: gi for gi, g in enumerate(rgroups) for i in g}
 
         def lm_stage(idxs):
             tj0 = time.perf_counter()
@@ -375,7 +387,7 @@ class CosyVoice:
             eos_min = torch.tensor(min_len, dtype=torch.int32, device=dev)
             ev0 = self._stage_mark()
             th0 = time.perf_counter()
-            toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft)
+            toks = eng.lm.decode(pre, n_steps, u.to(dev), ignore_eos=eos_min, key_start=ks, forced_tokens=ft, wide=self.wide_lm)
             self._stage_mark("lm", ev0)
             th1 = time.perf_counter()
             toks = toks.cpu()                                                      # one sync per job (this thread's stream)
@@ -442,7 +454,9 @@ class CosyVoice:
                 self._host_times.append(("render_group_host", time.perf_counter() - tr0))
 
         if len(jobs) == 1:                      # one job: nothing to overlap
-            render(rgroups[0], dict(zip(jobs[0][1], lm_stage(jobs[0][1]))))
+            toks1 = dict(zip(jobs[0][1], lm_stage(jobs[0][1])))
+            for g in rgroups:
+                render(g, toks1)
             for ev, _, _ in copies_done:
                 ev.synchronize()
             return out
@@ -505,8 +519,8 @@ class CosyVoice:
             if os.environ.get("ASTTS_RAGGED_EXCLUSIVE") == "1":       # experiment: every LM job first, then every render group
                 for th in threads:
                     th.join()
-            need = [sum(1 for gj, _ in jobs if gj == gi) for gi in range(len(rgroups))]      # LM jobs per render group
-            toks_of = [dict() for _ in rgroups]
+            need = [len(g) for g in rgroups]                   # rows of each render group whose tokens are still missing
+            toks_all = {}
             left = len(jobs)
             with torch.cuda.stream(rs):
                 while left:
@@ -514,11 +528,15 @@ class CosyVoice:
                     if err is not None:
                         raise err
                     left -= 1
-                    gi = jobs[j][0]
-                    toks_of[gi].update(zip(jobs[j][1], gen))
-                    need[gi] -= 1
-                    if need[gi] == 0:
-                        render(rgroups[gi], toks_of[gi])
+                    toks_all.update(zip(jobs[j][1], gen))
+                    ready = []
+                    for i in jobs[j][1]:
+                        gi = group_of[i]
+                        need[gi] -= 1
+                        if need[gi] == 0:
+                            ready.append(gi)
+                    for gi in ready:
+                        render(rgroups[gi], toks_all)
         finally:
             with pool_lock:
                 pool.clear()                    # (an error on this thread: the workers stop after their current job)

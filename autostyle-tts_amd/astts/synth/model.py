@@ -350,14 +350,20 @@ class AcousticLM:
                       key_start: Optional[torch.Tensor] = None):
         return self.decode_prefilled(self.prefill(prefix, n_steps, key_start), uniforms, ignore_eos, forced_tokens, return_logits)
 
+    WIDE_ROWS = 256      # ASTTS_LM_MAX_ROWS: rows of one wide-engine call
+
     def decode(self, prefix: torch.Tensor, n_steps: int, uniforms: torch.Tensor, ignore_eos: bool = True,
                forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, use_engine: bool = True,
-               key_start: Optional[torch.Tensor] = None, group_steps: Optional[List[int]] = None):
+               key_start: Optional[torch.Tensor] = None, group_steps: Optional[List[int]] = None, wide: bool = False):
         """Fixed-length autoregressive decode, no host synchronisation inside the loop.
-        prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1])."""
+        prefix: [S0, B, d]; uniforms [n_steps, B, 2] -> tokens int32 [B, n_steps] (+ logits [B, n_steps, V+1]).
+        ``wide`` (throughput runs): batches of 33 .. 256 rows go through ONE chain of plain GEMMs per projection (the engine's wide
+        path: the weights are read once per token for all rows) instead of 32-row groups on two streams.  Same fp16 products with fp32
+        accumulation, another summation order: a row's tokens then need not equal its <= 32-row run bit for bit (the default keeps the
+        groups, whose rows do)."""
         cfg = self.cfg
         s0, b = prefix.shape[0], prefix.shape[1]
-        if use_engine and b <= 32:
+        if use_engine and (b <= 32 or (wide and b <= self.WIDE_ROWS)):
             return self.decode_engine(prefix, n_steps, uniforms, ignore_eos, forced_tokens, return_logits, key_start)
         if use_engine:
             # larger batches (BASELINE config 3: 64 long-form utterances): independent rows, decoded in groups of 32.  The
@@ -922,18 +928,18 @@ class SynthEngine:
             self.hift = HiftVocoder(state["hift"], cfg, self.device)
 
     def tts(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int, uniforms, flow_prompt_tokens, flow_prompt_mel,
-            flow_spk, z, phase0, noise, forced_tokens=None):
+            flow_spk, z, phase0, noise, forced_tokens=None, wide: bool = False):
         """One fixed-length batch end to end (all inputs on the GPU):
         LM decode (style-conditioned) -> flow (timbre-conditioned) -> vocoder.  Returns
         (tokens [B, n_tokens], mel [B, Tm, 80], wav [B, 256*Tm])."""
-        toks = self.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, forced_tokens)
+        toks = self.tts_tokens(text, text_lens, lm_spk, lm_prompt_tokens, n_tokens, uniforms, forced_tokens, wide)
         mel, wav = self.tts_render(toks, flow_prompt_tokens, flow_prompt_mel, flow_spk, z, phase0, noise)
         return toks, mel, wav
 
     # the two halves of tts(): the latency-bound autoregressive stage and the throughput-bound rendering stage
-    def tts_tokens(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int, uniforms, forced_tokens=None) -> torch.Tensor:
+    def tts_tokens(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int, uniforms, forced_tokens=None, wide: bool = False) -> torch.Tensor:
         pre = self.lm.prefix(text, text_lens, lm_spk, lm_prompt_tokens)
-        return self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens)
+        return self.lm.decode(pre, n_tokens, uniforms, ignore_eos=True, forced_tokens=forced_tokens, wide=wide)
 
     # the same in two halves (<= 32 rows): what precedes the first sampled token, and the decode steps (PipelinedSynth)
     def tts_prefill(self, text, text_lens, lm_spk, lm_prompt_tokens, n_tokens: int):
@@ -977,7 +983,7 @@ class PipelinedSynth:
 
     def __init__(self, engine: "SynthEngine", lm_depth: int = 2, lm_priority: int = -1, render_priority: int = 0, streams=None,
                  cobatch: int = 1, render_depth: int = 1, pipe_classes=None, front_prefill: Optional[bool] = None,
-                 stagger_ms: Optional[float] = None):
+                 stagger_ms: Optional[float] = None, wide_lm: bool = False):
         import os
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
@@ -1032,6 +1038,10 @@ class PipelinedSynth:
         self._fifo = deque()
         self._pending = []                  # batches waiting for their (co-batched) LM stage to be launched
         self.cobatch = max(1, int(cobatch))
+        # ``wide_lm`` (throughput runs): LM stages of more than 32 rows decode as ONE chain on the engine's wide path (plain GEMMs, the
+        # weights read once per token for all rows) instead of 32-row groups; see AcousticLM.decode
+        self.wide_lm = bool(wide_lm)
+        self.lm_rows_max = AcousticLM.WIDE_ROWS if self.wide_lm else 32
         self.front_prefill = (os.environ.get("ASTTS_PIPE_FRONT_PREFILL", "1") != "0") if front_prefill is None else bool(front_prefill)
         self.stagger_ms = float(os.environ.get("ASTTS_PIPE_STAGGER_MS", "0")) if stagger_ms is None else float(stagger_ms)
         self._staggered = set()
@@ -1039,7 +1049,7 @@ class PipelinedSynth:
 
     @classmethod
     def autotune(cls, engine: "SynthEngine", sample_args, depths=(3, 2), trials: int = 3, steps: int = 4, verbose: bool = False,
-                 front=None, dist=None):
+                 front=None, dist=None, wide_lm: bool = False):
         """Build the pipeline by measurement.  How well the chains overlap depends on which hardware queues HIP hands the
         streams (it multiplexes streams onto a few queues in an order the caller cannot see; a chain that shares a queue
         with another busy stream, or with the stream the caller enqueues its own work on, stalls the hand-over events).
@@ -1062,7 +1072,7 @@ class PipelinedSynth:
             for _ in range(trials):
                 lm_prio = int(os.environ.get("ASTTS_PIPE_LM_PRIORITY", "0"))      # experiments: -1 = high-priority decode streams
                 pipe = cls(engine, lm_depth=depth, lm_priority=lm_prio, render_priority=0, cobatch=cob, render_depth=rdep,
-                           pipe_classes=classes if rdep == 1 and lm_prio == 0 else None)
+                           pipe_classes=classes if rdep == 1 and lm_prio == 0 else None, wide_lm=wide_lm)
                 with torch.cuda.stream(pipe.front_stream):
                     for _ in range((depth + 1) * cob):
                         if front is not None:
@@ -1132,7 +1142,7 @@ class PipelinedSynth:
         # GEMM launches) are enqueued HERE, on the caller's stream, and the chain is its decode steps only.  The chains are what
         # bounds the pipelined step: 95.5 -> 93.9 ms per batch (scripts/front_prefill_probe.py, alternating in one process, 4 of 4)
         state = None
-        if self.front_prefill and sum(sizes) <= 32:
+        if self.front_prefill and sum(sizes) <= self.lm_rows_max:
             state = self.eng.tts_prefill(*lm_args[:5])
             for t in self.eng.lm.prefill_tensors(state):
                 t.record_stream(stream)
@@ -1140,7 +1150,7 @@ class PipelinedSynth:
 
         def lm_stage():
             with torch.cuda.device(self.eng.device), torch.cuda.stream(stream):
-                toks = self.eng.tts_tokens(*lm_args) if state is None else self.eng.tts_decode(state, lm_args[5])
+                toks = self.eng.tts_tokens(*lm_args, wide=self.wide_lm) if state is None else self.eng.tts_decode(state, lm_args[5])
                 parts = list(torch.split(toks, sizes, 0)) if len(sizes) > 1 else [toks]
                 ev = torch.cuda.Event()
                 ev.record(stream)
@@ -1188,11 +1198,10 @@ class PipelinedSynth:
             return self._render(self._fifo.popleft())
         return None
 
-    @staticmethod
-    def _compatible(a, b) -> bool:
+    def _compatible(self, a, b) -> bool:
         """Batches can share a decode chain when their prefix and decode lengths agree (fixed-length batches of one job)."""
         return (a[4] == b[4] and a[0].shape[1] == b[0].shape[1] and a[3].shape[1] == b[3].shape[1] and a[5].shape[0] == b[5].shape[0]
-                and a[0].shape[0] + b[0].shape[0] <= 32)
+                and a[0].shape[0] + b[0].shape[0] <= self.lm_rows_max)
 
     def drain(self):
         if self._pending:

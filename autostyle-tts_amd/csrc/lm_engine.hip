@@ -157,6 +157,103 @@ static int decode_v2(astts_lm* h, const float* logits0, void* const* kv_cache, c
     return ASTTS_OK;
 }
 
+// ---- wide: one decode step over 33 .. 256 rows with PLAIN GEMMs (round 5).  The step kernels of lm_step.hip stage every input row of the
+// batch in each workgroup: right for <= 32 rows (a launch is a chain of latencies), wrong beyond -- a 256-row batch as eight 32-row chains
+// streams the 352 MB of weights eight times per token and pays 8 x 72 launches.  Here a layer is LayerNorm -> q GEMM, K|V GEMM (straight
+// into the cache row) -> per-row decode attention -> out-projection (+ residual) -> LayerNorm -> FFN-in (+ ReLU, fp16) -> FFN-out (+ residual),
+// the GEMMs on the LDS-DMA ring kernel wherever the activations are fp16 (LayerNorm output, FFN hidden): the weights are read ONCE per token
+// for all rows.  Measured alone at 256 rows x ~190 keys (scripts/bigbatch_probe.py): 3.9 ms per step as eight 32-row chains on two
+// streams, 2.5 ms on the operator path from Python (host-bound, fp32-activation tile GEMMs).  The KV reads (B x heads x keys x 256 bytes
+// per layer) are the same either way and take over at long contexts.  Arithmetic: the same fp16 products with fp32 accumulation; only the
+// summation order differs from the <= 32-row engines (tests hold the logits to the oracle, not to them).
+static size_t wide_workspace_bytes(const astts_lm* h, int b) {
+    const size_t d = h->cfg.d;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { o = align_up(o + bytes, 256); };
+    take(sizeof(float) * b * d);                      // h1: embedding rows
+    take(sizeof(float) * b * d);                      // xa
+    take(sizeof(float) * b * d);                      // xb
+    take(sizeof(_Float16) * b * d);                   // n16: LayerNorm output
+    take(sizeof(float) * b * d);                      // q
+    take(sizeof(float) * b * d);                      // attention output
+    take(sizeof(_Float16) * b * h->cfg.ffn);          // FFN hidden
+    take(sizeof(float) * b * h->cfg.vocab_out);       // logits
+    take(sizeof(int32_t) * b);                        // token
+    return o;
+}
+
+static int decode_wide(astts_lm* h, const float* logits0, void* const* kv_cache, const int32_t* key_start, int32_t t_max, int32_t b,
+                       int32_t pos0, int32_t n_steps, int32_t s_begin, int32_t s_end, const float* uniforms, const int32_t* forced_tokens,
+                       int32_t eos_min_steps, const int32_t* eos_min_rows, int32_t* tokens_out, float* logits_out, void* workspace,
+                       astts_stream_t stream) {
+    const astts_lm_config_t& c = h->cfg;
+    const astts_lm_globals_t& g = h->g;
+    hipStream_t st = (hipStream_t)stream;
+    const int d = c.d;
+    ASTTS_REQUIRE(c.kv_f16 && c.pos_f16 && g.embed_table && (d % 64) == 0 && (c.ffn % 64) == 0, ASTTS_ERR_UNSUPPORTED,
+                  "astts_lm_decode: batches of more than 32 rows need the fp16 cache / position tables and the projected embedding table");
+    char* ws = (char*)workspace;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        void* p = ws + o;
+        o = align_up(o + bytes, 256);
+        return p;
+    };
+    float* h1 = (float*)take(sizeof(float) * b * d);
+    float* xa = (float*)take(sizeof(float) * b * d);
+    float* xb = (float*)take(sizeof(float) * b * d);
+    _Float16* n16 = (_Float16*)take(sizeof(_Float16) * b * d);
+    float* q = (float*)take(sizeof(float) * b * d);
+    float* ao = (float*)take(sizeof(float) * b * d);
+    _Float16* ff = (_Float16*)take(sizeof(_Float16) * b * c.ffn);
+    float* lg = (float*)take(sizeof(float) * b * c.vocab_out);
+    int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
+    const float scale = 0.125f;
+    const int64_t kv_row = (int64_t)b * 2 * d;      // one time step of the time-major cache
+    // y[m, n] = act(x[m, :] . W[n, :] + bias) (+ residual): the GEMM family picks the ring kernel for fp16 activations at >= 64 rows
+    auto gemm = [&](const void* x, int x16, int k, const void* w, const float* bias, const float* res, void* out, int out16, int n, int ldc, int act) {
+        return astts_op_gemm_ex(x, x16, w, bias, res, nullptr, out, out16, b, n, k, k, 1, k, ldc, res ? d : 0, b, b, 1, 1, 0, act, 1.0f, 0.1f, stream);
+    };
+    const float* cur = s_begin == 0 ? logits0 : lg;
+    for (int s = s_begin; s < s_end; ++s) {
+        if (logits_out)
+            ASTTS_CHECK_HIP(hipMemcpy2DAsync(logits_out + (size_t)s * c.vocab_out, sizeof(float) * (size_t)n_steps * c.vocab_out,
+                                             cur, sizeof(float) * c.vocab_out, sizeof(float) * c.vocab_out, b,
+                                             hipMemcpyDeviceToDevice, st));
+        int rc = astts_op_ras_sample_ex(cur, tokens_out, uniforms + (size_t)s * b * 2, tok, b, c.vocab_out, s, n_steps,
+                                        c.top_k, c.top_p, c.ras_win, c.ras_tau, c.speech_vocab, (s < eos_min_steps ? 1 : 0) | (c.eos_policy ? 2 : 0), eos_min_rows, forced_tokens,
+                                        stream);
+        if (rc != ASTTS_OK) return rc;
+        if (s + 1 == n_steps) break;
+        const int pos = pos0 + s;
+        // the token's projected embedding (a row of the load-time table) -> LayerNorm -> ReLU -> * sqrt(d)
+        if ((rc = astts_op_embedding(g.embed_table, tok, h1, b, d, d, c.speech_vocab, 1.0f, stream)) != ASTTS_OK) return rc;
+        if ((rc = astts_op_layernorm_relu(h1, g.embed_ln_g, g.embed_ln_b, xa, 0, b, d, d, d, c.eps, sqrtf((float)d), stream)) != ASTTS_OK) return rc;
+        float* x = xa;
+        float* y = xb;
+        for (int l = 0; l < c.layers; ++l) {
+            const astts_lm_layer_t& L = h->layers[l];
+            char* kvc = (char*)kv_cache[l];
+            const _Float16* wqkv = (const _Float16*)L.wqkv;
+            if ((rc = astts_op_layernorm_ex(x, L.n1_g, L.n1_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
+            if ((rc = gemm(n16, 1, d, wqkv, L.bqkv, nullptr, q, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
+            if ((rc = gemm(n16, 1, d, wqkv + (size_t)d * d, L.bqkv + d, nullptr, kvc + (size_t)pos * kv_row * 2, 1, 2 * d, 2 * d, ASTTS_ACT_NONE)) != ASTTS_OK)
+                return rc;
+            rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * 2, 1, L.pos, 1, L.bias_u, L.bias_v, nullptr, key_start, ao, b, c.heads, 1, pos + 1,
+                                         b * d, (int32_t)kv_row, b * d, c.pos_ld, d, 2 * d, d, pos, c.pos_center, 1, scale, stream);
+            if (rc != ASTTS_OK) return rc;
+            if ((rc = gemm(ao, 0, d, L.wo, L.bo, x, y, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
+            if ((rc = astts_op_layernorm_ex(y, L.n2_g, L.n2_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
+            if ((rc = gemm(n16, 1, d, L.w1, L.b1, nullptr, ff, 1, c.ffn, c.ffn, ASTTS_ACT_RELU)) != ASTTS_OK) return rc;
+            if ((rc = gemm(ff, 1, c.ffn, L.w2, L.b2, y, x, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
+        }
+        if ((rc = astts_op_layernorm_ex(x, g.after_g, g.after_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
+        if ((rc = gemm(n16, 1, d, g.head_w, g.head_b, nullptr, lg, 0, c.vocab_out, c.vocab_out, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
+        cur = lg;
+    }
+    return ASTTS_OK;
+}
+
 extern "C" {
 
 int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* globals, const astts_lm_layer_t* layers,
@@ -180,6 +277,7 @@ int astts_lm_destroy(astts_lm_t* h) {
 }
 
 size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b) {
+    if (h && b > 32 && b <= ASTTS_LM_MAX_ROWS) return wide_workspace_bytes(h, b);      // the wide engine's layout (plain GEMMs)
     if (!h || b < 1 || b > 32) return 0;
     const size_t d = h->cfg.d;
     size_t o = 0;
@@ -217,11 +315,14 @@ int astts_lm_decode_range(astts_lm_t* h, const float* logits0, void* const* kv_c
                   "astts_lm_decode: null argument");
     ASTTS_REQUIRE(s_begin >= 0 && s_begin < s_end && s_end <= n_steps, ASTTS_ERR_INVALID, "astts_lm_decode_range: steps [%d, %d) of %d", s_begin,
                   s_end, n_steps);
-    ASTTS_REQUIRE(b >= 1 && b <= 32, ASTTS_ERR_INVALID, "astts_lm_decode: b=%d (1..32 per call)", b);
+    ASTTS_REQUIRE(b >= 1 && b <= ASTTS_LM_MAX_ROWS, ASTTS_ERR_INVALID, "astts_lm_decode: b=%d (1..%d per call)", b, ASTTS_LM_MAX_ROWS);
     ASTTS_REQUIRE(n_steps >= 1 && pos0 >= 1 && pos0 + n_steps - 1 <= t_max, ASTTS_ERR_INVALID,
                   "astts_lm_decode: pos0=%d n_steps=%d t_max=%d", pos0, n_steps, t_max);
     ASTTS_REQUIRE(workspace_bytes >= astts_lm_workspace_bytes(h, b) && ((uintptr_t)workspace & 255) == 0,
                   ASTTS_ERR_WORKSPACE, "astts_lm_decode: workspace too small or misaligned");
+    if (b > 32)
+        return decode_wide(h, logits0, kv_cache, key_start, t_max, b, pos0, n_steps, s_begin, s_end, uniforms, forced_tokens, eos_min_steps,
+                           eos_min_rows, tokens_out, logits_out, workspace, stream);
     const astts_lm_config_t& c = h->cfg;
     const astts_lm_globals_t& g = h->g;
     hipStream_t st = (hipStream_t)stream;

@@ -442,7 +442,13 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         inp = SynthInputs(cfg, rows, tt, args.prompt_tokens, args.speech_tokens, dev, seed=100 + rank)
         sample = (inp.text, inp.tlen, inp.spk_style, inp.style_tok, inp.ts, inp.u, inp.timbre_tok, inp.timbre_mel, inp.spk_timbre,
                   inp.z, inp.phase0, inp.noise)
-        pipe = PipelinedSynth.autotune(eng, sample, depths=(2, 3), trials=1 if steps <= 2 else 2, steps=4 if steps <= 2 else 6, dist=dist)
+        # Schedules tried by the calibration: 2 / 3 decode chains of one 32-row batch each (rounds 3-4), and -- round 5 -- the LM stages of 4
+        # or 8 consecutive batches co-batched into ONE 128- / 256-row chain on the engine's wide path (plain GEMMs: the weights are read
+        # once per token for all rows; AcousticLM.decode(wide=True)), every 32-row batch still rendered on its own.
+        wide = os.environ.get("ASTTS_BENCH_WIDE", "1") != "0" and rows == 32
+        cands = ((2, 1), (3, 1)) + (((2, 4), (3, 4), (2, 8)) if wide else ())
+        pipe = PipelinedSynth.autotune(eng, sample, depths=cands, trials=1 if steps <= 2 else 2, steps=8 if wide else (4 if steps <= 2 else 6), dist=dist,
+                                       wide_lm=wide)
         last = {}
 
         def step():
@@ -458,6 +464,9 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         audio = inp.audio_seconds / rows * total_rows * steps
         ok = bool(torch.isfinite(last["wav"]).all())
         extra["decode_chains"] = pipe.depth
+        extra["batches_per_decode_chain"] = pipe.cobatch
+        extra["lm_rows_per_chain"] = pipe.cobatch * rows
+        extra["calibration_ms_per_batch"] = getattr(pipe, "tuned_table_ms", None)
         del pipe
         # one sequential 32-row batch: stage times, then the kernel kinds against their rooflines
         e0 = ev()
@@ -496,6 +505,9 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
+        if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 128 rows on the engine's wide path (CosyVoice.wide_lm)
+            cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "128"))
+        extra["lm_rows_per_job"] = cv.lm_rows
         g = torch.Generator().manual_seed(0)
         t16 = torch.arange(int(2.5 * 16000)) / 16000
         style = (0.3 * torch.sin(2 * math.pi * 220 * t16) + 0.01 * torch.randn(t16.shape, generator=g))[None]

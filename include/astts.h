@@ -361,6 +361,9 @@ typedef struct astts_lm astts_lm_t;
 int astts_lm_create(const astts_lm_config_t* cfg, const astts_lm_globals_t* globals, const astts_lm_layer_t* layers,
                     astts_lm_t** out);
 int astts_lm_destroy(astts_lm_t* h);
+/* rows per decode call: <= 32 rows take the decode-step kernels (csrc/lm_step.hip), 33 .. ASTTS_LM_MAX_ROWS the wide engine (one plain GEMM
+ * per projection for all rows: the weights are read once per token; needs the fp16 cache / tables and globals.embed_table) */
+#define ASTTS_LM_MAX_ROWS 256
 size_t astts_lm_workspace_bytes(const astts_lm_t* h, int32_t b);
 /* logits0 [b, vocab_out]: logits of the last prefix position; kv_cache[l]: fp32 [t_max, b, 2d] (time-major,
  * rows < pos0 filled by the prefill; fp16 when cfg.kv_f16); uniforms [n_steps, b, 2]; forced_tokens [b, n_steps] or NULL;

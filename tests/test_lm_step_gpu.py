@@ -323,3 +323,57 @@ def test_group_steps_stop_each_32_row_group_at_its_own_length():
     assert torch.equal(part[32:, :5], full[32:, :5]) and int(part[32:, 5:].abs().sum()) == 0
     with pytest.raises(ValueError):
         lm.decode(pre, steps, u, True, None, group_steps=[steps])
+
+
+@pytest.mark.parametrize("size,b", [("tiny", 40), ("tiny", 97), ("full", 72)])
+def test_wide_engine_logits_match_oracle(size, b):
+    """Batches of 33 .. 256 rows on the engine's WIDE path (csrc/lm_engine.hip decode_wide: one plain GEMM per projection for all rows --
+    the ring kernel on the fp16 LayerNorm output / FFN hidden -- K|V straight into the cache row, per-row decode attention): teacher-forced
+    logits of every step within the usual 3e-3 of the oracle (rows sampled for the oracle: it runs one row in ~a second at full size),
+    free-running tokens valid, ragged rows (key_start) included, and steps issued in two ranges == one range (astts_lm_decode_range)."""
+    from astts.synth.config import SynthConfig
+    from astts.synth.model import AcousticLM
+    from astts.synth.weights import make_all, make_lm_weights
+    from oracle import synth as osyn
+
+    cfg = SynthConfig.tiny() if size == "tiny" else SynthConfig()
+    sd = make_all(cfg, 0)["llm"] if size == "tiny" else make_lm_weights(cfg, 0)
+    steps = 7 if size == "tiny" else 5
+    g = torch.Generator().manual_seed(900 + b)
+    # ragged rows: text lengths 3 .. 12, prompt lengths 5 .. 40 (full: up to 150)
+    tmax, pmax = 12, (40 if size == "tiny" else 150)
+    tls = torch.randint(3, tmax + 1, (b,), generator=g).tolist()
+    pls = torch.randint(5, pmax + 1, (b,), generator=g).tolist()
+    texts = [torch.randint(0, cfg.text_vocab, (n,), generator=g) for n in tls]
+    prompts = [torch.randint(0, cfg.speech_vocab, (n,), generator=g) for n in pls]
+    spk = torch.randn(b, cfg.spk_dim, generator=g)
+    forced = torch.randint(0, cfg.speech_vocab, (b, steps), generator=g)
+    u = torch.rand(steps, b, 2, generator=g)
+    lm = AcousticLM(sd, cfg, torch.device(DEV))
+    pre, ks = lm.prefix_ragged(texts, spk, prompts)
+    toks, logits = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True, key_start=ks, wide=True)
+    assert torch.equal(toks.cpu(), forced.to(torch.int32))
+    rows = list(range(b)) if size == "tiny" else [0, b // 2, b - 1]
+    worst = 0.0
+    for i in rows:
+        pre_ref = osyn.lm_prefix(sd, cfg, texts[i][None], torch.tensor([tls[i]]), spk[i:i + 1], prompts[i][None])
+        _, lref = osyn.lm_decode(sd, cfg, pre_ref, steps, u[:, i:i + 1], True, forced[i:i + 1])
+        err = float((logits[i].cpu() - lref[0]).abs().max()) / float(lref.abs().max())
+        worst = max(worst, err)
+        assert err < 3e-3, (i, err)
+    print(f"[parity] wide engine {size} b={b}: logits rel err vs oracle (rows {len(rows)}) {worst:.2e}")
+    # the same rows through the 32-row groups (the default for b > 32): logits agree to rounding
+    _, l32 = lm.decode(pre, steps, u.to(DEV), True, forced.to(DEV), return_logits=True, key_start=ks)
+    d = float((logits - l32).abs().max()) / float(l32.abs().max())
+    print(f"[parity] wide engine {size} b={b}: vs the 32-row groups {d:.2e}")
+    assert d < 2e-3
+    # free running: valid tokens, step 0 (sampled from the shared prefill logits) equal to the grouped path's
+    t_w = lm.decode(pre, steps, u.to(DEV), True, None, key_start=ks, wide=True)
+    t_g = lm.decode(pre, steps, u.to(DEV), True, None, key_start=ks)
+    assert int(t_w.max()) < cfg.speech_vocab and int(t_w.min()) >= 0 and torch.equal(t_w[:, 0], t_g[:, 0])
+    # two ranges of steps == one
+    st = lm.prefill(pre, steps, ks)
+    ctx = lm.decode_begin(st, u.to(DEV), True, None)
+    lm.decode_range(ctx, 3)
+    lm.decode_range(ctx)
+    assert torch.equal(ctx["toks"], t_w)
