@@ -206,7 +206,10 @@ struct Ctx {
     int tfm(const astts_flow_tfm_t& w, float* p, float* q, const int* lens, int t, const void* next_w = nullptr, uint32_t next_bytes = 0) const {
         const int C = h->cfg.channels, heads = h->cfg.heads, hd = heads * 64;
         const int64_t rows = (int64_t)b2 * t;
-        if (w.qkv_frag && astts_op_tfm_attn_fused_supported(C, heads, t)) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
+        // ASTTS_FLOW_UNFUSED_ATTN_MIN_ROWS=n (experiment): at >= n rows the attention half runs as LayerNorm + one q|k|v GEMM + the flash kernel
+        static const int64_t unfused_min = exp_env_int("ASTTS_FLOW_UNFUSED_ATTN_MIN_ROWS", 0);
+        const bool fused_attn = w.qkv_frag && astts_op_tfm_attn_fused_supported(C, heads, t) && !(unfused_min > 0 && rows >= unfused_min);
+        if (fused_attn) {      // LayerNorm + q|k|v + attention in one launch (ops_tfm_fused.hip)
             // the feed-forward launch that follows streams 1.25 MB of weights no launch has touched since the last Euler step:
             // requested into L2 from here
             const void* pf[3] = {w.wo_frag, w.w1_frag, w.w2_frag};

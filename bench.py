@@ -505,8 +505,9 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
-        if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 128 rows on the engine's wide path (CosyVoice.wide_lm)
-            cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "128"))
+        if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 64 rows on the engine's wide path (CosyVoice.wide_lm)
+            # (64 rows: 636x; 96: 609; 128: 604; 256: 488 -- with 3 workers finer jobs balance better than the fatter chains save, profiles/r05_config4_lm_rows.log)
+            cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "64"))
         extra["lm_rows_per_job"] = cv.lm_rows
         g = torch.Generator().manual_seed(0)
         t16 = torch.arange(int(2.5 * 16000)) / 16000
@@ -834,32 +835,41 @@ def main():
         dt = float(t.item())
     wav_ok = bool(torch.isfinite(result["wav"]).all()) and float(result["wav"].abs().max()) <= cfg.audio_limit + 1e-6
 
-    # ---- side measurement (NOT `value`): the same K steps with the LM stages of two consecutive batches co-batched into one
-    # 16-row decode chain (PipelinedSynth(cobatch=2); every batch's output stays bit-identical, tests/test_synth_gpu.py)
+    # ---- side measurement (NOT `value`): the same K steps with the LM stages of consecutive batches co-batched into ONE decode chain
+    # (PipelinedSynth(cobatch=c): rows are independent in every LM kernel; up to 32 rows a batch's output stays bit-identical --
+    # tests/test_synth_gpu.py -- beyond that the chain runs on the engine's wide path: plain GEMMs, the weights read once per token for
+    # all rows, logits equal to rounding).  Every candidate (decode chains, batches per chain) runs the benchmark's own protocol -- W
+    # warm-up steps, K timed steps with fill and drain inside -- and the fastest is reported, with the table of all of them.
     cob = {}
     main_pipe = pipe
     if args.steps >= 2 and not args.no_cobatch:
-        cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (3, 2), (2, 4), (1, 4))      # (decode chains, batches per chain): 16- and 32-row chains
-        pipe = PipelinedSynth.autotune(eng, sample, depths=cob_cfgs, trials=2, steps=max(2, min(args.steps, 8)),
-                                       front=lambda: sb.search_device(q_dev, args.topk, out_idx=out_idx, out_score=out_sc), dist=dist)
-        with torch.cuda.stream(pipe.front_stream):
-            for _ in range(args.warmup):
-                step()
-            take(pipe.drain())
-            barrier()
-            n_done[0] = 0
-            tc = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            take(pipe.drain())
-            barrier()
-            dtc = time.perf_counter() - tc
-        assert n_done[0] == args.steps
-        if dist is not None:
-            t = torch.tensor([dtc], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtc = float(t.item())
-        cob = {"ms_per_step": 1e3 * dtc / args.steps, "dt": dtc, "chains": pipe.depth, "batches_per_chain": pipe.cobatch}
+        cob_cfgs = ((2, 2),) if args.steps < 8 else ((2, 2), (3, 2), (2, 4), (1, 4), (2, 8), (2, 16), (1, 16))
+        classes = ops.stream_pipe_classes(device=dev)
+        table = {}
+        for cd, cc in cob_cfgs:
+            pipe = PipelinedSynth(eng, lm_depth=cd, lm_priority=0, render_priority=0, cobatch=cc, pipe_classes=classes, wide_lm=True)
+            with torch.cuda.stream(pipe.front_stream):
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                take(pipe.drain())
+                barrier()
+                n_done[0] = 0
+                tc = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                take(pipe.drain())
+                barrier()
+                dtc = time.perf_counter() - tc
+            assert n_done[0] == args.steps
+            if dist is not None:
+                t = torch.tensor([dtc], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtc = float(t.item())
+            table[f"{cd} chains x {cc} batches ({cc * args.batch} rows)"] = round(1e3 * dtc / args.steps, 2)
+            if not cob or dtc < cob["dt"]:
+                cob = {"ms_per_step": 1e3 * dtc / args.steps, "dt": dtc, "chains": cd, "batches_per_chain": cc}
+            pipe = None
+        cob["table_ms_per_step"] = table
         pipe = main_pipe
 
     # ---- stage breakdown (one more step with events on the current stream)
@@ -1104,9 +1114,11 @@ def main():
             "pipelining": f"{pipe_depth + 2} HIP streams (front: retrieval + LM prefix / prefill + submit, {pipe_depth} decode chains, render): the LM decode chains of {pipe_depth} consecutive batches overlap flow+vocoder of the batch before them (streams chosen by PipelinedSynth.autotune during setup: {pipe_tuned_ms:.1f} ms/batch in calibration; with several ranks all keep the configuration whose slowest rank is fastest); every one of the K batches completes inside the timed region",
             "cobatched_lm_side_measurement": ({"value": total_audio / cob["dt"], "ms_per_step": cob["ms_per_step"],
                                                "decode_chains": cob["chains"], "batches_per_chain": cob["batches_per_chain"],
-                                               "note": "same K steps, LM stages of consecutive batches co-batched into one 16- or 32-row decode "
-                                                       "chain (a row's tokens do not depend on the chain's width: outputs bit-identical per batch); "
-                                                       "the fastest of (2 chains x 2 batches, 3 x 2, 2 x 4, 1 x 4) by calibration; reported beside `value`, not as it"} if cob else None),
+                                               "rows_per_chain": cob["batches_per_chain"] * args.batch, "table_ms_per_step": cob["table_ms_per_step"],
+                                               "note": "same K steps (fill and drain inside), LM stages of consecutive batches co-batched into ONE decode chain: "
+                                                       "<= 32 rows on the decode-step kernels (a row's tokens do not depend on the chain's width: outputs "
+                                                       "bit-identical per batch), 64 / 128 rows on the engine's wide path (plain GEMMs, the weights read once "
+                                                       "per token for all rows; logits equal to rounding); the fastest candidate; reported beside `value`, not as it"} if cob else None),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "sequential_ms_per_step": round(sum(stages.values()), 3),
             "roofline": roof,
