@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASTTS_ABI_VERSION 3
+#define ASTTS_ABI_VERSION 4
 
 #define ASTTS_OK 0
 #define ASTTS_ERR_INVALID (-1)     /* bad argument (null pointer, size, dtype, k, ...)            */
