@@ -365,3 +365,43 @@ def test_cosyvoice_from_a_checkpoint_directory_with_its_json_config(tmp_path):
     err = float((a[0]["tts_speech"] - b[0]["tts_speech"]).abs().max())
     print(f"[checkpoint dir] max waveform difference vs the in-memory weights {err:.2e}")
     assert err < 5e-2, err            # the folded weights differ from the originals by fp32 rounding of v * (g / |v|) (f0 -> phase amplifies it)
+
+
+def test_batch_surface_with_wide_lm_jobs_spanning_render_groups(cosy, tmp_path):
+    """Throughput form of the batch surface (`CosyVoice.wide_lm`, `lm_rows` > 32): LM jobs on the engine's wide path, decoupled from the
+    render groups (a job spans several groups, a group several jobs).  With the tokens teacher-forced the LM's rounding is out of the
+    picture, so every row must come back BIT-IDENTICAL to the default form (32-row jobs) -- same render groups, same draws: what is
+    held here is the bookkeeping (which tokens reach which group, completion-order rendering, asynchronous result copies).  Free
+    running, tokens stay valid and most rows agree with the 32-row path (near-ties of the sampler may differ: another summation order)."""
+    from astts.compat.cosyvoice import load_wav
+
+    _tone(str(tmp_path / "s.wav"), 1.5, 220.0)
+    _tone(str(tmp_path / "t.wav"), 1.2, 330.0)
+    style, timbre = load_wav(str(tmp_path / "s.wav"), 16000), load_wav(str(tmp_path / "t.wav"), 16000)
+    n = 70
+    items = [(("row %d " % i) + "word " * (1 + (i * 5) % 9), "He did.", style, timbre) for i in range(n)]
+    seeds = [500 + i for i in range(n)]
+    fixed = [12 + (i * 11) % 40 for i in range(n)]
+    g = torch.Generator().manual_seed(8)
+    forced = [torch.randint(0, cosy.cfg.speech_vocab, (f,), generator=g) for f in fixed]
+
+    def run(wide, lm_rows, max_batch, forced_tokens):
+        cosy.wide_lm, cosy.lm_rows = wide, lm_rows
+        try:
+            outs = cosy.inference_tts_with_st_batch(items, max_batch=max_batch, split=False, seeds=seeds, fixed_tokens=fixed, forced=forced_tokens)
+        finally:
+            cosy.wide_lm, cosy.lm_rows = False, 32
+        return [t.clone() for t in cosy.last_tokens], [o[0]["tts_speech"] for o in outs]
+
+    t0, w0 = run(False, 32, 16, forced)
+    t1, w1 = run(True, 35, 16, forced)                     # two 35-row jobs over five 16-row render groups (14 rows in the last)
+    assert all(torch.equal(a, f.to(torch.int32)) for a, f in zip(t1, forced))
+    for i in range(n):
+        assert w1[i].shape == w0[i].shape and torch.equal(w1[i], w0[i]), i
+    tf0, _ = run(False, 32, 16, None)
+    tf1, wf1 = run(True, 70, 16, None)                     # one 70-row job
+    assert all(int(t.max()) < cosy.cfg.speech_vocab and int(t.numel()) == f for t, f in zip(tf1, fixed))
+    agree = sum(int(torch.equal(a, b)) for a, b in zip(tf0, tf1))
+    print(f"[wide lm] free-running rows whose tokens equal the 32-row path: {agree} of {n}")
+    assert agree >= n // 2, agree
+    assert all(bool(torch.isfinite(w).all()) for w in wf1)
