@@ -121,7 +121,8 @@ def main(args, client=None, embedder=None):
             embedder = load_embedder(args.model_path, getattr(args, "allow_random_init", False), args.seed)
         b0, b1, _ = parallel.shard_bounds(len(rows), world, rank)
         bios = load_biographies(getattr(args, "biography_json", ""))
-        q, labels = embed_rows(rows[b0:b1], embedder, bios, max_new_tokens=10, batch=getattr(args, "llm_batch", 32))
+        with parallel.rank_work(dist, "search_json: emotion label + embedding"):     # agreed before the search's all-gather
+            q, labels = embed_rows(rows[b0:b1], embedder, bios, max_new_tokens=10, batch=getattr(args, "llm_batch", 32))
         full = np.zeros((len(rows), q.shape[1] if len(q) else 2 * embedder.cfg.hidden), np.float32)
         full[b0:b1] = q
         q = full

@@ -103,36 +103,38 @@ def tts_for_infer(args, cosyvoice=None, now=None):
         return style_wav, load_wav(timbre_path, 16000)
 
     bs = max(1, int(getattr(args, "batch_size", 1)))
-    if bs == 1:     # the reference's schedule: one utterance at a time (tts_with_rag.py:172-197)
-        for cnt, item in enumerate(items, start=first + 1):
-            print(item)
-            style_wav, timbre_wav = wavs_of(item)
-            kw = {} if seed is None else {"seed": row_seed(cnt)}
-            for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
-                                                                  timbre_wav, stream=False, **kw)):
-                path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
-                audio.write_wav(path, j["tts_speech"], 22050)
-                written.append(path)
-        if dist is not None:
-            dist.barrier()
-        return written
-    # batched schedule: same files, same names; rows are independent so they share ragged GPU batches of `bs` rows.  The surface is
-    # handed up to 256 rows at a time: it sorts them by length, decodes their 32-row LM jobs on two streams and renders one group
-    # while the next ones decode (CosyVoice.synthesize_batch)
-    step = max(bs, 256)
-    for c0 in range(0, len(items), step):
-        chunk = items[c0:c0 + step]
-        for item in chunk:
-            print(item)
-        reqs = [(it["tts_text"], it["style_wav_text"], *wavs_of(it)) for it in chunk]
-        kw = {} if seed is None else {"seeds": [row_seed(first + c0 + k + 1) for k in range(len(chunk))]}
-        for k, segs in enumerate(cosyvoice.inference_tts_with_st_batch(reqs, max_batch=bs, **kw)):
-            for i, j in enumerate(segs):
-                path = os.path.join(result_dir, output_name(first + c0 + k + 1, chunk[k]["style_wav_path"], chunk[k]["speaker"], i))
-                audio.write_wav(path, j["tts_speech"], 22050)
-                written.append(path)
-    if dist is not None:
-        dist.barrier()
+
+    def rows_of_this_rank():
+        if bs == 1:     # the reference's schedule: one utterance at a time (tts_with_rag.py:172-197)
+            for cnt, item in enumerate(items, start=first + 1):
+                print(item)
+                style_wav, timbre_wav = wavs_of(item)
+                kw = {} if seed is None else {"seed": row_seed(cnt)}
+                for i, j in enumerate(cosyvoice.inference_tts_with_st(item["tts_text"], item["style_wav_text"], style_wav,
+                                                                      timbre_wav, stream=False, **kw)):
+                    path = os.path.join(result_dir, output_name(cnt, item["style_wav_path"], item["speaker"], i))
+                    audio.write_wav(path, j["tts_speech"], 22050)
+                    written.append(path)
+            return
+        # batched schedule: same files, same names; rows are independent so they share ragged GPU batches of `bs` rows.  The surface is
+        # handed up to 256 rows at a time: it sorts them by length, decodes their 32-row LM jobs on two streams and renders one group
+        # while the next ones decode (CosyVoice.synthesize_batch)
+        step = max(bs, 256)
+        for c0 in range(0, len(items), step):
+            chunk = items[c0:c0 + step]
+            for item in chunk:
+                print(item)
+            reqs = [(it["tts_text"], it["style_wav_text"], *wavs_of(it)) for it in chunk]
+            kw = {} if seed is None else {"seeds": [row_seed(first + c0 + k + 1) for k in range(len(chunk))]}
+            for k, segs in enumerate(cosyvoice.inference_tts_with_st_batch(reqs, max_batch=bs, **kw)):
+                for i, j in enumerate(segs):
+                    path = os.path.join(result_dir, output_name(first + c0 + k + 1, chunk[k]["style_wav_path"], chunk[k]["speaker"], i))
+                    audio.write_wav(path, j["tts_speech"], 22050)
+                    written.append(path)
+
+    # a rank whose rows fail (a bad wav path, an allocation) must not leave its peers waiting: the block ends in one agreed flag
+    with parallel.rank_work(dist, "tts_with_rag"):
+        rows_of_this_rank()
     return written
 
 

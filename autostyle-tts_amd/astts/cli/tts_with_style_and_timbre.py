@@ -59,23 +59,26 @@ def tts_for_infer(args, cosyvoice=None):
         written.append(path)
 
     bs = max(1, int(getattr(args, "batch_size", 1)))
-    if bs == 1:     # the reference's schedule: one line at a time (tts_with_style_and_timbre.py:91-95)
-        for cnt, line in enumerate(lines, start=first + 1):
-            kw = {} if seed is None else {"seed": int(seed) * 1000003 + cnt}
-            save(cnt, [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, args.style_wav_text, style_wav, timbre_wav, stream=False, **kw)])
-    else:           # lines are independent: the text segments of `batch_size` lines share ragged GPU batches (BASELINE config 3)
-        step = max(bs, 256)     # the surface schedules up to 256 lines' segments itself (LM jobs on two streams, render overlapped)
-        for c0 in range(0, len(lines), step):
-            chunk = lines[c0:c0 + step]
-            kw = {} if seed is None else {"seeds": [int(seed) * 1000003 + first + c0 + k + 1 for k in range(len(chunk))]}
-            if getattr(args, "fixed_tokens", None):
-                kw["fixed_tokens"] = int(args.fixed_tokens)
-            out = cosyvoice.inference_tts_with_st_batch([(line, args.style_wav_text, style_wav, timbre_wav) for line in chunk],
-                                                        max_batch=getattr(args, "max_segments", None) or 64, **kw)
-            for k, segs in enumerate(out):
-                save(first + c0 + k + 1, [j["tts_speech"] for j in segs])
-    if dist is not None:
-        dist.barrier()
+
+    def lines_of_this_rank():
+        if bs == 1:     # the reference's schedule: one line at a time (tts_with_style_and_timbre.py:91-95)
+            for cnt, line in enumerate(lines, start=first + 1):
+                kw = {} if seed is None else {"seed": int(seed) * 1000003 + cnt}
+                save(cnt, [j["tts_speech"] for j in cosyvoice.inference_tts_with_st(line, args.style_wav_text, style_wav, timbre_wav, stream=False, **kw)])
+        else:           # lines are independent: the text segments of `batch_size` lines share ragged GPU batches (BASELINE config 3)
+            step = max(bs, 256)     # the surface schedules up to 256 lines' segments itself (LM jobs on two streams, render overlapped)
+            for c0 in range(0, len(lines), step):
+                chunk = lines[c0:c0 + step]
+                kw = {} if seed is None else {"seeds": [int(seed) * 1000003 + first + c0 + k + 1 for k in range(len(chunk))]}
+                if getattr(args, "fixed_tokens", None):
+                    kw["fixed_tokens"] = int(args.fixed_tokens)
+                out = cosyvoice.inference_tts_with_st_batch([(line, args.style_wav_text, style_wav, timbre_wav) for line in chunk],
+                                                            max_batch=getattr(args, "max_segments", None) or 64, **kw)
+                for k, segs in enumerate(out):
+                    save(first + c0 + k + 1, [j["tts_speech"] for j in segs])
+
+    with parallel.rank_work(dist, "tts_with_style_and_timbre"):      # one agreed flag in place of a barrier: no rank waits for a failed peer
+        lines_of_this_rank()
     return written
 
 

@@ -19,6 +19,9 @@ from typing import Callable, Optional, Tuple
 import torch
 
 
+RANK_FAILED = -(1 << 62)     # an id no bank row has: a rank whose local search raised sends it in place of its rows (sharded_search)
+
+
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int, int]:
     """-> (begin, end, per_rank) with per_rank = ceil(n/world); trailing ranks may be short/empty."""
     per = (n_items + world - 1) // world if n_items > 0 else 0
@@ -52,8 +55,14 @@ def sharded_search(search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, 
         return search_fn(queries, k)
     world, rank = dist.get_world_size(), dist.get_rank()
     b, e, per = shard_bounds(nq, world, rank)
+    err = None
     if e > b:
-        idx, sc = search_fn(queries[b:e], k)
+        try:
+            idx, sc = search_fn(queries[b:e], k)
+        except Exception as ex:  # noqa: BLE001 -- a rank that left here would strand its peers inside the all-gather below: it
+            err = ex             # contributes rows marked RANK_FAILED instead and every rank raises once the gather is through
+            idx = torch.full((e - b, k), RANK_FAILED, dtype=torch.int64, device=queries.device)
+            sc = torch.zeros((e - b, k), dtype=torch.float32, device=queries.device)
     else:
         idx = torch.empty((0, k), dtype=torch.int64, device=queries.device)
         sc = torch.empty((0, k), dtype=torch.float32, device=queries.device)
@@ -64,6 +73,11 @@ def sharded_search(search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, 
     for r in range(world):
         rb, re, _ = shard_bounds(nq, world, r)
         keep.append(allp[r * per: r * per + (re - rb)])
+    if err is not None:
+        raise err
+    failed = [r for r in range(world) if keep[r].shape[0] and int(keep[r][0, 0]) == RANK_FAILED]
+    if failed:
+        raise RuntimeError(f"sharded_search: the bank search failed on rank(s) {failed} (their own error is on their stderr)")
     allp = torch.cat(keep, dim=0)
     out_idx = allp[:, :k].contiguous()
     out_sc = allp[:, k:].to(torch.int32).view(torch.float32)
@@ -134,6 +148,36 @@ def init_from_env(backend: Optional[str] = None):
             torch.cuda.set_device(local)
         dist.init_process_group(be, rank=rank, world_size=world)
     return dist, rank, world, local
+
+
+class rank_work:
+    """``with parallel.rank_work(dist, "what"):`` around the part of a data-parallel driver that a rank does ALONE (its shard of the
+    rows; no collective inside).  At the end of the block the ranks agree on one flag (an all-reduce of one int32 -- it takes the
+    place of the closing barrier): a rank whose block raised re-raises its own error, the others raise a RuntimeError naming the
+    failed ranks -- nobody waits in a barrier for a peer that has gone (a bad wav path on one rank stalled the
+    other seven until the collective timeout).  ``dist = None``: a plain ``with`` block."""
+
+    def __init__(self, dist, what: str = "data-parallel section"):
+        self.dist, self.what = dist, what
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.dist is None:
+            return False
+        dist = self.dist
+        flag = torch.zeros(dist.get_world_size(), dtype=torch.int32, device=comm_device(dist))
+        if et is not None:
+            flag[dist.get_rank()] = 1
+        dist.all_reduce(flag)
+        if et is not None:
+            return False                 # this rank's own exception propagates
+        failed = [r for r, f in enumerate(flag.tolist()) if f]
+        if failed:
+            raise RuntimeError(f"{self.what}: rank(s) {failed} of {dist.get_world_size()} failed (their error is on their stderr); "
+                               f"rank {dist.get_rank()}'s own rows are complete")
+        return False
 
 
 def broadcast_object(obj, dist, src: int = 0):

@@ -132,3 +132,52 @@ def test_merge_topk_total_order():
     assert idx.tolist() == [[3, 7, 99, 2]] and sc.tolist() == [[0.9, 0.9, 0.7, 0.5]]
     idx, sc = merge_topk(s[:, 3:4], r[:, 3:4], 2)           # nothing but an empty slot
     assert idx.tolist() == [[-1]]
+
+
+def _worker_failing(rank, world, port, ret):
+    """One rank's work raises: the peers must come out with an error of their own instead of waiting in a collective."""
+    for p in (ROOT, os.path.join(ROOT, "autostyle-tts_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+
+    import torch.distributed as dist
+
+    from astts import parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    seen = []
+    try:
+        with parallel.rank_work(dist, "unit"):
+            if rank == 1:
+                raise FileNotFoundError("no such wav")
+    except FileNotFoundError:
+        seen.append("own")
+    except RuntimeError as e:
+        seen.append("peer" if "rank(s) [1]" in str(e) else str(e))
+    with parallel.rank_work(dist, "unit"):            # a clean block stays silent on every rank
+        pass
+
+    def search_fn(q_local, k):
+        if rank == 0:
+            raise ValueError("bank search failed")
+        return torch.zeros((q_local.shape[0], k), dtype=torch.int64), torch.zeros((q_local.shape[0], k))
+
+    try:
+        parallel.sharded_search(search_fn, torch.zeros(5, 4), 2, dist)
+        seen.append("no error")
+    except ValueError:
+        seen.append("own")
+    except RuntimeError as e:
+        seen.append("peer" if "rank(s) [0]" in str(e) else str(e))
+    ret[rank] = seen
+    dist.destroy_process_group()
+
+
+def test_a_failed_rank_fails_its_peers_instead_of_stalling_them():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_failing, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: ["peer", "own"], 1: ["own", "peer"]}
