@@ -211,7 +211,10 @@ static int decode_wide(astts_lm* h, const float* logits0, void* const* kv_cache,
     const float scale = 0.125f;
     const int64_t kv_row = (int64_t)b * 2 * d;      // one time step of the time-major cache
     // y[m, n] = act(x[m, :] . W[n, :] + bias) (+ residual): the GEMM family picks the ring kernel for fp16 activations at >= 64 rows
+    // (astts_op_gemm_rows: a latency-sized kernel for these shapes; ASTTS_LM_WIDE_GEMM=tile goes back to the tile / ring family)
+    static const bool rows_kernel = !(getenv("ASTTS_LM_WIDE_GEMM") && !strcmp(getenv("ASTTS_LM_WIDE_GEMM"), "tile"));
     auto gemm = [&](const void* x, int x16, int k, const void* w, const float* bias, const float* res, void* out, int out16, int n, int ldc, int act) {
+        if (rows_kernel) return astts_op_gemm_rows(x, x16, w, bias, res, out, out16, b, n, k, k, ldc, res ? d : 0, act, stream);
         return astts_op_gemm_ex(x, x16, w, bias, res, nullptr, out, out16, b, n, k, k, 1, k, ldc, res ? d : 0, b, b, 1, 1, 0, act, 1.0f, 0.1f, stream);
     };
     const float* cur = s_begin == 0 ? logits0 : lg;

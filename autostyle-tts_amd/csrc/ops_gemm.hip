@@ -24,6 +24,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace astts {
 
@@ -946,6 +947,163 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
     }
 }
 
+// gemm_rows: 33 .. 256 rows (the wide decode engine's projections: every row of a big decode batch through ONE launch per
+// projection).  At these sizes a GEMM is a latency problem, not a flop problem (128 x 1024 x 1024 = 0.1 us of MFMA, 2 MB of weights):
+// the 64 x 64 ring tile leaves 32 workgroups walking K serially (11.8 us per launch measured in the engine).  Here a workgroup owns
+// (16 RT) rows x (16 CT) columns, its 8 waves take the 64-element K lines round robin, and EVERY operand fragment a wave needs
+// (PL lines x (RT + CT) x 32 bytes per lane) is requested before the first MFMA: one memory round trip, then
+// v_mfma_f32_16x16x32_f16 on registers, an LDS reduction over the waves in wave order (a fixed order: results do not depend on
+// timing) and the epilogue.  A row's sums do not depend on the other rows of the launch.  Column tiles are the fast block index:
+// workgroups that share a weight tile differ by a multiple of the tile count and land on the same XCD's L2 when that is a multiple of 8.
+template <int RT, int CT, int PL, bool A32>
+__global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gr_red[];    // [8][RT * CT][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int ncol = (a.n + 16 * CT - 1) / (16 * CT);
+    const int n0 = (int)(blockIdx.x % (unsigned)ncol) * 16 * CT, m0 = (int)(blockIdx.x / (unsigned)ncol) * 16 * RT;
+    const int M = (int)a.m;
+    const int lines = a.cin_pad >> 6;
+    const _Float16* wrow[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) wrow[u] = a.w + (int64_t)min(n0 + 16 * u + c, a.n - 1) * a.cin_pad + g * 16;
+    const char* arow[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+        arow[t] = reinterpret_cast<const char*>(a.x) + ((int64_t)min(m0 + 16 * t + c, M - 1) * a.lda + g * 16) * (A32 ? 4 : 2);
+    float4v acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][u][e] = 0.0f;
+    // epilogue operands of this thread's outputs: requested behind the first pass's fragments, consumed last
+    constexpr int NOUT = RT * CT / 2;                        // outputs per thread (RT * CT * 256 over 512 threads)
+    float e_bias[NOUT], e_res[NOUT];
+    for (int pass = 0; pass * PL * 8 < lines; ++pass) {
+        half8 fb[CT][PL][2];
+        half8 fa[A32 ? 1 : RT][A32 ? 1 : PL][2];
+        float4 fx[A32 ? RT : 1][A32 ? PL : 1][4];
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            // Unconditional loads from a clamped line, zeroed afterwards when the line does not exist: `if (on) x = load` compiles to a
+            // branch per load with an s_waitcnt between them (EXPERIMENTS.md G) -- the whole point here is ONE batch of loads.
+            const int line = wid + (pass * PL + i) * 8;
+            const bool on = line < lines;
+            const int lc = on ? line : 0;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if constexpr (A32) {
+                    const float* p = reinterpret_cast<const float*>(arow[t]) + lc * 64;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fx[t][i][j] = *reinterpret_cast<const float4*>(p + 4 * j);
+                } else {
+                    const _Float16* p = reinterpret_cast<const _Float16*>(arow[t]) + lc * 64;
+                    fa[t][i][0] = *reinterpret_cast<const half8*>(p);
+                    fa[t][i][1] = *reinterpret_cast<const half8*>(p + 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CT; ++u) {
+                fb[u][i][0] = *reinterpret_cast<const half8*>(wrow[u] + lc * 64);
+                fb[u][i][1] = *reinterpret_cast<const half8*>(wrow[u] + lc * 64 + 8);
+            }
+        }
+        if (pass == 0) {
+            const float* bp = a.bias ? a.bias : reinterpret_cast<const float*>(a.w);          // (a valid address either way; the value is
+            const float* rp = a.residual ? a.residual : reinterpret_cast<const float*>(a.w);  // dropped below when the operand is absent)
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                const int o = tid + j * 512;
+                const int tile = o >> 8, e = (o >> 6) & 3, ln = o & 63;
+                const int n = min(n0 + 16 * (tile % CT) + (ln & 15), a.n - 1), m = min(m0 + 16 * (tile / CT) + (ln >> 4) * 4 + e, M - 1);
+                e_bias[j] = bp[a.bias ? n : 0];
+                e_res[j] = rp[a.residual ? (int64_t)m * a.ldr + n : 0];
+            }
+        }
+        if (pass * PL * 8 + PL * 8 > lines) {       // a ragged last pass: lines that do not exist count as zeros (the B side suffices)
+#pragma unroll
+            for (int i = 0; i < PL; ++i)
+                if (wid + (pass * PL + i) * 8 >= lines) {
+#pragma unroll
+                    for (int u = 0; u < CT; ++u)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) fb[u][i][j][q] = (_Float16)0.0f;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                half8 x0, x1;
+                if constexpr (A32) {
+                    const float4 v0 = fx[t][i][0], v1 = fx[t][i][1], v2 = fx[t][i][2], v3 = fx[t][i][3];
+                    x0[0] = (_Float16)v0.x; x0[1] = (_Float16)v0.y; x0[2] = (_Float16)v0.z; x0[3] = (_Float16)v0.w;
+                    x0[4] = (_Float16)v1.x; x0[5] = (_Float16)v1.y; x0[6] = (_Float16)v1.z; x0[7] = (_Float16)v1.w;
+                    x1[0] = (_Float16)v2.x; x1[1] = (_Float16)v2.y; x1[2] = (_Float16)v2.z; x1[3] = (_Float16)v2.w;
+                    x1[4] = (_Float16)v3.x; x1[5] = (_Float16)v3.y; x1[6] = (_Float16)v3.z; x1[7] = (_Float16)v3.w;
+                } else {
+                    x0 = fa[t][i][0];
+                    x1 = fa[t][i][1];
+                }
+#pragma unroll
+                for (int u = 0; u < CT; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, fb[u][i][0], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, fb[u][i][1], acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gr_red[((wid * (RT * CT) + t * CT + u) * 4 + e) * 64 + lane] = acc[t][u][e];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        const int o = tid + j * 512;
+        const int tile = o >> 8, e = (o >> 6) & 3, ln = o & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += gr_red[((w * (RT * CT) + tile) * 4 + e) * 64 + ln];
+        const int n = n0 + 16 * (tile % CT) + (ln & 15), m = m0 + 16 * (tile / CT) + (ln >> 4) * 4 + e;
+        if (n < a.n && m < M) {
+            v = apply_act(v + (a.bias ? e_bias[j] : 0.0f), a.act, a.slope) * a.alpha + (a.residual ? e_res[j] : 0.0f);
+            if (a.out_f16) reinterpret_cast<_Float16*>(a.out)[(int64_t)m * a.ldc + n] = (_Float16)v;
+            else a.out[(int64_t)m * a.ldc + n] = v;
+        }
+    }
+}
+
+template <int RT, int CT, int PL, bool A32>
+static void launch_rows(const GemmArgs& a, hipStream_t st) {
+    static std::once_flag attr;
+    const size_t lds = (size_t)8 * RT * CT * 4 * 64 * sizeof(float);
+    std::call_once(attr, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows<RT, CT, PL, A32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    const unsigned grid = (unsigned)(cdiv(a.m, 16 * RT) * cdiv(a.n, 16 * CT));
+    hipLaunchKernelGGL((gemm_rows<RT, CT, PL, A32>), dim3(grid), dim3(512), lds, st, a);
+}
+
+// picks the workgroup tile of gemm_rows: the fattest one (fewest re-reads of the activation rows) that still gives every CU a workgroup
+template <int PL, bool A32>
+static void launch_rows_pl(const GemmArgs& a, hipStream_t st) {
+    auto blocks = [&](int rt, int ct) { return cdiv(a.m, 16 * rt) * cdiv(a.n, 16 * ct); };
+    if constexpr (PL <= 2) {
+        if (blocks(4, 2) >= 256) return launch_rows<4, 2, PL, A32>(a, st);
+    }
+    if constexpr (PL <= 4) {
+        if (blocks(2, 2) >= 256) return launch_rows<2, 2, PL, A32>(a, st);
+    }
+    launch_rows<2, 1, PL, A32>(a, st);
+}
+
 static size_t skinny_lds_bytes(int m, int cin_pad, int mt) {
     return (((size_t)m * (cin_pad + 8) * 2 + 15) & ~(size_t)15) + (size_t)SK_WAVES * mt * 4 * 64 * sizeof(float);
 }
@@ -1177,6 +1335,33 @@ int astts_op_gemm_lens(const void* x, int32_t x_f16, const void* w_f16, const fl
                nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
     a.in_lens = in_lens;
     return launch_gemm(a, (hipStream_t)stream);
+}
+
+int astts_op_gemm_rows(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual, void* out, int32_t out_f16,
+                       int32_t m, int32_t n, int32_t k, int32_t lda, int32_t ldc, int32_t ldr, int32_t act, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && w_f16 && out, ASTTS_ERR_INVALID, "astts_op_gemm_rows: null pointer");
+    ASTTS_REQUIRE(m >= 1 && m <= 4096 && n >= 1 && k >= 64 && (k % 64) == 0, ASTTS_ERR_UNSUPPORTED,
+                  "astts_op_gemm_rows: m=%d n=%d k=%d (1 <= m <= 4096 rows, k a multiple of 64)", m, n, k);
+    ASTTS_REQUIRE((lda % (x_f16 ? 8 : 4)) == 0 && (((uintptr_t)x | (uintptr_t)w_f16) & 15) == 0 && lda >= k && ldc >= n && (!residual || ldr >= n),
+                  ASTTS_ERR_INVALID, "astts_op_gemm_rows: operands must be 16-byte aligned (lda=%d), ld* >= the row's width", lda);
+    ASTTS_REQUIRE(act >= ACT_NONE && act <= ACT_LEAKY, ASTTS_ERR_INVALID, "astts_op_gemm_rows: act=%d", act);
+    GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, nullptr, (float*)out, m, n, k, k, 1,
+               lda, ldc, ldr, m, m, 1, 1, 0, act, 1.0f, 0.1f,
+               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)m * n * k);
+    const int per_wave = (k / 64 + 7) / 8;      // K lines per wave: one pass when the fragments fit the registers
+    if (x_f16) {
+        if (per_wave <= 2) launch_rows_pl<2, false>(a, st);
+        else if (per_wave <= 4) launch_rows_pl<4, false>(a, st);
+        else launch_rows_pl<8, false>(a, st);
+    } else {
+        if (per_wave <= 2) launch_rows_pl<2, true>(a, st);
+        else launch_rows_pl<4, true>(a, st);
+    }
+    if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
 }
 
 int astts_op_gemm_ln(const void* x_f16, const void* w_f16, const float* bias, const float* residual, float* out,

@@ -424,6 +424,48 @@ def test_gemm_fused_split_k_and_plain(m, k, n, act, use_res):
         outs.append(y)
 
 
+@pytest.mark.parametrize("m,k,n,act,x16,out16,use_res", [(128, 1024, 1024, "none", True, False, True), (128, 1024, 2048, "none", True, True, False),
+                                                         (128, 1024, 4096, "relu", True, True, False), (128, 4096, 1024, "none", True, False, True),
+                                                         (128, 1024, 1024, "none", False, False, True), (128, 1024, 4097, "none", True, False, False),
+                                                         (33, 1024, 1024, "none", True, False, True), (256, 1024, 4096, "relu", True, True, False),
+                                                         (77, 2048, 528, "gelu", False, False, True), (64, 1024, 1024, "none", False, False, False),
+                                                         (200, 576, 100, "silu", True, False, True), (40, 6144, 64, "none", True, False, False),
+                                                         (100, 2560, 1000, "none", False, True, True)])
+def test_gemm_rows_matches_definition_rows_are_independent(m, k, n, act, x16, out16, use_res):
+    """astts_op_gemm_rows (the wide decode engine's projections: 33 .. 256 rows, one memory round trip per workgroup) against the
+    fp16-operand reference over its tile shapes (wide / narrow outputs, K lines per wave 2 / 4 / 8 and a ragged last pass, fp32 and fp16
+    activations and outputs, a column count that is not a multiple of the tile) -- and a row's result does not depend on the rows
+    beside it: the first 40 rows run as a launch of their own give the same bits."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(m * 31 + n + k)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g) if use_res else None
+    pw = ops.PackedWeight(w, b)
+    xd = x.to(DEV).half() if x16 else x.to(DEV)
+    rd = None if res is None else res.to(DEV)
+    od = torch.float16 if out16 else torch.float32
+    y = ops.gemm_rows(xd, pw, act=act, residual=rd, out_dtype=od)
+    assert y.dtype == od and y.shape == (m, n)
+    ref = F.linear(h16(x), h16(w), b)
+    ref = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "gelu": F.gelu}[act](ref)
+    if res is not None:
+        ref = ref + res
+    assert rel_err(y.float(), ref) < (1.5e-3 if out16 else 2e-4)
+    assert torch.equal(y, ops.gemm_rows(xd, pw, act=act, residual=rd, out_dtype=od))            # run to run
+    sub = min(40, m)
+    y2 = ops.gemm_rows(xd[:sub].contiguous(), pw, act=act, residual=None if rd is None else rd[:sub].contiguous(), out_dtype=od)
+    assert torch.equal(y2, y[:sub])
+    # a slice of the weight rows (the engine's q and k|v halves of one packed projection) into a strided destination
+    if n >= 512:
+        big = torch.zeros((m, n + 64), dtype=od, device=DEV)
+        ops.gemm_rows(xd, pw, act=act, out=big[:, 32:32 + 256], n=256, row0=128)
+        want = ops.gemm_rows(xd, pw, act=act, out_dtype=od)[:, 128:384]
+        assert torch.equal(big[:, 32:288], want) and float(big[:, :32].abs().max()) == 0.0 and float(big[:, 288:].abs().max()) == 0.0
+
+
 def test_gemm_fused_layernorm_gather_split_output():
     """The fusions of the LM decode step: embedding-row gather, LayerNorm prologue, K|V half of the output written as
     fp16 into a strided destination (a KV-cache row)."""
