@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace astts {
 
@@ -246,6 +247,106 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
 #pragma unroll
         for (int g2 = 0; g2 < DG; ++g2) tot += part[g2 * DH + tid];
         a.out[(int64_t)b * a.o_bs + head * DH + tid] = l > 0.0f ? tot / l : 0.0f;
+    }
+}
+
+// attn_relpos_rows: the decode step of a WIDE batch (33 .. 256 rows through one launch: the wide decode engine) over an fp16 KV cache and
+// an fp16 position table.  At these sizes the step is the cache's HBM stream (128 rows x 220 keys x 4 KB = 114 MB per layer), and
+// attn_relpos_decode's (row, head) workgroups read it in 128-byte pieces half a megabyte apart, in two dependent phases (scores, then
+// values).  Here a workgroup owns HG heads of one row: 8 lanes share a (key, head) pair with 8 dims each, so one wave instruction reads
+// 16-byte pieces that cover HG x 128 CONTIGUOUS bytes of a key's row (512 B / 1 KB), and K, the position row and V of a key are
+// requested together: one pass over the keys with a running (max, sum, output) per (wave, key slot, head) -- the flash-decoding
+// recurrence -- merged through LDS in a fixed order at the end.  A row's result does not depend on the other rows of the launch.
+template <int HG>
+__global__ __launch_bounds__(512, 4) void attn_relpos_rows(RelPosArgs a) {
+    constexpr int KPI = 8 / HG;                  // keys per wave instruction (HG = 8: 1, HG = 4: 2)
+    constexpr int NSLOT = 8 * KPI;               // key slots of the workgroup: slot s takes keys ks0 + s, ks0 + s + NSLOT, ...
+    constexpr int DKR = 4;                       // keys per slot and pass (3 x 16-byte loads each in flight; two workgroups per CU)
+    __shared__ float s_m[NSLOT][HG], s_l[NSLOT][HG];
+    __shared__ __attribute__((aligned(16))) float s_o[NSLOT][HG][DH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = lane & 7, hq = (lane >> 3) % HG, kq = lane / (8 * HG);
+    const int slot = wid * KPI + kq;
+    const int head = blockIdx.x * HG + hq, b = blockIdx.y;
+    const int len = a.lens ? min(a.lens[b], a.len_all) : a.len_all;
+    const int ks0 = a.kstart ? min(a.kstart[b], len - 1) : 0;
+    const _Float16* kb = reinterpret_cast<const _Float16*>(a.k) + (int64_t)b * a.k_bs + head * DH + 8 * sub;
+    const _Float16* vb = reinterpret_cast<const _Float16*>(a.v) + (int64_t)b * a.k_bs + head * DH + 8 * sub;
+    const _Float16* pb = reinterpret_cast<const _Float16*>(a.pos) + head * DH + 8 * sub;
+    float qu[8], qv[8];
+    {
+        const float* qb = a.q + (int64_t)b * a.q_bs + head * DH + 8 * sub;
+        const float* up = a.bias_u + head * DH + 8 * sub;
+        const float* vp = a.bias_v + head * DH + 8 * sub;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const float4 x = *reinterpret_cast<const float4*>(qb + 4 * h2);
+            const float4 u = *reinterpret_cast<const float4*>(up + 4 * h2);
+            const float4 v = *reinterpret_cast<const float4*>(vp + 4 * h2);
+            qu[4 * h2] = (x.x + u.x) * a.scale; qu[4 * h2 + 1] = (x.y + u.y) * a.scale; qu[4 * h2 + 2] = (x.z + u.z) * a.scale; qu[4 * h2 + 3] = (x.w + u.w) * a.scale;
+            qv[4 * h2] = (x.x + v.x) * a.scale; qv[4 * h2 + 1] = (x.y + v.y) * a.scale; qv[4 * h2 + 2] = (x.z + v.z) * a.scale; qv[4 * h2 + 3] = (x.w + v.w) * a.scale;
+        }
+    }
+    float m = -INFINITY, l = 0.0f, o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = 0.0f;
+    for (int j0 = ks0 + slot; j0 < len; j0 += NSLOT * DKR) {
+        half8 kk[DKR], pp[DKR], vv[DKR];
+#pragma unroll
+        for (int u = 0; u < DKR; ++u) {
+            const int j = min(j0 + u * NSLOT, len - 1);            // clamped: always a valid row, masked below
+            kk[u] = *reinterpret_cast<const half8*>(kb + (int64_t)j * a.ldk);
+            pp[u] = *reinterpret_cast<const half8*>(pb + (int64_t)(a.q_pos0 - j + a.pos_center) * a.ldp);
+            vv[u] = *reinterpret_cast<const half8*>(vb + (int64_t)j * a.ldk);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the pass's 12 loads are ONE batch: no use may be scheduled between them
+        float sc[DKR];
+        float mp = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < DKR; ++u) {
+            float t = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) t += qu[d] * (float)kk[u][d] + qv[d] * (float)pp[u][d];
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 1, 64);
+            sc[u] = j0 + u * NSLOT < len ? t : -INFINITY;
+            mp = fmaxf(mp, sc[u]);
+        }
+        const float mn = fmaxf(m, mp);                             // finite: the pass's first key exists
+        const float resc = m == -INFINITY ? 0.0f : __expf(m - mn);
+        l *= resc;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] *= resc;
+#pragma unroll
+        for (int u = 0; u < DKR; ++u) {
+            const float pw = sc[u] == -INFINITY ? 0.0f : __expf(sc[u] - mn);
+            l += pw;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] += pw * (float)vv[u][d];
+        }
+        m = mn;
+    }
+    if (sub == 0) {
+        s_m[slot][hq] = m;
+        s_l[slot][hq] = l;
+    }
+    *reinterpret_cast<float4*>(&s_o[slot][hq][8 * sub]) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(&s_o[slot][hq][8 * sub + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    __syncthreads();
+    if (tid < HG * DH) {
+        const int h2 = tid >> 6, d = tid & 63;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int s2 = 0; s2 < NSLOT; ++s2) mm = fmaxf(mm, s_m[s2][h2]);
+        float lt = 0.0f, ot = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < NSLOT; ++s2) {
+            const float w = s_m[s2][h2] == -INFINITY ? 0.0f : __expf(s_m[s2][h2] - mm);
+            lt += s_l[s2][h2] * w;
+            ot += s_o[s2][h2][d] * w;
+        }
+        a.out[(int64_t)b * a.o_bs + (blockIdx.x * HG + h2) * DH + d] = lt > 0.0f ? ot / lt : 0.0f;
     }
 }
 
@@ -718,6 +819,20 @@ int astts_op_attn_relpos_ex(const float* q, const void* k, const void* v, int32_
         ASTTS_REQUIRE(lds <= 60 * 1024, ASTTS_ERR_INVALID, "astts_op_attn_relpos: tk=%d too long for the decode kernel", tk);
         const int esz = kv_f16 ? 2 : 4;
         const bool prof = prof_begin(ASTTS_PROF_ATTN_DECODE, st, (double)b * h * tk * DH * esz * 2.0);
+        // wide batches over an fp16 cache and position table: contiguous 16-byte pieces, one pass over the keys (attn_relpos_rows);
+        // ASTTS_ATTN_DECODE=v1 keeps the (row, head) kernel
+        static const bool rows_off = getenv("ASTTS_ATTN_DECODE") && !strcmp(getenv("ASTTS_ATTN_DECODE"), "v1");
+        const bool al16 = ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)pos & 15) == 0 && ((uintptr_t)q & 15) == 0 &&
+                          (ldk & 7) == 0 && (ldp & 7) == 0 && (k_bs & 7) == 0 && (q_bs & 3) == 0;
+        if (b > 32 && variant == 3 && (h % 4) == 0 && al16 && !rows_off) {
+            // (always four heads per workgroup: the partition of a row's keys, hence its sums, must not depend on the batch size)
+            static const int hg_env = getenv("ASTTS_ATTN_ROWS_HG") ? atoi(getenv("ASTTS_ATTN_ROWS_HG")) : 4;
+            if (hg_env == 8 && (h % 8) == 0) hipLaunchKernelGGL((attn_relpos_rows<8>), dim3(h / 8, b), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((attn_relpos_rows<4>), dim3(h / 4, b), dim3(512), 0, st, a);
+            if (prof) prof_end(ASTTS_PROF_ATTN_DECODE, st);
+            ASTTS_CHECK_LAUNCH();
+            return ASTTS_OK;
+        }
         const dim3 grid(h, b);
         switch (variant) {
             case 0: hipLaunchKernelGGL((attn_relpos_decode<float, float>), grid, dim3(512), lds, st, a); break;

@@ -228,6 +228,48 @@ def test_attn_relpos_decode_matches_prefill_row():
     assert rel_err(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("b,heads,tk", [(128, 16, 333), (40, 16, 77), (64, 4, 1030), (256, 8, 130), (33, 12, 5)])
+def test_attn_relpos_rows_wide_decode_batches(b, heads, tk):
+    """The wide decode batches' attention (attn_relpos_rows: more than 32 rows over an fp16 time-major cache and an fp16 position table,
+    one pass over the keys) against the fp32 definition on the fp16-rounded cache, with left-padded rows (key_start) -- and a row's
+    result does not depend on the rows beside it (a 32-row launch takes the (row, head) kernel: equal to rounding; a 40-row sub-batch
+    takes this kernel: equal bits)."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(b + tk)
+    hd = heads * 64
+    cap = tk + 7
+    kc = (torch.randn(cap, b, hd, generator=g)).half()            # time-major cache [T, B, 2 * hd]: K | V interleaved per row
+    vc = (torch.randn(cap, b, hd, generator=g)).half()
+    kv = torch.cat([kc, vc], dim=2).contiguous().to(DEV)
+    q = torch.randn(1, b, hd, generator=g)
+    center = 1100
+    pos = (torch.randn(2 * center + 1, hd, generator=g) * 0.5).half()
+    bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
+    ks = torch.randint(0, max(tk // 2, 1), (b,), generator=g).to(torch.int32)
+    ks[0] = 0
+    ks[-1] = tk - 1                                                # a row with a single valid key
+    kd, vd = kv[:tk, :, :hd], kv[:tk, :, hd:]
+    out = ops.attn_relpos(q.to(DEV), kd, vd, pos.to(DEV), bu.to(DEV), bv.to(DEV), heads, q_pos0=tk - 1, pos_center=center,
+                          time_major=True, key_start=ks.to(DEV))
+    assert out.shape == (1, b, hd) and bool(torch.isfinite(out).all())
+    for r in (0, 1, b // 2, b - 1):
+        k0 = int(ks[r])
+        lens = torch.tensor([tk - k0], dtype=torch.int32)
+        ref = _relpos_ref(q[:, r:r + 1].transpose(0, 1), kc[k0:tk, r:r + 1].float().transpose(0, 1), vc[k0:tk, r:r + 1].float().transpose(0, 1),
+                          pos.float(), center, bu, bv, heads, lens, tk - 1 - k0, False)
+        assert rel_err(out[0, r].cpu(), ref[0, 0]) < 2e-5, r
+    n2 = 32
+    small = ops.attn_relpos(q[:, :n2].contiguous().to(DEV), kv[:tk, :n2, :hd], kv[:tk, :n2, hd:], pos.to(DEV), bu.to(DEV), bv.to(DEV), heads,
+                            q_pos0=tk - 1, pos_center=center, time_major=True, key_start=ks[:n2].contiguous().to(DEV))
+    assert rel_err(small, out[:, :n2]) < 2e-5
+    if b >= 48:
+        n3 = 40
+        sub = ops.attn_relpos(q[:, :n3].contiguous().to(DEV), kv[:tk, :n3, :hd], kv[:tk, :n3, hd:], pos.to(DEV), bu.to(DEV), bv.to(DEV), heads,
+                              q_pos0=tk - 1, pos_center=center, time_major=True, key_start=ks[:n3].contiguous().to(DEV))
+        assert torch.equal(sub, out[:, :n3])
+
+
 @pytest.mark.parametrize("b,heads,t", [(2, 8, 344), (3, 8, 688), (1, 2, 31), (2, 4, 129)])
 def test_attn_mha_flash(b, heads, t):
     from astts import ops
