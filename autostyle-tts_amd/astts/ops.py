@@ -59,8 +59,8 @@ _SIGS = {
     "astts_op_istft16": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p]),
     "astts_op_stft16_lens": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "astts_op_istft16_lens": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_float, c_void_p, c_void_p]),
-    "astts_op_gemm_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                     c_int32, c_int32, c_void_p]),
+    "astts_op_gemm_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                     c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "astts_op_gemm_lens": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,
                                      c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_float, c_float, c_void_p, c_void_p]),
@@ -353,22 +353,24 @@ def linear_ln(x: torch.Tensor, w: PackedWeight, residual: torch.Tensor, ln, eps:
 
 
 def gemm_rows(x: torch.Tensor, w: PackedWeight, act: str = "none", residual: Optional[torch.Tensor] = None, out_dtype=torch.float32,
-              out: Optional[torch.Tensor] = None, n: Optional[int] = None, row0: int = 0) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, n: Optional[int] = None, row0: int = 0,
+              out2: Optional[torch.Tensor] = None, n_split: int = 0) -> torch.Tensor:
     """``act(x @ w[row0 : row0 + n]^T + bias) + residual`` for a few hundred rows (astts_op_gemm_rows: the wide decode engine's
     projection kernel -- one memory round trip per workgroup; a row's sums do not depend on the other rows).  ``x`` fp32 or fp16
-    ``[m, k]`` with k == w.cin == w.cin_pad."""
+    ``[m, k]`` with k == w.cin == w.cin_pad; ``out2``: columns >= n_split go there (e.g. a KV-cache row, fp16)."""
     x = _act_in(x)
     assert x.dim() == 2 and w.taps == 1 and w.cin == w.cin_pad == x.shape[1] and x.stride(1) == 1
     m, k = x.shape
     n = w.n - row0 if n is None else n
     if out is None:
-        out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+        out = torch.empty((m, n_split if out2 is not None else n), dtype=out_dtype, device=x.device)
     if residual is not None:
         residual = _f32(residual)
     bias = None if w.bias is None else w.bias[row0:]
-    _lib.check(_L().astts_op_gemm_rows(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, w.data.data_ptr() + 2 * row0 * w.cin_pad, _p(bias),
-                                       _p(residual), out.data_ptr(), 1 if out.dtype == torch.float16 else 0, m, n, k, x.stride(0), out.stride(0),
-                                       residual.stride(0) if residual is not None else 0, ACT[act], _st()))
+    _lib.check(_L().astts_op_gemm_rows(x.data_ptr(), 1 if x.dtype == torch.float16 else 0, w.data.data_ptr() + 2 * row0 * w.cin_pad,
+                                       _p(bias), _p(residual), out.data_ptr(), 1 if out.dtype == torch.float16 else 0, _p(out2),
+                                       1 if (out2 is not None and out2.dtype == torch.float16) else 0, m, n, n_split, k, x.stride(0), out.stride(0),
+                                       out2.stride(0) if out2 is not None else 0, residual.stride(0) if residual is not None else 0, ACT[act], _st()))
     return out
 
 

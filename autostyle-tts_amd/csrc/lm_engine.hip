@@ -210,12 +210,25 @@ static int decode_wide(astts_lm* h, const float* logits0, void* const* kv_cache,
     int32_t* tok = (int32_t*)take(sizeof(int32_t) * b);
     const float scale = 0.125f;
     const int64_t kv_row = (int64_t)b * 2 * d;      // one time step of the time-major cache
-    // y[m, n] = act(x[m, :] . W[n, :] + bias) (+ residual): the GEMM family picks the ring kernel for fp16 activations at >= 64 rows
-    // (astts_op_gemm_rows: a latency-sized kernel for these shapes; ASTTS_LM_WIDE_GEMM=tile goes back to the tile / ring family)
+    // astts_op_gemm_rows: a latency-sized kernel for these shapes; the K | V columns of the q | k | v projection go straight into the
+    // cache (seven launches per layer: two LayerNorms, q | k | v, attention, out-projection, FFN-in, FFN-out).  ASTTS_LM_WIDE_GEMM=tile
+    // goes back to the tile / ring family (eight per layer).
     static const bool rows_kernel = !(getenv("ASTTS_LM_WIDE_GEMM") && !strcmp(getenv("ASTTS_LM_WIDE_GEMM"), "tile"));
     auto gemm = [&](const void* x, int x16, int k, const void* w, const float* bias, const float* res, void* out, int out16, int n, int ldc, int act) {
-        if (rows_kernel) return astts_op_gemm_rows(x, x16, w, bias, res, out, out16, b, n, k, k, ldc, res ? d : 0, act, stream);
+        if (rows_kernel)
+            return astts_op_gemm_rows(x, x16, w, bias, res, out, out16, nullptr, 0, b, n, 0, k, k, ldc, 0, res ? d : 0, act, stream);
         return astts_op_gemm_ex(x, x16, w, bias, res, nullptr, out, out16, b, n, k, k, 1, k, ldc, res ? d : 0, b, b, 1, 1, 0, act, 1.0f, 0.1f, stream);
+    };
+    // LayerNorm(x) -> fp16 -> projection (optionally with a second destination for the columns >= n_split)
+    auto gemm_ln = [&](const float* x, const float* ga, const float* be, const void* w, const float* bias, void* out, int out16, int n, int ldc,
+                       int act, void* out2, int n_split, int ldc2) {
+        int rc = astts_op_layernorm_ex(x, ga, be, n16, 1, b, d, d, d, c.eps, stream);
+        if (rc != ASTTS_OK) return rc;
+        if (rows_kernel)
+            return astts_op_gemm_rows(n16, 1, w, bias, nullptr, out, out16, out2, 1, b, n, n_split, d, d, ldc, ldc2, 0, act, stream);
+        if (!out2) return gemm(n16, 1, d, w, bias, nullptr, out, out16, n, ldc, act);
+        if ((rc = gemm(n16, 1, d, w, bias, nullptr, out, out16, n_split, ldc, act)) != ASTTS_OK) return rc;
+        return gemm(n16, 1, d, (const _Float16*)w + (size_t)n_split * d, bias + n_split, nullptr, out2, 1, n - n_split, ldc2, act);
     };
     const float* cur = s_begin == 0 ? logits0 : lg;
     for (int s = s_begin; s < s_end; ++s) {
@@ -237,21 +250,16 @@ static int decode_wide(astts_lm* h, const float* logits0, void* const* kv_cache,
         for (int l = 0; l < c.layers; ++l) {
             const astts_lm_layer_t& L = h->layers[l];
             char* kvc = (char*)kv_cache[l];
-            const _Float16* wqkv = (const _Float16*)L.wqkv;
-            if ((rc = astts_op_layernorm_ex(x, L.n1_g, L.n1_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
-            if ((rc = gemm(n16, 1, d, wqkv, L.bqkv, nullptr, q, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
-            if ((rc = gemm(n16, 1, d, wqkv + (size_t)d * d, L.bqkv + d, nullptr, kvc + (size_t)pos * kv_row * 2, 1, 2 * d, 2 * d, ASTTS_ACT_NONE)) != ASTTS_OK)
+            if ((rc = gemm_ln(x, L.n1_g, L.n1_b, L.wqkv, L.bqkv, q, 0, 3 * d, d, ASTTS_ACT_NONE, kvc + (size_t)pos * kv_row * 2, d, 2 * d)) != ASTTS_OK)
                 return rc;
             rc = astts_op_attn_relpos_ex(q, kvc, kvc + (size_t)d * 2, 1, L.pos, 1, L.bias_u, L.bias_v, nullptr, key_start, ao, b, c.heads, 1, pos + 1,
                                          b * d, (int32_t)kv_row, b * d, c.pos_ld, d, 2 * d, d, pos, c.pos_center, 1, scale, stream);
             if (rc != ASTTS_OK) return rc;
             if ((rc = gemm(ao, 0, d, L.wo, L.bo, x, y, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
-            if ((rc = astts_op_layernorm_ex(y, L.n2_g, L.n2_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
-            if ((rc = gemm(n16, 1, d, L.w1, L.b1, nullptr, ff, 1, c.ffn, c.ffn, ASTTS_ACT_RELU)) != ASTTS_OK) return rc;
+            if ((rc = gemm_ln(y, L.n2_g, L.n2_b, L.w1, L.b1, ff, 1, c.ffn, c.ffn, ASTTS_ACT_RELU, nullptr, 0, 0)) != ASTTS_OK) return rc;
             if ((rc = gemm(ff, 1, c.ffn, L.w2, L.b2, y, x, 0, d, d, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
         }
-        if ((rc = astts_op_layernorm_ex(x, g.after_g, g.after_b, n16, 1, b, d, d, d, c.eps, stream)) != ASTTS_OK) return rc;
-        if ((rc = gemm(n16, 1, d, g.head_w, g.head_b, nullptr, lg, 0, c.vocab_out, c.vocab_out, ASTTS_ACT_NONE)) != ASTTS_OK) return rc;
+        if ((rc = gemm_ln(x, g.after_g, g.after_b, g.head_w, g.head_b, lg, 0, c.vocab_out, c.vocab_out, ASTTS_ACT_NONE, nullptr, 0, 0)) != ASTTS_OK) return rc;
         cur = lg;
     }
     return ASTTS_OK;

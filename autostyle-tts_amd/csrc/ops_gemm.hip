@@ -955,6 +955,9 @@ __global__ __launch_bounds__(512) void gemm_skinny16(GemmArgs a) {
 // v_mfma_f32_16x16x32_f16 on registers, an LDS reduction over the waves in wave order (a fixed order: results do not depend on
 // timing) and the epilogue.  A row's sums do not depend on the other rows of the launch.  Column tiles are the fast block index:
 // workgroups that share a weight tile differ by a multiple of the tile count and land on the same XCD's L2 when that is a multiple of 8.
+// Columns >= n_split may go to a second destination (a.out2: the K | V half of a q | k | v projection lands in the KV cache as fp16).
+// (A LayerNorm prologue -- fp32 rows normalised in registers while the weights are in flight -- was built, parity-green and slower than
+// a LayerNorm launch of its own: fp32 rows double the activation bytes every column tile re-reads.  EXPERIMENTS.md M.)
 template <int RT, int CT, int PL, bool A32>
 __global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gr_red[];    // [8][RT * CT][4][64]
@@ -985,13 +988,12 @@ __global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
         half8 fb[CT][PL][2];
         half8 fa[A32 ? 1 : RT][A32 ? 1 : PL][2];
         float4 fx[A32 ? RT : 1][A32 ? PL : 1][4];
+        // Unconditional loads from a clamped line, zeroed afterwards when the line does not exist: `if (on) x = load` compiles to a
+        // branch per load with an s_waitcnt between them (EXPERIMENTS.md G) -- the whole point here is ONE batch of loads.
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
-            // Unconditional loads from a clamped line, zeroed afterwards when the line does not exist: `if (on) x = load` compiles to a
-            // branch per load with an s_waitcnt between them (EXPERIMENTS.md G) -- the whole point here is ONE batch of loads.
             const int line = wid + (pass * PL + i) * 8;
-            const bool on = line < lines;
-            const int lc = on ? line : 0;
+            const int lc = line < lines ? line : 0;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 if constexpr (A32) {
@@ -1004,6 +1006,11 @@ __global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
                     fa[t][i][1] = *reinterpret_cast<const half8*>(p + 8);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int line = wid + (pass * PL + i) * 8;
+            const int lc = line < lines ? line : 0;
 #pragma unroll
             for (int u = 0; u < CT; ++u) {
                 fb[u][i][0] = *reinterpret_cast<const half8*>(wrow[u] + lc * 64);
@@ -1040,11 +1047,15 @@ __global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
             for (int t = 0; t < RT; ++t) {
                 half8 x0, x1;
                 if constexpr (A32) {
-                    const float4 v0 = fx[t][i][0], v1 = fx[t][i][1], v2 = fx[t][i][2], v3 = fx[t][i][3];
-                    x0[0] = (_Float16)v0.x; x0[1] = (_Float16)v0.y; x0[2] = (_Float16)v0.z; x0[3] = (_Float16)v0.w;
-                    x0[4] = (_Float16)v1.x; x0[5] = (_Float16)v1.y; x0[6] = (_Float16)v1.z; x0[7] = (_Float16)v1.w;
-                    x1[0] = (_Float16)v2.x; x1[1] = (_Float16)v2.y; x1[2] = (_Float16)v2.z; x1[3] = (_Float16)v2.w;
-                    x1[4] = (_Float16)v3.x; x1[5] = (_Float16)v3.y; x1[6] = (_Float16)v3.z; x1[7] = (_Float16)v3.w;
+                    float4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = fx[t][i][j];
+                    }
+                    x0[0] = (_Float16)v[0].x; x0[1] = (_Float16)v[0].y; x0[2] = (_Float16)v[0].z; x0[3] = (_Float16)v[0].w;
+                    x0[4] = (_Float16)v[1].x; x0[5] = (_Float16)v[1].y; x0[6] = (_Float16)v[1].z; x0[7] = (_Float16)v[1].w;
+                    x1[0] = (_Float16)v[2].x; x1[1] = (_Float16)v[2].y; x1[2] = (_Float16)v[2].z; x1[3] = (_Float16)v[2].w;
+                    x1[4] = (_Float16)v[3].x; x1[5] = (_Float16)v[3].y; x1[6] = (_Float16)v[3].z; x1[7] = (_Float16)v[3].w;
                 } else {
                     x0 = fa[t][i][0];
                     x1 = fa[t][i][1];
@@ -1074,8 +1085,14 @@ __global__ __launch_bounds__(512) void gemm_rows(GemmArgs a) {
         const int n = n0 + 16 * (tile % CT) + (ln & 15), m = m0 + 16 * (tile / CT) + (ln >> 4) * 4 + e;
         if (n < a.n && m < M) {
             v = apply_act(v + (a.bias ? e_bias[j] : 0.0f), a.act, a.slope) * a.alpha + (a.residual ? e_res[j] : 0.0f);
-            if (a.out_f16) reinterpret_cast<_Float16*>(a.out)[(int64_t)m * a.ldc + n] = (_Float16)v;
-            else a.out[(int64_t)m * a.ldc + n] = v;
+            if (a.out2 && n >= a.n_split) {
+                if (a.out2_f16) reinterpret_cast<_Float16*>(a.out2)[(int64_t)m * a.ldc2 + (n - a.n_split)] = (_Float16)v;
+                else a.out2[(int64_t)m * a.ldc2 + (n - a.n_split)] = v;
+            } else if (a.out_f16) {
+                reinterpret_cast<_Float16*>(a.out)[(int64_t)m * a.ldc + n] = (_Float16)v;
+            } else {
+                a.out[(int64_t)m * a.ldc + n] = v;
+            }
         }
     }
 }
@@ -1337,17 +1354,21 @@ int astts_op_gemm_lens(const void* x, int32_t x_f16, const void* w_f16, const fl
     return launch_gemm(a, (hipStream_t)stream);
 }
 
-int astts_op_gemm_rows(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual, void* out, int32_t out_f16,
-                       int32_t m, int32_t n, int32_t k, int32_t lda, int32_t ldc, int32_t ldr, int32_t act, astts_stream_t stream) {
+int astts_op_gemm_rows(const void* x, int32_t x_f16, const void* w_f16,
+                       const float* bias, const float* residual, void* out, int32_t out_f16, void* out2, int32_t out2_f16, int32_t m, int32_t n,
+                       int32_t n_split, int32_t k, int32_t lda, int32_t ldc, int32_t ldc2, int32_t ldr, int32_t act, astts_stream_t stream) {
     ASTTS_REQUIRE(x && w_f16 && out, ASTTS_ERR_INVALID, "astts_op_gemm_rows: null pointer");
     ASTTS_REQUIRE(m >= 1 && m <= 4096 && n >= 1 && k >= 64 && (k % 64) == 0, ASTTS_ERR_UNSUPPORTED,
                   "astts_op_gemm_rows: m=%d n=%d k=%d (1 <= m <= 4096 rows, k a multiple of 64)", m, n, k);
-    ASTTS_REQUIRE((lda % (x_f16 ? 8 : 4)) == 0 && (((uintptr_t)x | (uintptr_t)w_f16) & 15) == 0 && lda >= k && ldc >= n && (!residual || ldr >= n),
+    ASTTS_REQUIRE((lda % (x_f16 ? 8 : 4)) == 0 && (((uintptr_t)x | (uintptr_t)w_f16) & 15) == 0 && lda >= k && ldc >= (out2 ? n_split : n) &&
+                      (!residual || ldr >= n),
                   ASTTS_ERR_INVALID, "astts_op_gemm_rows: operands must be 16-byte aligned (lda=%d), ld* >= the row's width", lda);
+    ASTTS_REQUIRE(!out2 || (n_split >= 1 && n_split < n && ldc2 >= n - n_split), ASTTS_ERR_INVALID,
+                  "astts_op_gemm_rows: split output needs 1 <= n_split=%d < n=%d and ldc2=%d >= n - n_split", n_split, n, ldc2);
     ASTTS_REQUIRE(act >= ACT_NONE && act <= ACT_LEAKY, ASTTS_ERR_INVALID, "astts_op_gemm_rows: act=%d", act);
     GemmArgs a{(const float*)x, (const _Float16*)w_f16, bias, residual, nullptr, (float*)out, m, n, k, k, 1,
                lda, ldc, ldr, m, m, 1, 1, 0, act, 1.0f, 0.1f,
-               nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, x_f16 ? 1 : 0, out_f16 ? 1 : 0, 0};
+               nullptr, nullptr, nullptr, 0.0f, (float*)out2, ldc2, n_split, x_f16 ? 1 : 0, out_f16 ? 1 : 0, out2_f16 ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)m * n * k);
     const int per_wave = (k / 64 + 7) / 8;      // K lines per wave: one pass when the fragments fit the registers

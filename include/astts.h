@@ -174,11 +174,13 @@ int astts_op_gemm_lens(const void* x, int32_t x_f16, const void* w_f16, const fl
 /* Latency-sized GEMM for batches of a few hundred rows (the wide decode engine: one nn.Linear of TransformerLM's decoder layers for
  * every row of a 33 .. 256-row decode batch, /root/reference/tts_with_rag.py:195 -> cosyvoice llm.inference, one launch per
  * projection): out[m, n] = act(x[m, :] . w[n, :] + bias[n]) + residual[m, n].  x fp32 or fp16 [m, lda], w fp16 [>= n rows, k]
- * (k a multiple of 64, K contiguous), out fp32 or fp16 [m, ldc].  Every operand fragment of a workgroup is requested before its
- * first MFMA (one memory round trip); a row's sums do not depend on the other rows of the launch nor on timing. */
+ * (k a multiple of 64, K contiguous), out fp32 or fp16 [m, ldc].  out2 (or NULL): columns >= n_split go to out2[m, n - n_split]
+ * (row stride ldc2, fp16 when out2_f16: the K | V half of a q | k | v projection lands in the KV cache).  Every operand fragment
+ * of a workgroup is requested before its first MFMA (one memory round trip); a row's sums do not depend on the other rows of the
+ * launch nor on timing. */
 int astts_op_gemm_rows(const void* x, int32_t x_f16, const void* w_f16, const float* bias, const float* residual, void* out,
-                       int32_t out_f16, int32_t m, int32_t n, int32_t k, int32_t lda, int32_t ldc, int32_t ldr, int32_t act,
-                       astts_stream_t stream);
+                       int32_t out_f16, void* out2, int32_t out2_f16, int32_t m, int32_t n, int32_t n_split, int32_t k, int32_t lda,
+                       int32_t ldc, int32_t ldc2, int32_t ldr, int32_t act, astts_stream_t stream);
 /* Decode-sized GEMM (m <= 32, weight-bandwidth bound) with the fusions that take whole launches out of
  * an LM decode step: optional row gather (x row of output row i = x[gather[i]], i.e. an embedding lookup),
  * optional LayerNorm(gamma, beta, eps) over the cin inputs of every row applied while loading, and an

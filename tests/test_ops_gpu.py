@@ -508,6 +508,31 @@ def test_gemm_rows_matches_definition_rows_are_independent(m, k, n, act, x16, ou
         assert torch.equal(big[:, 32:288], want) and float(big[:, :32].abs().max()) == 0.0 and float(big[:, 288:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,k,n,n_split,x16", [(128, 1024, 3072, 1024, True), (256, 512, 1536, 512, True), (50, 1024, 2048, 1024, False)])
+def test_gemm_rows_split_output(m, k, n, n_split, x16):
+    """astts_op_gemm_rows with the columns >= n_split written as fp16 into a strided second destination (the KV-cache row of the wide
+    engine's q | k | v launch): both halves against the fp16-operand product, nothing written beside them, and bit-equal for a
+    sub-batch of the rows."""
+    from astts import ops
+
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    pw = ops.PackedWeight(w, b)
+    xd = x.to(DEV).half() if x16 else x.to(DEV)
+    cache = torch.zeros((m, 2 * (n - n_split)), dtype=torch.float16, device=DEV)
+    y = ops.gemm_rows(xd, pw, out2=cache[:, 16:16 + n - n_split], n_split=n_split)
+    ref = F.linear(h16(x), h16(w), b)
+    assert y.shape == (m, n_split) and rel_err(y, ref[:, :n_split]) < 2e-4
+    assert rel_err(cache[:, 16:16 + n - n_split].float(), ref[:, n_split:]) < 1.5e-3
+    assert float(cache[:, :16].abs().max()) == 0.0 and float(cache[:, 16 + n - n_split:].abs().max()) == 0.0
+    sub = min(40, m)
+    c2 = torch.zeros((sub, n - n_split), dtype=torch.float16, device=DEV)
+    y2 = ops.gemm_rows(xd[:sub].contiguous(), pw, out2=c2, n_split=n_split)
+    assert torch.equal(y2, y[:sub]) and torch.equal(c2, cache[:sub, 16:16 + n - n_split])
+
+
 def test_gemm_fused_layernorm_gather_split_output():
     """The fusions of the LM decode step: embedding-row gather, LayerNorm prologue, K|V half of the output written as
     fp16 into a strided destination (a KV-cache row)."""
