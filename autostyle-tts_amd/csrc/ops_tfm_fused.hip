@@ -65,6 +65,12 @@ struct TfmAttnArgs {
 // The kernel body: workgroup L of 2 * heads * b.  Every wave returns from it (no early exit, so that a caller can continue in the
 // same launch: the one-launch block kernel measured in DESIGN.md did); seq_out / unit_out: this workgroup's sequence and its index
 // (head * 2 + query half) among the sequence's.
+// FULL: one workgroup per (head, sequence) takes BOTH query halves, one after the other -- K and V are projected once instead of twice,
+// the weights and the sequence's rows are fetched and normalised once (batches of more than 16 sequences, where the 2 x heads x b
+// workgroups of the half form need several rounds on the 256 CUs anyway).  LDS has no room for the second half's Q rows: phase 1 parks them
+// in the rows of the OUTPUT tensor they will be replaced by (same size, same owner), and they come back into the Q buffer between the two
+// attention passes.  Every row goes through the same arithmetic in the same order as in the half form: the results are bit-identical.
+template <bool FULL>
 __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out, int* unit_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -75,27 +81,27 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     // batch is a multiple of 8, sequence b goes to XCD b mod 8: one L2 fetches its rows once for all 16 workgroups.
     int qs, head, b;
     {
-        const int units = 2 * a.heads;                  // workgroups per sequence
+        const int units = FULL ? a.heads : 2 * a.heads;  // workgroups per sequence
         const int L = blockIdx.x;
+        int hq;
         if ((a.b & 7) == 0) {
             const int xcd = L & 7, slot = L >> 3;
             b = xcd + 8 * (slot / units);
-            const int hq = slot % units;
-            head = hq >> 1;
-            qs = hq & 1;
+            hq = slot % units;
         } else {
             b = L / units;
-            const int hq = L % units;
-            head = hq >> 1;
-            qs = hq & 1;
+            hq = L % units;
         }
+        head = FULL ? hq : hq >> 1;
+        qs = FULL ? 0 : hq & 1;
     }
     const int T = a.t;
     const int nch = (T + 31) >> 5;                   // 32-frame chunks
     const int tkp = nch * 32;
     const int vs = tkp + 4;                          // halfs per V^T row: (tkp / 2 + 2) dwords = 2 * odd multiple: conflict-free b64 reads
-    const int qch0 = qs == 0 ? 0 : (nch + 1) / 2;    // this workgroup's query chunks [qch0, qch1)
-    const int qch1 = qs == 0 ? (nch + 1) / 2 : nch;
+    const int hsplit = (nch + 1) / 2;                // query half 0 = chunks [0, hsplit), half 1 = [hsplit, nch)
+    const int pq0 = FULL ? 0 : (qs == 0 ? 0 : hsplit);     // chunks whose Q rows this workgroup projects: [pq0, pq1)
+    const int pq1 = FULL ? nch : (qs == 0 ? hsplit : nch);
     _Float16* sK = tf_smem;                          // [tkp][72]
     _Float16* sVt = sK + (size_t)tkp * TF_KS;        // [64][vs]
     _Float16* sA = sVt + (size_t)TF_DH * vs;         // [2][32][264]
@@ -168,7 +174,9 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     };
     auto project_chunk = [&](int ch) {
         const int buf = ch & 1;
-        const bool q_chunk = ch >= qch0 && ch < qch1;
+        const bool q_chunk = ch >= pq0 && ch < pq1;
+        const bool q_parked = FULL && ch >= hsplit;      // second half's Q rows: to the output tensor's rows for now
+        const int qbase = FULL ? 0 : pq0;
         if (role < 2 || (role == 2 && q_chunk)) {
             const _Float16* ap = sA + (size_t)buf * 32 * TF_AS + c * TF_AS + 8 * hh;
             float16v acc;
@@ -200,13 +208,16 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
                     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s0 + s], af[s], acc, 0, 0, 0);
                 }
                 _Float16* kp = sK + (size_t)(ch * 32 + c) * TF_KS + (wid & 1) * 32 + 4 * hh;
-                const int qr = (ch - qch0) * 32 + c;
+                const int qr = (ch - qbase) * 32 + c;
+                const int fr = ch * 32 + c;
+                _Float16* park = a.out + ((int64_t)b * T + min(fr, T - 1)) * hd + head * TF_DH + (wid & 1) * 32 + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     half4 h4;
                     h4[0] = (_Float16)acc[4 * g]; h4[1] = (_Float16)acc[4 * g + 1]; h4[2] = (_Float16)acc[4 * g + 2]; h4[3] = (_Float16)acc[4 * g + 3];
                     if (role == 0) *reinterpret_cast<half4*>(kp + 8 * g) = h4;
-                    else *reinterpret_cast<half4*>(sQ + tf_q(qr, (wid & 1) * 32 + 4 * hh + 8 * g)) = h4;
+                    else if (!q_parked) *reinterpret_cast<half4*>(sQ + tf_q(qr, (wid & 1) * 32 + 4 * hh + 8 * g)) = h4;
+                    else if (fr < T) *reinterpret_cast<half4*>(park + 8 * g) = h4;
                 }
             }
         }
@@ -238,6 +249,26 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     // 2 / 3: instead the key range of tile 4 (5) is split between waves 4 and 6 (5 and 7) -- four ways over waves 4..7 when there
     // are five tiles -- and the owner merges the helpers' unnormalised partials through LDS (the staging buffers are free now):
     // 16.5 tile-units per SIMD.
+    unsigned pf_keep[3];
+    *seq_out = b;
+    *unit_out = FULL ? head * 2 : head * 2 + qs;
+    for (int hf = FULL ? 0 : qs; hf < (FULL ? 2 : qs + 1); ++hf) {
+    const int qch0 = hf == 0 ? 0 : hsplit;           // this pass's query chunks [qch0, qch1)
+    const int qch1 = hf == 0 ? hsplit : nch;
+    if (FULL && hf == 1) {
+        // the parked Q rows come back: every wave's stores of phase 1 are ordered before the barrier, the loads behind it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();                             // (also: pass 0's owners are done with the Q buffer as their transpose buffer)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int rows = (nch - hsplit) * 32;
+        for (int i = tid; i < rows * 8; i += 512) {
+            const int r = i >> 3, pc = i & 7;
+            const int fr = min(hsplit * 32 + r, T - 1);
+            const half8 v = *reinterpret_cast<const half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + pc * 8);
+            *reinterpret_cast<half8*>(sQ + tf_q(r, pc * 8)) = v;
+        }
+        __syncthreads();
+    }
     const int ntile = qch1 - qch0;
     int tile = -1, part = 0, parts = 1;
     if (wid < 4) {
@@ -249,8 +280,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
     } else if (ntile == 6) {
         tile = 4 + (wid & 1); part = (wid - 4) >> 1; parts = 2;
     }
-    unsigned pf_keep[3];
-    {   // L2 prefetch of the next launches' weights: the workgroups of one XCD (ids congruent mod 8) split each range between them, one
+    if (hf == (FULL ? 0 : qs)) {   // L2 prefetch of the next launches' weights: the workgroups of one XCD (ids congruent mod 8) split each range between them, one
         // 128-byte line per thread and range (a range beyond 512 lines per slot -- none today -- is left to its own launch).  Untracked asm
         // loads (xlane.h prefetch_line): the volatile loads used before compiled to system-scope flat loads with an immediate
         // s_waitcnt vmcnt(0) each -- the waves owning query tiles 0 and 1 sat out three HBM misses in a row before their first score
@@ -362,8 +392,6 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
         mp[33 * 64] = l_run;
     }
     __syncthreads();
-    *seq_out = b;
-    *unit_out = head * 2 + qs;
     if (!(tile < 0 || part > 0)) {
     for (int hp = 1; hp < parts; ++hp) {
         const float* mp = sM + (size_t)(ntile == 5 ? hp - 1 : wid - 4) * 34 * 64 + lane;
@@ -402,6 +430,7 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
             *reinterpret_cast<half8*>(a.out + ((int64_t)b * T + fr) * hd + head * TF_DH + seg) = *reinterpret_cast<const half8*>(qrow + tf_q(r, seg));
     }
     }
+    }   // query halves
     prefetch_keep(pf_keep[0]);                         // the prefetch destinations stay reserved to the end
     prefetch_keep(pf_keep[1]);
     prefetch_keep(pf_keep[2]);
@@ -409,12 +438,13 @@ __device__ __forceinline__ void tfm_attn_body(const TfmAttnArgs& a, int* seq_out
 
 // Leading parameters = what the first loads (weight fragments, the sequence's rows) need: preloaded into SGPRs by the command
 // processor (-amdgpu-kernarg-preload-count, csrc/Makefile; a by-value struct is not), the struct carries the rest.
+template <bool FULL>
 __global__ __launch_bounds__(512, 2) void tfm_attn_fused(const float* p_x, const _Float16* p_w, const float* p_bias, const int* p_lens, int p_b, int p_heads,
                                                          int p_t, float p_eps, float p_scale, TfmAttnArgs a_in) {
     TfmAttnArgs a = a_in;
     a.x = p_x; a.w = p_w; a.bias = p_bias; a.lens = p_lens; a.b = p_b; a.heads = p_heads; a.t = p_t; a.eps = p_eps; a.scale = p_scale;
     int seq, unit;
-    tfm_attn_body(a, &seq, &unit);
+    tfm_attn_body<FULL>(a, &seq, &unit);
 }
 
 // row-major fp16 [rows][k] (astts_op_pack_weight image) -> fragment order [rows / 32][k / 16 k-steps][64 lanes][8]:
@@ -815,7 +845,8 @@ int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const 
     const size_t lds = ((size_t)tkp * TF_KS + (size_t)TF_DH * (tkp + 4) + 2 * 32 * TF_AS + (size_t)TF_QROWS * TF_QS) * sizeof(_Float16);
     static std::once_flag attr;
     std::call_once(attr, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_attn_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     TfmAttnArgs a{x, (const _Float16*)wqkv_frag_f16, bias, lens, (_Float16*)out_f16, b, heads, t, eps, scale, getenv("ASTTS_TFM_BALANCE") ? atoi(getenv("ASTTS_TFM_BALANCE")) : 1,
                   {nullptr, nullptr, nullptr}, {0u, 0u, 0u}};
@@ -829,7 +860,13 @@ int astts_op_tfm_attn_fused_pf(const float* x, const void* wqkv_frag_f16, const 
     // the other query half's workgroup is this kernel's overhead, not work)
     const double flops = (double)b * heads * (3.0 * 2.0 * t * 64.0 * TF_C + 4.0 * (double)t * t * TF_DH);
     const bool prof = prof_begin(ASTTS_PROF_ATTN_FLASH, st, flops);
-    hipLaunchKernelGGL(tfm_attn_fused, dim3(2 * heads * b), dim3(512), lds, st, a.x, a.w, a.bias, a.lens, a.b, a.heads, a.t, a.eps, a.scale, a);
+    // more than one round of (query half, head, sequence) workgroups on the 256 CUs: one workgroup per (head, sequence) takes both halves
+    // (K / V projected once; bit-identical results).  ASTTS_TFM_ATTN_FULL=0 / 1 forces a form (tests, A/B).
+    const char* fe = getenv("ASTTS_TFM_ATTN_FULL");       // read per call: the tests switch forms inside one process
+    const int full_env = fe ? atoi(fe) : -1;
+    const bool full = full_env >= 0 ? full_env != 0 : 2 * heads * b > 256;
+    if (full) hipLaunchKernelGGL(tfm_attn_fused<true>, dim3(heads * b), dim3(512), lds, st, a.x, a.w, a.bias, a.lens, a.b, a.heads, a.t, a.eps, a.scale, a);
+    else hipLaunchKernelGGL(tfm_attn_fused<false>, dim3(2 * heads * b), dim3(512), lds, st, a.x, a.w, a.bias, a.lens, a.b, a.heads, a.t, a.eps, a.scale, a);
     if (prof) prof_end(ASTTS_PROF_ATTN_FLASH, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

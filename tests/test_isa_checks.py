@@ -112,7 +112,8 @@ def test_render_kernels_issue_their_prologue_loads_in_one_batch(tmp_path):
     rconv_lds (+ its two units of weights) and of conv_lds' staging pass, the weight fragments + first row chunks of tfm_attn_fused, the A / B
     chunks of a gemm_tile K tile."""
     cases = [("ops_resnet_conv.hip", r"rconv_ldsILi256E", 5 + 32), ("ops_resnet_conv.hip", r"rconv_ldsILi512E", 9 + 32),
-             ("ops_conv_lds.hip", r"conv_ldsILi128ELi128E", 12), ("ops_tfm_fused.hip", r"tfm_attn_fused", 16 + 4),
+             ("ops_conv_lds.hip", r"conv_ldsILi128ELi128E", 12), ("ops_tfm_fused.hip", r"tfm_attn_fusedILb0E", 16 + 4),
+             ("ops_tfm_fused.hip", r"tfm_attn_fusedILb1E", 16 + 4),
              ("ops_gemm.hip", r"gemm_tileILi2ELi2ELi1ELi1ELb0ELi128E", 8 + 4)]
     cache = {}
     for src, pat, batch in cases:

@@ -734,6 +734,40 @@ def test_tfm_attn_fused_matches_definition_and_unfused_path(b, t, ragged):
     assert bool(torch.isfinite(out).all())
 
 
+@pytest.mark.parametrize("b,t,ragged", [(64, 344, False), (24, 375, True), (5, 384, True), (3, 33, True), (8, 1, False), (17, 353, True)])
+def test_tfm_attn_fused_full_form_is_bit_identical_to_the_half_form(b, t, ragged, monkeypatch):
+    """Beyond one round of (query half, head, sequence) workgroups a workgroup takes BOTH query halves of its (head, sequence): K and V are
+    projected once, the second half's Q rows wait in the output tensor's rows.  Same arithmetic per row in the same order: the outputs
+    of the two forms are equal bit for bit (so which form a batch takes is invisible in the results), over ragged lengths, odd and
+    single chunk counts; the automatic choice (more than 16 sequences at 8 heads) equals both."""
+    from astts import ops
+    from astts.synth.model import fold_layernorm
+
+    heads, c = 8, 256
+    g = torch.Generator().manual_seed(b * 77 + t)
+    x = (torch.randn(b, t, c, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w = torch.randn(3 * heads * 64, c, generator=g) / 16
+    lens = torch.tensor([t] + [max(1, t - 5 * (i + 1)) for i in range(b - 1)]) if ragged else torch.full((b,), t)
+    wf, bf = fold_layernorm(w, torch.randn(w.shape[0], generator=g) * 0.1, gamma, beta)
+    pw = ops.PackedWeight(wf, bf)
+    frag = ops.tfm_pack_frag(pw)
+    ld = lens.to(DEV, torch.int32)
+    outs = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("ASTTS_TFM_ATTN_FULL", form)
+        outs[form] = ops.tfm_attn_fused(x, pw, frag, heads, lens=ld)
+        again = ops.tfm_attn_fused(x, pw, frag, heads, lens=ld)
+        assert torch.equal(outs[form], again)
+    monkeypatch.delenv("ASTTS_TFM_ATTN_FULL")
+    auto = ops.tfm_attn_fused(x, pw, frag, heads, lens=ld)
+    for i in range(b):
+        L = int(lens[i])
+        assert torch.equal(outs["0"][i, :L], outs["1"][i, :L]), i
+        assert torch.equal(auto[i, :L], outs["0"][i, :L]), i
+    assert bool(torch.isfinite(outs["1"].float()).all())
+
+
 @pytest.mark.parametrize("m,hidden", [(5504, 1024), (37, 1024), (1, 256), (11008, 1024), (96, 512), (40000, 2048)])
 def test_tfm_ffn_fused_matches_definition_and_unfused_path(m, hidden):
     """astts_op_tfm_ffn_fused (LayerNorm + Linear + exact-erf GELU + Linear + residual of a flow-estimator transformer block in one
