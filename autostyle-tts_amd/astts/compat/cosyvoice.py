@@ -161,7 +161,7 @@ class CosyVoice:
         # per job (the weights are read once per token for all rows) -- the same arithmetic in another summation order, so a row's tokens
         # may differ from its 32-row run at near-ties of the sampler.
         self.wide_lm = os.environ.get("ASTTS_WIDE_LM", "0") == "1"
-        self.lm_rows = int(os.environ.get("ASTTS_LM_ROWS", "128" if self.wide_lm else "32"))
+        self.lm_rows = int(os.environ.get("ASTTS_LM_ROWS", "48" if self.wide_lm else "32"))     # (48: the best of the config-4 sweep)
         # measurement only (bench.py): HIP events around the LM decode of every job and the flow / vocoder passes of every render group
         self.collect_stage_times = False
         self._stage_events = []

@@ -506,8 +506,9 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
             warnings.simplefilter("ignore")
             cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
         if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 64 rows on the engine's wide path (CosyVoice.wide_lm)
-            # (64 rows: 636x; 96: 609; 128: 604; 256: 488 -- with 3 workers finer jobs balance better than the fatter chains save, profiles/r05_config4_lm_rows.log)
-            cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "64"))
+            # (rows per LM job on the wide engine's round-5 kernels: 32 (decode-step kernels) 581x; 40: 674; 48: 687; 56: 681; 64: 662; 96: 647;
+            # 128: 624 -- fatter chains cost fewer LM stream-seconds and more flow seconds beside them, profiles/r05_config4_lm_rows.log)
+            cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "48"))
         extra["lm_rows_per_job"] = cv.lm_rows
         g = torch.Generator().manual_seed(0)
         t16 = torch.arange(int(2.5 * 16000)) / 16000
