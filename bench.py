@@ -446,7 +446,7 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         # or 8 consecutive batches co-batched into ONE 128- / 256-row chain on the engine's wide path (plain GEMMs: the weights are read
         # once per token for all rows; AcousticLM.decode(wide=True)), every 32-row batch still rendered on its own.
         wide = os.environ.get("ASTTS_BENCH_WIDE", "1") != "0" and rows == 32
-        cands = ((2, 1), (3, 1)) + (((2, 4), (3, 4), (2, 8)) if wide else ())      # (one wide chain alone -- (1, 4), (1, 8) -- measured 10 % behind two)
+        cands = ((2, 1), (3, 1)) + (((3, 2), (2, 4), (3, 4), (2, 8)) if wide else ())      # (one wide chain alone -- (1, 4), (1, 8) -- measured 10 % behind two)
         pipe = PipelinedSynth.autotune(eng, sample, depths=cands, trials=1 if steps <= 2 else 2, steps=8 if wide else (4 if steps <= 2 else 6), dist=dist,
                                        wide_lm=wide)
         last = {}
