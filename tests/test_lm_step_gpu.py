@@ -377,3 +377,12 @@ def test_wide_engine_logits_match_oracle(size, b):
     lm.decode_range(ctx, 3)
     lm.decode_range(ctx)
     assert torch.equal(ctx["toks"], t_w)
+    # inside the wide engine a row does not depend on the rows beside it (gemm_rows / attn_relpos_rows sum a row's terms in an order of
+    # its own): the first 36 rows as a wide batch of their own
+    if b >= 72:
+        n2 = 36
+        _, lsub = lm.decode(pre[:, :n2].contiguous(), steps, u[:, :n2].contiguous().to(DEV), True, forced[:n2].to(DEV), return_logits=True,
+                            key_start=ks[:n2].contiguous(), wide=True)
+        dsub = float((lsub - logits[:n2]).abs().max())
+        print(f"[parity] wide engine {size} b={b}: rows 0..{n2 - 1} as their own wide batch differ by {dsub:.3e}")
+        assert dsub == 0.0
