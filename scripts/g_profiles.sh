@@ -38,4 +38,9 @@ print("traffic table:", {n: v["hbm_bytes_per_launch"] for n, v in t.items()})
 PY
 rm -rf /tmp/p3 && FLOW_N=1 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES -d /tmp/p3 -o p --output-format csv -- python3 scripts/flow_only.py > /dev/null 2>&1
 ( echo "== rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES -- python3 scripts/flow_only.py (FLOW_N=1: warm-up + 1 solve); per kernel: (launches, mean counter value per launch)"; python scripts/pmc_summary.py /tmp/p3 ) > gpurun_out/${R}_pmc_flow_lds.txt
+# the wide decode engine alone (128 rows x ~220 keys, 66 steps) and the flow solve at 64 sequences (32 utterances): what configs 3 / 4 / 5 run beside the headline's kernels
+rm -rf /tmp/p7 && rocprofv3 --kernel-trace --stats -d /tmp/p7 -o w --output-format csv -- python3 scripts/wide_probe.py > gpurun_out/${R}_wide_probe.log 2>&1
+python3 scripts/demangle_csv.py $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_wide_engine_kernel_stats.csv
+rm -rf /tmp/p8 && FLOW_B=32 FLOW_N=2 rocprofv3 --kernel-trace --stats -d /tmp/p8 -o f --output-format csv -- python3 scripts/flow_only.py > gpurun_out/${R}_flow_b32.log 2>&1
+python3 scripts/demangle_csv.py $(find /tmp/p8 -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_flow_b32_kernel_stats.csv
 head -12 gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-150; cat gpurun_out/${R}_pmc_fetch_synth.txt | head -12; cat gpurun_out/${R}_pmc_flow_lds.txt | head -8
