@@ -615,6 +615,18 @@ def bench_embedder(args, dev, cfg, eng):
     hq, hk = shape.heads * shape.head_dim, shape.kv_heads * shape.head_dim
     per_tok_layer = 2.0 * (shape.hidden * (hq + 2 * hk) + hq * shape.hidden + 3 * shape.hidden * shape.ffn)
     flops = b * t * shape.layers * per_tok_layer + b * shape.layers * 4.0 * shape.heads * shape.head_dim * t * (t + 1) / 2
+    # the batch of BASELINE configs[4]'s 256 queries in one pass (15 360 rows per GEMM instead of 1 920)
+    b2 = 256
+    ids2 = torch.randint(3, shape.vocab, (b2, t), generator=g)
+    lens2 = torch.full((b2,), t, dtype=torch.int32)
+    emb.embed_ids(ids2, lens2)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(5):
+        e2 = emb.embed_ids(ids2, lens2)
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t3) / 5
+    flops2 = flops * b2 / b
     prompts = [ids[i].tolist() for i in range(b)]
     emb.generate_greedy_batch(prompts, n_new)
     torch.cuda.synchronize()
@@ -636,7 +648,10 @@ def bench_embedder(args, dev, cfg, eng):
                              "ms_one_text_prompt_rerun_per_token": d1 * 1e3,
                              "note": "KV cache + argmax on the device, one host synchronisation per batch (rounds 3-4 re-ran the prompt per token "
                                      "with a host sync each: the last figure, ONE text)"},
-            "extrapolated_28_layers_texts_per_s": b / (dt * 28.0 / shape.layers)}
+            "extrapolated_28_layers_texts_per_s": b / (dt * 28.0 / shape.layers),
+            "batch_of_256_texts": {"texts_per_s": b2 / dt2, "ms_per_pass": dt2 * 1e3, "finite": bool(torch.isfinite(e2).all()),
+                                   "mfma_frac": flops2 / dt2 / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                   "note": "the same pass over 256 texts (configs[4]'s query batch): 15 360 rows per GEMM"}}
 
 
 def bench_streaming(args, dev, cfg, eng):
