@@ -745,7 +745,9 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.rt = (h->n >= 16384) ? (p.qt == 1 ? 4 : p.qt == 2 ? 2 : 1) : 1;
     p.tiles = (int)cdiv(h->n, 32 * p.rt);
     const int total_lines = h->dp / 64;
-    int ks = (int)cdiv(512, p.tiles);
+    // K split: a small bank needs it to fill the chip at all (32 tiles x 16 slices); a large one gets two slices when one would leave a
+    // ragged last round (100k x 6144, Q = 8: 782 blocks of 128 rows = three per CU and 14 left over: 336 -> 302 us per search with two)
+    int ks = (int)cdiv(p.tiles >= 256 ? 1536 : 512, p.tiles);
     int ks_max = total_lines / 4;
     if (ks_max < 1) ks_max = 1;
     if (ks > ks_max) ks = ks_max;
