@@ -741,12 +741,13 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     const int qgroup = nq < kMaxQPerPass ? nq : kMaxQPerPass;
     p.qt = qgroup <= 32 ? 1 : qgroup <= 64 ? 2 : qgroup <= 128 ? 4 : 8;
     p.qpad = p.qt * 32;
-    // rows per wave tile: reuse each query fragment over several bank tiles once the bank is large
-    p.rt = (h->n >= 16384) ? (p.qt == 1 ? 4 : p.qt == 2 ? 2 : 1) : 1;
+    // row tiles per wave: ONE for up to 32 queries -- the scan is an HBM stream and what it needs is waves in flight (48 VGPRs: eight waves
+    // per SIMD), not reuse of the query fragments (L2 hits): 100k x 6144, Q = 8: 336 us per search with four tiles per wave (782 blocks of
+    // 160 VGPRs), 277 with one; 100k x 768: 75.8 -> 57.6.  Two tiles for 33 .. 63 queries on a large bank (342 against 383 us at Q = 48).
+    p.rt = (h->n >= 16384 && p.qt == 2) ? 2 : 1;
     p.tiles = (int)cdiv(h->n, 32 * p.rt);
     const int total_lines = h->dp / 64;
-    // K split: a small bank needs it to fill the chip at all (32 tiles x 16 slices); a large one gets two slices when one would leave a
-    // ragged last round (100k x 6144, Q = 8: 782 blocks of 128 rows = three per CU and 14 left over: 336 -> 302 us per search with two)
+    // K split: a small bank needs it to fill the chip at all (32 tiles x 16 slices); a mid-sized one gets enough slices for ~six blocks per CU
     int ks = (int)cdiv(p.tiles >= 256 ? 1536 : 512, p.tiles);
     int ks_max = total_lines / 4;
     if (ks_max < 1) ks_max = 1;
@@ -993,7 +994,6 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
         } else
         switch (p.qt * 10 + p.rt) {
             case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, st); break;
-            case 14: rc = launch_scan<1, 4>(h, p, qh_g, qg, spart, st); break;
             case 21: rc = launch_scan<2, 1>(h, p, qh_g, qg, spart, st); break;
             case 22: rc = launch_scan<2, 2>(h, p, qh_g, qg, spart, st); break;
             case 41: rc = launch_scan<4, 1>(h, p, qh_g, qg, spart, st); break;
