@@ -307,6 +307,32 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 #pragma unroll
     for (int a = 0; a < QT; ++a) aptr[a] = qh + ((int64_t)a * total_lines << 11) + lane * 8;
 
+    if constexpr (QT * RT == 1) {
+        // one tile pair per wave: the next line's fragments are requested before this line's MFMAs (two lines in flight per wave; the
+        // loop is unrolled by two so that neither set is ever copied)
+        half8 b0[4], a0[4], b1[4], a1[4];
+        auto ld = [&](int line, half8 (&bf)[4], half8 (&af)[4]) {
+            const int64_t koff = (int64_t)min(line, line_end - 1) << 11;       // clamped: a valid address, the result unused past the end
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const half8*>(bptr[0] + koff + i * 512);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(aptr[0] + koff + i * 512);
+        };
+        auto mm = [&](const half8 (&bf)[4], const half8 (&af)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[i], acc[0][0], 0, 0, 0);
+        };
+        int line = line_begin + wid;
+        if (line < line_end) ld(line, b0, a0);
+        for (; line < line_end; line += 8) {
+            ld(line + 4, b1, a1);
+            mm(b0, a0);
+            if (line + 4 < line_end) {
+                ld(line + 8, b0, a0);
+                mm(b1, a1);
+            }
+        }
+    } else
     for (int line = line_begin + wid; line < line_end; line += 4) {
         const int64_t koff = (int64_t)line << 11;
         half8 bf[RT][4];
