@@ -541,17 +541,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
-template <int TM, int TN, int STAGES, int WN = 2>      // 4 waves as (4 / WN) x WN; wave tile (32 TM) x (32 TN)
-__global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
+template <int TM, int TN, int STAGES, int WN = 2, int NW = 4>      // NW waves as (NW / WN) x WN; wave tile (32 TM) x (32 TN)
+__global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (it cannot parse the LDS-DMA builtin)
-    constexpr int WM = 4 / WN;
+    constexpr int WM = NW / WN;
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE_BYTES = ROWS * 128;
-    constexpr int IPW = ROWS / 32;                 // DMA instructions per wave and stage (8 rows each, 4 waves)
+    constexpr int IPW = ROWS / (8 * NW);           // DMA instructions per wave and stage (8 rows each)
     constexpr int EPI_W = 32 * TN + 4;
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-    static_assert(4 * 32 * EPI_W * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the ring");
+    static_assert(ROWS % (8 * NW) == 0, "whole DMA instructions per wave");
+    static_assert(NW * 32 * EPI_W * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the ring");
     static_assert((STAGES - 2) * IPW <= 63, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
 
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
     const _Float16* src[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int row = 8 * (wid + 4 * i) + (lane >> 3);
+        const int row = 8 * (wid + NW * i) + (lane >> 3);
         const int slot = lane & 7;
         if (row < BM) {
             const int c = slot ^ ((row >> 1) & 7);
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
 #ifndef RING_SKIP_LOAD
 #pragma unroll
         for (int i = 0; i < IPW; ++i)
-            __builtin_amdgcn_global_load_lds(src[i] + kt * 64, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src[i] + kt * 64, (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
 #endif
     };
 
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void gemm_ring(GemmArgs a) {
     }
     __syncthreads();                               // all fragment reads done (and no DMA outstanding): the ring becomes slab space
 #ifndef RING_SKIP_EPI
-    if constexpr (WN == 4 && TM == 1) {
+    if constexpr (WN == 4 && TM == 1 && NW == 4) {
         if (a.ln_gamma) {      // block = whole output rows (n == BN): residual add + LayerNorm of the result fused in
             tile_epilogue_ln<TN>(a, acc[0], reinterpret_cast<float*>(ring), reinterpret_cast<float*>(ring + 4 * 32 * EPI_W * 4), m0, wn, wid, lane);
             return;
@@ -1224,16 +1225,30 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         // the deep-K tiles differently).  Wide outputs (K = 256: four K tiles) take two-stage rings -- 48 KB of LDS puts three
         // blocks on a CU and the overlap of one block's epilogue with its neighbours' loads beats a deeper ring (16 -> 12 us);
         // the n <= 256 projections (K = 512 / 1024 from cold weights) keep the 4-stage 64x64 ring.
-        //   1: 128x128 x2 (once there are >= 4-8 tiles per CU)   2: 128x64 x2 (wide outputs)   3: 64x64 x4 (n <= 256)
+        //   1: 128x128 x2 (once there are >= 4-8 tiles per CU)   2: 128x64 x2 (wide outputs)   3: 64x64 x4 (n <= 256)   4: 256x256 x2, 8 waves
         const int64_t b128 = blocks(128, 128);
         int mode;
         // (deep K with enough tiles -- the kNN scan as a GEMM, K = 6144: 128 x 128 measured 727 us per 256-query search against 797 for
         // 128 x 64 and 906 for 64 x 64, profiles/r05_knn_gemm_ab.log)
-        if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512)) mode = 1;
+        // 4: 256 x 256 with eight waves (two stages = 128 KB, one block per CU).  The ring kernels are bound by the bytes a CU can keep in
+        // flight (latency x rate, against the LDS left beside the tile being multiplied): 128 x 128 holds 2 blocks x 32 KB for 2.1 MFLOP
+        // each, 256 x 256 holds 64 KB for 8.4 MFLOP.  scripts/ring_shapes.py, TFLOP/s 128 x 128 -> 256 x 256: 15 360 x 3072 x 5120 (the
+        // embedder's q|k|v) 807 -> 1025, 15 360 x 8192 x 3072 832 -> 1037, 23 680 x 1024 x 4096 700 -> 916, the kNN scan 256 x 6144 x 100k
+        // 639 -> 796; needs more than a round of blocks (86 blocks: 349 against 548) and deep K (the flow's K = 256 projections at 44 032
+        // rows: 532 against 463 back to back, but the 64-sequence flow solve measured 123.8 ms with it and 121.0 without).
+        const int64_t b256 = blocks(256, 256);
+        if (a.n > 128 && b256 >= 320 && a.cin_pad >= 1024) mode = 4;
+        else if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512)) mode = 1;
         else if (a.n >= 512 && blocks(128, 64) >= 160) mode = 2;
         else mode = 3;
         if (ring_env > 0) mode = ring_env;
-        if (mode == 1 && a.n > 64) {
+        if (mode == 4 && a.n > 128) {       // 256 x 256, eight waves, two stages (128 KB): twice the flops per byte in flight
+            static std::once_flag attr8;
+            std::call_once(attr8, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<4, 2, 2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+            });
+            hipLaunchKernelGGL((gemm_ring<4, 2, 2, 4, 8>), dim3((unsigned)(cdiv(a.m, 256) * cdiv(a.n, 256))), dim3(512), 2 * 512 * 128, st, a);
+        } else if ((mode == 1 || mode == 4) && a.n > 64) {
             hipLaunchKernelGGL((gemm_ring<2, 2, 2>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 128))), dim3(256), 2 * 256 * 128, st, a);
         } else if (mode == 2 || mode == 1) {
             hipLaunchKernelGGL((gemm_ring<2, 1, 2>), dim3((unsigned)(cdiv(a.m, 128) * cdiv(a.n, 64))), dim3(256), 2 * 192 * 128, st, a);
@@ -1295,7 +1310,7 @@ static int check_gemm_args(const char* who, const float* x, const void* w, float
 extern "C" {
 
 int astts_op_gemm_set_ring_mode(int32_t mode) {
-    ASTTS_REQUIRE(mode >= -1 && mode <= 3, ASTTS_ERR_INVALID, "astts_op_gemm_set_ring_mode: mode=%d (-1 auto, 0 off, 1..3 tile)", mode);
+    ASTTS_REQUIRE(mode >= -1 && mode <= 4, ASTTS_ERR_INVALID, "astts_op_gemm_set_ring_mode: mode=%d (-1 auto, 0 off, 1..4 tile)", mode);
     g_ring_mode_override = mode;
     return ASTTS_OK;
 }

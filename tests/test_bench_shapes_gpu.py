@@ -29,10 +29,11 @@ RING_SHAPES = [
     (11008, 1024, 256, "none", False, True),
     (32768, 256, 1024, "gelu", True, False),     # 256 x 8 = 2048 tiles of 128x128: ring mode 1 by the rule
     (5520, 256, 512, "none", False, False),      # ragged last row tile
+    (5000, 1024, 4097, "none", False, True),     # 20 x 17 = 340 tiles of 256x256 at K = 1024: ring mode 4 by the rule; ragged in both directions
 ]
 
 
-@pytest.mark.parametrize("mode", [-1, 1, 2, 3, 0])
+@pytest.mark.parametrize("mode", [-1, 1, 2, 3, 4, 0])
 @pytest.mark.parametrize("shape", RING_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}-{s[3]}")
 def test_ring_gemm_bench_shapes_every_tile(shape, mode):
     from astts import ops
