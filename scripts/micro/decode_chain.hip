@@ -22,6 +22,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
     fprintf(stderr, "\n");
 }
+int exp_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }   // the library's experiment switches: plain env here
 bool prof_begin(int, hipStream_t, double) { return false; }   // the library's bench-only launch profiler: off here
 void prof_end(int, hipStream_t) {}
 bool prof_events(int, double, hipEvent_t*, hipEvent_t*) { return false; }
