@@ -688,6 +688,15 @@ def test_new_entry_points_validate_arguments():
                                     8, 128, 0, 128, 128, 128, 128, 0, 0, 0, ctypes.c_float(1.0), ctypes.c_float(0.1), ctypes.c_void_p(256), 16,
                                     _lib.stream_ptr())
     assert rc == _lib.ERR_WORKSPACE
+    # astts_op_gemm_rows: K must be whole 64-element lines, the split output needs a second destination wide enough, operands aligned
+    x16 = torch.randn(64, 128, device=DEV).half()
+    y = torch.empty(64, 128, device=DEV)
+    args = lambda k, n_split, out2, ldc2, lda: (x16.data_ptr(), 1, pw.data.data_ptr(), None, None, y.data_ptr(), 0, out2, 1, 64, 128, n_split, k, lda, 128, ldc2,
+                                                 0, 0, _lib.stream_ptr())
+    assert lib.astts_op_gemm_rows(*args(96, 0, None, 0, 128)) == _lib.ERR_UNSUPPORTED and b"multiple of 64" in lib.astts_last_error_string()
+    assert lib.astts_op_gemm_rows(*args(128, 64, y.data_ptr(), 32, 128)) == _lib.ERR_INVALID and b"split output" in lib.astts_last_error_string()
+    assert lib.astts_op_gemm_rows(*args(128, 0, None, 0, 100)) == _lib.ERR_INVALID
+    assert lib.astts_op_gemm_rows(*args(128, 0, None, 0, 128)) == 0
 
 
 @pytest.mark.parametrize("b,t,ragged", [(2, 70, True), (16, 344, False), (3, 352, True), (1, 33, False), (2, 1, False),
