@@ -505,7 +505,7 @@ def run_side(args, which, dev, dist, rank, world, cfg, weights, eng=None, steps=
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             cv = CosyVoice("/nonexistent", config=cfg, seed=0, device=dev, allow_random_init=True, engine=eng)
-        if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 64 rows on the engine's wide path (CosyVoice.wide_lm)
+        if os.environ.get("ASTTS_BENCH_WIDE", "1") != "0":      # throughput run: LM jobs of 48 rows on the engine's wide path (CosyVoice.wide_lm)
             # (rows per LM job on the wide engine's round-5 kernels: 32 (decode-step kernels) 581x; 40: 674; 48: 687; 56: 681; 64: 662; 96: 647;
             # 128: 624 -- fatter chains cost fewer LM stream-seconds and more flow seconds beside them, profiles/r05_config4_lm_rows.log)
             cv.wide_lm, cv.lm_rows = True, int(os.environ.get("ASTTS_BENCH_LM_ROWS", "48"))
