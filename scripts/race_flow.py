@@ -8,7 +8,7 @@ from astts.synth.model import SynthEngine
 from astts import ops
 cfg = SynthConfig(); W = make_all(cfg, 0); eng = SynthEngine(W, cfg, 'cuda'); del W
 g = torch.Generator(device='cuda').manual_seed(0)
-B, Tt, Tp, Ts = 8, 32, 150, 250
+B, Tt, Tp, Ts = int(os.environ.get("RACE_B", 8)), 32, 150, 250
 dev = 'cuda'
 text = torch.randint(0, cfg.text_vocab, (B, Tt), device=dev, generator=g); tlen = torch.full((B,), Tt, dtype=torch.int32, device=dev)
 spk_s = torch.randn(B, cfg.spk_dim, device=dev, generator=g)
