@@ -42,7 +42,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_RANGE = -1, -2, -3, -4, -5
 DTYPE_F16, DTYPE_F32 = 1, 2
 METRIC_COSINE, METRIC_IP, METRIC_L2 = 0, 1, 2
-KNN_MAX_K = 32
+KNN_MAX_K = 1024
 KNN_FORCE_EXACT = 1
 
 
@@ -70,6 +70,8 @@ _SIGNATURES = {
                                    c_size_t, c_int32, c_void_p]),
     "astts_knn_search_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_size_t, c_int32, c_void_p]),
+    "astts_knn_search_masked": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                          c_size_t, c_int32, c_void_p]),
     "astts_knn_last_fallbacks": (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(c_int32)]),
     "astts_knn_profile_enable": (c_int32, [c_void_p, c_int32]),
     "astts_knn_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

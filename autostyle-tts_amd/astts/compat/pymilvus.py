@@ -14,7 +14,10 @@ Mirrors exactly the calls the reference makes (paths under /root/reference):
                                                             milvus/insert_embeddings.py:52-79 (auto_id pk, VARCHAR fields)
 Result shape: ``list[Q]`` of ``list[k]`` of ``{'id': pk, 'distance': cosine_similarity,
 'entity': {field: value}}`` sorted by similarity descending (``distance`` IS the similarity for
-COSINE: output_emb/search_results.json holds 0.81..0.95, larger = closer).
+COSINE: output_emb/search_results.json holds 0.81..0.95, larger = closer).  Collections created with ``metric_type`` IP / L2
+return the inner product (descending) / the squared Euclidean distance (ascending), as Milvus does.  ``filter``: scalar
+expressions over the primary key and the dynamic fields (astts.milvus_filter) become a row mask of the search kernels;
+``limit`` up to 1024 (32 hits per selection pass over one scan).
 
 The file behind ``db_path`` is read with astts.milvus_lite (SQLite + protobuf wire format); the
 vectors go to HBM once per collection and stay there.  Errors raise ``MilvusException`` -- the
@@ -240,8 +243,13 @@ class MilvusClient:
         THIS call over the ranks and all-gather its result (astts.parallel.sharded_search); ``hits_from_rows`` turns rows into the
         pymilvus result shape wherever the records are written."""
         c = self._get(collection_name)
-        if filter:
-            raise MilvusException(1, "filter expressions are not implemented by astts (the reference only passes None)")
+        mask = None
+        if filter:          # (the reference passes None: milvus/search_json.py:246-252)
+            from ..milvus_filter import FilterSyntaxError, row_mask
+            try:
+                mask = row_mask(filter, c.pk_field, c.pks, c.metas)
+            except FilterSyntaxError as e:
+                raise MilvusException(1100, f"failed to create query plan: cannot parse expression: {filter}, error: {e}") from None
         if anns_field is not None and anns_field != c.vector_field:
             raise MilvusException(1, f"anns_field {anns_field!r} does not exist (vector field is {c.vector_field!r})")
         mt = metric_type or (search_params or {}).get("metric_type") or (param or {}).get("metric_type")
@@ -261,10 +269,10 @@ class MilvusClient:
         from .._lib import KNN_MAX_K
         if k > KNN_MAX_K:
             # pymilvus accepts limit up to 16384; the reference asks for 1 or 3 (milvus/search_json.py:411,
-            # milvus/search_embeddings.py:64).  The certified top-k kernel keeps k <= 32 candidates lists in registers.
+            # milvus/search_embeddings.py:64).  Here: 32 certified hits per selection pass, at most 32 passes.
             raise MilvusException(1100, f"limit {limit} is not supported by this build: at most {KNN_MAX_K} hits per query "
                                         f"(collection holds {len(c.pks)} rows)")
-        idx, score = c.bank().search(q, k)
+        idx, score = c.bank().search(q, k, row_mask=mask)
         return np.asarray(idx, dtype=np.int64), np.asarray(score, dtype=np.float32)
 
     def hits_from_rows(self, collection_name: str, idx, score, output_fields: Optional[Sequence[str]] = None) -> List[List[Dict[str, Any]]]:

@@ -1,4 +1,4 @@
-"""Style bank resident in HBM + brute-force cosine kNN (host side of astts_knn_*).
+"""Style bank resident in HBM + brute-force kNN -- COSINE (the reference's collection), IP, L2 -- (host side of astts_knn_*).
 
 This is the engine under the ``MilvusClient.search`` shim (astts/compat/pymilvus.py).  It
 replaces what the reference gets from milvus-lite for
@@ -50,6 +50,7 @@ class StyleBank:
                 _lib.DTYPE_F16 if src.dtype == torch.float16 else _lib.DTYPE_F32,
                 metric_id, _lib.stream_ptr(), ctypes.byref(h)))
         self._h = h
+        self.metric = metric.upper()
         self.n, self.d = int(src.shape[0]), int(src.shape[1])
         exact = ctypes.c_int32()
         _lib.check(lib.astts_knn_info(self._h, None, None, ctypes.byref(exact)))
@@ -77,10 +78,13 @@ class StyleBank:
         return self._ws
 
     def search_device(self, queries: torch.Tensor, k: int, force_exact: bool = False,
-                      out_idx: Optional[torch.Tensor] = None, out_score: Optional[torch.Tensor] = None, return_f64: bool = False):
+                      out_idx: Optional[torch.Tensor] = None, out_score: Optional[torch.Tensor] = None, return_f64: bool = False,
+                      row_mask: Optional[torch.Tensor] = None):
         """queries: fp32 ``[Q, D]`` on this bank's GPU.  Returns (idx int64 [Q,k], score fp32 [Q,k])
-        on the GPU, enqueued on the current stream (no synchronisation).  ``return_f64``: a third tensor with the fp64
-        cosines (what a bank-sharded search merges on: astts.parallel.bank_sharded_search)."""
+        on the GPU, enqueued on the current stream (no synchronisation), closest first (COSINE / IP: score descending; L2:
+        squared distance ascending; ties by row index).  ``return_f64``: a third tensor with the fp64 scores (what a
+        bank-sharded search merges on: astts.parallel.bank_sharded_search).  ``row_mask``: uint8 / bool ``[N]`` (one mask for
+        every query) or ``[Q, N]`` on the GPU -- only rows with a non-zero entry can be hits (a Milvus ``filter``)."""
         if queries.dim() != 2 or queries.shape[1] != self.d:
             raise ValueError(f"queries must be [Q, {self.d}], got {tuple(queries.shape)}")
         if not 1 <= k <= _lib.KNN_MAX_K:
@@ -99,18 +103,31 @@ class StyleBank:
             if out_score is None:
                 out_score = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             s64 = torch.empty((nq, k), dtype=torch.float64, device=self.device) if return_f64 else None
-            _lib.check(_lib.load().astts_knn_search_f64(
+            mptr, mstride = None, 0
+            if row_mask is not None:
+                m = row_mask.to(device=self.device)
+                m = (m if m.dtype == torch.uint8 else (m != 0).to(torch.uint8)).contiguous()
+                if m.shape == (self.n,):
+                    mstride = 0
+                elif m.shape == (nq, self.n):
+                    mstride = self.n
+                else:
+                    raise ValueError(f"row_mask must be [{self.n}] or [{nq}, {self.n}], got {tuple(m.shape)}")
+                mptr = m.data_ptr()
+            _lib.check(_lib.load().astts_knn_search_masked(
                 self._h, q.data_ptr(), nq, k, out_idx.data_ptr(), out_score.data_ptr(), None if s64 is None else s64.data_ptr(),
-                aligned, ws.numel() - (aligned - base), _lib.KNN_FORCE_EXACT if force_exact else 0,
+                mptr, mstride, aligned, ws.numel() - (aligned - base), _lib.KNN_FORCE_EXACT if force_exact else 0,
                 _lib.stream_ptr()))
         return (out_idx, out_score, s64) if return_f64 else (out_idx, out_score)
 
-    def search(self, queries, k: int, force_exact: bool = False):
+    def search(self, queries, k: int, force_exact: bool = False, row_mask=None):
         """Host convenience: accepts numpy / lists, returns numpy (idx int64 [Q,k], score fp32 [Q,k])."""
         q = torch.as_tensor(np.asarray(queries, dtype=np.float32))
         if q.dim() == 1:
             q = q[None, :]
-        idx, sc = self.search_device(q.to(self.device), k, force_exact)
+        if row_mask is not None and not isinstance(row_mask, torch.Tensor):
+            row_mask = torch.from_numpy(np.ascontiguousarray(np.asarray(row_mask) != 0).astype(np.uint8))
+        idx, sc = self.search_device(q.to(self.device), k, force_exact, row_mask=row_mask)
         return idx.cpu().numpy(), sc.cpu().numpy()
 
     def last_fallbacks(self) -> int:

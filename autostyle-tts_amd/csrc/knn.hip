@@ -1,8 +1,14 @@
-// knn.hip -- brute-force cosine kNN over an HBM-resident style bank (gfx950 / MI355X).
+// knn.hip -- brute-force kNN (COSINE / IP / L2) over an HBM-resident style bank (gfx950 / MI355X).
 //
 // Replaces MilvusClient.search on the COSINE collection of the reference
 // (/root/reference/milvus/search_embeddings.py:15-22, /root/reference/src/search_milvus.py:140-147).
-// Result definition = oracle/knn.py: fp64 cosine, order (score desc, row asc).
+// Result definition = oracle/knn.py: fp64 score, order (closer first, row asc).  COSINE is what the reference's collection
+// uses; IP and L2 (squared distance, Milvus' convention) are the other two metrics of the MilvusClient surface, and L2 with
+// k = 1 is the arg-min of the speech tokenizer's vector quantiser (astts/frontend_nets.py).
+// Internally every metric is a score S to MAXIMISE: cos, <q,b>, -|q-b|^2; the scan proposes with
+// T = <q,b>/|b| (COSINE), <q,b> (IP), <q,b> - |b|^2/2 (L2: the same order as -|q-b|^2 for one query).
+// Optional row mask (a Milvus `filter` evaluated by the host, or the rows already returned by earlier passes of a
+// k > 32 search): masked rows are never candidates, in the approximate and in the exact path alike.
 //
 // Pipeline (five launches on one stream, no host sync, no allocation):
 //   1 knn_prep_queries     fp32 queries -> power-of-two scaled fp16 image + padded fp32 copy + fp64 norms
@@ -80,6 +86,46 @@ __device__ __forceinline__ double cos_from_parts(double dot, double qn, double b
     return isfinite(c) ? c : 0.0;
 }
 
+// fp64 squared distance sum_i (q_i - b_i)^2, one wave; the summation tree of wave_dot64 (identical rows give identical results,
+// a row equal to the query gives exactly 0)
+template <typename RowT>
+__device__ __forceinline__ double wave_dist64(const float* __restrict__ q, const RowT* __restrict__ row, int dp, int lane) {
+    double acc = 0.0;
+    for (int k = lane * 8; k < dp; k += kWave * 8) {
+        float4 q0 = *reinterpret_cast<const float4*>(q + k);
+        float4 q1 = *reinterpret_cast<const float4*>(q + k + 4);
+        const float qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        float b[8];
+        if constexpr (sizeof(RowT) == 2) {
+            half8 hb = *reinterpret_cast<const half8*>(row + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (float)hb[j];
+        } else {
+            float4 b0 = *reinterpret_cast<const float4*>(row + k);
+            float4 b1 = *reinterpret_cast<const float4*>(row + k + 4);
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
+            b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double df = (double)qq[j] - (double)b[j];
+            acc = fma(df, df, acc);
+        }
+    }
+    return wave_sum_f64(acc);
+}
+
+// the exact score S (larger = closer) of query row `q` against bank row `row` under `metric`
+template <typename RowT>
+__device__ __forceinline__ double exact_score(int metric, const float* __restrict__ q, const RowT* __restrict__ row, int dp, int lane,
+                                              double qn, double bn) {
+    if (metric == ASTTS_METRIC_L2) return -wave_dist64<RowT>(q, row, dp, lane);
+    const double dot = wave_dot64<RowT>(q, row, dp, lane);
+    return metric == ASTTS_METRIC_IP ? dot : cos_from_parts(dot, qn, bn);
+}
+// what the caller sees: cosine, inner product, squared distance
+__device__ __forceinline__ double user_score(int metric, double s) { return metric == ASTTS_METRIC_L2 ? -s : s; }
+
 // ------------------------------------------------------------------------------------------
 // bank construction: one wave per row -- copy/convert into the padded planes, fp64 norm,
 // exactness + range flags
@@ -88,7 +134,8 @@ template <typename SrcT>
 __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, int dp,
                                _Float16* __restrict__ scan_tiled, _Float16* __restrict__ plane16,
                                float* __restrict__ plane32, double* __restrict__ norm64,
-                               float* __restrict__ inv_norm, int* __restrict__ flags /* [0]=inexact, [1]=overflow */) {
+                               float* __restrict__ inv_norm, int* __restrict__ flags /* [0]=inexact, [1]=overflow, [2..3]=max norm (fp64 bits) */,
+                               int metric, float* __restrict__ bias /* L2: -|b|^2 / 2 */) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -115,7 +162,9 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
     if (lane == 0) {
         double nrm = sqrt(acc);
         norm64[row] = nrm;
-        inv_norm[row] = nrm > 0.0 ? (float)(1.0 / nrm) : 0.0f;
+        inv_norm[row] = metric != ASTTS_METRIC_COSINE ? 1.0f : (nrm > 0.0 ? (float)(1.0 / nrm) : 0.0f);
+        if (bias) bias[row] = (float)(-0.5 * acc);
+        if (isfinite(nrm)) atomicMax(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)__double_as_longlong(nrm));
     }
     if (__any(inexact) && lane == 0) atomicOr(&flags[0], 1);
     if (__any(overflow) && lane == 0) atomicOr(&flags[1], 1);
@@ -129,7 +178,7 @@ __global__ void knn_build_bank(const SrcT* __restrict__ src, int64_t n, int d, i
 // original values.  Elements more than 2^37 below their row's maximum still flush: |error| <= sqrt(dp) * 2^-38 on the cosine
 // scale, inside the 2^-20 term of the bound.
 __global__ void knn_rescale_rows(const float* __restrict__ plane32, int64_t n, int dp, _Float16* __restrict__ scan_tiled,
-                                 _Float16* __restrict__ plane16, const double* __restrict__ norm64, float* __restrict__ inv_norm) {
+                                 _Float16* __restrict__ plane16, const double* __restrict__ norm64, float* __restrict__ inv_norm, int metric) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -152,7 +201,7 @@ __global__ void knn_rescale_rows(const float* __restrict__ plane32, int64_t n, i
     }
     if (lane == 0) {
         const double nrm = norm64[row];
-        inv_norm[row] = nrm > 0.0 ? (float)ldexp(1.0 / nrm, -sh) : 0.0f;
+        inv_norm[row] = metric != ASTTS_METRIC_COSINE ? ldexpf(1.0f, -sh) : (nrm > 0.0 ? (float)ldexp(1.0 / nrm, -sh) : 0.0f);
     }
 }
 
@@ -170,7 +219,7 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
     __shared__ double ssum[4];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (row == 0 && tid == 0) *nflag = 0;
+    if (row == 0 && tid == 0 && nflag) *nflag = 0;
     if (row >= nq) {  // zero rows completing the last 32-query tile
         const int qt = row >> 5, r = row & 31;
         _Float16* tb = qh + (int64_t)qt * (dp >> 6) * 2048;
@@ -281,7 +330,7 @@ template <int QT, int RT>
 __global__ __launch_bounds__(kScanThreads) void knn_scan(
     const _Float16* __restrict__ bank, const _Float16* __restrict__ qh,
     const float* __restrict__ inv_norm, float* __restrict__ s_part, int64_t n, int dp, int nld,
-    int qpad, int nq_group, int lines_per_split) {
+    int qpad, int nq_group, int lines_per_split, const float* __restrict__ bias, const float* __restrict__ qscale_g) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3][QT*RT*16][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -374,6 +423,8 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
             for (int b = 0; b < RT; ++b) {
                 const int64_t col = row0 + b * 32 + r;  // bank row = MFMA column
                 const float inv = (col < n) ? inv_norm[col] : 0.0f;
+                // L2: the proposal score is qscale * (<q,b> - |b|^2 / 2); the constant rides on K slice 0
+                const float bcol = (bias != nullptr && blockIdx.y == 0 && col < n) ? bias[col] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v = acc[a][b][i];
@@ -382,7 +433,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
                         v += red[(size_t)w * (QT * RT * 16 * 64) + ((a * RT + b) * 16 + i) * 64 + lane];
                     const int qrow = a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // MFMA row = query
                     if (col < nld && qrow < nq_group)
-                        s_part[((size_t)blockIdx.y * qpad + qrow) * nld + col] = v * inv;
+                        s_part[((size_t)blockIdx.y * qpad + qrow) * nld + col] = bias ? fmaf(qscale_g[qrow], bcol, v * inv) : v * inv;
                 }
             }
     }
@@ -411,7 +462,8 @@ static constexpr int kSelThreads = 1024;
 // stand-alone kernel; LDS: the fused select + re-score kernel)
 __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all, int c,
                                                 int seg_len, int q, int segy, int* cand_idx, float* cand_s,
-                                                const float* __restrict__ inv_norm) {
+                                                const float* __restrict__ inv_norm, const float* __restrict__ bias, float qs,
+                                                const uint8_t* __restrict__ mask) {
     __shared__ float seg[kSelSeg];
     __shared__ float sh_s[kSelThreads];
     __shared__ int sh_i[kSelThreads];
@@ -435,10 +487,17 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
             v[u] = base[at];
             w[u] = inv_norm ? inv_norm[at] : 1.0f;
         }
+        if (bias) {         // (the GEMM scan leaves raw dot products: L2's constant is added here)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = fmaf(qs, bias[seg0 + min(tid + u * kSelThreads, nl - 1)] , v[u] * w[u]);
+        } else if (inv_norm) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] *= w[u];
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = tid + u * kSelThreads;
-            if (i < nl) seg[i] = inv_norm ? v[u] * w[u] : v[u];
+            if (i < nl) seg[i] = v[u];
         }
     } else
     for (int i = tid; i < nl; i += kSelThreads) {
@@ -452,9 +511,19 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         }
         for (; ks < ksplit; ++ks) v[0] += pp[(size_t)ks * plane];
         const float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        seg[i] = inv_norm ? sum * inv_norm[seg0 + i] : sum;      // the GEMM scan leaves raw dot products
+        float sc = inv_norm ? sum * inv_norm[seg0 + i] : sum;      // the GEMM scan leaves raw dot products
+        if (bias) sc = fmaf(qs, bias[seg0 + i], sc);
+        seg[i] = sc;
     }
-    if (tid == 0) s_cnt = 0;
+    if (mask) {             // masked rows leave the ranking (a filter, or rows an earlier pass of a k > 32 search returned)
+        __syncthreads();
+        for (int i = tid; i < nl; i += kSelThreads)
+            if (!mask[seg0 + i]) seg[i] = -INFINITY;
+    }
+    if (tid == 0) {
+        s_cnt = 0;
+        s_sel_bin = 2048;       // (nothing to gather unless the histogram walk finds the bin)
+    }
     __syncthreads();
     TopList<float> tl;
     tl.init();
@@ -467,9 +536,12 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         // holds ~13 of 8 192 scores), and only the TOP of the histogram is walked: the bin b* in which the c-th largest score falls;
         // everything in bins >= b* is gathered (a superset of the top c: the map score -> bin is monotone) and sorted by one wave.
         __shared__ float s_mn[kSelThreads / 64], s_mx[kSelThreads / 64];
+        __shared__ int s_nr[kSelThreads / 64];
         float mn = INFINITY, mx = -INFINITY;
+        int nr = 0;                 // scores that take part in the ranking (masked rows and NaNs sit at -inf and do not)
         for (int i = tid; i < nl; i += kSelThreads) {
             const float v = seg[i];
+            if (v > -INFINITY) ++nr;
             if (v > -INFINITY && v < INFINITY) {
                 mn = fminf(mn, v);
                 mx = fmaxf(mx, v);
@@ -479,17 +551,21 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         for (int off = 32; off >= 1; off >>= 1) {
             mn = fminf(mn, __shfl_xor(mn, off, 64));
             mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            nr += __shfl_xor(nr, off, 64);
         }
         if (lane == 0) {
             s_mn[wid] = mn;
             s_mx[wid] = mx;
+            s_nr[wid] = nr;
         }
         for (int i = tid; i < 2048; i += kSelThreads) hist[i] = 0u;
         __syncthreads();
+        nr = 0;
 #pragma unroll
         for (int w = 0; w < kSelThreads / 64; ++w) {
             mn = fminf(mn, s_mn[w]);
             mx = fmaxf(mx, s_mx[w]);
+            nr += s_nr[w];
         }
         const float bscale = mx > mn ? 2047.0f / (mx - mn) : 0.0f;
         auto bin_of = [&](float v) -> int {
@@ -498,8 +574,9 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
             const int bq = (int)((v - mn) * bscale);                      // monotone in v (fp subtraction, product, truncation all are)
             return bq < 0 ? 0 : (bq > 2047 ? 2047 : bq);
         };
-        const int remaining = c < nl ? c : nl;
-        for (int i = tid; i < nl; i += kSelThreads) atomicAdd(&hist[bin_of(seg[i])], 1u);
+        const int remaining = c < nr ? c : nr;
+        for (int i = tid; i < nl; i += kSelThreads)
+            if (seg[i] > -INFINITY) atomicAdd(&hist[bin_of(seg[i])], 1u);
         __syncthreads();
         if (wid == 0) {
             constexpr int per = 32;                          // 2048 bins / 64 lanes
@@ -512,7 +589,7 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
                 if (lane + off < 64) incl += tv;
             }
             const unsigned above = incl - local;
-            if (above < (unsigned)remaining && (unsigned)remaining <= incl) {
+            if (remaining > 0 && above < (unsigned)remaining && (unsigned)remaining <= incl) {
                 unsigned acc = above;
                 for (int j = per - 1; j >= 0; --j) {
                     const unsigned hcount = hist[lane * per + j];
@@ -527,7 +604,7 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         __syncthreads();
         const int bstar = s_sel_bin;
         for (int i = tid; i < nl; i += kSelThreads) {
-            if (bin_of(seg[i]) >= bstar) {
+            if (seg[i] > -INFINITY && bin_of(seg[i]) >= bstar) {
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < 64) {
                     sh_s[pos] = seg[i];
@@ -564,16 +641,21 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         merge_lists<float>(tl, sh_s, sh_i, c);
     }
     if (tid < c) {
-        cand_idx[tid] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        int id = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        if (id >= 0 && mask && !mask[id]) id = -1;          // fewer than c allowed rows in the segment
+        cand_idx[tid] = id;
         cand_s[tid] = tl.s;
     }
 }
 
 __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all,
                                                           int c, int seg_len, int* __restrict__ cand_idx, float* __restrict__ cand_s,
-                                                          const float* __restrict__ inv_norm) {
+                                                          const float* __restrict__ inv_norm, const float* __restrict__ bias,
+                                                          const float* __restrict__ qscale_g, const uint8_t* __restrict__ mask,
+                                                          int64_t mask_stride) {
     const size_t o = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64;
-    knn_select_body(s_part, ksplit, qpad, nld, n_all, c, seg_len, blockIdx.x, blockIdx.y, cand_idx + o, cand_s + o, inv_norm);
+    knn_select_body(s_part, ksplit, qpad, nld, n_all, c, seg_len, blockIdx.x, blockIdx.y, cand_idx + o, cand_s + o, inv_norm, bias,
+                    bias ? qscale_g[blockIdx.x] : 0.0f, mask ? mask + (int64_t)blockIdx.x * mask_stride : nullptr);
 }
 
 // merge the per-segment candidate lists of one query (one wave) into the final top-C
@@ -609,17 +691,17 @@ __device__ __forceinline__ void knn_rescore_body(
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
     const int* cand_idx, const float* cand_s, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
-    int* __restrict__ nflag, int* __restrict__ flagged) {
+    int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const uint8_t* __restrict__ mask,
+    int out_ld, int out_off) {
+    // out_*: row q starts at q * out_ld + out_off (a k > 32 search emits 32 hits per pass into its [nq, k] result)
     __shared__ double sh_cos[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const double qn = qn64[q];
+    const int64_t ob = (int64_t)q * out_ld + out_off;
     for (int ci = wid; ci < c; ci += 16) {
         const int idx = cand_idx[ci];
         double cs = -INFINITY;
-        if (idx >= 0) {
-            const double dot = wave_dot64<RowT>(qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
-            cs = cos_from_parts(dot, qn, norm64[idx]);
-        }
+        if (idx >= 0) cs = exact_score<RowT>(metric, qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane, qn, norm64[idx]);
         if (lane == 0) sh_cos[ci] = cs;
     }
     __syncthreads();
@@ -636,16 +718,20 @@ __device__ __forceinline__ void knn_rescore_body(
         const int ij = __shfl(idx, j, 64);
         if (ij >= 0 && j != lane && better<double>(sj, ij, cs, idx)) ++rank;
     }
-    const int kk = (int64_t)k < n ? k : (int)n;  // hits that exist
+    // hits that exist: fewer live candidates than the list holds means EVERY allowed row is a candidate (each segment returns
+    // its best c rows, masked ones last and dropped; the merge keeps the best c of the union)
+    const int n_live = __popcll(__ballot(live));
+    const int kk = k < n_live ? k : n_live;
+    const double no_hit = metric == ASTTS_METRIC_L2 ? INFINITY : -INFINITY;
     if (live && rank < kk) {
-        out_idx[(int64_t)q * k + rank] = idx;
-        out_score[(int64_t)q * k + rank] = (float)cs;
-        if (out_score64) out_score64[(int64_t)q * k + rank] = cs;
+        out_idx[ob + rank] = idx;
+        out_score[ob + rank] = (float)user_score(metric, cs);
+        if (out_score64) out_score64[ob + rank] = user_score(metric, cs);
     }
-    if (lane >= kk && lane < k) {  // fewer than k rows in the bank
-        out_idx[(int64_t)q * k + lane] = -1;
-        out_score[(int64_t)q * k + lane] = -INFINITY;
-        if (out_score64) out_score64[(int64_t)q * k + lane] = -INFINITY;
+    if (lane >= kk && lane < k) {  // fewer than k (allowed) rows in the bank
+        out_idx[ob + lane] = -1;
+        out_score[ob + lane] = (float)no_hit;
+        if (out_score64) out_score64[ob + lane] = no_hit;
     }
     float tau = ap;  // smallest approximate score among the candidates bounds every non-candidate
 #pragma unroll
@@ -655,17 +741,24 @@ __device__ __forceinline__ void knn_rescore_body(
     for (int off = 32; off >= 1; off >>= 1) kth = fmax(kth, __shfl_xor(kth, off, 64));
     if (lane == 0) {
         bool certified;
-        if (n <= (int64_t)c) {
-            certified = true;  // every row is a candidate
-        } else {
+        if (n <= (int64_t)c || n_live < c) {
+            certified = true;  // every (allowed) row is a candidate
+        } else if (metric == ASTTS_METRIC_COSINE) {
             const double denom = (double)qscale[q] * qn;
             const double tau_cos = denom > 0.0 ? (double)tau / denom : INFINITY;
             certified = isfinite(tau_cos) && (kth > tau_cos + err_bound);
+        } else {
+            // IP / L2: the proposal score is T = <q,b> (- |b|^2 / 2), its error |q||b| * err_bound <= |q| * max|b| * err_bound
+            // (+ the fp32 rounding of the L2 constant and of the sum); the k-th exact hit in T units: L2  T = (|q|^2 - d^2) / 2
+            const double tau_t = (double)tau / (double)qscale[q];
+            const double kth_t = metric == ASTTS_METRIC_L2 ? 0.5 * (qn * qn + kth) : kth;
+            const double err = qn * bmax * err_bound + (metric == ASTTS_METRIC_L2 ? (qn * bmax + bmax * bmax) * 4.8e-7 : 0.0);
+            certified = isfinite(tau_t) && isfinite(kth_t) && (kth_t > tau_t + err);
         }
         s_exact = (!certified || force_exact) ? 1 : 0;
         if (s_exact) {
-            const int slot = atomicAdd(nflag, 1);     // astts_knn_last_fallbacks
-            flagged[slot] = q;
+            atomicAdd(nflag, 1);     // astts_knn_last_fallbacks
+            (void)flagged;
         }
     }
     }
@@ -682,20 +775,23 @@ __device__ __forceinline__ void knn_rescore_body(
     for (int64_t base = (int64_t)wid * 64; base < n; base += 16 * 64) {
         double mine = -INFINITY;
         const int64_t lim = (n - base) < 64 ? (n - base) : 64;
+        const bool allowed = lane < lim && (!mask || mask[base + lane]);
+        const unsigned long long todo = __ballot(allowed);
         for (int j = 0; j < lim; ++j) {
+            if (!((todo >> j) & 1ull)) continue;              // (wave-uniform)
             const int64_t row = base + j;
-            const double dot = wave_dot64<RowT>(qrow, plane + row * (int64_t)dp, dp, lane);
-            const double csx = cos_from_parts(dot, qn, norm64[row]);
+            const double csx = exact_score<RowT>(metric, qrow, plane + row * (int64_t)dp, dp, lane, qn, norm64[row]);
             if (lane == j) mine = csx;
         }
-        tl.offer(mine, (int)(base + lane), lane < lim, lane, k);
+        tl.offer(mine, (int)(base + lane), allowed, lane, k);
     }
     merge_lists<double>(tl, ex_s, ex_i, k);
     if (tid < k) {
         const bool ok = tl.idx != kNoIdx;
-        out_idx[(int64_t)q * k + tid] = ok ? tl.idx : -1;
-        out_score[(int64_t)q * k + tid] = ok ? (float)tl.s : -INFINITY;
-        if (out_score64) out_score64[(int64_t)q * k + tid] = ok ? tl.s : -INFINITY;
+        const double no_hit = metric == ASTTS_METRIC_L2 ? INFINITY : -INFINITY;
+        out_idx[ob + tid] = ok ? tl.idx : -1;
+        out_score[ob + tid] = ok ? (float)user_score(metric, tl.s) : (float)no_hit;
+        if (out_score64) out_score64[ob + tid] = ok ? user_score(metric, tl.s) : no_hit;
     }
 }
 
@@ -705,10 +801,27 @@ __global__ __launch_bounds__(1024) void knn_rescore_finalize(
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k,
     const int* __restrict__ cand_idx, const float* __restrict__ cand_s, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
-    int* __restrict__ nflag, int* __restrict__ flagged) {
+    int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const uint8_t* __restrict__ mask, int64_t mask_stride,
+    int out_ld, int out_off) {
     const int q = blockIdx.x;
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, cand_idx + q * 64, cand_s + q * 64, err_bound, force_exact,
-                           out_idx, out_score, out_score64, nflag, flagged);
+                           out_idx, out_score, out_score64, nflag, flagged, metric, bmax, mask ? mask + (int64_t)q * mask_stride : nullptr,
+                           out_ld, out_off);
+}
+
+// rows a pass of a k > 32 search has returned leave the per-query mask before the next pass
+__global__ void knn_mask_out(const int64_t* __restrict__ out_idx, int out_ld, int out_off, int kp, uint8_t* __restrict__ mask, int64_t n) {
+    const int q = blockIdx.x;
+    if ((int)threadIdx.x < kp) {
+        const int64_t id = out_idx[(int64_t)q * out_ld + out_off + threadIdx.x];
+        if (id >= 0) mask[(int64_t)q * n + id] = 0;
+    }
+}
+// per-query masks of a k > 32 search: the caller's row mask (one for all queries, or one per query) or all ones
+__global__ void knn_mask_init(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t src_stride, int64_t n) {
+    const int q = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[(int64_t)q * n + i] = src ? (src[(int64_t)q * src_stride + i] ? 1 : 0) : 1;
 }
 
 // Selection + re-score in one launch when a query's score row is one segment (N <= 8192) and all queries fit one pass: the
@@ -719,14 +832,16 @@ __global__ __launch_bounds__(1024) void knn_select_rescore(
     const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
-    int* __restrict__ nflag, int* __restrict__ flagged) {
+    int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const float* __restrict__ bias,
+    const uint8_t* __restrict__ mask, int64_t mask_stride) {
     __shared__ int f_ci[64];
     __shared__ float f_cs[64];
     const int q = blockIdx.x;
-    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm);
+    const uint8_t* mq = mask ? mask + (int64_t)q * mask_stride : nullptr;
+    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? qscale[q] : 0.0f, mq);
     __syncthreads();
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
-                           out_score64, nflag, flagged);
+                           out_score64, nflag, flagged, metric, bmax, mq, k, 0);
 }
 
 }  // namespace astts
@@ -745,7 +860,9 @@ struct astts_knn {
     _Float16* plane16 = nullptr;  // [n][dp] row-major (exact plane when exact16)
     float* plane32 = nullptr;     // [n][dp], only when !exact16
     double* norm64 = nullptr;     // [n]
-    float* inv_norm = nullptr;    // [n]
+    float* inv_norm = nullptr;    // [n]  COSINE: 1 / |b| (x the row's power-of-two scale); IP / L2: that scale alone
+    float* bias = nullptr;        // [n]  L2 only: -|b|^2 / 2
+    double bmax = 0.0;            // largest row norm (IP / L2 certification works on the absolute scale)
     double err_bound = 0.0;
     // bench-only profiling (astts_knn_profile_*)
     bool profile = false;
@@ -759,11 +876,20 @@ struct KnnPlan {
     int qt, rt, ksplit, lines_per_split, tiles, qpad, c, nseg, seg_len;
     bool gemm;       // query groups of >= 64: the scan is a plain GEMM on the ring kernel (MFMA-side regime)
     size_t off_qrow;
-    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, total;
+    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, off_mask, total;
+    int passes;      // k > 32: ceil(k / 32) selection + re-score passes over ONE scan, per chunk of <= 256 queries
 };
+
+static constexpr int kPassK = 32;         // hits per pass (the certified top-k kernel keeps k <= 32 of a 64-entry candidate list)
 
 KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     KnnPlan p{};
+    p.passes = 1;
+    if (k > kPassK) {        // multi-pass search: chunks of <= 256 queries, 32 hits per pass, per-query masks of the rows already returned
+        p.passes = (int)cdiv(k, kPassK);
+        if (nq > kMaxQPerPass) nq = kMaxQPerPass;
+        k = kPassK;
+    }
     const int qgroup = nq < kMaxQPerPass ? nq : kMaxQPerPass;
     p.qt = qgroup <= 32 ? 1 : qgroup <= 64 ? 2 : qgroup <= 128 ? 4 : 8;
     p.qpad = p.qt * 32;
@@ -803,7 +929,7 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
         return at;
     };
     p.off_nflag = take(256);
-    p.off_flagged = take(sizeof(int) * (size_t)nq);
+    p.off_flagged = take(sizeof(int) * (size_t)nq * p.passes);
     p.off_qh = take(sizeof(_Float16) * (align_up((size_t)nq, 32) + 256) * h->dp);  // whole 32-query tiles (+ one group's tail)
     p.off_qf = take(sizeof(float) * (size_t)nq * h->dp);
     p.off_qrow = take(p.gemm ? sizeof(_Float16) * (size_t)nq * h->dp : 16);
@@ -814,13 +940,14 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.off_cs = take(sizeof(float) * (size_t)nq * 64);
     p.off_sidx = take(sizeof(int) * (size_t)kMaxQPerPass * p.nseg * 64);
     p.off_ss = take(sizeof(float) * (size_t)kMaxQPerPass * p.nseg * 64);
+    p.off_mask = take(p.passes > 1 ? (size_t)nq * (size_t)h->n : 16);
     p.total = o;
     return p;
 }
 
 template <int QT, int RT>
 int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq_group, float* spart,
-                hipStream_t st) {
+                const float* qscale_g, hipStream_t st) {
     dim3 grid(p.tiles, p.ksplit);
     size_t lds = (size_t)3 * QT * RT * 16 * 64 * sizeof(float);
     if (lds > 64 * 1024) {
@@ -836,7 +963,7 @@ int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq
         }
     }
     hipLaunchKernelGGL((knn_scan<QT, RT>), grid, dim3(kScanThreads), lds, st, h->scan, qh,
-                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split);
+                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split, h->bias, qscale_g);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -857,10 +984,8 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     ASTTS_REQUIRE(d >= 1 && d <= (1 << 20), ASTTS_ERR_INVALID, "astts_knn_create: d=%d out of range", d);
     ASTTS_REQUIRE(dtype == ASTTS_DTYPE_F16 || dtype == ASTTS_DTYPE_F32, ASTTS_ERR_INVALID,
                   "astts_knn_create: dtype %d (want ASTTS_DTYPE_F16|F32)", dtype);
-    if (metric != ASTTS_METRIC_COSINE) {
-        set_error("astts_knn_create: metric %d not implemented (COSINE only, as the reference collection)", metric);
-        return ASTTS_ERR_UNSUPPORTED;
-    }
+    ASTTS_REQUIRE(metric == ASTTS_METRIC_COSINE || metric == ASTTS_METRIC_IP || metric == ASTTS_METRIC_L2, ASTTS_ERR_INVALID,
+                  "astts_knn_create: metric %d (want ASTTS_METRIC_COSINE|IP|L2)", metric);
     hipStream_t st = (hipStream_t)stream;
     astts_knn* h = new astts_knn();
     h->n = n;
@@ -890,22 +1015,24 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
     KNN_TRY(hipMalloc(&h->plane16, sizeof(_Float16) * (size_t)n * h->dp));
     KNN_TRY(hipMalloc(&h->norm64, sizeof(double) * (size_t)n));
     KNN_TRY(hipMalloc(&h->inv_norm, sizeof(float) * (size_t)n));
-    KNN_TRY(hipMalloc(&flags, 2 * sizeof(int)));
-    KNN_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
+    if (metric == ASTTS_METRIC_L2) KNN_TRY(hipMalloc(&h->bias, sizeof(float) * (size_t)n));
+    KNN_TRY(hipMalloc(&flags, 4 * sizeof(int)));
+    KNN_TRY(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     const int rows_per_block = 4;
     dim3 grid((unsigned)cdiv(n, rows_per_block));
     if (dtype == ASTTS_DTYPE_F32) {
         KNN_TRY(hipMalloc(&p32, sizeof(float) * (size_t)n * h->dp));
         hipLaunchKernelGGL((knn_build_bank<float>), grid, dim3(256), 0, st, (const float*)bank, n, d,
-                           h->dp, h->scan, h->plane16, p32, h->norm64, h->inv_norm, flags);
+                           h->dp, h->scan, h->plane16, p32, h->norm64, h->inv_norm, flags, metric, h->bias);
     } else {
         hipLaunchKernelGGL((knn_build_bank<_Float16>), grid, dim3(256), 0, st, (const _Float16*)bank,
-                           n, d, h->dp, h->scan, h->plane16, (float*)nullptr, h->norm64, h->inv_norm, flags);
+                           n, d, h->dp, h->scan, h->plane16, (float*)nullptr, h->norm64, h->inv_norm, flags, metric, h->bias);
     }
     KNN_TRY(hipGetLastError());
-    int hf[2] = {0, 0};
+    int hf[4] = {0, 0, 0, 0};
     KNN_TRY(hipMemcpyAsync(hf, flags, sizeof(hf), hipMemcpyDeviceToHost, st));
     KNN_TRY(hipStreamSynchronize(st));
+    memcpy(&h->bmax, &hf[2], sizeof(double));
     if (hf[1]) {
         set_error("astts_knn_create: bank holds non-finite values");
         return fail(ASTTS_ERR_RANGE);
@@ -915,7 +1042,7 @@ int astts_knn_create(const void* bank, int64_t n, int32_t d, int32_t dtype, int3
         h->plane32 = p32;  // keep the fp32 image for exact re-scoring
         p32 = nullptr;
         // approximate planes re-written with a per-row power-of-two scale (see knn_rescale_rows)
-        hipLaunchKernelGGL(knn_rescale_rows, grid, dim3(256), 0, st, h->plane32, n, h->dp, h->scan, h->plane16, h->norm64, h->inv_norm);
+        hipLaunchKernelGGL(knn_rescale_rows, grid, dim3(256), 0, st, h->plane32, n, h->dp, h->scan, h->plane16, h->norm64, h->inv_norm, metric);
         KNN_TRY(hipGetLastError());
         KNN_TRY(hipStreamSynchronize(st));
     }
@@ -944,6 +1071,7 @@ int astts_knn_destroy(astts_knn_t* h) {
     if (h->plane32) (void)hipFree(h->plane32);
     if (h->norm64) (void)hipFree(h->norm64);
     if (h->inv_norm) (void)hipFree(h->inv_norm);
+    if (h->bias) (void)hipFree(h->bias);
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return ASTTS_OK;
@@ -965,24 +1093,26 @@ size_t astts_knn_workspace_bytes(const astts_knn_t* h, int32_t nq, int32_t k) {
 int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k, int64_t* out_idx,
                      float* out_score, void* workspace, size_t workspace_bytes, int32_t flags,
                      astts_stream_t stream) {
-    return astts_knn_search_f64(h, queries, nq, k, out_idx, out_score, nullptr, workspace, workspace_bytes, flags, stream);
+    return astts_knn_search_masked(h, queries, nq, k, out_idx, out_score, nullptr, nullptr, 0, workspace, workspace_bytes, flags, stream);
 }
 
 int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32_t k, int64_t* out_idx,
                          float* out_score, double* out_score64, void* workspace, size_t workspace_bytes, int32_t flags,
                          astts_stream_t stream) {
-    ASTTS_REQUIRE(h != nullptr, ASTTS_ERR_INVALID, "astts_knn_search: handle is null");
-    ASTTS_REQUIRE(queries && out_idx && out_score, ASTTS_ERR_INVALID, "astts_knn_search: null pointer argument");
-    ASTTS_REQUIRE(nq >= 1, ASTTS_ERR_INVALID, "astts_knn_search: nq=%d", nq);
-    ASTTS_REQUIRE(k >= 1 && k <= ASTTS_KNN_MAX_K, ASTTS_ERR_INVALID,
-                  "astts_knn_search: k=%d (1..%d)", k, ASTTS_KNN_MAX_K);
-    ASTTS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 255) == 0, ASTTS_ERR_WORKSPACE,
-                  "astts_knn_search: workspace must be 256-byte aligned");
-    const KnnPlan p = make_plan(h, nq, k);
-    ASTTS_REQUIRE(workspace_bytes >= p.total, ASTTS_ERR_WORKSPACE,
-                  "astts_knn_search: workspace %zu < required %zu", workspace_bytes, p.total);
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
+    return astts_knn_search_masked(h, queries, nq, k, out_idx, out_score, out_score64, nullptr, 0, workspace, workspace_bytes, flags, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+// One chunk of queries (all of them when k <= 32; <= 256 when k > 32): preparation, ONE scan per query group, then `passes` rounds of
+// selection + fp64 re-score that each emit `kp` <= 32 hits per query into out[q * out_ld + done ..] -- between rounds the rows just
+// returned leave the chunk's per-query masks, so round r + 1 ranks what is left (same certification, same exact path).
+int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int nq, int k, int64_t* out_idx, float* out_score,
+                     double* out_score64, const uint8_t* row_mask, int64_t mask_stride, char* ws, int flags, bool clear_flag,
+                     hipStream_t st) {
+    astts_stream_t stream = (astts_stream_t)st;
     int* nflag = (int*)(ws + p.off_nflag);
     int* flagged = (int*)(ws + p.off_flagged);
     _Float16* qh = (_Float16*)(ws + p.off_qh);
@@ -995,10 +1125,35 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
     float* cs = (float*)(ws + p.off_cs);
     int* sidx = (int*)(ws + p.off_sidx);
     float* ss = (float*)(ws + p.off_ss);
+    const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
+    const bool multi = p.passes > 1;
+    const uint8_t* mask = row_mask;
+    int64_t mstride = mask_stride;
+    if (multi) {
+        uint8_t* pm = (uint8_t*)(ws + p.off_mask);
+        hipLaunchKernelGGL(knn_mask_init, dim3((unsigned)(cdiv(h->n, 256 * 16) < 1024 ? cdiv(h->n, 256 * 16) : 1024), nq), dim3(256), 0, st,
+                           pm, row_mask, mask_stride, h->n);
+        ASTTS_CHECK_LAUNCH();
+        mask = pm;
+        mstride = h->n;
+    }
 
     hipLaunchKernelGGL(knn_prep_queries, dim3((unsigned)align_up((size_t)nq, 32)), dim3(256), 0, st, queries, nq, h->d, h->dp,
-                       qh, qf, qn, qscale, nflag, qrow);
+                       qh, qf, qn, qscale, clear_flag ? nflag : nullptr, qrow);
     ASTTS_CHECK_LAUNCH();
+
+    // (PLANE: the exact plane in its own type -- fp16 when the bank is fp16-exact, else fp32)
+#define KNN_RESCORE(KERNEL, GRID, ...)                                                                                              \
+    do {                                                                                                                            \
+        if (h->exact16) {                                                                                                           \
+            const _Float16* PLANE = h->plane16;                                                                                     \
+            hipLaunchKernelGGL((KERNEL<_Float16>), GRID, dim3(1024), 0, st, __VA_ARGS__);                                          \
+        } else {                                                                                                                    \
+            const float* PLANE = h->plane32;                                                                                        \
+            hipLaunchKernelGGL((KERNEL<float>), GRID, dim3(1024), 0, st, __VA_ARGS__);                                             \
+        }                                                                                                                           \
+        ASTTS_CHECK_LAUNCH();                                                                                                       \
+    } while (0)
 
     for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {
         const int qg = (nq - q0) < kMaxQPerPass ? (nq - q0) : kMaxQPerPass;
@@ -1006,11 +1161,12 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
         int rc;
         const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
         if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
-        if (p.gemm && qg >= 64) {
+        const bool as_gemm = p.gemm && qg >= 64;
+        if (as_gemm) {
             // S[q][n] = <q, b_n> as one GEMM: activations = this group's queries (row-major fp16), "weights" = the bank's
             // row-major fp16 plane [n][dp]; the LDS-DMA ring kernel runs it at 400+ TFLOP/s where the register-streaming scan
-            // (built for the HBM-bound small-Q regime) re-reads the query tile from L2 per bank tile.  1 / |b_n| is applied
-            // by the selection kernel.
+            // (built for the HBM-bound small-Q regime) re-reads the query tile from L2 per bank tile.  1 / |b_n| (and L2's
+            // constant) are applied by the selection kernel.
             static const bool n_first = exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0) != 0;     // A/B: the projections' tile order (bank read once per panel)
             if (n_first)
                 rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
@@ -1019,11 +1175,11 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
                 rc = gemm_scan(qrow + (size_t)q0 * h->dp, h->plane16, spart, qg, h->n, h->dp, h->nld, st);
         } else
         switch (p.qt * 10 + p.rt) {
-            case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, st); break;
-            case 21: rc = launch_scan<2, 1>(h, p, qh_g, qg, spart, st); break;
-            case 22: rc = launch_scan<2, 2>(h, p, qh_g, qg, spart, st); break;
-            case 41: rc = launch_scan<4, 1>(h, p, qh_g, qg, spart, st); break;
-            case 81: rc = launch_scan<8, 1>(h, p, qh_g, qg, spart, st); break;
+            case 11: rc = launch_scan<1, 1>(h, p, qh_g, qg, spart, qscale + q0, st); break;
+            case 21: rc = launch_scan<2, 1>(h, p, qh_g, qg, spart, qscale + q0, st); break;
+            case 22: rc = launch_scan<2, 2>(h, p, qh_g, qg, spart, qscale + q0, st); break;
+            case 41: rc = launch_scan<4, 1>(h, p, qh_g, qg, spart, qscale + q0, st); break;
+            case 81: rc = launch_scan<8, 1>(h, p, qh_g, qg, spart, qscale + q0, st); break;
             default:
                 set_error("astts_knn_search: no scan variant for qt=%d rt=%d", p.qt, p.rt);
                 return ASTTS_ERR_INVALID;
@@ -1033,45 +1189,86 @@ int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32
             ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_used += 2;
         }
-        const float* sel_inv = (p.gemm && qg >= 64) ? h->inv_norm : nullptr;
-        const int sel_ks = (p.gemm && qg >= 64) ? 1 : p.ksplit;
-        if (p.nseg == 1 && nq <= kMaxQPerPass) {      // one segment, one query group: selection + re-score in one launch
-            const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
-            if (h->exact16)
-                hipLaunchKernelGGL((knn_select_rescore<_Float16>), dim3(nq), dim3(1024), 0, st, spart, sel_ks, p.qpad, h->nld, p.seg_len,
-                                   sel_inv, qf, qn, qscale, h->plane16, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force, out_idx,
-                                   out_score, out_score64, nflag, flagged);
-            else
-                hipLaunchKernelGGL((knn_select_rescore<float>), dim3(nq), dim3(1024), 0, st, spart, sel_ks, p.qpad, h->nld, p.seg_len,
-                                   sel_inv, qf, qn, qscale, h->plane32, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force, out_idx,
-                                   out_score, out_score64, nflag, flagged);
-            ASTTS_CHECK_LAUNCH();
+        const float* sel_inv = as_gemm ? h->inv_norm : nullptr;
+        const float* sel_bias = as_gemm ? h->bias : nullptr;
+        const int sel_ks = as_gemm ? 1 : p.ksplit;
+        const uint8_t* mask_g = mask ? mask + (int64_t)q0 * mstride : nullptr;
+        if (p.nseg == 1 && nq <= kMaxQPerPass && !multi) {      // one segment, one query group: selection + re-score in one launch
+            KNN_RESCORE(knn_select_rescore, dim3(nq), spart, sel_ks, p.qpad, h->nld, p.seg_len, sel_inv, qf, qn, qscale,
+                        PLANE, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force,
+                        out_idx, out_score, out_score64, nflag, flagged, h->metric, h->bmax, sel_bias, mask_g, mstride);
             return ASTTS_OK;
         }
-        if (p.nseg == 1) {
-            hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
-                               h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv);
-            ASTTS_CHECK_LAUNCH();
-        } else {
-            hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
-                               h->n, p.c, p.seg_len, sidx, ss, sel_inv);
-            ASTTS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(knn_select_merge, dim3(qg), dim3(64), 0, st, sidx, ss, p.nseg, p.c,
-                               cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
-            ASTTS_CHECK_LAUNCH();
+        // (a k > 32 search re-ranks the SAME score plane once per pass, so its groups finish before the next group's scan overwrites it)
+        const int rounds = multi ? p.passes : 1;
+        for (int r = 0; r < rounds; ++r) {
+            if (p.nseg == 1) {
+                hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
+                                   h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0,
+                                   mask_g, mstride);
+                ASTTS_CHECK_LAUNCH();
+            } else {
+                hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
+                                   h->n, p.c, p.seg_len, sidx, ss, sel_inv, sel_bias, qscale + q0, mask_g, mstride);
+                ASTTS_CHECK_LAUNCH();
+                hipLaunchKernelGGL(knn_select_merge, dim3(qg), dim3(64), 0, st, sidx, ss, p.nseg, p.c,
+                                   cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
+                ASTTS_CHECK_LAUNCH();
+            }
+            if (!multi) break;
+            const int done = r * kPassK;
+            const int kp = (k - done) < kPassK ? (k - done) : kPassK;
+            // this group's queries only: grid offset through the pointer arguments
+            KNN_RESCORE(knn_rescore_finalize, dim3(qg), qf + (size_t)q0 * h->dp, qn + q0, qscale + q0,
+                        PLANE, h->norm64, h->n, h->dp, p.c, kp,
+                        cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, h->err_bound, force, out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k,
+                        out_score64 ? out_score64 + (size_t)q0 * k : nullptr, nflag, flagged + (size_t)r * nq + q0, h->metric, h->bmax,
+                        mask_g, mstride, k, done);
+            if (r + 1 < rounds) {
+                hipLaunchKernelGGL(knn_mask_out, dim3(qg), dim3(64), 0, st, out_idx + (size_t)q0 * k, k, done, kp,
+                                   (uint8_t*)(ws + p.off_mask) + (int64_t)q0 * h->n, h->n);
+                ASTTS_CHECK_LAUNCH();
+            }
         }
     }
-    const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
-    if (h->exact16) {
-        hipLaunchKernelGGL((knn_rescore_finalize<_Float16>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
-                           h->plane16, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
-                           out_idx, out_score, out_score64, nflag, flagged);
-    } else {
-        hipLaunchKernelGGL((knn_rescore_finalize<float>), dim3(nq), dim3(1024), 0, st, qf, qn, qscale,
-                           h->plane32, h->norm64, h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force,
-                           out_idx, out_score, out_score64, nflag, flagged);
+    if (multi) return ASTTS_OK;
+    KNN_RESCORE(knn_rescore_finalize, dim3(nq), qf, qn, qscale, PLANE, h->norm64,
+                h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force, out_idx, out_score, out_score64, nflag, flagged, h->metric, h->bmax,
+                mask, mstride, k, 0);
+#undef KNN_RESCORE
+    return ASTTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int astts_knn_search_masked(astts_knn_t* h, const float* queries, int32_t nq, int32_t k, int64_t* out_idx,
+                            float* out_score, double* out_score64, const uint8_t* row_mask, int64_t mask_stride,
+                            void* workspace, size_t workspace_bytes, int32_t flags, astts_stream_t stream) {
+    ASTTS_REQUIRE(h != nullptr, ASTTS_ERR_INVALID, "astts_knn_search: handle is null");
+    ASTTS_REQUIRE(queries && out_idx && out_score, ASTTS_ERR_INVALID, "astts_knn_search: null pointer argument");
+    ASTTS_REQUIRE(nq >= 1, ASTTS_ERR_INVALID, "astts_knn_search: nq=%d", nq);
+    ASTTS_REQUIRE(k >= 1 && k <= ASTTS_KNN_MAX_K, ASTTS_ERR_INVALID,
+                  "astts_knn_search: k=%d (1..%d)", k, ASTTS_KNN_MAX_K);
+    ASTTS_REQUIRE(row_mask == nullptr || mask_stride == 0 || mask_stride >= h->n, ASTTS_ERR_INVALID,
+                  "astts_knn_search: mask_stride %lld (0 = one mask for every query, else >= n = %lld)", (long long)mask_stride, (long long)h->n);
+    ASTTS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 255) == 0, ASTTS_ERR_WORKSPACE,
+                  "astts_knn_search: workspace must be 256-byte aligned");
+    const KnnPlan p = make_plan(h, nq, k);
+    ASTTS_REQUIRE(workspace_bytes >= p.total, ASTTS_ERR_WORKSPACE,
+                  "astts_knn_search: workspace %zu < required %zu", workspace_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.passes == 1)
+        return knn_search_chunk(h, p, queries, nq, k, out_idx, out_score, out_score64, row_mask, mask_stride, (char*)workspace, flags, true, st);
+    for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {       // k > 32: chunks of <= 256 queries share the workspace, in stream order
+        const int qc = (nq - q0) < kMaxQPerPass ? (nq - q0) : kMaxQPerPass;
+        const int rc = knn_search_chunk(h, p, queries + (size_t)q0 * h->d, qc, k, out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k,
+                                        out_score64 ? out_score64 + (size_t)q0 * k : nullptr,
+                                        row_mask ? row_mask + (int64_t)q0 * mask_stride : nullptr, mask_stride, (char*)workspace, flags,
+                                        q0 == 0, st);
+        if (rc != ASTTS_OK) return rc;
     }
-    ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
 

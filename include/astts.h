@@ -75,8 +75,8 @@ int astts_selftest_xlane(int32_t* mismatches, astts_stream_t stream);
  * Style-bank kNN.  Replaces MilvusClient.search(collection, data=[vec], anns_field="vector",
  * metric_type="COSINE", limit=k) -- milvus/search_embeddings.py:15-22.
  *
- * Result definition (identical to oracle/knn.py): score(q,n) = <q,b_n>/(|q||b_n|) evaluated in
- * fp64, hits ordered by (score descending, row index ascending).  Returned ids are ROW INDICES
+ * Result definition (identical to oracle/knn.py): score(q,n) = <q,b_n>/(|q||b_n|) (COSINE; <q,b_n> for IP, |q - b_n|^2 for L2)
+ * evaluated in fp64, hits ordered by (closest first, row index ascending).  Returned ids are ROW INDICES
  * into the bank (the reference's pk restarts per speaker and is not unique, RAG.py:507); ids are
  * bit-exact w.r.t. that definition: an fp16-MFMA scan proposes candidates, every candidate is
  * re-scored in fp64, and a query whose candidate set cannot be certified complete (error bound
@@ -85,11 +85,11 @@ int astts_selftest_xlane(int32_t* mismatches, astts_stream_t stream);
 #define ASTTS_DTYPE_F16 1
 #define ASTTS_DTYPE_F32 2
 
-#define ASTTS_METRIC_COSINE 0
-#define ASTTS_METRIC_IP 1 /* reserved: ASTTS_ERR_UNSUPPORTED */
-#define ASTTS_METRIC_L2 2 /* reserved: ASTTS_ERR_UNSUPPORTED */
+#define ASTTS_METRIC_COSINE 0 /* score = cosine similarity, larger = closer (the reference's collection) */
+#define ASTTS_METRIC_IP 1     /* score = inner product, larger = closer */
+#define ASTTS_METRIC_L2 2     /* score = SQUARED Euclidean distance (Milvus' convention), smaller = closer */
 
-#define ASTTS_KNN_MAX_K 32
+#define ASTTS_KNN_MAX_K 1024  /* k > 32 runs ceil(k / 32) selection passes over one scan */
 #define ASTTS_KNN_FORCE_EXACT 1 /* flags: send every query through the exact fp64 scan */
 
 typedef struct astts_knn astts_knn_t;
@@ -116,6 +116,14 @@ int astts_knn_search(astts_knn_t* h, const float* queries, int32_t nq, int32_t k
 int astts_knn_search_f64(astts_knn_t* h, const float* queries, int32_t nq, int32_t k,
                          int64_t* out_idx, float* out_score, double* out_score64, void* workspace, size_t workspace_bytes,
                          int32_t flags, astts_stream_t stream);
+/* The general form: `row_mask` (uint8 [n] when mask_stride == 0, else one row of mask_stride >= n bytes per query; NULL = every
+ * row) restricts the search to the rows whose byte is non-zero -- a Milvus `filter` expression evaluated by the host
+ * (milvus/search_json.py:246-252 passes filter=None).  Hits are ordered closest first under the handle's metric
+ * (COSINE / IP: score descending; L2: squared distance ascending), ties by row index ascending; out_score / out_score64 hold the
+ * metric's own value; rows beyond the hits that exist get idx -1 and score -inf (+inf for L2).  1 <= k <= ASTTS_KNN_MAX_K. */
+int astts_knn_search_masked(astts_knn_t* h, const float* queries, int32_t nq, int32_t k,
+                            int64_t* out_idx, float* out_score, double* out_score64, const uint8_t* row_mask, int64_t mask_stride,
+                            void* workspace, size_t workspace_bytes, int32_t flags, astts_stream_t stream);
 /* Number of queries of the last search on `workspace` that took the exact-scan fallback.
  * Copies one word back and synchronises `stream` (diagnostics; not a launch-path call). */
 int astts_knn_last_fallbacks(const astts_knn_t* h, const void* workspace, astts_stream_t stream,

@@ -63,7 +63,8 @@ def scores_f64(bank, queries, metric: int = METRIC_COSINE, chunk_rows: int = 409
             elif metric == METRIC_IP:
                 s = dot
             elif metric == METRIC_L2:
-                s = -((qn[qi] * qn[qi]) - 2.0 * dot + bn2)
+                df = b - q64[qi]
+                s = -(df * df).sum(axis=1)          # the difference first (faiss fvec_L2sqr, what Milvus' FLAT scan calls): exactly 0 for a row equal to the query
             else:
                 raise ValueError(f"unknown metric {metric}")
             out[qi, r0:r0 + b.shape[0]] = s
@@ -84,9 +85,22 @@ def topk_from_scores(scores: np.ndarray, k: int):
     return idx, val
 
 
-def knn_search(bank, queries, k: int, metric: int = METRIC_COSINE):
-    """Oracle top-k.  Returns (idx int64 [Q,k], score float64 [Q,k])."""
-    return topk_from_scores(scores_f64(bank, queries, metric), k)
+def knn_search(bank, queries, k: int, metric: int = METRIC_COSINE, row_mask=None):
+    """Oracle top-k.  Returns (idx int64 [Q,k], score float64 [Q,k]); the score is the metric's own value (COSINE: similarity,
+    IP: inner product, L2: SQUARED distance -- Milvus' convention), hits closest first, ties by row index ascending.
+    ``row_mask`` ([N] or [Q, N], non-zero = allowed): a Milvus ``filter`` -- rows outside it cannot be hits; missing hits are
+    (-1, -inf) (+inf for L2)."""
+    sc = scores_f64(bank, queries, metric)
+    if row_mask is not None:
+        m = np.broadcast_to(np.asarray(row_mask) != 0, sc.shape)
+        sc = np.where(m, sc, -np.inf)
+    idx, val = topk_from_scores(sc, k)
+    if row_mask is not None:
+        dead = ~np.isfinite(val) & (val < 0)
+        idx = np.where(dead, -1, idx)
+    if metric == METRIC_L2:
+        val = -val
+    return idx, val
 
 
 def knn_search_fast_f32(bank_f32: np.ndarray, inv_norm: np.ndarray, queries, k: int):

@@ -18,11 +18,12 @@ from astts.llm.config import LlamaShape  # noqa: E402
 from astts.llm.weights import make_llama_weights  # noqa: E402
 
 
-def run(name, cfg, seed, lens, gen_len):
+def run(name, cfg, seed, lens, gen_len, per_layer=False):
     torch.manual_seed(0)
     sd = make_llama_weights(cfg, seed)
     model = LlamaForCausalLM(LlamaConfig(**cfg.hf_kwargs())).eval().float()
-    missing = model.load_state_dict(sd, strict=False)
+    missing = model.load_state_dict(sd, strict=False, assign=True)      # (assign: the 13 GB of the full-depth model are held once)
+    model.tie_weights()
     assert set(missing.missing_keys) <= {"lm_head.weight"} and not missing.unexpected_keys, missing
     g = torch.Generator().manual_seed(seed + 1)
     out = {"seed": np.int64(seed), "lens": np.asarray(lens, np.int64)}
@@ -41,6 +42,8 @@ def run(name, cfg, seed, lens, gen_len):
             if i == 0:
                 out["hidden_layer1_row0"] = o.hidden_states[1][0].numpy()  # input of layer 1: localises a mismatch
                 out["hidden_final_row0"] = hs[0].numpy()
+                if per_layer:       # the last token's residual stream after every layer (before the final norm; the last entry after it):
+                    out["hidden_by_layer_last_token_row0"] = np.stack([h[0, -1].numpy() for h in o.hidden_states])   # error growth by depth
         prompt = ids[:1, :lens[0]]
         gen = model.generate(prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=gen_len, do_sample=False,
                              eos_token_id=cfg.eos_token_id, pad_token_id=cfg.eos_token_id)
@@ -52,5 +55,10 @@ def run(name, cfg, seed, lens, gen_len):
 
 
 if __name__ == "__main__":
-    run("tiny", LlamaShape.tiny(), seed=7, lens=[23, 5, 64, 130], gen_len=10)
-    run("wide", LlamaShape.wide(), seed=8, lens=[40, 17], gen_len=6)
+    if "--3b" in sys.argv:
+        # the model the reference runs (src/search_milvus.py:75-108): all 28 layers of Llama-3.2-3B over its 128 256-entry vocabulary.
+        # 3.2 B fp32 parameters = 13 GB on the build container's CPU; a few short prompts; ~10 minutes.
+        run("3b", LlamaShape.llama32_3b(), seed=9, lens=[40, 17, 60], gen_len=4, per_layer=True)
+    else:
+        run("tiny", LlamaShape.tiny(), seed=7, lens=[23, 5, 64, 130], gen_len=10)
+        run("wide", LlamaShape.wide(), seed=8, lens=[40, 17], gen_len=6)

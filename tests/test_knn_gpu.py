@@ -202,8 +202,10 @@ def test_argument_errors():
         sb.search(np.ones((1, 64), np.float32), _lib.KNN_MAX_K + 1)
     with pytest.raises(_lib.AsttsError):
         StyleBank(np.full((4, 64), np.inf, np.float32))    # non-finite values
-    with pytest.raises(_lib.AsttsError):
-        StyleBank(np.ones((4, 64), np.float16), metric="L2")
+    with pytest.raises(ValueError):
+        StyleBank(np.ones((4, 64), np.float16), metric="HAMMING")
+    with pytest.raises(ValueError):
+        sb.search(np.ones((1, 64), np.float32), 3, row_mask=np.ones(9, np.uint8))       # mask of the wrong length
 
 
 def test_full_size_bank_properties():
@@ -288,3 +290,136 @@ def test_bank_sharded_shards_on_one_gpu_equal_unsharded():
     assert idx[0, :2].tolist() == [17, 3100]
     full_idx, _ = StyleBank(bank).search_device(qd, k)
     assert torch.equal(full_idx, idx)
+
+
+# ------------------------------------------------------------------------------------------ IP / L2, row masks, k > 32 (round 6)
+METRICS = {"COSINE": oknn.METRIC_COSINE, "IP": oknn.METRIC_IP, "L2": oknn.METRIC_L2}
+
+
+def _check_metric(bank_np, q, k, metric, mask=None, force_exact=False, sb=None, atol=None):
+    from astts.knn import StyleBank
+
+    sb = sb or StyleBank(bank_np, metric=metric)
+    idx, sc = sb.search(q, k, force_exact=force_exact, row_mask=mask)
+    eidx, esc = oknn.knn_search(bank_np, q, k, METRICS[metric], row_mask=mask)
+    kk = eidx.shape[1]
+    assert np.array_equal(idx[:, :kk], eidx), (metric, np.argwhere(idx[:, :kk] != eidx)[:5], idx[:, :kk][idx[:, :kk] != eidx][:5], eidx[idx[:, :kk] != eidx][:5])
+    live = eidx >= 0
+    scale = max(1.0, float(np.abs(esc[live]).max())) if live.any() else 1.0
+    assert np.allclose(sc[:, :kk][live], esc[live], atol=(atol or SCORE_ATOL) * scale, rtol=0)
+    dead = ~live
+    if dead.any():
+        assert np.all(np.isposinf(sc[:, :kk][dead]) if metric == "L2" else np.isneginf(sc[:, :kk][dead]))
+    if kk < k:
+        assert np.all(idx[:, kk:] == -1)
+    return sb
+
+
+@pytest.mark.parametrize("metric", ["IP", "L2"])
+def test_ip_and_l2_on_the_real_bank(real_bank, metric):
+    """The shipped 130 x 6144 bank under the other two MilvusClient metrics: ids bit-exact against the fp64 oracle, scores to fp32
+    rounding; self-queries (L2: distance exactly 0 first), noisy queries, both paths (certified candidates / exact scan)."""
+    q = real_bank.astype(np.float32)
+    sb = _check_metric(real_bank, q, 5, metric)
+    if metric == "L2":
+        idx, sc = sb.search(q, 1)
+        assert np.array_equal(idx[:, 0], np.arange(130)) and np.all(sc[:, 0] == 0.0)
+    rng = np.random.default_rng(3)
+    noisy = q[:32] + 0.5 * rng.standard_normal((32, 6144)).astype(np.float32)
+    _check_metric(real_bank, noisy, 3, metric, sb=sb)
+    _check_metric(real_bank, noisy, 3, metric, sb=sb, force_exact=True)
+    _check_metric(real_bank, noisy[:4] * 1e-3, 8, metric, sb=sb)      # tiny queries: the power-of-two pre-scale keeps the fp16 image exact
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "IP", "L2"])
+@pytest.mark.parametrize("n,d,nq", [(1000, 6144, 8), (20000, 768, 96), (9000, 1280, 300)])
+def test_metrics_on_synthetic_banks(metric, n, d, nq):
+    """fp32 (not fp16-exact) Gaussian banks with rows of very different norms: the K-split scan (small bank), the GEMM scan (>= 64
+    queries against a large bank), several selection segments (n > 8192) and several query groups (nq > 256)."""
+    rng = np.random.default_rng(n + d)
+    bank = (rng.standard_normal((n, d)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    q = (bank[rng.integers(0, n, nq)] + 0.7 * rng.standard_normal((nq, d))).astype(np.float32)
+    sb = _check_metric(bank, q, 3, metric, atol=2e-6)
+    assert sb.last_fallbacks() <= nq
+    _check_metric(bank, q[:5], 20, metric, sb=sb, atol=2e-6)           # the 64-entry candidate list
+
+
+def test_vq_argmin_shape():
+    """What the speech tokenizer's quantiser asks for: k = 1, L2, a 4096 x 1280 codebook, a few hundred unit-norm frames."""
+    rng = np.random.default_rng(11)
+    code = rng.standard_normal((4096, 1280)).astype(np.float32)
+    code /= np.linalg.norm(code, axis=1, keepdims=True)
+    x = code[rng.integers(0, 4096, 375)] + 0.05 * rng.standard_normal((375, 1280)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    _check_metric(code, x, 1, "L2", atol=2e-6)
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_row_masks(real_bank, metric):
+    """A filter's row mask: hits are the exact top-k of the allowed rows -- one mask for every query, one per query, masks that
+    leave fewer than k rows (missing hits are -1), an empty mask, and the exact path."""
+    q = real_bank[:16].astype(np.float32)
+    rng = np.random.default_rng(5)
+    shared = (rng.random(130) < 0.5).astype(np.uint8)
+    sb = _check_metric(real_bank, q, 5, metric, mask=shared)
+    per_q = (rng.random((16, 130)) < 0.3).astype(np.uint8)
+    _check_metric(real_bank, q, 5, metric, mask=per_q, sb=sb)
+    few = np.zeros(130, np.uint8)
+    few[[7, 99]] = 1
+    _check_metric(real_bank, q, 5, metric, mask=few, sb=sb)
+    _check_metric(real_bank, q, 5, metric, mask=few, sb=sb, force_exact=True)
+    _check_metric(real_bank, q, 3, metric, mask=np.zeros(130, np.uint8), sb=sb)
+    # a large bank: several selection segments, most rows masked in some of them
+    n = 30000
+    bank = rng.standard_normal((n, 256)).astype(np.float16)
+    big = (rng.random(n) < 0.02).astype(np.uint8)
+    big[:9000] = 0
+    _check_metric(bank, bank[:40].astype(np.float32) + 0.1, 10, metric, mask=big)
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "IP", "L2"])
+def test_limits_beyond_32_hits(real_bank, metric):
+    """limit up to 1024: 32 certified hits per selection pass over ONE scan, the rows of earlier passes masked out -- the
+    concatenation is the oracle's order, through every pass boundary; k > n returns every row, then -1."""
+    q = real_bank[:6].astype(np.float32) + 0.25
+    sb = _check_metric(real_bank, q, 33, metric)
+    _check_metric(real_bank, q, 100, metric, sb=sb)
+    _check_metric(real_bank, q, 130, metric, sb=sb)
+    _check_metric(real_bank, q, 200, metric, sb=sb)                    # more hits than rows
+    half = np.zeros(130, np.uint8)
+    half[::2] = 1
+    _check_metric(real_bank, q, 70, metric, sb=sb, mask=half)          # 65 allowed rows
+    rng = np.random.default_rng(8)
+    bank = rng.standard_normal((20000, 128)).astype(np.float16)
+    qq = rng.standard_normal((300, 128)).astype(np.float32)            # two chunks of <= 256 queries
+    _check_metric(bank, qq, 1024 if metric == "COSINE" else 80, metric, atol=2e-6)
+
+
+def test_milvus_client_filter_limit_and_metrics(tmp_path):
+    """The client surface of those three: filter expressions over the dynamic fields and the primary key, limit > 32, and an L2 / IP
+    collection (distance ascending / inner product descending), each against the oracle on the rows the filter allows."""
+    from astts.compat.pymilvus import MilvusClient, MilvusException
+
+    rng = np.random.default_rng(21)
+    n, d = 300, 64
+    vecs = rng.standard_normal((n, d)).astype(np.float32)
+    rows = [{"id": i, "vector": vecs[i].tolist(), "file_id": f"spk{i % 7}_{i}.wav", "text": "yes" if i % 3 == 0 else "no", "dur": float(i) / 10}
+            for i in range(n)]
+    q = vecs[5] + 0.1
+    for metric in ("COSINE", "L2", "IP"):
+        c = MilvusClient(str(tmp_path / f"{metric}.db"))
+        c.create_collection(collection_name="bank", dimension=d, metric_type=metric)
+        c.insert("bank", rows)
+        for flt, allow in (('text == "yes"', [i % 3 == 0 for i in range(n)]),
+                           ('file_id like "spk3%" and id >= 100', [i % 7 == 3 and i >= 100 for i in range(n)]),
+                           ('$meta["text"] in ["no"] or dur < 1.55', [i % 3 != 0 or i / 10 < 1.55 for i in range(n)]),
+                           ('not (id in [5, 6, 7])', [i not in (5, 6, 7) for i in range(n)])):
+            hits = c.search("bank", data=[q.tolist()], limit=40, filter=flt, output_fields=["file_id"])[0]
+            ei, es = oknn.knn_search(vecs, q[None], 40, METRICS[metric], row_mask=np.asarray(allow))
+            want = [int(i) for i in ei[0] if i >= 0]
+            assert [h["row"] for h in hits] == want and [h["id"] for h in hits] == want, (metric, flt)
+            assert np.allclose([h["distance"] for h in hits], es[0][:len(want)], atol=1e-4)
+            assert all(h["entity"]["file_id"] == rows[h["row"]]["file_id"] for h in hits)
+        with pytest.raises(MilvusException):
+            c.search("bank", data=[q.tolist()], limit=3, filter="text === 3")
+        c.close()

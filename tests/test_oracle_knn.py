@@ -110,3 +110,44 @@ def test_fast_cpu_baseline_agrees_with_oracle(real_bank):
     i0, s0 = oknn.knn_search(real_bank, q, k=3)
     i1, s1 = oknn.knn_search_fast_f32(b32, inv, q, k=3)
     assert np.array_equal(i0, i1) and np.allclose(s0, s1, atol=1e-12)
+
+
+def test_other_metrics_masks_and_filters(real_bank):
+    """IP / L2 (squared distance, ascending) and row masks of the oracle against brute-force definitions written out here; the
+    filter grammar of astts.milvus_filter against Python comprehensions."""
+    rng = np.random.default_rng(2)
+    b = real_bank[:40].astype(np.float64)
+    q = b[:3] + 0.3 * rng.standard_normal((3, b.shape[1]))
+    for qi in range(3):
+        d2 = ((b - q[qi]) ** 2).sum(axis=1)
+        idx, val = oknn.knn_search(real_bank[:40], q[qi].astype(np.float32), 5, oknn.METRIC_L2)
+        q32 = q[qi].astype(np.float32).astype(np.float64)
+        d2 = ((b - q32) ** 2).sum(axis=1)
+        assert idx[0].tolist() == np.argsort(d2, kind="stable")[:5].tolist() and np.allclose(val[0], np.sort(d2)[:5], rtol=1e-12)
+        ip = b @ q32
+        idx, val = oknn.knn_search(real_bank[:40], q[qi].astype(np.float32), 5, oknn.METRIC_IP)
+        assert idx[0].tolist() == np.argsort(-ip, kind="stable")[:5].tolist() and np.allclose(val[0], -np.sort(-ip)[:5], rtol=1e-12)
+    i0, s0 = oknn.knn_search(real_bank[:40], real_bank[:40].astype(np.float32), 1, oknn.METRIC_L2)
+    assert i0[:, 0].tolist() == list(range(40)) and np.all(s0 == 0.0)
+    mask = np.zeros(40, bool)
+    mask[[3, 9, 30]] = True
+    idx, val = oknn.knn_search(real_bank[:40], q.astype(np.float32), 5, oknn.METRIC_COSINE, row_mask=mask)
+    assert set(idx[0, :3].tolist()) == {3, 9, 30} and idx[0, 3:].tolist() == [-1, -1] and np.all(np.isneginf(val[0, 3:]))
+    idx, val = oknn.knn_search(real_bank[:40], q.astype(np.float32), 5, oknn.METRIC_L2, row_mask=mask)
+    assert set(idx[0, :3].tolist()) == {3, 9, 30} and np.all(np.isposinf(val[0, 3:]))
+
+    from astts.milvus_filter import FilterSyntaxError, row_mask
+    metas = [{"file_id": f"s{i % 3}/{i}.wav", "text": ["Yeah.", "No way!", 'say "x"'][i % 3], "n": i} for i in range(12)]
+    pks = list(range(100, 112))
+    chk = lambda e, f: row_mask(e, "id", pks, metas).tolist() == [int(bool(f(i, pks[i], metas[i]))) for i in range(12)]
+    assert chk('text == "Yeah."', lambda i, pk, m: m["text"] == "Yeah.")
+    assert chk("text == 'say \"x\"' || id > 109", lambda i, pk, m: m["text"] == 'say "x"' or pk > 109)
+    assert chk('$meta["file_id"] like "s1/%" and n != 4', lambda i, pk, m: m["file_id"].startswith("s1/") and m["n"] != 4)
+    assert chk('id in [100, 105, 111] or (n >= 3 and n < 5)', lambda i, pk, m: pk in (100, 105, 111) or 3 <= m["n"] < 5)
+    assert chk('not text in ["Yeah."] && !(n == 1)', lambda i, pk, m: m["text"] != "Yeah." and m["n"] != 1)
+    assert chk('missing == 3 or text not like "%!"', lambda i, pk, m: not m["text"].endswith("!"))
+    assert chk('n == "3"', lambda i, pk, m: False)                      # a number never equals a string
+    import pytest
+    for bad in ('text = "x"', 'text == ', '(n > 3', 'n in 3', 'n > 3 4'):
+        with pytest.raises(FilterSyntaxError):
+            row_mask(bad, "id", pks, metas)
