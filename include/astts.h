@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASTTS_ABI_VERSION 4
+#define ASTTS_ABI_VERSION 5
 
 #define ASTTS_OK 0
 #define ASTTS_ERR_INVALID (-1)     /* bad argument (null pointer, size, dtype, k, ...)            */
@@ -323,6 +323,31 @@ int astts_op_whisper_log_mel(const float* wav, const float* window, const float*
  * -> out [b, frames, n_mels]. */
 int astts_op_kaldi_fbank(const float* wav, const float* window, const float* mel_fb, float* out, int32_t b, int64_t n_samples, int32_t frame_len,
                          int32_t hop, int32_t n_fft, int32_t n_mels, float scale, float preemph, float log_floor, astts_stream_t stream);
+/* The learned half of the frontend: glue operators of the CAM++ speaker network (campplus.onnx [EXT]) and the
+ * speech tokenizer (speech_tokenizer_v1.onnx [EXT]) that CosyVoice(model_dir) loads (tts_with_rag.py:159) and runs on every prompt
+ * (tts_with_rag.py:179-195); their contractions run on astts_op_gemm_* / astts_op_attn_mha_ex, the quantiser's arg-min on
+ * astts_knn_* with ASTTS_METRIC_L2 (csrc/ops_frontend.hip; host: astts/frontend_nets.py; definition: oracle/frontend_nets.py).
+ * affine_act: y[r, k] = act(x[r, k] * scale[k] + shift[k]) (eval-mode BatchNorm + ReLU in front of a convolution; scale / shift NULL
+ *   = identity; act 0 none, 1 relu; x / y fp32 or fp16 with row strides ldx / ldy).
+ * freq_unfold: y[b, fo, t, kf * c + k] = x[b, fo * sf + kf - (nkf - 1) / 2, t, k] (0 outside the input rows) as fp16: the nkf = 3
+ *   frequency rows of a 3 x 3 convolution window side by side, so that the convolution is a 3-tap astts_op_gemm_ex over time.
+ * ftc_to_tfc: [b, f, t, c] -> [b, t, f * c].
+ * cam_context: ctx[b, s, k] = mean_t h[b, t, k] + mean over segment s (seg_len frames, the last one shorter) of h[b, t, k].
+ * cam_gate: out[b, t, k] = y[b, t, k] * sigmoid(m[b, t / seg_len, k]) with output row stride ldo (a column block of the dense
+ *   block's concatenation buffer).
+ * stats_pool: out[b, k] = mean_t x[b, t, k], out[b, c + k] = unbiased standard deviation.
+ * l2_normalize: y[r, :] = x[r, :] / max(|x[r, :]|, eps). */
+int astts_op_affine_act(const void* x, int32_t x_f16, int64_t ldx, const float* scale, const float* shift, void* y, int32_t y_f16,
+                        int64_t ldy, int64_t rows, int32_t c, int32_t act, astts_stream_t stream);
+int astts_op_freq_unfold(const void* x, int32_t x_f16, void* y_f16, int32_t b, int32_t f_in, int32_t t, int32_t c, int32_t f_out, int32_t sf,
+                         int32_t nkf, astts_stream_t stream);
+int astts_op_ftc_to_tfc(const float* x, float* y, int32_t b, int32_t f, int32_t t, int32_t c, astts_stream_t stream);
+int astts_op_cam_context(const void* h, int32_t h_f16, int64_t ldh, float* ctx, int32_t b, int32_t t, int32_t c, int32_t seg_len,
+                         astts_stream_t stream);
+int astts_op_cam_gate(const float* y, const float* m, float* out, int64_t ldo, int32_t b, int32_t t, int32_t c, int32_t seg_len,
+                      astts_stream_t stream);
+int astts_op_stats_pool(const float* x, int64_t ldx, float* out, int32_t b, int32_t t, int32_t c, astts_stream_t stream);
+int astts_op_l2_normalize(const float* x, float* y, int64_t rows, int32_t c, float eps, astts_stream_t stream);
 /* Repetition-aware sampling with injected uniforms [b, 2] (definition: csrc/ops_audio.hip, mirrored by oracle/synth.py::ras_sample).
  * ignore_eos: bit 0 = EOS may not be produced at this step (with eos_min_rows: per row, while hist_len < eos_min_rows[b]); bit 1 = the
  * policy inside that window: 0 mask, 1 reject (astts_lm_config_t.eos_policy). */

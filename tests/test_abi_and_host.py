@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     import astts.ops  # noqa: F401  (registers its part of the ABI)
     assert set(_lib.declared_symbols()) == set(syms)
     lib2 = _lib.load()
-    assert lib2.astts_abi_version() == 4
+    assert lib2.astts_abi_version() == 5
 
 
 def test_product_path_fails_loudly_without_gpu():
