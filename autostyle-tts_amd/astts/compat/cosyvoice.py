@@ -116,11 +116,16 @@ class CosyVoice:
         """``model_dir`` must hold ``llm.pt`` / ``flow.pt`` / ``hift.pt`` (the CosyVoice-300M state dicts), as it must for
         the reference (tts_with_rag.py:159).  Without them the constructor RAISES -- a synthesis run on random weights
         writes noise and must not look like a success -- unless the caller opts in: ``allow_random_init=True`` (the CLIs'
-        ``--allow_random_init``) or ``ASTTS_ALLOW_RANDOM_INIT=1`` (tests, benchmarks: no checkpoint exists offline)."""
+        ``--allow_random_init``) or ``ASTTS_ALLOW_RANDOM_INIT=1`` (tests, benchmarks: no checkpoint exists offline).
+        The frontend (text tokenizer vocabulary, speech tokenizer, speaker network: upstream's ``*.tiktoken``,
+        ``speech_tokenizer_v1.onnx``, ``campplus.onnx``) is wired from the same directory (``Frontend.from_model_dir``); LOADED
+        synthesis weights next to a missing frontend file RAISE too (``allow_standin_frontend=True`` /
+        ``ASTTS_ALLOW_STANDIN_FRONTEND=1`` to run on synthetic frontend networks anyway)."""
         from ..synth.model import SynthEngine
         from ..synth.weights import load_state_dicts, make_all
 
         engine = _kw.pop("engine", None)          # an existing SynthEngine (benchmarks: one engine for several surfaces)
+        allow_standin_frontend = _kw.pop("allow_standin_frontend", None)
         self.model_dir = model_dir
         if config is None:
             cfg_file = os.path.join(model_dir, "astts.json")          # this build's plain-JSON model config (sample rate, max_positions,
@@ -148,7 +153,12 @@ class CosyVoice:
             self.random_init = True
         self.engine = engine if engine is not None else SynthEngine(state, config, device)    # raises without a GPU: no CPU fallback
         self.device = self.engine.device
-        self.frontend = frontend or Frontend(config, device=self.device)
+        if frontend is None:
+            # real weights are never paired silently with an untrained frontend (an engine handed over in memory counts as loaded
+            # only when it says so: engine.random_init = False)
+            frontend = Frontend.from_model_dir(model_dir, config, self.device, weights_loaded=not self.random_init,
+                                               allow_standins=allow_standin_frontend, seed=seed)
+        self.frontend = frontend
         self._gen = torch.Generator().manual_seed(seed)
         self.min_token_text_ratio, self.max_token_text_ratio = 2, 20
         # stream=True: render chunk k while the LM decodes the tokens of chunk k + 1 (False: one decode pass, then the chunks -- rounds 3-4,

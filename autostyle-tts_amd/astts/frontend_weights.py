@@ -69,9 +69,16 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
     return torch.cat([t.sin(), t.cos()], dim=1)
 
 
-def make_speech_tokenizer_weights(cfg: SpeechTokenizerShape, seed: int = 0) -> StateDict:
+def _drawer(seed):
+    """``r(*shape, std=)``: seeded Gaussians -- or, for ``seed`` None, meta tensors (shapes only: the manifest of a network)."""
+    if seed is None:
+        return lambda *s, std: torch.empty(*s, device="meta")
     g = torch.Generator().manual_seed(seed)
-    r = lambda *s, std: torch.randn(*s, generator=g) * std
+    return lambda *s, std: torch.randn(*s, generator=g) * std
+
+
+def make_speech_tokenizer_weights(cfg: SpeechTokenizerShape, seed: Optional[int] = 0) -> StateDict:
+    r = _drawer(seed)
     d = cfg.d
     sd: StateDict = {
         "encoder.conv1.weight": r(d, cfg.n_mels, 3, std=1.0 / math.sqrt(3 * cfg.n_mels)), "encoder.conv1.bias": r(d, std=0.1),
@@ -107,9 +114,8 @@ def _bn(sd: StateDict, name: str, c: int, r, affine: bool = True) -> None:
     sd[name + ".running_var"] = (1.0 + r(c, std=0.3)).abs() + 0.2
 
 
-def make_campplus_weights(cfg: CamPlusShape, seed: int = 0) -> StateDict:
-    g = torch.Generator().manual_seed(seed)
-    r = lambda *s, std: torch.randn(*s, generator=g) * std
+def make_campplus_weights(cfg: CamPlusShape, seed: Optional[int] = 0) -> StateDict:
+    r = _drawer(seed)
     m = cfg.m_channels
     sd: StateDict = {"head.conv1.weight": r(m, 1, 3, 3, std=1.0 / 3.0)}
     _bn(sd, "head.bn1", m, r)
@@ -154,6 +160,11 @@ def make_campplus_weights(cfg: CamPlusShape, seed: int = 0) -> StateDict:
 
 def manifest(sd: StateDict) -> Dict[str, Tuple[int, ...]]:
     return {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def manifest_for(maker, shape) -> Dict[str, Tuple[int, ...]]:
+    """name -> shape of a network at ``shape`` without drawing its weights (``maker(shape, None)`` runs on meta tensors)."""
+    return manifest(maker(shape, None))
 
 
 def check_against_manifest(sd: StateDict, want: Dict[str, Tuple[int, ...]], what: str) -> StateDict:

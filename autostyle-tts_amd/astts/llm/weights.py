@@ -13,12 +13,13 @@ from .config import LlamaShape
 StateDict = Dict[str, torch.Tensor]
 
 
-def make_llama_weights(cfg: LlamaShape, seed: int = 0) -> StateDict:
+def make_llama_weights(cfg: LlamaShape, seed: int = 0, device=None) -> StateDict:
     """Deterministic (torch.Generator, CPU) fp32 weights: projections N(0, 0.02^2 * 4) so that activations stay O(1)
     through a few layers, norm scales 1 + 0.1 N(0,1).  The fixture generator, the oracle tests and the GPU tests all
-    call this -- the weights never travel, only the seed does."""
-    g = torch.Generator().manual_seed(seed)
-    r = lambda *s, std: torch.randn(*s, generator=g) * std
+    call this -- the weights never travel, only the seed does.  ``device``: draw on that device instead (its own generator, so
+    OTHER values than the CPU stream's: for throughput runs of the full 3.2 B-parameter model, where no fixture is compared)."""
+    g = torch.Generator(device=device).manual_seed(seed) if device is not None else torch.Generator().manual_seed(seed)
+    r = lambda *s, std: torch.randn(*s, generator=g, device=device) * std
     sd: StateDict = {"model.embed_tokens.weight": r(cfg.vocab, cfg.hidden, std=0.5)}
     kv = cfg.kv_heads * cfg.head_dim
     q = cfg.heads * cfg.head_dim

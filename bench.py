@@ -15,6 +15,7 @@ region starts, the waveform stays on the GPU.  value = synthesized audio seconds
 whole job.  The retrieval leg is additionally reported as queries/s (``knn_qps``).
 """
 import argparse
+import dataclasses
 import json
 import math
 import os
@@ -590,15 +591,15 @@ def side_extras(args, dev, cfg, eng):
 
 def bench_embedder(args, dev, cfg, eng):
     """SURVEY.md 8f rank 2, the step before the retrieval (milvus/search_json.py:154-229, src/search_milvus.py:75-108): the Llama query
-    embedder at Llama-3.2-3B's WIDTHS (hidden 3072, 24 / 8 heads of 128, FFN 8192) with the test fixture's layer count (3 of 28: the
-    weights regenerate from a seed in seconds; per-layer work is what the kernels see, the 28-layer figure is the per-layer one x 28 / 3),
+    embedder AS THE REFERENCE RUNS IT -- Llama-3.2-3B: 28 layers, hidden 3072, 24 / 8 heads of 128, FFN 8192, vocabulary 128 256 (3.2 B
+    seeded random parameters drawn on the GPU; parity at this depth: tests/test_llm_gpu.py::test_embedder_at_full_depth_*) --
     32 texts of 60 tokens per pass: mean-pooled embeddings per second, and the 10-token greedy label decode with the KV cache."""
     from astts.llm.config import LlamaShape
     from astts.llm.embedder import LlamaEmbedder
     from astts.llm.weights import make_llama_weights
 
-    shape = LlamaShape.wide()
-    emb = LlamaEmbedder(make_llama_weights(shape, 0), shape, dev)
+    shape = LlamaShape.llama32_3b() if not args.embedder_layers else dataclasses.replace(LlamaShape.llama32_3b(), layers=args.embedder_layers)
+    emb = LlamaEmbedder(make_llama_weights(shape, 0, device=dev), shape, dev)
     b, t, n_new = 32, 60, 10
     g = torch.Generator().manual_seed(5)
     ids = torch.randint(3, shape.vocab, (b, t), generator=g)
@@ -638,17 +639,17 @@ def bench_embedder(args, dev, cfg, eng):
     emb.generate_greedy_recompute(prompts[0], n_new)
     d1 = time.perf_counter() - t2
     return {"texts_per_s": b / dt, "ms_per_pass": dt * 1e3, "texts": b, "tokens_per_text": t, "layers": shape.layers, "hidden": shape.hidden,
+            "vocab": shape.vocab, "parameters": sum(int(w.data.numel()) for L in emb.L for w in (L["wqkv"], L["wo"], L["wgu"], L["wd"])) + int(emb.embed.numel()),
             "finite": bool(torch.isfinite(e).all()),
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_pass": flops,
-                         "note": "whole embedding pass (embedding lookup, 3 x [RMSNorm, q|k|v GEMM, RoPE, MFMA causal GQA attention, out GEMM, RMSNorm, "
+                         "note": f"whole embedding pass (embedding lookup, {shape.layers} x [RMSNorm, q|k|v GEMM, RoPE, MFMA causal GQA attention, out GEMM, RMSNorm, "
                                  "gate|up GEMM, SwiGLU, down GEMM], final norm, mean-pool) over the pass's wall time; 1 920 rows per GEMM: launch- and "
                                  "ingest-bound, not MFMA-bound"},
             "greedy_label": {"texts": b, "prompt_tokens": t, "new_tokens": n_new, "ms_per_batch": dg * 1e3, "labels_per_s": b / dg,
                              "ms_one_text_prompt_rerun_per_token": d1 * 1e3,
                              "note": "KV cache + argmax on the device, one host synchronisation per batch (rounds 3-4 re-ran the prompt per token "
                                      "with a host sync each: the last figure, ONE text)"},
-            "extrapolated_28_layers_texts_per_s": b / (dt * 28.0 / shape.layers),
             "batch_of_256_texts": {"texts_per_s": b2 / dt2, "ms_per_pass": dt2 * 1e3, "finite": bool(torch.isfinite(e2).all()),
                                    "mfma_frac": flops2 / dt2 / 1e12 / MFMA_F16_PEAK_TFLOPS,
                                    "note": "the same pass over 256 texts (configs[4]'s query batch): 15 360 rows per GEMM"}}
@@ -738,6 +739,7 @@ def main():
     ap.add_argument("--speech-tokens", type=int, default=250)
     ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--embedder-layers", type=int, default=0, help="query-embedder side probe: layers of the Llama-3.2-3B shape (0 = all 28)")
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
     ap.add_argument("--no-cobatch", action="store_true", help="skip the co-batched side measurement (16 / 32-row decode chains): profiling "
                     "runs use it so that the kernel population is the timed region's")

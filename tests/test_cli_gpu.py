@@ -355,8 +355,13 @@ def test_cosyvoice_from_a_checkpoint_directory_with_its_json_config(tmp_path):
     state = make_all(cfg, 9)
     d = str(tmp_path / "CosyVoice-300M")
     _write_model_dir(d, cfg, state)
-    cv = CosyVoice(d, seed=4)
+    # loaded synthesis weights without the frontend's files: refused (byte ids / untrained tokens into trained networks = garbage, status OK)
+    with pytest.raises(FileNotFoundError) as ei:
+        CosyVoice(d, seed=4)
+    assert "speech_tokenizer_v1" in str(ei.value) and "campplus" in str(ei.value) and "tiktoken" in str(ei.value)
+    cv = CosyVoice(d, seed=4, allow_standin_frontend=True)
     assert cv.random_init is False and cv.sample_rate == 24000 and cv.cfg == cfg
+    assert cv.frontend.describe() == {"text_tokenizer": "stand-in", "speech_tokenizer": "synthetic-weights", "speaker_embedder": "synthetic-weights"}
     ref = CosyVoice("/nonexistent", config=cfg, seed=4, allow_random_init=True, engine=SynthEngine(state, cfg))
     style, timbre = _stream_inputs()
     a = list(cv.inference_tts_with_st("Guess what?", "I do. Yeah.", style, timbre, seed=3))
@@ -405,3 +410,57 @@ def test_batch_surface_with_wide_lm_jobs_spanning_render_groups(cosy, tmp_path):
     print(f"[wide lm] free-running rows whose tokens equal the 32-row path: {agree} of {n}")
     assert agree >= n // 2, agree
     assert all(bool(torch.isfinite(w).all()) for w in wf1)
+
+
+def test_cosyvoice_wires_its_frontend_from_the_model_directory(tmp_path):
+    """A model directory that holds everything the reference's holds (tts_with_rag.py:159 [EXT]: llm / flow / hift weights, the BPE
+    vocabulary, the speech tokenizer and the speaker network -- the last two once as .pt state dicts, once as ONNX initializers):
+    CosyVoice(model_dir) loads all of it without a flag, text ids come from the BPE, prompt features from the loaded networks (equal to
+    the same networks built in memory), and the directory WITHOUT one of the files is refused."""
+    import os
+
+    from test_checkpoint_cpu import _write_model_dir
+
+    from astts.bpe import TiktokenBPE
+
+    from astts import frontend_nets as fn
+    from astts import frontend_weights as fw
+    from astts.compat.cosyvoice import CosyVoice
+    from astts.onnx_weights import write_initializers
+    from astts.synth.config import SynthConfig
+    from astts.synth.weights import make_all
+
+    cfg = SynthConfig.tiny()
+    d = str(tmp_path / "CosyVoice-300M")
+    _write_model_dir(d, cfg, make_all(cfg, 9))
+    tshape, cshape = fn.shapes_for(cfg)
+    tsd, csd = fw.make_speech_tokenizer_weights(tshape, 41), fw.make_campplus_weights(cshape, 42)
+    torch.save(tsd, os.path.join(d, "speech_tokenizer_v1.pt"))
+    write_initializers(os.path.join(d, "campplus.onnx"), [(k, v.numpy()) for k, v in csd.items()])
+    ranks = {bytes([b]): b for b in range(256)}                       # a byte-level vocabulary with a few merges (tiny config: 300 text ids)
+    for i, m in enumerate([b"he", b"ll", b"llo", b"hello", b" w", b"or", b" wor", b"ld"]):
+        ranks[m] = 256 + i
+    bpe = TiktokenBPE(ranks)
+    bpe.to_file(os.path.join(d, "multilingual.tiktoken"))
+    cv = CosyVoice(d, seed=1)
+    assert cv.frontend.describe() == {"text_tokenizer": "loaded", "speech_tokenizer": "loaded", "speaker_embedder": "loaded"}
+    assert cv.frontend.text_ids("hello world")[0].tolist() == bpe.encode("hello world")
+    style, _ = _stream_inputs()
+    feats = cv.frontend.prompt(style)
+    tok = fn.SpeechTokenizerV1(tsd, tshape, "cuda")(style)
+    emb = fn.CamPlusSpeakerNet(csd, cshape, "cuda")(style)
+    assert torch.equal(feats.speech_tokens, tok[:, :feats.speech_tokens.shape[1]]) and torch.equal(feats.spk_embedding, emb)
+    assert int(feats.speech_tokens.max()) < cfg.speech_vocab and feats.spk_embedding.shape == (1, cfg.spk_dim)
+    out = list(cv.inference_tts_with_st("Guess what?", "I do. Yeah.", style, style, seed=3, fixed_tokens=20))
+    assert len(out) == 1 and bool(torch.isfinite(out[0]["tts_speech"]).all())
+    os.remove(os.path.join(d, "campplus.onnx"))
+    with pytest.raises(FileNotFoundError) as ei:
+        CosyVoice(d, seed=1)
+    assert "campplus" in str(ei.value) and "speech_tokenizer_v1" not in str(ei.value)
+    # a mis-shaped weight file is reported tensor by tensor
+    bad = dict(csd)
+    bad["xvector.dense.linear.weight"] = bad["xvector.dense.linear.weight"][:5]
+    torch.save(bad, os.path.join(d, "campplus.pt"))
+    with pytest.raises(ValueError) as ei:
+        CosyVoice(d, seed=1)
+    assert "xvector.dense.linear.weight" in str(ei.value)

@@ -287,3 +287,66 @@ def test_search_json_text_to_style_ids_in_one_command(tmp_path, capsys):
     drv.main(args2)
     assert out1.read_text() == out2.read_text()
     capsys.readouterr()
+
+
+def test_embedder_at_full_depth_matches_transformers_fixture():
+    """The model the reference runs (src/search_milvus.py:75-108, milvus/search_json.py:154-198): all 28 layers of Llama-3.2-3B at its
+    real widths over its 128 256-entry vocabulary -- 3.2 B seeded parameters, fp32 transformers on the build container's CPU
+    (tests/golden/make_llama_fixtures.py --3b -> llama_3b.npz).  What 28 layers of fp16 MFMA operands do to the residual stream is
+    measured layer by layer (printed) and held at the end: final hidden states and the mean-pooled embedding <= 2e-2 of their
+    scale, logits over the full vocabulary <= 2e-2, the greedy continuation equal."""
+    import time
+    from astts import ops
+    from astts.llm.config import LlamaShape
+    from astts.llm.embedder import LlamaEmbedder
+    from astts.llm.weights import make_llama_weights
+
+    fx = np.load(os.path.join(GOLD, "llama_3b.npz"))
+    cfg = LlamaShape.llama32_3b()
+    assert cfg.layers == 28 and cfg.vocab == 128256
+    t0 = time.time()
+    sd = make_llama_weights(cfg, int(fx["seed"]))
+    t1 = time.time()
+    emb = LlamaEmbedder(sd, cfg, DEV)
+    del sd
+    print(f"[3b] weights drawn in {t1 - t0:.1f} s, packed in {time.time() - t1:.1f} s; {torch.cuda.memory_allocated() / 2**30:.1f} GiB resident")
+    ids, lens = torch.from_numpy(fx["ids"]), fx["lens"]
+    row0 = ids[:1, :lens[0]]
+    # error growth by depth: the last token's residual stream after every layer
+    x = ops.embedding(emb.embed, row0.to(DEV))
+    by_layer = fx["hidden_by_layer_last_token_row0"]
+    growth = [_rel(x[0, -1].cpu().numpy(), by_layer[0])]
+    cos, sin = emb._rope
+    hq, hk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+    for li, L in enumerate(emb.L):
+        h = ops.rmsnorm(x, L["n1"], cfg.rms_eps)
+        qkv = ops.linear(h, L["wqkv"], out_dtype=torch.float16)
+        ops.rope_llama_(qkv, cos, sin, cfg.heads + cfg.kv_heads, cfg.head_dim)
+        a = ops.attn_gqa(qkv[..., :hq], qkv[..., hq:hq + hk], qkv[..., hq + hk:], cfg.heads, cfg.kv_heads, cfg.head_dim)
+        x = ops.linear(a, L["wo"], residual=x)
+        h = ops.rmsnorm(x, L["n2"], cfg.rms_eps)
+        x = ops.linear(ops.swiglu(ops.linear(h, L["wgu"], out_dtype=torch.float16)), L["wd"], residual=x)
+        if li + 1 < cfg.layers:                       # (transformers' last entry is taken after the final norm)
+            growth.append(_rel(x[0, -1].cpu().numpy(), by_layer[li + 1]))
+    print("[3b] residual-stream rel err of the last token after layers 0, 1, 2, 4, 8, 16, 27: " +
+          ", ".join(f"{growth[i]:.1e}" for i in (0, 1, 2, 4, 8, 16, 27)))
+    h = emb.hidden(row0).cpu().numpy()[0]
+    e_h = _rel(h, fx["hidden_final_row0"])
+    one = np.stack([emb.embed_ids(ids[i:i + 1, :n]).cpu().numpy()[0] for i, n in enumerate(lens)])
+    e_1 = _rel(one, fx["embedding"])
+    batched = emb.embed_ids(ids, torch.from_numpy(lens)).cpu().numpy()
+    e_b = _rel(batched, fx["embedding"])
+    lg = emb.logits_last(row0.to(DEV)).cpu().numpy()[0]
+    e_l = _rel(lg, fx["logits_last_row0"])
+    # what the retrieval sees: the cosine between this embedding and the fixture's
+    cosv = [float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b))) for a, b in zip(one.astype(np.float64), fx["embedding"].astype(np.float64))]
+    print(f"[parity] llama 3b (28 layers, vocab 128256): final hidden {e_h:.2e}, embedding {e_1:.2e} (one at a time) {e_b:.2e} (padded batch), "
+          f"logits {e_l:.2e}; cosine to the fixture's embeddings {min(cosv):.7f}")
+    assert e_h < 2e-2 and e_1 < 2e-2 and e_b < 2e-2 and e_l < 2e-2 and min(cosv) > 0.9999
+    assert max(growth) < 2e-2
+    n_new = len(fx["greedy"]) - int(lens[0])
+    ref = fx["greedy"].tolist()
+    gen = emb.generate_greedy(row0[0].tolist(), n_new)
+    top2 = np.sort(fx["logits_last_row0"])[-2:]
+    print(f"[3b] greedy continuation {gen[-n_new:]} (fixture {ref[-n_new:]}); the fixture's first-step top-2 logit gap {float(top2[1] - top2[0]):.3f}")
+    assert gen == ref
