@@ -272,7 +272,7 @@ class MilvusClient:
             # milvus/search_embeddings.py:64).  Here: 32 certified hits per selection pass, at most 32 passes.
             raise MilvusException(1100, f"limit {limit} is not supported by this build: at most {KNN_MAX_K} hits per query "
                                         f"(collection holds {len(c.pks)} rows)")
-        idx, score = c.bank().search(q, k, row_mask=mask)
+        idx, score = c.bank().search(q, k, row_mask=mask) if mask is not None else c.bank().search(q, k)
         return np.asarray(idx, dtype=np.int64), np.asarray(score, dtype=np.float32)
 
     def hits_from_rows(self, collection_name: str, idx, score, output_fields: Optional[Sequence[str]] = None) -> List[List[Dict[str, Any]]]:

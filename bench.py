@@ -589,6 +589,90 @@ def side_extras(args, dev, cfg, eng):
     return out
 
 
+def bench_host_io(args, dev, cfg, eng, sb, pipe, inp, q_host, out_idx, out_sc, dist, barrier, world):
+    """The headline workload with its host I/O and its frontend inside the timed region (see the call site).  Returns the dict that
+    rides in the line as `host_io` (`value` = `value_with_host_io`)."""
+    import statistics
+
+    from astts.frontend import Frontend
+    from astts.parallel import gather_style_ids
+
+    b = args.batch
+    fe = Frontend.from_model_dir("/nonexistent", cfg, dev, weights_loaded=False)
+    g = torch.Generator().manual_seed(11)
+    n16 = int(args.prompt_tokens / cfg.token_rate * 16000)
+    t16 = torch.arange(n16) / 16000.0
+    wavs = [(0.3 * torch.sin(2 * math.pi * (180.0 + 17.0 * i) * t16) + 0.02 * torch.randn(n16, generator=g))[None].pin_memory() for i in range(2 * b)]
+    q_pin = torch.from_numpy(q_host).pin_memory()
+    text_host = inp.text.cpu()
+
+    def featurise():
+        feats = [fe.prompt(w) for w in wavs]                   # host waveform -> (speech tokens, speaker vector, prompt mel); one sync each
+        st, tb = feats[:b], feats[b:]
+        n_tok = min(int(f.speech_tokens.shape[1]) for f in feats)
+        n_mel = min(int(f.mel.shape[1]) for f in tb)
+        to = lambda xs, dt=None: torch.cat(xs, 0).to(dev, dt, non_blocking=True) if dt else torch.cat(xs, 0).to(dev, non_blocking=True)
+        return (to([f.spk_embedding for f in st]), to([f.speech_tokens[:, :n_tok] for f in st]), to([f.speech_tokens[:, :n_tok] for f in tb]),
+                to([f.mel[:, :n_mel] for f in tb]), to([f.spk_embedding for f in tb]), n_mel)
+
+    spk_s, tok_s, tok_t, mel_t, spk_t, n_mel = featurise()     # (builds the synthetic-weight networks: untimed)
+    z = torch.randn(b, n_mel + inp.tm, cfg.mel, device=dev)
+    host_out = [None]
+    n_done = [0]
+
+    def take(done):
+        if done is None:
+            return
+        for d in (done if isinstance(done, list) else [done]):
+            host_out[0] = d[2].to("cpu", non_blocking=False)   # the step's waveforms, device -> host
+            n_done[0] += 1
+
+    def step():
+        qd = q_pin.to(dev, non_blocking=True)
+        sb.search_device(qd, args.topk, out_idx=out_idx, out_score=out_sc)
+        if dist is not None:
+            gather_style_ids(out_idx, dist)
+        spk_s, tok_s, tok_t, mel_t, spk_t, _ = featurise()
+        text = text_host.to(dev, non_blocking=True)
+        take(pipe.submit(text, inp.tlen, spk_s, tok_s, inp.ts, inp.u, tok_t, mel_t, spk_t, z, inp.phase0, inp.noise))
+
+    k = max(2, min(args.steps, 8))
+    with torch.cuda.stream(pipe.front_stream):
+        for _ in range(max(1, min(args.warmup, 2))):
+            step()
+        take(pipe.drain())
+        barrier()
+        n_done[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        take(pipe.drain())
+        barrier()
+        dt = time.perf_counter() - t0
+    assert n_done[0] == k
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the frontend alone: one prompt, host waveform in, host features out
+    per = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fe.prompt(wavs[0])
+        per.append((time.perf_counter() - t1) * 1e3)
+    audio = b * inp.tm * cfg.upsample_total / cfg.sample_rate
+    return {"value": audio * k * world / dt, "unit": "audio-s/wall-s", "steps": k, "ms_per_step": 1e3 * dt / k,
+            "frontend_ms_per_prompt": statistics.median(per), "frontend_ms_per_prompt_max": max(per), "prompts_per_step": 2 * b,
+            "frontend": fe.describe(),
+            "h2d_bytes_per_step": int(q_pin.numel() * 4 + sum(w.numel() for w in wavs) * 4 + text_host.numel() * 8),
+            "d2h_bytes_per_step": int(host_out[0].numel() * 4), "waveform_finite": bool(torch.isfinite(host_out[0]).all()),
+            "includes": "H2D of the query vectors, the 16 prompt waveforms and the text ids; kNN; the GPU frontend of every prompt (resample, prompt "
+                        "log-mel, Whisper log-mel -> speech tokenizer (6-block encoder + L2 codebook search), Kaldi fbank -> CAM++), each with its "
+                        "host synchronisation (features are handed over on the host, as the call surface does); LM prefill + decode, flow, vocoder; "
+                        "D2H of the waveforms"}
+
+
 def bench_embedder(args, dev, cfg, eng):
     """SURVEY.md 8f rank 2, the step before the retrieval (milvus/search_json.py:154-229, src/search_milvus.py:75-108): the Llama query
     embedder AS THE REFERENCE RUNS IT -- Llama-3.2-3B: 28 layers, hidden 3072, 24 / 8 heads of 128, FFN 8192, vocabulary 128 256 (3.2 B
@@ -695,7 +779,8 @@ def bench_streaming(args, dev, cfg, eng):
                                   "one_pass_first_chunk_ms": once[0], "one_pass_segment_ms": once[1],
                                   "floor_note": f"120 of {n_tok} decode steps precede the first chunk by upstream's schedule"}
     res["first_chunk_ms"] = res["tokens_250"]["first_chunk_ms"]
-    res["includes"] = "prompt featurisation (resample, log-mel, stand-in tokenizer / speaker net), LM prefill, decode, flow + vocoder of the chunk, D2H copy"
+    res["includes"] = ("prompt featurisation on the GPU (resample, prompt log-mel, Whisper log-mel -> speech tokenizer, Kaldi fbank -> CAM++ "
+                       f"speaker network; {cv.frontend.describe()}), LM prefill, decode, flow + vocoder of the chunk, D2H copy")
     return res
 
 
@@ -739,6 +824,7 @@ def main():
     ap.add_argument("--speech-tokens", type=int, default=250)
     ap.add_argument("--sample-rate", type=int, default=22050)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host-I/O-inclusive side pass (value_with_host_io, frontend_ms)")
     ap.add_argument("--embedder-layers", type=int, default=0, help="query-embedder side probe: layers of the Llama-3.2-3B shape (0 = all 28)")
     ap.add_argument("--no-24khz", action="store_true", help="skip the 24 kHz side measurement (a second engine at sample_rate 24000)")
     ap.add_argument("--no-cobatch", action="store_true", help="skip the co-batched side measurement (16 / 32-row decode chains): profiling "
@@ -852,6 +938,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     wav_ok = bool(torch.isfinite(result["wav"]).all()) and float(result["wav"].abs().max()) <= cfg.audio_limit + 1e-6
+
+    # ---- side measurement (NOT `value`): the headline's second number "including host I/O" (SURVEY.md 8d).  The same pipeline, the same
+    # protocol (warm-up, barrier + synchronize on both sides, MAX over ranks), but every step STARTS from host memory and ENDS in it:
+    # the 8 query vectors and the 16 prompt waveforms (3 s @ 16 kHz: a style and a timbre prompt per utterance, as tts_with_rag.py:179-186
+    # loads them) go host -> device, the frontend runs on the GPU (resampler, prompt log-mel, Whisper log-mel + speech tokenizer, Kaldi
+    # fbank + CAM++ speaker network: astts/frontend.py, frontend_nets.py -- synthetic weights at the published shapes), the retrieval and
+    # the synthesis run as in the headline, and the step's waveforms come back device -> host (pinned).
+    host_io = None
+    if not args.no_host_io:
+        host_io = bench_host_io(args, dev, cfg, eng, sb, pipe, inp, q_host, out_idx, out_sc, dist, barrier, world)
 
     # ---- side measurement (NOT `value`): the same K steps with the LM stages of consecutive batches co-batched into ONE decode chain
     # (PipelinedSynth(cobatch=c): rows are independent in every LM kernel; up to 32 rows a batch's output stays bit-identical --
@@ -1142,6 +1238,9 @@ def main():
             "roofline": roof,
             "roofline_by_stage": by_stage,
             "value_24khz": v24,
+            "value_with_host_io": host_io["value"] if host_io else None,
+            "host_io": host_io,
+            "frontend_ms": host_io["frontend_ms_per_prompt"] if host_io else None,
             "side_workloads": side or None,
         }
     if dist is not None:

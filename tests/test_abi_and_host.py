@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
     # the ctypes table mirrors the header one to one
-    import astts.ops  # noqa: F401  (registers its part of the ABI)
+    import astts.frontend_nets  # noqa: F401
+    import astts.ops  # noqa: F401  (register their parts of the ABI)
     assert set(_lib.declared_symbols()) == set(syms)
     lib2 = _lib.load()
     assert lib2.astts_abi_version() == 5
