@@ -66,29 +66,43 @@ def load_biographies(path):
 
 
 def embed_rows(rows, embedder, biographies, max_new_tokens=10, batch=32):
-    """milvus/search_json.py:382-411 for a list of rows -> (queries float32 [n, 2 * hidden], labels).  The labels come from batched
-    KV-cached greedy decodes (``batch`` rows at a time, sorted by prompt length so that the left padding stays small); each DISTINCT
-    label / biography text is embedded once (the reference re-embeds them per row: same vectors)."""
+    """milvus/search_json.py:382-411 for a list of rows -> (queries float32 [n, 2 * hidden], labels, failed bool [n]).  The labels come
+    from batched KV-cached greedy decodes (``batch`` rows at a time, sorted by prompt length so that the left padding stays small); each
+    DISTINCT label / biography text is embedded once (the reference re-embeds them per row: same vectors).  Failures keep the reference's
+    per-row semantics (milvus/search_json.py:389-404): a label that cannot be generated becomes "neutral", a row whose embedding fails is
+    marked ``failed`` (its record says "Error") -- the other rows of the shard go on."""
     texts = [r.get("zh_text", "").strip() for r in rows]
     labels = [None] * len(rows)
     order = sorted(range(len(rows)), key=lambda i: len(texts[i]))
     for c0 in range(0, len(order), batch):
         chunk = order[c0:c0 + batch]
-        for i, lab in zip(chunk, embedder.generate_emotion_labels([texts[i] for i in chunk], max_new_tokens)):
+        try:
+            labs = embedder.generate_emotion_labels([texts[i] for i in chunk], max_new_tokens)
+        except Exception as e:  # noqa: BLE001
+            print(f"Error during emotion generation: {e}")
+            labs = ["neutral"] * len(chunk)
+        for i, lab in zip(chunk, labs):
             labels[i] = lab
     bio_of = [biographies.get(r.get("speaker", "UNKNOWN_SPEAKER"), PLACEHOLDER_BIOGRAPHY) for r in rows]
     uniq = sorted(set(labels) | set(bio_of), key=len)
     vec = {}
     for c0 in range(0, len(uniq), batch):
         chunk = uniq[c0:c0 + batch]
-        for t, e in zip(chunk, embedder.get_embeddings(chunk)):
-            vec[t] = e
+        try:
+            for t, e in zip(chunk, embedder.get_embeddings(chunk)):
+                vec[t] = e
+        except Exception as e:  # noqa: BLE001
+            print(f"Error getting embedding: {e}")
     h = embedder.cfg.hidden
     q = np.zeros((len(rows), 2 * h), np.float32)
+    failed = np.zeros(len(rows), bool)
     for i in range(len(rows)):
-        q[i, :h] = vec[labels[i]]                      # :263-264 concatenate((emotion_emb, bio_emb))
-        q[i, h:] = vec[bio_of[i]]
-    return q, labels
+        if labels[i] in vec and bio_of[i] in vec:
+            q[i, :h] = vec[labels[i]]                  # :263-264 concatenate((emotion_emb, bio_emb))
+            q[i, h:] = vec[bio_of[i]]
+        else:
+            failed[i] = True
+    return q, labels, failed
 
 
 def main(args, client=None, embedder=None):
@@ -111,18 +125,20 @@ def main(args, client=None, embedder=None):
             print(f"Skipping empty text for speaker '{rows[i].get('speaker', 'UNKNOWN_SPEAKER')}'.")
     rows = [rows[i] for i in keep]
     labels = None
+    failed_local = None
     if q is not None:
         q = q[keep]
     elif len(rows):
         # the LLM half (:372-411) for THIS rank's rows only: the full-size query array is filled in the rank's shard and nowhere
         # else (sharded_search reads exactly that slice; no query vector crosses GPUs)
-        if embedder is None:
-            from astts.cli.search_milvus import load_embedder
-            embedder = load_embedder(args.model_path, getattr(args, "allow_random_init", False), args.seed)
         b0, b1, _ = parallel.shard_bounds(len(rows), world, rank)
-        bios = load_biographies(getattr(args, "biography_json", ""))
-        with parallel.rank_work(dist, "search_json: emotion label + embedding"):     # agreed before the search's all-gather
-            q, labels = embed_rows(rows[b0:b1], embedder, bios, max_new_tokens=10, batch=getattr(args, "llm_batch", 32))
+        with parallel.rank_work(dist, "search_json: load the embedder, emotion label + embedding"):     # agreed before the search's all-gather:
+            # a rank that cannot even load its model / biographies fails its peers here instead of leaving them inside the collective
+            if embedder is None:
+                from astts.cli.search_milvus import load_embedder
+                embedder = load_embedder(args.model_path, getattr(args, "allow_random_init", False), args.seed)
+            bios = load_biographies(getattr(args, "biography_json", ""))
+            q, labels, failed_local = embed_rows(rows[b0:b1], embedder, bios, max_new_tokens=10, batch=getattr(args, "llm_batch", 32))
         full = np.zeros((len(rows), q.shape[1] if len(q) else 2 * embedder.cfg.hidden), np.float32)
         full[b0:b1] = q
         q = full
@@ -140,11 +156,17 @@ def main(args, client=None, embedder=None):
                 pad = k - idx.shape[1]
                 idx = np.concatenate([idx, np.full((idx.shape[0], pad), -1, np.int64)], 1)
                 score = np.concatenate([score, np.zeros((score.shape[0], pad), np.float32)], 1)
+            if failed_local is not None and failed_local.any() and len(failed_local) == idx.shape[0]:
+                idx = idx.copy()
+                idx[failed_local] = -2  # this rank's rows whose embedding failed: every rank learns it through the all-gather
             return torch.from_numpy(idx).to(dev), torch.from_numpy(score).to(dev)
 
         try:
             idx, score = parallel.sharded_search(search_fn, torch.from_numpy(q).to(dev), 1, dist)
-            hits = client.hits_from_rows(args.collection_name, idx.cpu().numpy(), score.cpu().numpy(), ["file_id", "text"])
+            idx_np = idx.cpu().numpy()
+            hits = client.hits_from_rows(args.collection_name, idx_np, score.cpu().numpy(), ["file_id", "text"])
+            for i in np.nonzero(idx_np[:, 0] == -2)[0]:
+                hits[i] = "Error"
         except Exception as e:  # noqa: BLE001
             if dist is not None:        # a rank that fails alone would leave the others inside the collective: fail the job
                 raise
@@ -154,7 +176,7 @@ def main(args, client=None, embedder=None):
     for i, sample in enumerate(rows):
         zh_text = sample.get("zh_text", "").strip()
         speaker = sample.get("speaker", "UNKNOWN_SPEAKER")
-        if hits is None:
+        if hits is None or hits[i] == "Error":
             rec = {"zh_text": zh_text, "speaker": speaker, "retrieved_file_id": "Error", "retrieved_text": "Error", "distance": "Error"}
         elif hits[i]:
             top = hits[i][0]

@@ -64,13 +64,27 @@ class _LmTokenStream:
         self.issued = [threading.Event() for _ in self.ranges]
         self.have, self.finished, self.cancel, self.error = 0, False, False, None
         self._done_ranges = 0
+        self._cv = threading.Condition()
         self.thread = threading.Thread(target=self._issue, daemon=True)
         self.thread.start()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _issue(self):
         try:
             with torch.cuda.device(self.lm.device), torch.cuda.stream(self.stream):
                 for k, (b, e) in enumerate(self.ranges):
+                    # ONE range ahead of what the renderer has consumed (a range is ~100 steps x 72 launches = tens of ms of queued
+                    # work: plenty to hide the launch latency): an early EOS / close() then cancels promptly instead of waiting for
+                    # every range of the 20x window, and a queue shared with the renderer delays a chunk by one range at most
+                    with self._cv:
+                        while not self.cancel and k > self._done_ranges + 1:
+                            self._cv.wait()
                     if self.cancel:
                         break
                     self.lm.decode_range(self.ctx, e)
@@ -92,7 +106,9 @@ class _LmTokenStream:
                 raise self.error
             self.events[k].synchronize()                             # this range's tokens are in pinned memory
             b, e = self.ranges[k]
-            self._done_ranges += 1
+            with self._cv:
+                self._done_ranges += 1
+                self._cv.notify_all()
             row = self.host[b:e]
             eos = (row >= self.eos).nonzero() if not self.fixed else torch.empty(0)
             if eos.numel():                                          # the segment ends here: later ranges are not needed
@@ -105,7 +121,9 @@ class _LmTokenStream:
         return self.host[:self.have].clone(), self.finished
 
     def close(self):
-        self.cancel = True
+        with self._cv:
+            self.cancel = True
+            self._cv.notify_all()
         self.thread.join()
         torch.cuda.current_stream(self.lm.device).wait_stream(self.stream)
 
@@ -245,11 +263,11 @@ class CosyVoice:
             hop = min(c.token_max_hop, int(hop * c.scale))
             e += hop
         edges.append(max_len)
-        if getattr(self, "_stream_lm_stream", None) is None:
-            from .. import ops
-            firsts = [cl[0] for cl in ops.stream_pipe_classes(device=self.device)]      # a hardware queue of its own (another pipe)
-            self._stream_lm_stream = firsts[1] if len(firsts) > 1 else torch.cuda.Stream(device=self.device)
-        return _LmTokenStream(lm, state, u, min_len, max_len, cfg.speech_vocab, list(zip(edges[:-1], edges[1:])), self._stream_lm_stream,
+        # the decode chain goes beside the stream the CALLER renders on: another hardware queue on another command-processor pipe,
+        # probed against that very stream (ops.stream_beside; cached per stream)
+        from .. import ops
+        lm_stream = ops.stream_beside(torch.cuda.current_stream(self.device), device=self.device)
+        return _LmTokenStream(lm, state, u, min_len, max_len, cfg.speech_vocab, list(zip(edges[:-1], edges[1:])), lm_stream,
                               fixed_tokens is not None)
 
     def _cap_tokens(self, want: int, prefix_len: int, what: str = "this segment") -> int:
@@ -281,9 +299,15 @@ class CosyVoice:
         from ..synth.stream import StreamConsts, stream_render
         cfg, dev, eng = self.cfg, self.device, self.engine
         nh = cfg.nb_harmonics + 1
-        ptok = flow_prompt.speech_tokens.to(torch.int32)
-        pmel, spk = flow_prompt.mel.to(dev), flow_prompt.spk_embedding.to(dev)
-        tmp = pmel.shape[1]
+        try:
+            ptok = flow_prompt.speech_tokens.to(torch.int32)
+            pmel, spk = flow_prompt.mel.to(dev), flow_prompt.spk_embedding.to(dev)
+            tmp = pmel.shape[1]
+            consts = StreamConsts.for_config(cfg)
+        except BaseException:
+            if hasattr(tokens, "close"):          # (a live decode is already running on its own stream: stop it)
+                tokens.close()
+            raise
         g = gen or self._gen            # the item's own random stream when it has one (seed=): chunks then do not depend on what ran before
 
         def flow_mel(tok: torch.Tensor) -> torch.Tensor:
@@ -301,7 +325,7 @@ class CosyVoice:
 
         toks_in = tokens if hasattr(tokens, "wait") else tokens.view(-1)
         try:
-            for wav in stream_render(toks_in, StreamConsts.for_config(cfg), flow_mel, eng.hift.f0, source, eng.hift.decode):
+            for wav in stream_render(toks_in, consts, flow_mel, eng.hift.f0, source, eng.hift.decode):
                 yield wav.cpu()
         finally:
             if hasattr(tokens, "close"):
@@ -415,8 +439,25 @@ class CosyVoice:
 
         copies_done = []
 
+        def release_staging(block: bool):
+            """Results leave their page-locked staging as soon as their copies have landed: the caller gets pageable tensors (a kept
+            waveform must not pin its whole render group's block -- a config-4 pass would leave GBs of host memory page-locked), and
+            the block goes back to torch's pinned allocator for the next group."""
+            rest = []
+            for ev, wavs_d, mels_d, idxs_g in copies_done:
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    rest.append((ev, wavs_d, mels_d, idxs_g))
+                    continue
+                for i in idxs_g:
+                    out[i] = out[i].clone()
+                    self.last_mels[i] = self.last_mels[i].clone()
+            copies_done[:] = rest
+
         def render(idxs, gen_tokens):
             tr0 = time.perf_counter()
+            release_staging(block=False)
             all_tok, pmels, zs, dr = [], [], [], []
             for i in idxs:
                 fp = requests[i][3]
@@ -459,7 +500,7 @@ class CosyVoice:
                 om += n_m[j]
             ev = torch.cuda.Event()
             ev.record()
-            copies_done.append((ev, wavs, mels))          # (the device tensors stay alive until their copies have landed)
+            copies_done.append((ev, wavs, mels, list(idxs)))          # (the device tensors stay alive until their copies have landed)
             if self.collect_stage_times:
                 self._host_times.append(("render_group_host", time.perf_counter() - tr0))
 
@@ -467,8 +508,7 @@ class CosyVoice:
             toks1 = dict(zip(jobs[0][1], lm_stage(jobs[0][1])))
             for g in rgroups:
                 render(g, toks1)
-            for ev, _, _ in copies_done:
-                ev.synchronize()
+            release_staging(block=True)
             return out
         # Schedule of the LM jobs (round 5).  The jobs are taken from ONE list sorted by cost (decode steps of the job's longest row): all
         # workers but the last take the LONGEST remaining job, the last worker the SHORTEST.  Rounds 3-4 ran every worker longest-first
@@ -555,8 +595,7 @@ class CosyVoice:
             for st in list(self._lm_streams) + [rs]:
                 cur.wait_stream(st)
         t_sync = time.perf_counter()
-        for ev, _, _ in copies_done:            # every waveform / mel has landed in its host buffer
-            ev.synchronize()
+        release_staging(block=True)             # every waveform / mel has landed and left its staging block
         if self.collect_stage_times:
             self._host_times.append(("final_copy_wait", time.perf_counter() - t_sync))
             self._host_times.append(("synthesize_batch_wall", time.perf_counter() - t_entry))

@@ -54,29 +54,36 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 template <typename RowT>
 __device__ __forceinline__ double wave_dot64(const float* __restrict__ q, const RowT* __restrict__ row,
                                              int dp, int lane) {
+    // (the element pairs of FOUR steps are requested before the first FMA: as a rolled loop every step of 512 elements was a
+    // dependent global round trip -- twelve in a row for a 6144-wide row, most of the re-score's time; the sums are taken in the same order)
     double acc = 0.0;
-    for (int k = lane * 8; k < dp; k += kWave * 8) {
-        float4 q0 = *reinterpret_cast<const float4*>(q + k);
-        float4 q1 = *reinterpret_cast<const float4*>(q + k + 4);
-        float b[8];
-        if constexpr (sizeof(RowT) == 2) {
-            half8 hb = *reinterpret_cast<const half8*>(row + k);
+    constexpr int U = 4;
+    for (int k0 = lane * 8; k0 < dp; k0 += U * kWave * 8) {
+        float qv[U][8], b[U][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = (float)hb[j];
-        } else {
-            float4 b0 = *reinterpret_cast<const float4*>(row + k);
-            float4 b1 = *reinterpret_cast<const float4*>(row + k + 4);
-            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
-            b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        for (int u = 0; u < U; ++u) {
+            const int k = min(k0 + u * kWave * 8, dp - 8);          // clamped: a valid address, unused past the end
+            const float4 q0 = *reinterpret_cast<const float4*>(q + k);
+            const float4 q1 = *reinterpret_cast<const float4*>(q + k + 4);
+            qv[u][0] = q0.x; qv[u][1] = q0.y; qv[u][2] = q0.z; qv[u][3] = q0.w;
+            qv[u][4] = q1.x; qv[u][5] = q1.y; qv[u][6] = q1.z; qv[u][7] = q1.w;
+            if constexpr (sizeof(RowT) == 2) {
+                const half8 hb = *reinterpret_cast<const half8*>(row + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[u][j] = (float)hb[j];
+            } else {
+                const float4 b0 = *reinterpret_cast<const float4*>(row + k);
+                const float4 b1 = *reinterpret_cast<const float4*>(row + k + 4);
+                b[u][0] = b0.x; b[u][1] = b0.y; b[u][2] = b0.z; b[u][3] = b0.w;
+                b[u][4] = b1.x; b[u][5] = b1.y; b[u][6] = b1.z; b[u][7] = b1.w;
+            }
         }
-        acc = fma((double)q0.x, (double)b[0], acc);
-        acc = fma((double)q0.y, (double)b[1], acc);
-        acc = fma((double)q0.z, (double)b[2], acc);
-        acc = fma((double)q0.w, (double)b[3], acc);
-        acc = fma((double)q1.x, (double)b[4], acc);
-        acc = fma((double)q1.y, (double)b[5], acc);
-        acc = fma((double)q1.z, (double)b[6], acc);
-        acc = fma((double)q1.w, (double)b[7], acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u * kWave * 8 < dp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fma((double)qv[u][j], (double)b[u][j], acc);
+            }
     }
     return wave_sum_f64(acc);
 }
@@ -115,13 +122,19 @@ __device__ __forceinline__ double wave_dist64(const float* __restrict__ q, const
     return wave_sum_f64(acc);
 }
 
-// the exact score S (larger = closer) of query row `q` against bank row `row` under `metric`
+// the exact score S (larger = closer) of query row `q` against bank row `row` under `metric`, in two steps: the wave-wide sum
+// (<q, b> or -|q - b|^2), then the part that needs the norms (COSINE)
+template <typename RowT>
+__device__ __forceinline__ double exact_raw(int metric, const float* __restrict__ q, const RowT* __restrict__ row, int dp, int lane) {
+    return metric == ASTTS_METRIC_L2 ? -wave_dist64<RowT>(q, row, dp, lane) : wave_dot64<RowT>(q, row, dp, lane);
+}
+__device__ __forceinline__ double exact_finish(int metric, double raw, double qn, double bn) {
+    return metric == ASTTS_METRIC_COSINE ? cos_from_parts(raw, qn, bn) : raw;
+}
 template <typename RowT>
 __device__ __forceinline__ double exact_score(int metric, const float* __restrict__ q, const RowT* __restrict__ row, int dp, int lane,
                                               double qn, double bn) {
-    if (metric == ASTTS_METRIC_L2) return -wave_dist64<RowT>(q, row, dp, lane);
-    const double dot = wave_dot64<RowT>(q, row, dp, lane);
-    return metric == ASTTS_METRIC_IP ? dot : cos_from_parts(dot, qn, bn);
+    return exact_finish(metric, exact_raw<RowT>(metric, q, row, dp, lane), qn, bn);
 }
 // what the caller sees: cosine, inner product, squared distance
 __device__ __forceinline__ double user_score(int metric, double s) { return metric == ASTTS_METRIC_L2 ? -s : s; }
@@ -326,11 +339,17 @@ __global__ __launch_bounds__(256) void knn_prep_queries(const float* __restrict_
 // Block = 4 waves that split the block's K range line by line and reduce through LDS.
 // Query rows past the group's last query are clamped to it (their results are never read).
 // ------------------------------------------------------------------------------------------
-template <int QT, int RT>
+// DIRECT (one tile pair per wave only): the query fragments come straight from the caller's fp32 rows [nq][dp] (dp == d, 16-byte
+// aligned), rounded to fp16 as they are -- no preparation launch in front of the scan (a 12 MB bank is launch-bound: three dependent
+// launches of ~5 us each).  Without the power-of-two pre-scale elements below fp16's normal range lose relative precision: the
+// certification bound of that path carries the extra term (knn_rescore_body, `direct`); block (0, 0) clears the fallback counter.
+template <int QT, int RT, bool DIRECT = false>
 __global__ __launch_bounds__(kScanThreads) void knn_scan(
     const _Float16* __restrict__ bank, const _Float16* __restrict__ qh,
     const float* __restrict__ inv_norm, float* __restrict__ s_part, int64_t n, int dp, int nld,
-    int qpad, int nq_group, int lines_per_split, const float* __restrict__ bias, const float* __restrict__ qscale_g) {
+    int qpad, int nq_group, int lines_per_split, const float* __restrict__ bias, const float* __restrict__ qscale_g,
+    const float* __restrict__ qdirect, int* __restrict__ nflag_clear) {
+    if (DIRECT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nflag_clear = 0;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3][QT*RT*16][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -356,7 +375,38 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
 #pragma unroll
     for (int a = 0; a < QT; ++a) aptr[a] = qh + ((int64_t)a * total_lines << 11) + lane * 8;
 
-    if constexpr (QT * RT == 1) {
+    if constexpr (QT * RT == 1 && DIRECT) {
+        half8 b0[4], b1[4];
+        float4 q0[8], q1[8];
+        const float* qp = qdirect + (int64_t)min(r, nq_group - 1) * dp + 32 * h;
+        auto ld = [&](int line, half8 (&bf)[4], float4 (&qf)[8]) {
+            const int lc = min(line, line_end - 1);
+            const int64_t koff = (int64_t)lc << 11;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const half8*>(bptr[0] + koff + i * 512);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + lc * 64 + 4 * i);
+        };
+        auto mm = [&](const half8 (&bf)[4], const float4 (&qf)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half8 af;
+                af[0] = (_Float16)qf[2 * i].x; af[1] = (_Float16)qf[2 * i].y; af[2] = (_Float16)qf[2 * i].z; af[3] = (_Float16)qf[2 * i].w;
+                af[4] = (_Float16)qf[2 * i + 1].x; af[5] = (_Float16)qf[2 * i + 1].y; af[6] = (_Float16)qf[2 * i + 1].z; af[7] = (_Float16)qf[2 * i + 1].w;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[i], acc[0][0], 0, 0, 0);
+            }
+        };
+        int line = line_begin + wid;
+        if (line < line_end) ld(line, b0, q0);
+        for (; line < line_end; line += 8) {
+            ld(line + 4, b1, q1);
+            mm(b0, q0);
+            if (line + 4 < line_end) {
+                ld(line + 8, b0, q0);
+                mm(b1, q1);
+            }
+        }
+    } else if constexpr (QT * RT == 1) {
         // one tile pair per wave: the next line's fragments are requested before this line's MFMAs (two lines in flight per wave; the
         // loop is unrolled by two so that neither set is ever copied)
         half8 b0[4], a0[4], b1[4], a1[4];
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan(
                         v += red[(size_t)w * (QT * RT * 16 * 64) + ((a * RT + b) * 16 + i) * 64 + lane];
                     const int qrow = a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // MFMA row = query
                     if (col < nld && qrow < nq_group)
-                        s_part[((size_t)blockIdx.y * qpad + qrow) * nld + col] = bias ? fmaf(qscale_g[qrow], bcol, v * inv) : v * inv;
+                        s_part[((size_t)blockIdx.y * qpad + qrow) * nld + col] = bias ? fmaf(DIRECT ? 1.0f : qscale_g[qrow], bcol, v * inv) : v * inv;
                 }
             }
     }
@@ -505,6 +555,15 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         const float* pp = base + seg0 + i;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int ks = 0;
+        for (; ks + 16 <= ksplit; ks += 16) {          // sixteen loads in flight (a 1000-row bank: 16 K slices = one round trip)
+            float w16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w16[u] = pp[(size_t)(ks + u) * plane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] += w16[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] += w16[8 + u];
+        }
         for (; ks + 8 <= ksplit; ks += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] += pp[(size_t)(ks + u) * plane];
@@ -528,6 +587,41 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
     TopList<float> tl;
     tl.init();
     bool fast = true;
+    if (nl <= kSelThreads && c <= 16) {
+        // a small bank (one score per thread) and a 16-entry list: three rounds of one-wave sorts -- 16 waves keep their best 16 of 64,
+        // four waves the best 16 of those 4 x 16, one wave the best 16 of the last 64 -- instead of the histogram walk (min / max,
+        // 2048-bin histogram, prefix walk, gather, sort: eight barriers on a 1 000-score row).  The same total order (score desc, row asc).
+        __syncthreads();
+        {
+            const bool valid = tid < nl;
+            tl.seed(valid ? seg[tid] : -INFINITY, (int)(seg0 + tid), valid, lane);
+            if (lane < 16) {
+                sh_s[wid * 16 + lane] = tl.s;
+                sh_i[wid * 16 + lane] = tl.idx;
+            }
+        }
+        __syncthreads();
+        if (wid < 4) {
+            const int vi = sh_i[wid * 64 + lane];
+            tl.seed(sh_s[wid * 64 + lane], vi, vi != kNoIdx, lane);
+            if (lane < 16) {
+                sh_s[512 + wid * 16 + lane] = tl.s;
+                sh_i[512 + wid * 16 + lane] = tl.idx;
+            }
+        }
+        __syncthreads();
+        if (wid == 0) {
+            const int vi = sh_i[512 + lane];
+            tl.seed(sh_s[512 + lane], vi, vi != kNoIdx, lane);
+        }
+        if (tid < c) {
+            int id = (tl.idx == kNoIdx) ? -1 : tl.idx;
+            if (id >= 0 && mask && !mask[id]) id = -1;
+            cand_idx[tid] = id;
+            cand_s[tid] = tl.s;
+        }
+        return;
+    }
     if (nl > 64) {
         // ONE histogram pass over 2048 LINEAR bins of [min, max] of the segment (round 5).  The 3-pass radix select on the float bits
         // that stood here put cosine scores -- a narrow band around zero on a large bank -- into a handful of bins per pass: up to 8 192
@@ -692,25 +786,64 @@ __device__ __forceinline__ void knn_rescore_body(
     const int* cand_idx, const float* cand_s, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const uint8_t* __restrict__ mask,
-    int out_ld, int out_off) {
+    int out_ld, int out_off, int direct = 0) {
     // out_*: row q starts at q * out_ld + out_off (a k > 32 search emits 32 hits per pass into its [nq, k] result)
+    // direct: no preparation launch ran (knn_scan<.., DIRECT>): qf is the caller's query matrix (dp == d, dp % 128 == 0), the fp16
+    // image was taken without a pre-scale (qscale = 1), and the query norm is formed here -- 16 waves, one slice each, summed in wave order
     __shared__ double sh_cos[64];
+    __shared__ double sh_qq[16];
+    __shared__ float sh_qmax[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const double qn = qn64[q];
+    double qn = direct ? 0.0 : qn64[q];
     const int64_t ob = (int64_t)q * out_ld + out_off;
+    float qmax = 0.0f;
+    if (direct) {
+        const int per = dp >> 4;
+        double a = 0.0;
+        if (lane * 8 < per) {
+            const float* qp = qf + (int64_t)q * dp + wid * per + lane * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+            a = fma((double)a0.x, (double)a0.x, a); a = fma((double)a0.y, (double)a0.y, a);
+            a = fma((double)a0.z, (double)a0.z, a); a = fma((double)a0.w, (double)a0.w, a);
+            a = fma((double)a1.x, (double)a1.x, a); a = fma((double)a1.y, (double)a1.y, a);
+            a = fma((double)a1.z, (double)a1.z, a); a = fma((double)a1.w, (double)a1.w, a);
+            // (NaN-propagating maximum: a non-finite element must end in the exact path too)
+            const float m8 = fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fmaxf(fabsf(a0.z), fabsf(a0.w))),
+                                   fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w))));
+            qmax = isfinite(a) ? m8 : INFINITY;
+        }
+        a = wave_sum_f64(a);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) qmax = fmaxf(qmax, __shfl_xor(qmax, off, 64));
+        if (lane == 0) {
+            sh_qq[wid] = a;
+            sh_qmax[wid] = qmax;
+        }
+    }
     for (int ci = wid; ci < c; ci += 16) {
         const int idx = cand_idx[ci];
-        double cs = -INFINITY;
-        if (idx >= 0) cs = exact_score<RowT>(metric, qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane, qn, norm64[idx]);
-        if (lane == 0) sh_cos[ci] = cs;
+        double raw = -INFINITY;
+        if (idx >= 0) raw = exact_raw<RowT>(metric, qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
+        if (lane == 0) sh_cos[ci] = raw;
     }
     __syncthreads();
+    if (direct) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            t += sh_qq[w];
+            qmax = fmaxf(qmax, sh_qmax[w]);
+        }
+        qn = sqrt(t);
+    }
+    // direct: an element beyond fp16's range became +-inf in the scan's query image -- its scores are inf / NaN and bound nothing
+    const bool q_overflow = direct && !(qmax <= 65504.0f);
     __shared__ int s_exact;
     if (wid == 0) {
     const bool valid = lane < c;
     const int idx = valid ? cand_idx[lane] : -1;
     const bool live = valid && idx >= 0;
-    const double cs = live ? sh_cos[lane] : -INFINITY;
+    const double cs = live ? exact_finish(metric, sh_cos[lane], qn, norm64[idx]) : -INFINITY;
     const float ap = live ? cand_s[lane] : INFINITY;
     int rank = 0;
     for (int j = 0; j < c; ++j) {
@@ -744,18 +877,22 @@ __device__ __forceinline__ void knn_rescore_body(
         if (n <= (int64_t)c || n_live < c) {
             certified = true;  // every (allowed) row is a candidate
         } else if (metric == ASTTS_METRIC_COSINE) {
-            const double denom = (double)qscale[q] * qn;
+            const double denom = (direct ? 1.0 : (double)qscale[q]) * qn;
             const double tau_cos = denom > 0.0 ? (double)tau / denom : INFINITY;
-            certified = isfinite(tau_cos) && (kth > tau_cos + err_bound);
+            // direct: query elements below fp16's normal range were rounded with an ABSOLUTE error of 2^-25 each (no pre-scale):
+            // |sum_i dq_i b_i| <= 2^-25 sqrt(dp) |b|, i.e. 2^-25 sqrt(dp) / |q| on the cosine scale
+            const double extra = direct ? ldexp(sqrt((double)dp), -25) / qn : 0.0;
+            certified = isfinite(tau_cos) && (kth > tau_cos + err_bound + extra);
         } else {
             // IP / L2: the proposal score is T = <q,b> (- |b|^2 / 2), its error |q||b| * err_bound <= |q| * max|b| * err_bound
             // (+ the fp32 rounding of the L2 constant and of the sum); the k-th exact hit in T units: L2  T = (|q|^2 - d^2) / 2
-            const double tau_t = (double)tau / (double)qscale[q];
+            const double tau_t = (double)tau / (direct ? 1.0 : (double)qscale[q]);
             const double kth_t = metric == ASTTS_METRIC_L2 ? 0.5 * (qn * qn + kth) : kth;
-            const double err = qn * bmax * err_bound + (metric == ASTTS_METRIC_L2 ? (qn * bmax + bmax * bmax) * 4.8e-7 : 0.0);
+            const double err = qn * bmax * err_bound + (metric == ASTTS_METRIC_L2 ? (qn * bmax + bmax * bmax) * 4.8e-7 : 0.0) +
+                               (direct ? ldexp(sqrt((double)dp), -25) * bmax : 0.0);
             certified = isfinite(tau_t) && isfinite(kth_t) && (kth_t > tau_t + err);
         }
-        s_exact = (!certified || force_exact) ? 1 : 0;
+        s_exact = (!certified || force_exact || q_overflow) ? 1 : 0;
         if (s_exact) {
             atomicAdd(nflag, 1);     // astts_knn_last_fallbacks
             (void)flagged;
@@ -833,15 +970,15 @@ __global__ __launch_bounds__(1024) void knn_select_rescore(
     const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const float* __restrict__ bias,
-    const uint8_t* __restrict__ mask, int64_t mask_stride) {
+    const uint8_t* __restrict__ mask, int64_t mask_stride, int direct) {
     __shared__ int f_ci[64];
     __shared__ float f_cs[64];
     const int q = blockIdx.x;
     const uint8_t* mq = mask ? mask + (int64_t)q * mask_stride : nullptr;
-    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? qscale[q] : 0.0f, mq);
+    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? (direct ? 1.0f : qscale[q]) : 0.0f, mq);
     __syncthreads();
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
-                           out_score64, nflag, flagged, metric, bmax, mq, k, 0);
+                           out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct);
 }
 
 }  // namespace astts
@@ -878,6 +1015,7 @@ struct KnnPlan {
     size_t off_qrow;
     size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, off_mask, total;
     int passes;      // k > 32: ceil(k / 32) selection + re-score passes over ONE scan, per chunk of <= 256 queries
+    bool direct_ok;  // shape allows the two-launch form (scan straight from the caller's fp32 queries + fused select / re-score)
 };
 
 static constexpr int kPassK = 32;         // hits per pass (the certified top-k kernel keeps k <= 32 of a 64-entry candidate list)
@@ -942,18 +1080,20 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.off_ss = take(sizeof(float) * (size_t)kMaxQPerPass * p.nseg * 64);
     p.off_mask = take(p.passes > 1 ? (size_t)nq * (size_t)h->n : 16);
     p.total = o;
+    // small bank, one query tile: no preparation launch (the caller's pointer alignment is checked at the call)
+    p.direct_ok = p.passes == 1 && nq <= 32 && p.nseg == 1 && !p.gemm && p.qt == 1 && p.rt == 1 && h->dp == h->d && (h->dp & 127) == 0;
     return p;
 }
 
-template <int QT, int RT>
+template <int QT, int RT, bool DIRECT = false>
 int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq_group, float* spart,
-                const float* qscale_g, hipStream_t st) {
+                const float* qscale_g, hipStream_t st, const float* qdirect = nullptr, int* nflag_clear = nullptr) {
     dim3 grid(p.tiles, p.ksplit);
     size_t lds = (size_t)3 * QT * RT * 16 * 64 * sizeof(float);
     if (lds > 64 * 1024) {
         static bool once = false;
         if (!once) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan<QT, RT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan<QT, RT, DIRECT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -962,8 +1102,8 @@ int launch_scan(const astts_knn* h, const KnnPlan& p, const _Float16* qh, int nq
             once = true;
         }
     }
-    hipLaunchKernelGGL((knn_scan<QT, RT>), grid, dim3(kScanThreads), lds, st, h->scan, qh,
-                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split, h->bias, qscale_g);
+    hipLaunchKernelGGL((knn_scan<QT, RT, DIRECT>), grid, dim3(kScanThreads), lds, st, h->scan, qh,
+                       h->inv_norm, spart, h->n, h->dp, h->nld, p.qpad, nq_group, p.lines_per_split, h->bias, qscale_g, qdirect, nflag_clear);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }
@@ -1127,6 +1267,17 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
     float* ss = (float*)(ws + p.off_ss);
     const int force = (flags & ASTTS_KNN_FORCE_EXACT) ? 1 : 0;
     const bool multi = p.passes > 1;
+#define KNN_RESCORE_D(KERNEL, GRID, ...)                                                                                            \
+    do {                                                                                                                            \
+        if (h->exact16) {                                                                                                           \
+            const _Float16* PLANE = h->plane16;                                                                                     \
+            hipLaunchKernelGGL((KERNEL<_Float16>), GRID, dim3(1024), 0, st, __VA_ARGS__);                                          \
+        } else {                                                                                                                    \
+            const float* PLANE = h->plane32;                                                                                        \
+            hipLaunchKernelGGL((KERNEL<float>), GRID, dim3(1024), 0, st, __VA_ARGS__);                                             \
+        }                                                                                                                           \
+        ASTTS_CHECK_LAUNCH();                                                                                                       \
+    } while (0)
     const uint8_t* mask = row_mask;
     int64_t mstride = mask_stride;
     if (multi) {
@@ -1138,6 +1289,24 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
         mstride = h->n;
     }
 
+    static const bool no_direct = getenv("ASTTS_KNN_NO_DIRECT") != nullptr;       // A/B: the three-launch form for small banks
+    const bool direct = p.direct_ok && !no_direct && (((uintptr_t)queries) & 15) == 0;
+    if (direct) {
+        // two launches: the scan reads the fp32 queries itself; selection + fp64 re-score + certification in one kernel
+        const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
+        if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
+        const int rc = launch_scan<1, 1, true>(h, p, nullptr, nq, spart, nullptr, st, queries, nflag);
+        if (rc != ASTTS_OK) return rc;
+        if (prof) {
+            ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+        }
+        const uint8_t* mask_g = mask;
+        KNN_RESCORE_D(knn_select_rescore, dim3(nq), spart, p.ksplit, p.qpad, h->nld, p.seg_len, (const float*)nullptr, queries, qn, qscale,
+                      PLANE, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force, out_idx, out_score, out_score64, nflag, flagged, h->metric,
+                      h->bmax, (const float*)nullptr, mask_g, mstride, 1);
+        return ASTTS_OK;
+    }
     hipLaunchKernelGGL(knn_prep_queries, dim3((unsigned)align_up((size_t)nq, 32)), dim3(256), 0, st, queries, nq, h->d, h->dp,
                        qh, qf, qn, qscale, clear_flag ? nflag : nullptr, qrow);
     ASTTS_CHECK_LAUNCH();
@@ -1196,7 +1365,7 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
         if (p.nseg == 1 && nq <= kMaxQPerPass && !multi) {      // one segment, one query group: selection + re-score in one launch
             KNN_RESCORE(knn_select_rescore, dim3(nq), spart, sel_ks, p.qpad, h->nld, p.seg_len, sel_inv, qf, qn, qscale,
                         PLANE, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force,
-                        out_idx, out_score, out_score64, nflag, flagged, h->metric, h->bmax, sel_bias, mask_g, mstride);
+                        out_idx, out_score, out_score64, nflag, flagged, h->metric, h->bmax, sel_bias, mask_g, mstride, 0);
             return ASTTS_OK;
         }
         // (a k > 32 search re-ranks the SAME score plane once per pass, so its groups finish before the next group's scan overwrites it)

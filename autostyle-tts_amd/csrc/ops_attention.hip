@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_relpos(RelPosArgs a) {
     const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * RP_QB;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
-    const int ks0 = a.kstart ? a.kstart[b] : 0;
+    const int ks0 = a.kstart ? max(a.kstart[b], 0) : 0;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void attn_relpos_decode(RelPosArgs a) {
     const int sub = lane & 15, grp = tid >> 4;
     const int head = blockIdx.x, b = blockIdx.y;
     const int len = a.lens ? min(a.lens[b], a.len_all) : a.len_all;
-    const int ks0 = a.kstart ? min(a.kstart[b], len - 1) : 0;
+    const int ks0 = a.kstart ? max(min(a.kstart[b], len - 1), 0) : 0;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;  // tq == 1
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH + 4 * sub;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512, 4) void attn_relpos_rows(RelPosArgs a) {
     const int slot = wid * KPI + kq;
     const int head = blockIdx.x * HG + hq, b = blockIdx.y;
     const int len = a.lens ? min(a.lens[b], a.len_all) : a.len_all;
-    const int ks0 = a.kstart ? min(a.kstart[b], len - 1) : 0;
+    const int ks0 = a.kstart ? max(min(a.kstart[b], len - 1), 0) : 0;
     const _Float16* kb = reinterpret_cast<const _Float16*>(a.k) + (int64_t)b * a.k_bs + head * DH + 8 * sub;
     const _Float16* vb = reinterpret_cast<const _Float16*>(a.v) + (int64_t)b * a.k_bs + head * DH + 8 * sub;
     const _Float16* pb = reinterpret_cast<const _Float16*>(a.pos) + head * DH + 8 * sub;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void attn_relpos_mfma(RelPosArgs a) {
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0b = blockIdx.x * 128, q0 = q0b + wid * 32;
     const int len = a.lens ? min(a.lens[b], a.tk) : a.tk;
-    const int ks0 = a.kstart ? a.kstart[b] : 0;
+    const int ks0 = a.kstart ? max(a.kstart[b], 0) : 0;
     const float* qb = a.q + (int64_t)b * a.q_bs + head * DH;
     const KVT* kb = reinterpret_cast<const KVT*>(a.k) + (int64_t)b * a.k_bs + head * DH;
     const KVT* vb = reinterpret_cast<const KVT*>(a.v) + (int64_t)b * a.k_bs + head * DH;

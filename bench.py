@@ -138,7 +138,11 @@ def cpu_baseline(cfg, weights, bank16, q_host, k, ts=250):
         wav = osyn.hift_forward(weights["hift"], cfg, mel, ph, noise)
     t3 = time.perf_counter()
     audio = wav.shape[1] / cfg.sample_rate
-    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s", "cores": threads, "threads_by_stage": {"lm": lm_threads, "flow": threads, "vocoder": threads},
+    return {"value": audio / (t3 - t0), "unit": "audio-s/wall-s, ONE utterance at a time (the reference's own loop: tts_with_rag.py:172-197)",
+            "batch": 1, "gpu_leg_batch": 8,
+            "comparison_note": "the GPU leg runs 8 utterances per step, this leg one (8 in a row would take 8x as long, not run 8x as fast: the "
+                               "CPU decode is one-row GEMVs either way): a reported baseline beside `value`, not a like-for-like ratio",
+            "cores": threads, "threads_by_stage": {"lm": lm_threads, "flow": threads, "vocoder": threads},
             "cpu": cpu_model_string(), "kind": "port",
             "sample": f"one full-length utterance of the batch (B=1, Tt={tt}, {tp}-token prompt, Ts={ts} tokens = {audio:.2f} s of audio) "
                       f"+ kNN of the 8 queries; oracle/ fp32 torch-CPU",
@@ -769,16 +773,23 @@ def bench_streaming(args, dev, cfg, eng):
             samples += out["tts_speech"].shape[1]
         return first * 1e3, (time.perf_counter() - t0) * 1e3, n, samples
 
+    import statistics
     res = {}
     for n_tok in (250, 500):
-        run(True, n_tok), run(False, n_tok)          # warm both paths (allocator, frontend cache)
-        live = min((run(True, n_tok) for _ in range(3)), key=lambda r: r[0])
-        once = min((run(False, n_tok) for _ in range(3)), key=lambda r: r[0])
-        res[f"tokens_{n_tok}"] = {"first_chunk_ms": live[0], "segment_ms": live[1], "chunks": live[2], "audio_s": live[3] / cfg.sample_rate,
+        run(True, n_tok), run(False, n_tok)          # warm both paths (allocator, stream probe, frontend networks)
+        lives = [run(True, n_tok) for _ in range(5)]
+        onces = [run(False, n_tok) for _ in range(5)]
+        live = sorted(lives, key=lambda r: r[0])[len(lives) // 2]
+        once = sorted(onces, key=lambda r: r[0])[len(onces) // 2]
+        res[f"tokens_{n_tok}"] = {"first_chunk_ms": live[0], "first_chunk_ms_max": max(r[0] for r in lives), "first_chunk_ms_min": min(r[0] for r in lives),
+                                  "trials": len(lives), "segment_ms": live[1], "chunks": live[2], "audio_s": live[3] / cfg.sample_rate,
                                   "first_chunk_over_segment": live[0] / live[1],
-                                  "one_pass_first_chunk_ms": once[0], "one_pass_segment_ms": once[1],
+                                  "one_pass_first_chunk_ms": once[0], "one_pass_first_chunk_ms_max": max(r[0] for r in onces), "one_pass_segment_ms": once[1],
+                                  "live_first_chunk_below_0p9_of_one_pass": bool(statistics.median(r[0] for r in lives) < 0.9 * statistics.median(r[0] for r in onces)),
                                   "floor_note": f"120 of {n_tok} decode steps precede the first chunk by upstream's schedule"}
     res["first_chunk_ms"] = res["tokens_250"]["first_chunk_ms"]
+    res["first_chunk_independent_of_segment_length_ms"] = abs(res["tokens_500"]["first_chunk_ms"] - res["tokens_250"]["first_chunk_ms"])
+    res["statistic"] = "median of 5 trials per form (max / min beside it); the decode stream is probed against the caller's stream (ops.stream_beside)"
     res["includes"] = ("prompt featurisation on the GPU (resample, prompt log-mel, Whisper log-mel -> speech tokenizer, Kaldi fbank -> CAM++ "
                        f"speaker network; {cv.frontend.describe()}), LM prefill, decode, flow + vocoder of the chunk, D2H copy")
     return res

@@ -149,7 +149,7 @@ def test_config3_longform_through_its_driver(tmp_path):
             body = " ".join(words[(i + k + j) % 8] for j in range(12))[:63 - len(tag)] + tag
             sents.append(body.ljust(63, "x") + ".")
         assert all(len(x.encode()) == 64 for x in sents)
-        lines.append(" ".join(sents))
+        lines.append("".join(sents))          # (no blank between sentences: split_paragraph keeps a leading blank with its sentence)
     (tmp_path / "long.txt").write_text("\n".join(lines) + "\n", encoding="utf-8")
     from astts.frontend import text_normalize
     assert [len(cv.frontend.tokenizer.encode(x)) for x in text_normalize(lines[5], cv.frontend.tokenizer)] == [64] * 6

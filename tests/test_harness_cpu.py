@@ -166,6 +166,52 @@ def test_search_json_skips_rows_without_text(golden_dir, tmp_path, monkeypatch):
     assert res[1]["retrieved_file_id"] == meta["rows"][129]["file_id"]          # row 3's vector stayed with row 3
 
 
+def test_search_json_llm_half_keeps_the_references_per_row_failure_semantics(golden_dir, tmp_path, monkeypatch, capsys):
+    """milvus/search_json.py:389-404: a label that cannot be generated becomes "neutral", a row whose embedding fails gets an "Error"
+    record -- and the rows around it still get their hits (one bad row failed the rank's whole shard)."""
+    from astts.cli import search_json
+    from astts.compat import pymilvus as pm
+
+    bank = np.load(os.path.join(golden_dir, "style_bank_130x6144.f16.npy")).astype(np.float32)
+
+    class OracleBank:
+        def __init__(self, m):
+            self.m = m
+
+        def search(self, q, k):
+            from oracle import knn as oknn
+            idx, sc = oknn.knn_search(self.m.astype(np.float16), np.asarray(q, np.float32), k)
+            return idx, sc.astype(np.float32)
+
+    class Cfg:
+        hidden = 3072
+
+    class FlakyEmbedder:
+        cfg = Cfg()
+
+        def generate_emotion_labels(self, texts, max_new_tokens):
+            if any("boom" in t for t in texts):
+                raise RuntimeError("generation failed")
+            return ["happy" if "!" in t else "sad" for t in texts]
+
+        def get_embeddings(self, texts):
+            if any(t == "sad" for t in texts):
+                raise RuntimeError("embedding failed")
+            return [bank[5, :3072] if t in ("happy", "neutral") else bank[5, 3072:] for t in texts]
+
+    monkeypatch.setattr(pm._Collection, "bank", lambda self: OracleBank(self.matrix()))
+    rows = [{"zh_text": "great!", "speaker": "w1"}, {"zh_text": "boom", "speaker": "w1"}, {"zh_text": "so so", "speaker": "w1"}]
+    q, labels, failed = search_json.embed_rows(rows, FlakyEmbedder(), {}, batch=1)
+    assert labels == ["happy", "neutral", "sad"] and failed.tolist() == [False, False, True]
+    inp = tmp_path / "in.jsonl"
+    inp.write_text("\n".join(json.dumps(r) for r in rows) + "\n", encoding="utf-8")
+    args = search_json.build_parser().parse_args(["--input_json", str(inp), "--db_path", os.path.join(golden_dir, "milvus_demo.db"), "--llm_batch", "1"])
+    res = search_json.main(args, embedder=FlakyEmbedder())
+    assert [r["retrieved_file_id"] == "Error" for r in res] == [False, False, True]
+    assert res[0]["retrieved_file_id"] == res[1]["retrieved_file_id"] != "N/A" and res[2]["distance"] == "Error"
+    assert "Error during emotion generation" in capsys.readouterr().out
+
+
 def test_cosyvoice_needs_weights_or_an_explicit_opt_in(tmp_path, monkeypatch):
     """A missing model_dir must not silently synthesise noise: the constructor raises before anything touches the
     GPU unless random-init weights are explicitly allowed."""

@@ -423,3 +423,26 @@ def test_milvus_client_filter_limit_and_metrics(tmp_path):
         with pytest.raises(MilvusException):
             c.search("bank", data=[q.tolist()], limit=3, filter="text === 3")
         c.close()
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "IP", "L2"])
+def test_small_bank_two_launch_form_at_the_extremes(real_bank, metric):
+    """Banks of one selection segment searched with <= 32 queries skip the query-preparation launch: the scan rounds the caller's
+    fp32 queries to fp16 as they are (no power-of-two pre-scale).  What that costs must end in the certification bound or in the exact
+    path, never in the ids: tiny queries (elements far below fp16's normal range), huge ones (beyond fp16's range: +-inf in the scan's
+    image), mixed magnitudes inside one query, a zero query, k larger than the candidate list's fast form."""
+    q = real_bank[:12].astype(np.float32)
+    sb = _check_metric(real_bank, q * 1e-7, 3, metric)
+    _check_metric(real_bank, q * 1e-3, 3, metric, sb=sb)
+    _check_metric(real_bank, q * 3e4, 3, metric, sb=sb)                 # elements up to ~1e5: past 65504
+    assert sb.last_fallbacks() == 12
+    mixed = q.copy() * 1e-6
+    mixed[:, ::97] = q[:, ::97] * 50.0
+    _check_metric(real_bank, mixed, 3, metric, sb=sb)
+    z = np.zeros((2, 6144), np.float32)
+    z[1, 5] = 1.0
+    _check_metric(real_bank, z, 3, metric, sb=sb)
+    _check_metric(real_bank, q, 20, metric, sb=sb)                      # 64-entry candidate list (histogram selection)
+    # a plain run certifies (no query takes the exact scan)
+    _check_metric(real_bank, q + 0.3, 3, metric, sb=sb)
+    assert sb.last_fallbacks() == 0

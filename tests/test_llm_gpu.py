@@ -273,7 +273,8 @@ def test_search_json_text_to_style_ids_in_one_command(tmp_path, capsys):
     res = drv.main(args, embedder=emb)
     assert len(res) == 4 and all(r["retrieved_file_id"].startswith("/data/seg_wav/") for r in res)
     kept = [r for r in rows if r["zh_text"].strip()]
-    q, labels = drv.embed_rows(kept, emb, drv.load_biographies(str(bios)), batch=3)
+    q, labels, failed = drv.embed_rows(kept, emb, drv.load_biographies(str(bios)), batch=3)
+    assert not failed.any()
     assert labels == [emb.generate_emotion_label(r["zh_text"]) for r in kept]            # batched labels == one at a time
     h = cfg.hidden
     assert _rel(q[2, h:], emb.get_embedding(drv.PLACEHOLDER_BIOGRAPHY)) < 2e-3           # w2 has no biography: the reference's fallback text
