@@ -650,6 +650,13 @@ class CosyVoice:
         if seeds is not None and "draws" in controls:
             raise ValueError("inference_tts_with_st_batch: pass seeds or draws, not both")
         cache = {}
+        distinct = {}
+        for (_t, _s, style_wav, timbre_wav) in items:        # every distinct prompt tensor once, equal lengths as one GPU batch
+            for w in (style_wav, timbre_wav):
+                distinct.setdefault(id(w), w)
+        if hasattr(fe, "prompts"):
+            for k_, f_ in zip(distinct, fe.prompts(list(distinct.values()))):
+                cache[k_] = f_
 
         def prompt(w):
             k = id(w)

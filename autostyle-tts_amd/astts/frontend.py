@@ -343,6 +343,36 @@ class Frontend:
         ids = self.tokenizer.encode(text) or [0]
         return torch.tensor([ids], dtype=torch.int64)
 
+    def prompts(self, wavs: List[torch.Tensor]) -> List[PromptFeatures]:
+        """``prompt`` for many 16 kHz prompts at once: prompts of ONE length go through the GPU frontend as a batch (one pass of the
+        speech tokenizer, one of the speaker network -- its ~400 small launches are the same for 1 and for 16 prompts -- one resample +
+        log-mel) and come back with one host synchronisation per group instead of three per prompt.  Neither network pads or masks
+        inside an equal-length batch, so a row differs from ``prompt(wav)`` only by the summation order of the GEMM tiles its row
+        count selects (speaker vectors to ~1e-6, a speech token only at a near-tie of the codebook search).  Stand-in / injected
+        parts fall back to the per-prompt path."""
+        st, se = self.speech_tokenizer, self.speaker_embedder
+        st = st.get() if isinstance(st, _Lazy) else st
+        se = se.get() if isinstance(se, _Lazy) else se
+        if self.device is None or not hasattr(st, "tokens_device") or not hasattr(se, "embed_device"):
+            return [self.prompt(w) for w in wavs]
+        cfg = self.cfg
+        out: List[Optional[PromptFeatures]] = [None] * len(wavs)
+        groups: Dict[int, List[int]] = {}
+        for i, w in enumerate(wavs):
+            groups.setdefault(int(w.shape[-1]), []).append(i)
+        for n, idxs in groups.items():
+            batch = torch.cat([wavs[i].reshape(1, -1) for i in idxs], 0).to(self.device, non_blocking=True)
+            tok = st.tokens_device(batch)
+            emb = se.embed_device(batch)
+            wav_sr = audio.resample(batch, 16000, cfg.sample_rate)
+            mel = audio.mel_spectrogram(wav_sr, sr=cfg.sample_rate, n_fft=1024, hop=cfg.hop, win=1024, n_mels=cfg.mel, fmin=0.0, fmax=8000.0)
+            n_tok = min(tok.shape[1], int(mel.shape[1] * cfg.token_rate * cfg.hop / cfg.sample_rate))
+            n_mel = cfg.mel_frames_for_tokens(n_tok)
+            tok_h, emb_h, mel_h = tok[:, :n_tok].cpu(), emb.cpu(), mel[:, :n_mel].cpu()
+            for j, i in enumerate(idxs):
+                out[i] = PromptFeatures(tok_h[j:j + 1].contiguous(), emb_h[j:j + 1].contiguous(), mel_h[j:j + 1].contiguous())
+        return out
+
     def prompt(self, wav16k: torch.Tensor, key: Optional[str] = None) -> PromptFeatures:
         """16 kHz mono prompt -> speech tokens, speaker embedding and the mel at the model rate; the mel and the
         token sequence are trimmed to the same duration (token_len = min(mel_len / 2, token_len), upstream)."""

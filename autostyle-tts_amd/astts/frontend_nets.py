@@ -151,27 +151,29 @@ class SpeechTokenizerV1:
             self.codebook = StyleBank(f("quantizer._codebook.embed"), device=dev, metric="L2")
 
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
-        """mel ``[1, n_mels, T]`` on the GPU -> encoder frames fp32 ``[ceil(T / 2), d]``."""
+        """mel ``[B, n_mels, T]`` on the GPU (B prompts of ONE length: no padding mask is involved, so a row does not depend on the
+        batch it runs in) -> encoder frames fp32 ``[ceil(T / 2), d]`` for B = 1, ``[B, ceil(T / 2), d]`` otherwise."""
         cfg = self.cfg
-        assert mel.is_cuda and mel.dim() == 3 and mel.shape[0] == 1 and mel.shape[1] == cfg.n_mels
-        t = int(mel.shape[2])
+        assert mel.is_cuda and mel.dim() == 3 and mel.shape[1] == cfg.n_mels
+        nb, t = int(mel.shape[0]), int(mel.shape[2])
         t2 = (t - 1) // 2 + 1
         if t2 > cfg.n_ctx:
             raise ValueError(f"speech tokenizer: {t2} frames exceed the {cfg.n_ctx} positions of the encoder")
         with torch.cuda.device(self.device):
-            x = mel.transpose(1, 2).contiguous()                                     # [1, T, n_mels] channels-last
+            x = mel.transpose(1, 2).contiguous()                                     # [B, T, n_mels] channels-last
             x = ops.conv1d(x, self.conv1, pad=1, act="gelu", out_dtype=torch.float16)
-            x = ops.conv1d(x, self.conv2, stride=2, pad=1, act="gelu", residual=self.pos[:t2])[0]   # + positions: [T', d] fp32
+            pos = self.pos[:t2] if nb == 1 else self.pos[:t2].repeat(nb, 1)           # the positions ride on conv2's residual operand
+            x = ops.conv1d(x, self.conv2, stride=2, pad=1, act="gelu", residual=pos).view(nb * t2, cfg.d)
             d, h = cfg.d, cfg.heads
             for b in self.blocks:
                 y = ops.layernorm(x, b["ln1"][0], b["ln1"][1], 1e-5, out_dtype=torch.float16)
-                qkv = ops.linear(y, b["qkv"], out_dtype=torch.float16).view(1, t2, 3 * d)
+                qkv = ops.linear(y, b["qkv"], out_dtype=torch.float16).view(nb, t2, 3 * d)
                 a = ops.attn_mha(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], h, out_dtype=torch.float16)
-                x = ops.linear(a.view(t2, d), b["out"], residual=x)
+                x = ops.linear(a.view(nb * t2, d), b["out"], residual=x)
                 y = ops.layernorm(x, b["ln2"][0], b["ln2"][1], 1e-5, out_dtype=torch.float16)
                 y = ops.linear(y, b["fc1"], act="gelu", out_dtype=torch.float16)
                 x = ops.linear(y, b["fc2"], residual=x)
-        return x
+        return x if nb == 1 else x.view(nb, t2, cfg.d)
 
     def quantize(self, frames: torch.Tensor) -> torch.Tensor:
         """fp32 ``[T, d]`` -> int32 ``[T]``: arg-min squared distance of the normalised frame (ties: the lower code)."""
@@ -181,13 +183,20 @@ class SpeechTokenizerV1:
             return idx[:, 0].to(torch.int32)
 
     def tokens_from_mel(self, mel: torch.Tensor) -> torch.Tensor:
-        return self.quantize(self.encode(mel))
+        """mel [B, n_mels, T] -> int32 [T'] (B = 1) or [B, T']"""
+        x = self.encode(mel)
+        q = self.quantize(x.reshape(-1, self.cfg.d))
+        return q if x.dim() == 2 else q.view(x.shape[0], x.shape[1])
 
-    def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
+    def tokens_device(self, wav16k: torch.Tensor) -> torch.Tensor:
+        """wav [B, n] (B prompts of one length) -> int32 [B, T'] on the GPU, no synchronisation"""
         if wav16k.shape[-1] > 30 * 16000:
             raise ValueError("do not support extract speech token for audio longer than 30s")  # upstream assert
         mel = audio.whisper_log_mel(wav16k.to(self.device), n_mels=self.cfg.n_mels)
-        return self.tokens_from_mel(mel).cpu()[None, :]
+        return self.tokens_from_mel(mel).view(mel.shape[0], -1)
+
+    def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
+        return self.tokens_device(wav16k).cpu()
 
 
 # ------------------------------------------------------------------------------------------ CAM++
@@ -310,9 +319,13 @@ class CamPlusSpeakerNet:
             st = stats_pool(self.frames(self.head(fbank)))
             return ops.gemm(st, self.dense)
 
-    def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
+    def embed_device(self, wav16k: torch.Tensor) -> torch.Tensor:
+        """wav [B, n] (one length) -> fp32 [B, emb] on the GPU, no synchronisation"""
         fb = audio.kaldi_fbank(wav16k.to(self.device), n_mels=self.cfg.feat_dim, subtract_mean=True)
-        return self.embed(fb).cpu()
+        return self.embed(fb)
+
+    def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
+        return self.embed_device(wav16k).cpu()
 
 
 # ------------------------------------------------------------------------------------------ construction from a model directory

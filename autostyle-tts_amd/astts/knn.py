@@ -31,6 +31,8 @@ class StyleBank:
         _require_gpu()
         lib = _lib.load()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if isinstance(vectors, np.ndarray):
             t = torch.from_numpy(np.ascontiguousarray(vectors))
         else:
@@ -57,6 +59,8 @@ class StyleBank:
         self.scan_plane_exact = bool(exact.value)
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Tuple[int, int] = (0, 0)
+        self._plans: dict = {}                       # (nq, k) -> (workspace tensor, aligned pointer, bytes)
+        self._search = lib.astts_knn_search_masked
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -75,6 +79,7 @@ class StyleBank:
             raise ValueError(f"invalid search shape nq={nq} k={k}")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._plans = {}                         # (plans of the smaller workspace point into freed memory)
         return self._ws
 
     def search_device(self, queries: torch.Tensor, k: int, force_exact: bool = False,
@@ -89,15 +94,27 @@ class StyleBank:
             raise ValueError(f"queries must be [Q, {self.d}], got {tuple(queries.shape)}")
         if not 1 <= k <= _lib.KNN_MAX_K:
             raise ValueError(f"k must be in 1..{_lib.KNN_MAX_K}, got {k}")
-        q = queries.to(device=self.device, dtype=torch.float32).contiguous()
+        # (a config-2 search is ~12 us of GPU time: the host side of this call is kept to a handful of attribute reads and ONE ctypes
+        # call -- the workspace and its size are cached per (queries, k), tensors that already are what the ABI takes are passed as is)
+        q = queries
+        if q.dtype != torch.float32 or q.device != self.device or not q.is_contiguous():
+            q = queries.to(device=self.device, dtype=torch.float32).contiguous()
         nq = int(q.shape[0])
         if nq == 0:
             e = (torch.empty((0, k), dtype=torch.int64, device=self.device), torch.empty((0, k), dtype=torch.float32, device=self.device))
             return e + (torch.empty((0, k), dtype=torch.float64, device=self.device),) if return_f64 else e
-        with torch.cuda.device(self.device):
-            ws = self._workspace(nq, k)
-            base = ws.data_ptr()
-            aligned = (base + 255) // 256 * 256
+        switch = torch.cuda.current_device() != self.device.index
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.device)
+        try:
+            plan = self._plans.get((nq, k))
+            if plan is None:
+                ws = self._workspace(nq, k)
+                base = ws.data_ptr()
+                aligned = (base + 255) // 256 * 256
+                plan = self._plans[(nq, k)] = (ws, aligned, ws.numel() - (aligned - base))
+            ws, aligned, ws_bytes = plan
             if out_idx is None:
                 out_idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
             if out_score is None:
@@ -114,10 +131,14 @@ class StyleBank:
                 else:
                     raise ValueError(f"row_mask must be [{self.n}] or [{nq}, {self.n}], got {tuple(m.shape)}")
                 mptr = m.data_ptr()
-            _lib.check(_lib.load().astts_knn_search_masked(
-                self._h, q.data_ptr(), nq, k, out_idx.data_ptr(), out_score.data_ptr(), None if s64 is None else s64.data_ptr(),
-                mptr, mstride, aligned, ws.numel() - (aligned - base), _lib.KNN_FORCE_EXACT if force_exact else 0,
-                _lib.stream_ptr()))
+            rc = self._search(self._h, q.data_ptr(), nq, k, out_idx.data_ptr(), out_score.data_ptr(), None if s64 is None else s64.data_ptr(),
+                              mptr, mstride, aligned, ws_bytes, _lib.KNN_FORCE_EXACT if force_exact else 0,
+                              torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                _lib.check(rc)
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
         return (out_idx, out_score, s64) if return_f64 else (out_idx, out_score)
 
     def search(self, queries, k: int, force_exact: bool = False, row_mask=None):

@@ -453,6 +453,16 @@ def test_cosyvoice_wires_its_frontend_from_the_model_directory(tmp_path):
     assert int(feats.speech_tokens.max()) < cfg.speech_vocab and feats.spk_embedding.shape == (1, cfg.spk_dim)
     out = list(cv.inference_tts_with_st("Guess what?", "I do. Yeah.", style, style, seed=3, fixed_tokens=20))
     assert len(out) == 1 and bool(torch.isfinite(out[0]["tts_speech"]).all())
+    # many prompts at once: equal lengths run as one GPU batch; every row is what prompt() gives it (up to GEMM tile order)
+    other = torch.roll(style, 777, dims=1) * 0.8
+    short = style[:, :20000].contiguous()
+    many = cv.frontend.prompts([style, short, other, style])
+    for w, f in zip([style, short, other, style], many):
+        one = cv.frontend.prompt(w)
+        assert f.speech_tokens.shape == one.speech_tokens.shape and f.mel.shape == one.mel.shape
+        assert float((f.speech_tokens == one.speech_tokens).float().mean()) >= 0.97
+        assert torch.allclose(f.spk_embedding, one.spk_embedding, atol=2e-3 * float(one.spk_embedding.abs().max()))
+        assert torch.allclose(f.mel, one.mel, atol=1e-4)
     os.remove(os.path.join(d, "campplus.onnx"))
     with pytest.raises(FileNotFoundError) as ei:
         CosyVoice(d, seed=1)
