@@ -758,335 +758,6 @@ __global__ __launch_bounds__(512, 1) void tfm_ffn_fused(const float* p_x, const 
     tfm_ffn_body<WO>(a, m0, min(m0 + 32, a.m), blockIdx.x >> 3);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// tfm_ffn_w4: the same block (attention output projection + residual -> LayerNorm -> W1 + GELU -> W2 + residual) for MORE THAN ONE
-// ROUND of row tiles (batches of more than 16 sequences: BASELINE configs 3 / 4 / 5 are bound by this stage).
-//
-// What bounded tfm_ffn_fused there (EXPERIMENTS.md M): one 8-wave workgroup per CU, every wave one 32-feature tile -- per (tile, chunk)
-// each LDS fragment read feeds ONE MFMA (256 KB of LDS reads = the MFMA time), every stage is ONE accumulator chain of 16 dependent
-// MFMAs, and reads, MFMAs and the GELU's VALU work (each ~2 048 cycles) run in series at two waves per SIMD; the prologue's dependent
-// chain (rows in, Wo GEMM, LayerNorm: 8 us) has nothing to hide behind.  Here:
-//   * workgroup = 32 rows, FOUR waves; wave w owns 64 features (two 32-feature tiles) in every stage: one LDS fragment read feeds TWO
-//     MFMAs (half the LDS traffic) and the two tiles are two independent accumulator chains;
-//   * 55 KB of LDS and <= 256 VGPRs: TWO workgroups per CU -- one's prologue / barriers / GELU under the other's MFMAs, with no
-//     common barrier between them;
-//   * x' = x + attn Wo^T + bo is formed in registers, normalised through two small LDS exchanges of row sums (mean, then squared
-//     deviations), and PARKED in the output rows it is about to be replaced by (as tfm_attn_fused parks its second Q half): no
-//     32 x 260 fp32 tile in LDS;
-//   * weights stream through registers in half-chunks (8 k-steps x 2 tiles), each half requested one MFMA phase ahead.
-// Same arithmetic per row as tfm_ffn_fused up to the LayerNorm's summation order (not bit-identical to it; rows independent).
-template <int DUMMY = 0>
-__device__ __forceinline__ void tfm_ffn_w4_body(const TfmFfnArgs& a, const int64_t m0, const int64_t mend, const unsigned rot_seed) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 tf_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;        // 4 waves
-    const int c = lane & 31, hh = lane >> 5;
-    _Float16* sA = tf_smem;                          // [32][264] normalised rows
-    _Float16* sH = sA + 32 * TF_AS;                  // [2][32][264] hidden chunk (prologue: the attention rows [32][k0 + 8])
-    float* sB1 = reinterpret_cast<float*>(sH + 2 * 32 * FF_HS);   // [hidden]
-    float* sR = sB1 + a.hidden;                      // [2][4][32] row-sum exchange
-    const int nchunk = a.hidden >> 8;
-    const int ksteps2 = a.hidden >> 4;
-    const int rot = (int)(rot_seed % (unsigned)nchunk);
-    auto wrap = [&](int j) { return j >= nchunk ? j - nchunk : j; };
-    const int f0 = wid * 64;                         // this wave's first feature (of a chunk / of the output)
-    const int64_t rowc = min(m0 + c, mend - 1);      // the row this lane holds in the (feature on element, row on lane) layouts
-
-    // ---- first loads: x (this lane's 2 x 16 elements of row c), the attention rows (staging), the first Wo half
-    float4 xr[2][4];
-    {
-        const float* xp = a.x + rowc * TF_C + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xr[t][g] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * g);
-    }
-    const int as0 = a.k0 + 8;
-    _Float16* sAtt = sH;
-    {
-        const int srow = tid >> 3, seg = (tid & 7) * 8;                  // 8 threads per row, 64 halfs apart
-        const _Float16* p = a.attn + min(m0 + srow, mend - 1) * a.k0 + seg;
-        half8 at[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i * 64 < a.k0) at[i] = *reinterpret_cast<const half8*>(p + 64 * i);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i * 64 < a.k0) *reinterpret_cast<half8*>(sAtt + srow * as0 + seg + 64 * i) = at[i];
-    }
-    for (int i = tid; i < a.hidden; i += 256) sB1[i] = a.b1 ? a.b1[i] : 0.0f;
-    // weight halves: wa / wb hold [tile][k-step] fragments of whatever streams next (Wo in the prologue, then W1 / W2)
-    half8 wa[2][8], wb[2][8];
-    const int kso = a.k0 >> 4;                       // k-steps of a Wo tile
-    const _Float16* wop = a.wo + ((int64_t)(2 * wid) * kso * 64 + lane) * 8;
-    auto load_wo = [&](half8 (&w)[2][8], int s0) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) w[t][s] = *reinterpret_cast<const half8*>(wop + ((int64_t)t * kso + s0 + s) * 512);
-    };
-    load_wo(wa, 0);
-    float16v acc0[2];
-    {
-        const float* bp = a.bo + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = a.bo ? *reinterpret_cast<const float4*>(bp + 32 * t + 8 * g) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                acc0[t][4 * g] = b4.x; acc0[t][4 * g + 1] = b4.y; acc0[t][4 * g + 2] = b4.z; acc0[t][4 * g + 3] = b4.w;
-            }
-    }
-    __syncthreads();                                 // attention rows staged
-    // ---- x' = x + attn Wo^T + bo: k0 / 16 k-steps in halves of 8, the next half requested before this half's MFMAs
-    {
-        const _Float16* atp = sAtt + c * as0 + 8 * hh;
-        auto wo_half = [&](const half8 (&w)[2][8], int s0) {
-#pragma unroll
-            for (int s4 = 0; s4 < 8; s4 += 4) {
-                half8 af[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) af[s] = *reinterpret_cast<const half8*>(atp + 16 * (s0 + s4 + s));
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][s4 + s], af[s], acc0[0], 0, 0, 0);
-                    acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][s4 + s], af[s], acc0[1], 0, 0, 0);
-                }
-            }
-        };
-        for (int s0 = 0; s0 < kso; s0 += 16) {       // (k0 is 256 or 512: 16 or 32 k-steps)
-            load_wo(wb, s0 + 8);
-            wo_half(wa, s0);
-            if (s0 + 16 < kso) load_wo(wa, s0 + 16);
-            wo_half(wb, s0 + 8);
-        }
-    }
-    // ---- the first chunk's W1 half while the LayerNorm runs
-    const _Float16* w1p = a.w1 + ((int64_t)(2 * wid) * 16 * 64 + lane) * 8;           // hidden tile 8 j + 2 wid + t
-    const _Float16* w2p = a.w2 + ((int64_t)(2 * wid) * ksteps2 * 64 + lane) * 8;      // output tile 2 wid + t, k-step 16 j + s
-    auto load_w1 = [&](half8 (&w)[2][8], int j, int s0) {
-        const _Float16* np = w1p + (int64_t)j * 8 * 16 * 512;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) w[t][s] = *reinterpret_cast<const half8*>(np + ((int64_t)t * 16 + s0 + s) * 512);
-    };
-    auto load_w2 = [&](half8 (&w)[2][8], int j, int s0) {
-        const _Float16* np = w2p + (int64_t)j * 16 * 512;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) w[t][s] = *reinterpret_cast<const half8*>(np + ((int64_t)t * ksteps2 + s0 + s) * 512);
-    };
-    load_w1(wa, rot, 0);
-    // x' in registers: element e of tile t <-> feature f0 + 32 t + (e & 3) + 8 (e >> 2) + 4 hh of row c
-    float xs[2][16];
-    float rs = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            xs[t][4 * g] = xr[t][g].x + acc0[t][4 * g];
-            xs[t][4 * g + 1] = xr[t][g].y + acc0[t][4 * g + 1];
-            xs[t][4 * g + 2] = xr[t][g].z + acc0[t][4 * g + 2];
-            xs[t][4 * g + 3] = xr[t][g].w + acc0[t][4 * g + 3];
-            rs += (xs[t][4 * g] + xs[t][4 * g + 1]) + (xs[t][4 * g + 2] + xs[t][4 * g + 3]);
-        }
-    rs += __shfl_xor(rs, 32, 64);                    // both halves of the row's 64 features in this wave
-    if (hh == 0) sR[wid * 32 + c] = rs;
-    // park x' in the output rows (replaced by the result in the epilogue; same owner)
-    if (m0 + c < mend) {
-        float* op = a.out + (m0 + c) * TF_C + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(op + 32 * t + 8 * g) = make_float4(xs[t][4 * g], xs[t][4 * g + 1], xs[t][4 * g + 2], xs[t][4 * g + 3]);
-    }
-    __syncthreads();
-    const float mean = ((sR[c] + sR[32 + c]) + (sR[64 + c] + sR[96 + c])) * (1.0f / TF_C);
-    float qs = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float d = xs[t][e] - mean;
-            qs = fmaf(d, d, qs);
-        }
-    qs += __shfl_xor(qs, 32, 64);
-    if (hh == 0) sR[128 + wid * 32 + c] = qs;
-    __syncthreads();
-    {
-        const float var = ((sR[128 + c] + sR[160 + c]) + (sR[192 + c] + sR[224 + c])) * (1.0f / TF_C);
-        const float rstd = rsqrtf(var + a.eps);
-        _Float16* d = sA + c * TF_AS + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 h4;
-                h4[0] = (_Float16)((xs[t][4 * g] - mean) * rstd); h4[1] = (_Float16)((xs[t][4 * g + 1] - mean) * rstd);
-                h4[2] = (_Float16)((xs[t][4 * g + 2] - mean) * rstd); h4[3] = (_Float16)((xs[t][4 * g + 3] - mean) * rstd);
-                *reinterpret_cast<half4*>(d + 32 * t + 8 * g) = h4;
-            }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // the parked rows are read back by other waves of this workgroup
-    __syncthreads();                                 // sA complete; the attention rows are dead (the H buffers are free)
-
-    unsigned pf_keep;
-    {
-        const unsigned slot = blockIdx.x >> 3, nslots = max((gridDim.x + 7) >> 3, 1u);
-        const unsigned lines = a.pf ? (a.pf_bytes + 127) >> 7 : 0u;
-        const unsigned per = (lines + nslots - 1) / nslots;
-        const unsigned ln = slot * per + tid;
-        const char* base = a.pf ? a.pf : reinterpret_cast<const char*>(a.x);
-        prefetch_line(base + (tid < per && ln < lines ? (size_t)ln << 7 : (size_t)0), pf_keep);
-    }
-    float16v acc1[2], acc2[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[t][e] = 0.0f;
-    const _Float16* ap = sA + c * TF_AS + 8 * hh;
-    auto init1 = [&](int j) {                        // stage-1 accumulators start at the bias
-        const float* bp = sB1 + j * 256 + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bp + 32 * t + 8 * g);
-                acc1[t][4 * g] = b4.x; acc1[t][4 * g + 1] = b4.y; acc1[t][4 * g + 2] = b4.z; acc1[t][4 * g + 3] = b4.w;
-            }
-    };
-    auto s1_half = [&](const half8 (&w)[2][8], int s0) {     // 8 k-steps of stage 1: one row-fragment read feeds both tiles
-#pragma unroll
-        for (int s4 = 0; s4 < 8; s4 += 4) {
-            half8 af[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) af[s] = *reinterpret_cast<const half8*>(ap + 16 * (s0 + s4 + s));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][s4 + s], af[s], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][s4 + s], af[s], acc1[1], 0, 0, 0);
-            }
-        }
-    };
-    auto s2_half = [&](const half8 (&w)[2][8], const _Float16* hp, int s0) {
-#pragma unroll
-        for (int s4 = 0; s4 < 8; s4 += 4) {
-            half8 hf[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) hf[s] = *reinterpret_cast<const half8*>(hp + 16 * (s0 + s4 + s));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w[0][s4 + s], acc2[0], 0, 0, 0);
-                acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w[1][s4 + s], acc2[1], 0, 0, 0);
-            }
-        }
-    };
-    // the same 8 k-steps with the GELU of the stage-1 accumulators woven in: two elements per MFMA pair
-    auto s2_half_gelu = [&](const half8 (&w)[2][8], const _Float16* hp, int s0) {
-#pragma unroll
-        for (int s4 = 0; s4 < 8; s4 += 4) {
-            half8 hf[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) hf[s] = *reinterpret_cast<const half8*>(hp + 16 * (s0 + s4 + s));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int e0 = 2 * (s4 + s);         // elements e0, e0 + 1 of both tiles: 8 k-steps x 2 = 16 elements
-                float g0 = acc1[0][e0], g1 = acc1[0][e0 + 1], g2 = acc1[1][e0], g3 = acc1[1][e0 + 1];
-                asm volatile("" : "+v"(hf[s]), "+v"(g0), "+v"(g1));
-                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w[0][s4 + s], acc2[0], 0, 0, 0);
-                g0 = gelu_erf_fast(g0);
-                g1 = gelu_erf_fast(g1);
-                asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
-                acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf[s], w[1][s4 + s], acc2[1], 0, 0, 0);
-                g2 = gelu_erf_fast(g2);
-                g3 = gelu_erf_fast(g3);
-                asm volatile("" : "+v"(g2), "+v"(g3), "+v"(hf[s]));
-                acc1[0][e0] = g0; acc1[0][e0 + 1] = g1; acc1[1][e0] = g2; acc1[1][e0 + 1] = g3;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    auto store_h = [&](int buf) {                    // acc1 (GELU applied) -> fp16 hidden chunk
-        _Float16* hp = sH + (size_t)buf * 32 * FF_HS + c * FF_HS + f0 + 4 * hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 h4;
-                h4[0] = (_Float16)acc1[t][4 * g]; h4[1] = (_Float16)acc1[t][4 * g + 1]; h4[2] = (_Float16)acc1[t][4 * g + 2]; h4[3] = (_Float16)acc1[t][4 * g + 3];
-                *reinterpret_cast<half4*>(hp + 32 * t + 8 * g) = h4;
-            }
-    };
-    // ---- chunk `rot`: stage 1, GELU, store
-    init1(rot);
-    load_w1(wb, rot, 8);
-    s1_half(wa, 0);
-    load_w2(wa, rot, 0);
-    s1_half(wb, 8);
-    if (nchunk > 1) load_w1(wb, wrap(rot + 1), 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[t][e] = gelu_erf_fast(acc1[t][e]);
-    store_h(0);
-    __syncthreads();
-    // invariant at the top of an iteration: wa = W2(j) k-steps 0..7, wb = W1(jn) k-steps 0..7
-    int j = rot;
-    for (int it = 0; it + 1 < nchunk; ++it) {
-        const int jn = wrap(j + 1);
-        const _Float16* hp = sH + (size_t)(it & 1) * 32 * FF_HS + c * FF_HS + 8 * hh;
-        init1(jn);
-        s1_half(wb, 0);                              // stage 1 of the next chunk, first half
-        load_w1(wb, jn, 8);
-        s2_half(wa, hp, 0);                          // stage 2 of this chunk, first half
-        load_w2(wa, j, 8);
-        s1_half(wb, 8);                              // stage 1, second half: acc1 complete
-        if (it + 2 < nchunk) load_w1(wb, wrap(jn + 1), 0);
-        s2_half_gelu(wa, hp, 8);                     // stage 2, second half, with the next chunk's GELU
-        load_w2(wa, jn, 0);
-        store_h((it + 1) & 1);
-        __syncthreads();
-        j = jn;
-    }
-    // ---- last stage 2; the parked x' rows come back first (element e: row (e & 3) + 8 (e >> 2) + 4 hh, feature f0 + 32 t + c)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    float xp[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = min(m0 + (e & 3) + 8 * (e >> 2) + 4 * hh, mend - 1);
-            xp[t][e] = a.out[row * TF_C + f0 + 32 * t + c];
-        }
-    const float b2a = a.b2 ? a.b2[f0 + c] : 0.0f, b2b = a.b2 ? a.b2[f0 + 32 + c] : 0.0f;
-    {
-        const _Float16* hp = sH + (size_t)((nchunk - 1) & 1) * 32 * FF_HS + c * FF_HS + 8 * hh;
-        load_w2(wb, j, 8);
-        s2_half(wa, hp, 0);
-        s2_half(wb, hp, 8);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (row < mend) a.out[row * TF_C + f0 + 32 * t + c] = (xp[t][e] + (t == 0 ? b2a : b2b)) + acc2[t][e];
-        }
-    prefetch_keep(pf_keep);
-}
-
-__global__ __launch_bounds__(256, 2) void tfm_ffn_w4(const float* p_x, const _Float16* p_w1, const _Float16* p_attn, const _Float16* p_wo, int64_t p_m,
-                                                      int p_hidden, int p_k0, float p_eps, TfmFfnArgs a_in) {
-    TfmFfnArgs a = a_in;
-    a.x = p_x; a.w1 = p_w1; a.attn = p_attn; a.wo = p_wo; a.m = p_m; a.hidden = p_hidden; a.k0 = p_k0; a.eps = p_eps;
-    const int64_t m0 = (int64_t)blockIdx.x * 32;
-    tfm_ffn_w4_body<0>(a, m0, min(m0 + 32, a.m), blockIdx.x >> 3);
-}
-
 }  // namespace astts
 
 using namespace astts;
@@ -1144,19 +815,6 @@ int astts_op_tfm_ffn_fused_pf(const float* x, const void* w1_frag_f16, const flo
         a.pf_bytes = pf_bytes;
     }
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 4.0 * (double)m * TF_C * hidden + (wo ? 2.0 * (double)m * TF_C * k0 : 0.0));
-    // more than one round of 32-row workgroups at one per CU: the four-wave form, two workgroups per CU (tfm_ffn_w4).
-    // ASTTS_TFM_FFN_W4=0 / 1 forces a form (tests, A/B); read per call.
-    const char* w4e = getenv("ASTTS_TFM_FFN_W4");
-    const int w4_env = w4e ? atoi(w4e) : -1;
-    const bool w4 = wo && (w4_env >= 0 ? w4_env != 0 : (m + 31) / 32 > 256);
-    if (w4) {
-        static std::once_flag attr4;
-        std::call_once(attr4, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfm_ffn_w4), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        });
-        const size_t lds4 = (size_t)(32 * TF_AS + 2 * 32 * FF_HS) * sizeof(_Float16) + (size_t)hidden * sizeof(float) + 256 * sizeof(float);
-        hipLaunchKernelGGL(tfm_ffn_w4, dim3((unsigned)((m + 31) / 32)), dim3(256), lds4, st, a.x, a.w1, a.attn, a.wo, a.m, a.hidden, a.k0, a.eps, a);
-    } else
     if (wo) hipLaunchKernelGGL(tfm_ffn_fused<true>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a.x, a.w1, a.attn, a.wo, a.m, a.hidden, a.k0, a.eps, a);
     else hipLaunchKernelGGL(tfm_ffn_fused<false>, dim3((unsigned)((m + 31) / 32)), dim3(512), lds, st, a.x, a.w1, a.attn, a.wo, a.m, a.hidden, a.k0, a.eps, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);

@@ -847,47 +847,6 @@ def test_tfm_ffn_fused_with_output_projection(m, k0):
     assert bool(torch.isfinite(out).all())
 
 
-@pytest.mark.parametrize("m,k0,hidden", [(22016, 512, 1024), (8200, 512, 1024), (45, 512, 1024), (1, 256, 256), (11008, 256, 512)])
-def test_tfm_ffn_w4_form_for_several_rounds_of_tiles(m, k0, hidden, monkeypatch):
-    """The four-wave / two-workgroups-per-CU form of the fused feed-forward launch (tfm_ffn_w4: what runs beyond one round of 32-row
-    tiles, i.e. batches of more than 16 sequences) against the fp64 definition and against the eight-wave form on the same inputs
-    (equal up to the LayerNorm's summation order), at the 64-sequence shape of BASELINE configs 3 - 5 (22 016 rows), ragged last tiles,
-    a single row; two runs bit-equal; the parked x' rows leave nothing behind in rows the launch does not own."""
-    import torch.nn.functional as F
-
-    from astts import ops
-    from astts.synth.model import fold_layernorm
-
-    c = 256
-    g = torch.Generator().manual_seed(m + k0 + hidden)
-    x = torch.randn(m, c, generator=g) * 2 + 0.3
-    attn = torch.randn(m, k0, generator=g)
-    wo, bo = torch.randn(c, k0, generator=g) / 24, 0.1 * torch.randn(c, generator=g)
-    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
-    w1, b1 = torch.randn(hidden, c, generator=g) / 16, 0.1 * torch.randn(hidden, generator=g)
-    w2, b2 = torch.randn(c, hidden, generator=g) / 32, 0.1 * torch.randn(c, generator=g)
-    w1f, b1f = fold_layernorm(w1, b1, gamma, beta)
-    p1, p2, po = ops.PackedWeight(w1f, b1f), ops.PackedWeight(w2, b2), ops.PackedWeight(wo, bo)
-    f1, f2, fo = ops.tfm_pack_frag(p1), ops.tfm_pack_frag(p2), ops.tfm_pack_frag(po)
-    xd, ad = x.to(DEV), attn.to(DEV, torch.float16)
-    monkeypatch.setenv("ASTTS_TFM_FFN_W4", "0")
-    old = ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu()
-    monkeypatch.setenv("ASTTS_TFM_FFN_W4", "1")
-    out = ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu()
-    assert torch.equal(out, ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu())
-    monkeypatch.delenv("ASTTS_TFM_FFN_W4")
-    if m > 256 * 32:                                  # the automatic choice beyond one round IS this form
-        assert torch.equal(out, ops.tfm_ffn_fused(xd, p1, f1, p2, f2, attn=ad, wo=po, wo_frag=fo).cpu())
-    x1 = x.double() + ad.cpu().double() @ wo.double().T + bo.double()
-    n = F.layer_norm(x1, (c,), gamma.double(), beta.double(), 1e-5)
-    ref = (x1 + F.gelu(n @ w1.double().T + b1.double()) @ w2.double().T + b2.double()).float()
-    scale = float((ref - x).abs().max())
-    e_ref, e_old = float((out - ref).abs().max()) / scale, float((out - old).abs().max()) / scale
-    print(f"[parity] tfm_ffn_w4 m={m} k0={k0} hidden={hidden}: {e_ref:.2e} of the definition, {e_old:.2e} of the eight-wave form")
-    assert e_ref < 3e-3 and e_old < 1e-3, (e_ref, e_old)
-    assert bool(torch.isfinite(out).all())
-
-
 @pytest.mark.parametrize("c,l,taps,dil", [(128, 700, 3, 1), (128, 700, 7, 3), (128, 515, 11, 5), (128, 40, 11, 5), (256, 300, 3, 1),
                                           (256, 300, 7, 5), (256, 129, 11, 3), (128, 1, 7, 1)])
 def test_conv1d_snake_matches_definition(c, l, taps, dil):
