@@ -54,10 +54,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 template <typename RowT>
 __device__ __forceinline__ double wave_dot64(const float* __restrict__ q, const RowT* __restrict__ row,
                                              int dp, int lane) {
-    // (the element pairs of FOUR steps are requested before the first FMA: as a rolled loop every step of 512 elements was a
+    // (the element pairs of SIX steps are requested before the first FMA: as a rolled loop every step of 512 elements was a
     // dependent global round trip -- twelve in a row for a 6144-wide row, most of the re-score's time; the sums are taken in the same order)
     double acc = 0.0;
-    constexpr int U = 4;
+    constexpr int U = 6;
     for (int k0 = lane * 8; k0 < dp; k0 += U * kWave * 8) {
         float qv[U][8], b[U][8];
 #pragma unroll
@@ -786,7 +786,8 @@ __device__ __forceinline__ void knn_rescore_body(
     const int* cand_idx, const float* cand_s, double err_bound,
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const uint8_t* __restrict__ mask,
-    int out_ld, int out_off, int direct = 0) {
+    int out_ld, int out_off, int direct = 0, bool have_pre = false, float4 pre0 = float4{0.f, 0.f, 0.f, 0.f},
+    float4 pre1 = float4{0.f, 0.f, 0.f, 0.f}) {
     // out_*: row q starts at q * out_ld + out_off (a k > 32 search emits 32 hits per pass into its [nq, k] result)
     // direct: no preparation launch ran (knn_scan<.., DIRECT>): qf is the caller's query matrix (dp == d, dp % 128 == 0), the fp16
     // image was taken without a pre-scale (qscale = 1), and the query norm is formed here -- 16 waves, one slice each, summed in wave order
@@ -802,7 +803,7 @@ __device__ __forceinline__ void knn_rescore_body(
         double a = 0.0;
         if (lane * 8 < per) {
             const float* qp = qf + (int64_t)q * dp + wid * per + lane * 8;
-            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+            const float4 a0 = have_pre ? pre0 : *reinterpret_cast<const float4*>(qp), a1 = have_pre ? pre1 : *reinterpret_cast<const float4*>(qp + 4);
             a = fma((double)a0.x, (double)a0.x, a); a = fma((double)a0.y, (double)a0.y, a);
             a = fma((double)a0.z, (double)a0.z, a); a = fma((double)a0.w, (double)a0.w, a);
             a = fma((double)a1.x, (double)a1.x, a); a = fma((double)a1.y, (double)a1.y, a);
@@ -845,10 +846,21 @@ __device__ __forceinline__ void knn_rescore_body(
     const bool live = valid && idx >= 0;
     const double cs = live ? exact_finish(metric, sh_cos[lane], qn, norm64[idx]) : -INFINITY;
     const float ap = live ? cand_s[lane] : INFINITY;
+    // rank among the candidates: every lane reads all c (score, row) pairs back from LDS -- uniform addresses, all reads in flight at
+    // once (as __shfl of a double and an int this loop was three dependent ds_bpermute round trips per candidate: 3.5 us of a 17 us kernel)
+    __shared__ double sh_fin[64];
+    __shared__ int sh_fid[64];
+    if (valid) {
+        sh_fin[lane] = cs;
+        sh_fid[lane] = idx;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
     int rank = 0;
+#pragma unroll 16
     for (int j = 0; j < c; ++j) {
-        const double sj = __shfl(cs, j, 64);
-        const int ij = __shfl(idx, j, 64);
+        const double sj = sh_fin[j];
+        const int ij = sh_fid[j];
         if (ij >= 0 && j != lane && better<double>(sj, ij, cs, idx)) ++rank;
     }
     // hits that exist: fewer live candidates than the list holds means EVERY allowed row is a candidate (each segment returns
@@ -975,10 +987,18 @@ __global__ __launch_bounds__(1024) void knn_select_rescore(
     __shared__ float f_cs[64];
     const int q = blockIdx.x;
     const uint8_t* mq = mask ? mask + (int64_t)q * mask_stride : nullptr;
+    // direct: this wave's slice of the query (for |q|) is requested before the selection and used after it
+    float4 pre0 = float4{0.f, 0.f, 0.f, 0.f}, pre1 = pre0;
+    if (direct) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, per = dp >> 4;
+        const float* qp = qf + (int64_t)q * dp + wid * per + min(lane * 8, per - 8);
+        pre0 = *reinterpret_cast<const float4*>(qp);
+        pre1 = *reinterpret_cast<const float4*>(qp + 4);
+    }
     knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? (direct ? 1.0f : qscale[q]) : 0.0f, mq);
     __syncthreads();
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
-                           out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct);
+                           out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct, direct != 0, pre0, pre1);
 }
 
 }  // namespace astts
