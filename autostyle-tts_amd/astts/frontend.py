@@ -360,12 +360,17 @@ class Frontend:
         groups: Dict[int, List[int]] = {}
         for i, w in enumerate(wavs):
             groups.setdefault(int(w.shape[-1]), []).append(i)
-        for n, idxs in groups.items():
-            batch = torch.cat([wavs[i].reshape(1, -1) for i in idxs], 0).to(self.device, non_blocking=True)
+
+        def features(batch):        # [B, n] on the GPU -> (tokens [B, T'], speaker vectors [B, spk], prompt mel [B, Tm, mel]) on the GPU
             tok = st.tokens_device(batch)
             emb = se.embed_device(batch)
             wav_sr = audio.resample(batch, 16000, cfg.sample_rate)
             mel = audio.mel_spectrogram(wav_sr, sr=cfg.sample_rate, n_fft=1024, hop=cfg.hop, win=1024, n_mels=cfg.mel, fmin=0.0, fmax=8000.0)
+            return tok, emb, mel
+
+        for n, idxs in groups.items():
+            batch = torch.cat([wavs[i].reshape(1, -1) for i in idxs], 0).to(self.device, non_blocking=True)
+            tok, emb, mel = features(batch)
             n_tok = min(tok.shape[1], int(mel.shape[1] * cfg.token_rate * cfg.hop / cfg.sample_rate))
             n_mel = cfg.mel_frames_for_tokens(n_tok)
             tok_h, emb_h, mel_h = tok[:, :n_tok].cpu(), emb.cpu(), mel[:, :n_mel].cpu()

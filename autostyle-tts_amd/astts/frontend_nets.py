@@ -36,6 +36,7 @@ _lib.register_signatures({
     "astts_op_cam_gate": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 4 + [c_void_p]),
     "astts_op_stats_pool": (c_int32, [c_void_p, c_int64, c_void_p] + [c_int32] * 3 + [c_void_p]),
     "astts_op_l2_normalize": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "astts_op_sub_time_mean": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
 })
 
 SD = Dict[str, torch.Tensor]
@@ -105,6 +106,13 @@ def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     y = torch.empty_like(x)
     _lib.check(_L().astts_op_l2_normalize(x.data_ptr(), y.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps, _lib.stream_ptr()))
     return y
+
+
+def sub_time_mean_(x: torch.Tensor) -> torch.Tensor:
+    """x [B, T, C] fp32 on the GPU: minus its mean over time, in place."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    _lib.check(_L().astts_op_sub_time_mean(x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], _lib.stream_ptr()))
+    return x
 
 
 def _bn_fold(sd: SD, p: str, eps: float):
@@ -321,8 +329,8 @@ class CamPlusSpeakerNet:
 
     def embed_device(self, wav16k: torch.Tensor) -> torch.Tensor:
         """wav [B, n] (one length) -> fp32 [B, emb] on the GPU, no synchronisation"""
-        fb = audio.kaldi_fbank(wav16k.to(self.device), n_mels=self.cfg.feat_dim, subtract_mean=True)
-        return self.embed(fb)
+        fb = audio.kaldi_fbank(wav16k.to(self.device), n_mels=self.cfg.feat_dim)
+        return self.embed(sub_time_mean_(fb))                 # (upstream's frontend: feat - feat.mean(dim=0) in front of campplus)
 
     def __call__(self, wav16k: torch.Tensor) -> torch.Tensor:
         return self.embed_device(wav16k).cpu()

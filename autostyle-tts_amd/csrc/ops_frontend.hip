@@ -167,6 +167,24 @@ __global__ __launch_bounds__(256) void l2_normalize_k(const float* __restrict__ 
     for (int k = lane; k < c; k += 64) y[row * c + k] = xr[k] * inv;
 }
 
+// x[b, t, k] -= mean_t x[b, t, k] in place (the speaker network's input: Kaldi fbank minus its mean over time); block = (64 channels,
+// batch row), 4 row groups, sums in a fixed order
+__global__ __launch_bounds__(256) void sub_time_mean_k(float* __restrict__ x, int t, int c) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, k = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const bool live = k < c;
+    float* xb = x + (int64_t)b * t * c;
+    float acc = 0.0f;
+    if (live)
+        for (int tt = g; tt < t; tt += 4) acc += xb[(int64_t)tt * c + k];
+    part[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    const float mean = ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l])) / (float)t;
+    if (live)
+        for (int tt = g; tt < t; tt += 4) xb[(int64_t)tt * c + k] -= mean;
+}
+
 static inline unsigned grid_for(int64_t total, int threads = 256) {
     int64_t g = cdiv(total, threads);
     return (unsigned)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g));
@@ -247,6 +265,13 @@ int astts_op_cam_gate(const float* y, const float* m, float* out, int64_t ldo, i
 int astts_op_stats_pool(const float* x, int64_t ldx, float* out, int32_t b, int32_t t, int32_t c, astts_stream_t stream) {
     ASTTS_REQUIRE(x && out && b >= 1 && t >= 1 && c >= 1 && ldx >= c, ASTTS_ERR_INVALID, "astts_op_stats_pool: bad arguments");
     hipLaunchKernelGGL(stats_pool_k, dim3((unsigned)cdiv(c, 64), b), dim3(256), 0, (hipStream_t)stream, x, ldx, out, t, c);
+    ASTTS_CHECK_LAUNCH();
+    return ASTTS_OK;
+}
+
+int astts_op_sub_time_mean(float* x, int32_t b, int32_t t, int32_t c, astts_stream_t stream) {
+    ASTTS_REQUIRE(x && b >= 1 && t >= 1 && c >= 1, ASTTS_ERR_INVALID, "astts_op_sub_time_mean: bad arguments");
+    hipLaunchKernelGGL(sub_time_mean_k, dim3((unsigned)cdiv(c, 64), b), dim3(256), 0, (hipStream_t)stream, x, t, c);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;
 }

@@ -336,7 +336,8 @@ int astts_op_kaldi_fbank(const float* wav, const float* window, const float* mel
  * cam_gate: out[b, t, k] = y[b, t, k] * sigmoid(m[b, t / seg_len, k]) with output row stride ldo (a column block of the dense
  *   block's concatenation buffer).
  * stats_pool: out[b, k] = mean_t x[b, t, k], out[b, c + k] = unbiased standard deviation.
- * l2_normalize: y[r, :] = x[r, :] / max(|x[r, :]|, eps). */
+ * l2_normalize: y[r, :] = x[r, :] / max(|x[r, :]|, eps).
+ * sub_time_mean: x[b, t, k] -= mean_t x[b, t, k] in place (upstream's frontend removes the fbank's mean over time before campplus). */
 int astts_op_affine_act(const void* x, int32_t x_f16, int64_t ldx, const float* scale, const float* shift, void* y, int32_t y_f16,
                         int64_t ldy, int64_t rows, int32_t c, int32_t act, astts_stream_t stream);
 int astts_op_freq_unfold(const void* x, int32_t x_f16, void* y_f16, int32_t b, int32_t f_in, int32_t t, int32_t c, int32_t f_out, int32_t sf,
@@ -348,6 +349,7 @@ int astts_op_cam_gate(const float* y, const float* m, float* out, int64_t ldo, i
                       astts_stream_t stream);
 int astts_op_stats_pool(const float* x, int64_t ldx, float* out, int32_t b, int32_t t, int32_t c, astts_stream_t stream);
 int astts_op_l2_normalize(const float* x, float* y, int64_t rows, int32_t c, float eps, astts_stream_t stream);
+int astts_op_sub_time_mean(float* x, int32_t b, int32_t t, int32_t c, astts_stream_t stream);
 /* Repetition-aware sampling with injected uniforms [b, 2] (definition: csrc/ops_audio.hip, mirrored by oracle/synth.py::ras_sample).
  * ignore_eos: bit 0 = EOS may not be produced at this step (with eos_min_rows: per row, while hist_len < eos_min_rows[b]); bit 1 = the
  * policy inside that window: 0 mask, 1 reject (astts_lm_config_t.eos_policy). */

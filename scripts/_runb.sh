@@ -1,11 +1,8 @@
-cd /root/repo; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_knn_gpu.py -m gpu -q 2>&1 | tail -3
-rm -rf /tmp/pk; KNN_ITERS=300 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k --output-format csv -- python3 scripts/knn_small.py > /dev/null 2>&1
-python3 -c "
-import csv,sys,glob
-for r in csv.DictReader(open(glob.glob('/tmp/pk/**/*kernel_stats.csv',recursive=True)[0])):
-    if 'knn_' in r['Name']: print(r['Name'][:40], r['Calls'], r['AverageNs'])
-"
-timeout 100 python scripts/knn_small.py
-KNN_N=100000 KNN_Q=8 KNN_ITERS=200 timeout 100 python scripts/knn_small.py
-KNN_N=100000 KNN_Q=256 KNN_ITERS=100 timeout 100 python scripts/knn_small.py
+cd /root/repo
+timeout 900 python -m pytest tests/test_cli_gpu.py -k "wires_its_frontend or checkpoint_directory" tests/test_frontend_nets_gpu.py -m gpu -q -x 2>&1 | grep -E "passed|failed|^E |Error|Warning: astts" | tail -12
+timeout 600 python bench.py --steps 8 --warmup 2 --no-side --no-cobatch --no-24khz --no-cpu-baseline > /tmp/b.json 2>/tmp/b.err; python - <<'PY'
+import json
+r=json.load(open('/tmp/b.json'))
+print('value',r['value'],'host_io',{k:r['host_io'][k] for k in ('value','ms_per_step','frontend_ms_per_prompt','frontend_ms_per_step_batched')})
+PY
+grep -i "graph" /tmp/b.err | head -3
