@@ -306,7 +306,7 @@ def kind_rooflines(ops, fn, dist=None, dev=None, traffic_table=None, max_launche
 
 
 def load_traffic_table():
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f), name

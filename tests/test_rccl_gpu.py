@@ -152,5 +152,16 @@ def test_default_bench_line_carries_every_baseline_config():
         assert k["ids_match_oracle_sample"] is True and k["qps"] > 0, (name, k)
         _roofline_ok(k["roofline"])
     assert ks["N100000_D6144_Q8"]["roofline"]["bound"] == "hbm" and ks["N100000_D6144_Q256"]["roofline"]["bound"] == "mfma"
+    # round 6: the embedder at its real depth (measured, not extrapolated), the host-I/O-inclusive number with the GPU frontend inside,
+    # streaming statistics with the 0.9 bar
+    emb = res["embedder"]
+    assert emb.get("error") is None and emb["layers"] == 28 and emb["vocab"] == 128256 and emb["texts_per_s"] > 0 and emb["finite"] is True
+    assert not any(k.startswith("extrapolated") for k in emb)
+    assert res["value_with_host_io"] > 50.0 and res["value_with_host_io"] < res["value"] and res["frontend_ms"] > 0
+    assert res["host_io"]["frontend"]["speech_tokenizer"] == "synthetic-weights" and res["host_io"]["frontend"]["speaker_embedder"] == "synthetic-weights"
+    st = res["streaming"]
+    assert st.get("error") is None and st["tokens_250"]["trials"] >= 5
+    assert st["tokens_250"]["live_first_chunk_below_0p9_of_one_pass"] is True and st["tokens_500"]["live_first_chunk_below_0p9_of_one_pass"] is True
+    assert res.get("cpu_baseline") is None or "ONE utterance" in res["cpu_baseline"]["unit"]
     print("default line:", round(res["value"], 1), "x;", {n: round(s["value"], 1) for n, s in side.items()},
           {n: (round(k["qps"]), round(k["roofline"]["frac"], 3)) for n, k in ks.items()})
