@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace astts {
@@ -117,6 +118,52 @@ __device__ __forceinline__ double wave_dist64(const float* __restrict__ q, const
         for (int j = 0; j < 8; ++j) {
             const double df = (double)qq[j] - (double)b[j];
             acc = fma(df, df, acc);
+        }
+    }
+    return wave_sum_f64(acc);
+}
+
+// The same two sums with the QUERY in LDS (the small-bank finishing kernel stages it once per workgroup: sixteen waves no longer fetch the
+// same 4 dp bytes each) and ALL of the row's pieces requested before the first FMA (dp <= 8192: at most 16 steps; fp32 rows six steps at
+// a time).  Same products, same order: bit-identical to wave_dot64 / wave_dist64.
+template <typename RowT, bool DIST>
+__device__ __forceinline__ double wave_sum64_ldsq(const float* q_lds, const RowT* __restrict__ row, int dp, int lane) {
+    double acc = 0.0;
+    constexpr int U = sizeof(RowT) == 2 ? 16 : 6;
+    typedef typename std::conditional<sizeof(RowT) == 2, half8, float4>::type Piece;      // 8 fp16 values, or 4 of the 8 fp32 values
+    for (int k0 = lane * 8; k0 < dp; k0 += U * kWave * 8) {
+        Piece pa[U], pb[U];                          // (pb: the second four fp32 values; unused for fp16 rows)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(k0 + u * kWave * 8, dp - 8);
+            pa[u] = *reinterpret_cast<const Piece*>(row + k);
+            if constexpr (sizeof(RowT) != 2) pb[u] = *reinterpret_cast<const Piece*>(row + k + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * kWave * 8;
+            if (k < dp) {
+                const float4 q0 = *reinterpret_cast<const float4*>(q_lds + k);
+                const float4 q1 = *reinterpret_cast<const float4*>(q_lds + k + 4);
+                const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                float bv[8];
+                if constexpr (sizeof(RowT) == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = (float)pa[u][j];
+                } else {
+                    bv[0] = pa[u].x; bv[1] = pa[u].y; bv[2] = pa[u].z; bv[3] = pa[u].w;
+                    bv[4] = pb[u].x; bv[5] = pb[u].y; bv[6] = pb[u].z; bv[7] = pb[u].w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (DIST) {
+                        const double df = (double)qv[j] - (double)bv[j];
+                        acc = fma(df, df, acc);
+                    } else {
+                        acc = fma((double)qv[j], (double)bv[j], acc);
+                    }
+                }
+            }
         }
     }
     return wave_sum_f64(acc);
@@ -513,8 +560,7 @@ static constexpr int kSelThreads = 1024;
 __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all, int c,
                                                 int seg_len, int q, int segy, int* cand_idx, float* cand_s,
                                                 const float* __restrict__ inv_norm, const float* __restrict__ bias, float qs,
-                                                const uint8_t* __restrict__ mask) {
-    __shared__ float seg[kSelSeg];
+                                                const uint8_t* __restrict__ mask, float* seg /* LDS [kSelSeg], the caller's */) {
     __shared__ float sh_s[kSelThreads];
     __shared__ int sh_i[kSelThreads];
     __shared__ unsigned hist[2048];
@@ -747,9 +793,10 @@ __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restric
                                                           const float* __restrict__ inv_norm, const float* __restrict__ bias,
                                                           const float* __restrict__ qscale_g, const uint8_t* __restrict__ mask,
                                                           int64_t mask_stride) {
+    __shared__ float seg[kSelSeg];
     const size_t o = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64;
     knn_select_body(s_part, ksplit, qpad, nld, n_all, c, seg_len, blockIdx.x, blockIdx.y, cand_idx + o, cand_s + o, inv_norm, bias,
-                    bias ? qscale_g[blockIdx.x] : 0.0f, mask ? mask + (int64_t)blockIdx.x * mask_stride : nullptr);
+                    bias ? qscale_g[blockIdx.x] : 0.0f, mask ? mask + (int64_t)blockIdx.x * mask_stride : nullptr, seg);
 }
 
 // merge the per-segment candidate lists of one query (one wave) into the final top-C
@@ -787,11 +834,13 @@ __device__ __forceinline__ void knn_rescore_body(
     int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
     int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax, const uint8_t* __restrict__ mask,
     int out_ld, int out_off, int direct = 0, bool have_pre = false, float4 pre0 = float4{0.f, 0.f, 0.f, 0.f},
-    float4 pre1 = float4{0.f, 0.f, 0.f, 0.f}) {
+    float4 pre1 = float4{0.f, 0.f, 0.f, 0.f}, const float* q_lds = nullptr) {
+    // q_lds (with have_pre): the query sits in LDS, thread t staged elements [8 t, 8 t + 8) from pre0 / pre1 (zeros beyond dp)
     // out_*: row q starts at q * out_ld + out_off (a k > 32 search emits 32 hits per pass into its [nq, k] result)
     // direct: no preparation launch ran (knn_scan<.., DIRECT>): qf is the caller's query matrix (dp == d, dp % 128 == 0), the fp16
     // image was taken without a pre-scale (qscale = 1), and the query norm is formed here -- 16 waves, one slice each, summed in wave order
     __shared__ double sh_cos[64];
+    __shared__ double sh_bn[64];
     __shared__ double sh_qq[16];
     __shared__ float sh_qmax[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -801,7 +850,7 @@ __device__ __forceinline__ void knn_rescore_body(
     if (direct) {
         const int per = dp >> 4;
         double a = 0.0;
-        if (lane * 8 < per) {
+        if (have_pre ? tid * 8 < dp : lane * 8 < per) {      // (pre: thread t holds elements [8 t, 8 t + 8); else wave w's slice of dp / 16)
             const float* qp = qf + (int64_t)q * dp + wid * per + lane * 8;
             const float4 a0 = have_pre ? pre0 : *reinterpret_cast<const float4*>(qp), a1 = have_pre ? pre1 : *reinterpret_cast<const float4*>(qp + 4);
             a = fma((double)a0.x, (double)a0.x, a); a = fma((double)a0.y, (double)a0.y, a);
@@ -824,8 +873,18 @@ __device__ __forceinline__ void knn_rescore_body(
     for (int ci = wid; ci < c; ci += 16) {
         const int idx = cand_idx[ci];
         double raw = -INFINITY;
-        if (idx >= 0) raw = exact_raw<RowT>(metric, qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
-        if (lane == 0) sh_cos[ci] = raw;
+        const double bn = idx >= 0 ? norm64[idx] : 0.0;      // (requested with the row: the ranking below does not wait for it again)
+        if (idx >= 0) {
+            if (q_lds)
+                raw = metric == ASTTS_METRIC_L2 ? -wave_sum64_ldsq<RowT, true>(q_lds, plane + (int64_t)idx * dp, dp, lane)
+                                                : wave_sum64_ldsq<RowT, false>(q_lds, plane + (int64_t)idx * dp, dp, lane);
+            else
+                raw = exact_raw<RowT>(metric, qf + (int64_t)q * dp, plane + (int64_t)idx * dp, dp, lane);
+        }
+        if (lane == 0) {
+            sh_cos[ci] = raw;
+            sh_bn[ci] = bn;
+        }
     }
     __syncthreads();
     if (direct) {
@@ -844,7 +903,7 @@ __device__ __forceinline__ void knn_rescore_body(
     const bool valid = lane < c;
     const int idx = valid ? cand_idx[lane] : -1;
     const bool live = valid && idx >= 0;
-    const double cs = live ? exact_finish(metric, sh_cos[lane], qn, norm64[idx]) : -INFINITY;
+    const double cs = live ? exact_finish(metric, sh_cos[lane], qn, sh_bn[lane]) : -INFINITY;
     const float ap = live ? cand_s[lane] : INFINITY;
     // rank among the candidates: every lane reads all c (score, row) pairs back from LDS -- uniform addresses, all reads in flight at
     // once (as __shfl of a double and an int this loop was three dependent ds_bpermute round trips per candidate: 3.5 us of a 17 us kernel)
@@ -985,20 +1044,26 @@ __global__ __launch_bounds__(1024) void knn_select_rescore(
     const uint8_t* __restrict__ mask, int64_t mask_stride, int direct) {
     __shared__ int f_ci[64];
     __shared__ float f_cs[64];
+    __shared__ __attribute__((aligned(16))) float seg[kSelSeg];      // the selection's score segment, then (direct) the query
     const int q = blockIdx.x;
     const uint8_t* mq = mask ? mask + (int64_t)q * mask_stride : nullptr;
-    // direct: this wave's slice of the query (for |q|) is requested before the selection and used after it
+    // direct (dp <= 8192 = 8 floats per thread): the whole query is requested before the selection -- thread t elements [8 t, 8 t + 8) --
+    // and goes to LDS behind it: the fp64 dots read it from there, and the sixteen waves' loads are their candidate rows only
     float4 pre0 = float4{0.f, 0.f, 0.f, 0.f}, pre1 = pre0;
-    if (direct) {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, per = dp >> 4;
-        const float* qp = qf + (int64_t)q * dp + wid * per + min(lane * 8, per - 8);
+    if (direct && (int)threadIdx.x * 8 < dp) {
+        const float* qp = qf + (int64_t)q * dp + threadIdx.x * 8;
         pre0 = *reinterpret_cast<const float4*>(qp);
         pre1 = *reinterpret_cast<const float4*>(qp + 4);
     }
-    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? (direct ? 1.0f : qscale[q]) : 0.0f, mq);
+    knn_select_body(s_part, ksplit, qpad, nld, n, c, seg_len, q, 0, f_ci, f_cs, inv_norm, bias, bias ? (direct ? 1.0f : qscale[q]) : 0.0f, mq, seg);
     __syncthreads();
+    if (direct) {
+        *reinterpret_cast<float4*>(seg + threadIdx.x * 8) = pre0;
+        *reinterpret_cast<float4*>(seg + threadIdx.x * 8 + 4) = pre1;
+        __syncthreads();
+    }
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
-                           out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct, direct != 0, pre0, pre1);
+                           out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct, direct != 0, pre0, pre1, direct ? seg : nullptr);
 }
 
 }  // namespace astts
@@ -1101,7 +1166,8 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.off_mask = take(p.passes > 1 ? (size_t)nq * (size_t)h->n : 16);
     p.total = o;
     // small bank, one query tile: no preparation launch (the caller's pointer alignment is checked at the call)
-    p.direct_ok = p.passes == 1 && nq <= 32 && p.nseg == 1 && !p.gemm && p.qt == 1 && p.rt == 1 && h->dp == h->d && (h->dp & 127) == 0;
+    p.direct_ok = p.passes == 1 && nq <= 32 && p.nseg == 1 && !p.gemm && p.qt == 1 && p.rt == 1 && h->dp == h->d && (h->dp & 127) == 0 &&
+                  h->dp <= 8192;      // (the finishing kernel stages the query in its 8192-float segment buffer)
     return p;
 }
 
