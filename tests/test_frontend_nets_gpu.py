@@ -57,9 +57,10 @@ def test_glue_operators_against_their_definitions():
     assert torch.equal(fn.l2_normalize(torch.zeros(2, 8, device=DEV)).cpu(), torch.zeros(2, 8))
 
 
-@pytest.mark.parametrize("shape,frames", [("tiny", 180), ("full", 300), ("full", 1502)])
+@pytest.mark.parametrize("shape,frames", [("tiny", 180), ("full", 300), ("full", 1502), ("full", 3000), ("full", 21)])
 def test_speech_tokenizer_matches_oracle(shape, frames):
-    """``frames`` log-mel frames (100 Hz): 3 s and 15 s prompts at the published widths (d 1280, 20 heads, 6 blocks, 4096 codes)."""
+    """``frames`` log-mel frames (100 Hz): 3 s, 15 s, the 30 s maximum (all 1500 encoder positions) and a 0.2 s prompt at the published
+    widths (d 1280, 20 heads, 6 blocks, 4096 codes)."""
     from astts.frontend_nets import SpeechTokenizerV1
     from astts.frontend_weights import SpeechTokenizerShape, make_speech_tokenizer_weights
     from oracle import frontend_nets as ofn
@@ -95,9 +96,10 @@ def test_speech_tokenizer_matches_oracle(shape, frames):
     assert agree > 0.9
 
 
-@pytest.mark.parametrize("shape,frames,batch", [("tiny", 130, 2), ("full", 298, 1), ("full", 1498, 2)])
+@pytest.mark.parametrize("shape,frames,batch", [("tiny", 130, 2), ("full", 298, 1), ("full", 1498, 2), ("full", 2998, 1), ("full", 18, 3)])
 def test_campplus_matches_oracle(shape, frames, batch):
-    """3 s and 15 s prompts (10 ms fbank frames) at the published CAM++ shape; stage by stage, then the embedding."""
+    """3 s, 15 s, 30 s and 0.2 s prompts (10 ms fbank frames; the last one shorter than a context segment) at the published CAM++ shape;
+    stage by stage, then the embedding."""
     from astts.frontend_nets import CamPlusSpeakerNet
     from astts.frontend_weights import CamPlusShape, make_campplus_weights
     from oracle import frontend_nets as ofn
