@@ -541,6 +541,20 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
+// Logical tile L -> (row tile bx, column tile by) of the ring kernels: GROUPS of `gm` row tiles, column-major inside a group, so that
+// the tiles one XCD multiplies at the same time (32 consecutive L for the one-block-per-CU 256 x 256 tile) form a gm x (32 / gm)
+// rectangle and share gm + 32 / gm operand panels in that XCD's L2 instead of 1 + 32.  gm = 0: one group of all row tiles (row tile
+// fastest: GemmArgs::m_first).
+__device__ __forceinline__ void ring_tile_of(int L, int gx, int gy, int gm, int& bx, int& by) {
+    if (gm <= 0 || gm > gx) gm = gx;
+    const int per = gm * gy;
+    const int grp = L / per, idx = L - grp * per;
+    const int first = grp * gm;
+    const int gsz = gx - first < gm ? gx - first : gm;
+    by = idx / gsz;
+    bx = first + idx - by * gsz;
+}
+
 template <int TM, int TN, int STAGES, int WN = 2, int NW = 4>      // NW waves as (NW / WN) x WN; wave tile (32 TM) x (32 TN)
 __global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (it cannot parse the LDS-DMA builtin)
@@ -560,23 +574,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
     const int wm = wid / WN, wn = wid % WN;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware tile order (1-D launch): the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
-    // its own L2.  Workgroup w becomes logical tile L = (its XCD's contiguous range) + w / 8, and L walks the N tiles of
-    // one row panel first: the blocks that share an activation panel sit on ONE XCD, so the panel is fetched into one L2
-    // instead of eight (PMC FETCH_SIZE per launch on 5504 x 1536 x 256: 39 MB -> see profiles/r01_pmc_flow.txt).
+    // its own L2.  Workgroup w becomes logical tile L = (its XCD's contiguous range) + w / 8, and L walks groups of 4 (256 x 256)
+    // or 8 row panels column by column (ring_tile_of): the blocks that run on one XCD at the same time share a few activation AND
+    // weight panels in its L2.  PMC on 8192^3 with the 256 x 256 tile, one row panel at a time -> groups of 4: TCC hit rate 48 % -> 80 %,
+    // FETCH_SIZE 4.45 GB -> 1.7 GB per launch, +4 % (profiles/r06_ring_group_ab.log, r06_pmc_ring8.txt).
     const int gy = (a.n + BN - 1) / BN;
     int bx, by;
     {
         const int nwg = gridDim.x, w = blockIdx.x;
         const int xcd = w & 7, q = nwg >> 3, r = nwg & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-        if (a.m_first) {
-            const int gx = (int)((a.m + BM - 1) / BM);
-            by = L / gx;
-            bx = L - by * gx;
-        } else {
-            bx = L / gy;
-            by = L - bx * gy;
-        }
+        ring_tile_of(L, (int)((a.m + BM - 1) / BM), gy, a.m_first ? 0 : (BM >= 256 ? 4 : 8), bx, by);
     }
     const int64_t m0 = (int64_t)bx * BM;
     const int n0 = by * BN;
@@ -677,6 +685,196 @@ __global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
 #else
     if (acc[0][0][0] == 123.0f) a.out[0] = 1.0f;
 #endif
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_ring8: the 256 x 256 tile of gemm_ring<4, 2, 2, 4, 8> on the CDNA guide's EIGHT-PHASE schedule (cdna_hip_programming.md, "The
+// 256^2 8-phase template"): instead of one barrier, 24 fragment reads and 32 MFMAs per K tile and wave, a K tile is four PHASES of
+// (fragment reads of ONE accumulator quadrant's operands + one sub-tile's LDS-DMA, barrier, 8 MFMAs, barrier), and the two wave groups
+// of a SIMD (waves w and w + 4: the two row halves of the tile) run ONE BARRIER APART, so that one group's MFMAs cover the other's
+// reads and DMA issue.  Same LDS image per stage as gemm_ring (512 rows of 128 B, swizzle on the DMA source and on the reads), two
+// stages = 128 KB = eight sub-tile slots.
+//
+// Sub-tiles (16 KB = 2 DMA instructions per wave) are cut by what a PHASE reads, not by halves of the tile:
+//   A0 = row tiles 0, 1 of both wave rows (rows 0-63, 128-191)    A1 = row tiles 2, 3 (rows 64-127, 192-255)
+//   B0 = column tile 0 of all four wave columns (32 of every 64)   B1 = column tile 1
+// and form ONE sequence S_j, j = 4 t + (0: A0, 1: B0, 2: B1, 3: A1) over the K tiles t.  Phase P = 4 t + p multiplies quadrant
+//   p0: (A0, B0) after reading both    p1: (A0, B1) after reading B1    p2: (A1, B1) after reading A1    p3: (A1, B0), B0 kept in registers
+// so S_j is read for the first time in phase j (A0) or j - 1 and for the LAST time no later than phase j.
+//
+// Depth.  The kernel is bound by the bytes a CU keeps in flight against the latency of L2 / the fabric, so the DMA runs as far ahead as
+// the slots allow: phase P requests S_(P+6) into the slot of S_(P-2), whose last read is two phases back (the restaging distance the
+// guide asks for with staggered groups) -- five sub-tiles (80 KB) in flight after the request, four after the wait.
+//
+// Ordering of the LDS-DMA data (nothing but the issuing wave's counted vmcnt followed by a barrier the READER has passed orders it):
+// what phase P + 1 reads first -- everything up to S_(P+2); up to S_(P+1) when P + 1 is a p3 -- is waited for by every wave before global
+// barrier 2 (P + 1): the leading group at the end of its phase P, the trailing group (one barrier behind) in the read section of ITS
+// phase P, with the same count in both places: vmcnt(2 x the sub-tiles requested behind the needed one).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_ring8(GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = 256, STAGE_BYTES = 512 * 128, EPI_W = 32 * 2 + 4;
+    static_assert(8 * 32 * EPI_W * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the ring");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the group branches below)
+    const int wm = wid >> 2, wn = wid & 3;           // wave tile: rows [128 wm, +128), columns [64 wn, +64)
+    const int r = lane & 31, h = lane >> 5;
+    const int gy = (a.n + BN - 1) / BN;
+    int bx, by;
+    {
+        const int nwg = gridDim.x, w = blockIdx.x;
+        const int xcd = w & 7, q = nwg >> 3, rr = nwg & 7;
+        const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (w >> 3);
+        ring_tile_of(L, (int)((a.m + BM - 1) / BM), gy, a.m_first ? 0 : 4, bx, by);
+    }
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
+    const int ktot = a.cin_pad;
+    const int nkt = ktot / 64;
+    const _Float16* x16 = reinterpret_cast<const _Float16*>(a.x);
+
+    // ---- DMA: sub-tile s (0 A0, 1 B0, 2 B1, 3 A1) = 16 row groups of 8 rows; wave w takes groups w and w + 8.
+    //   A sub-tiles: group g -> tile rows 128 (g / 8) + 64 (s == 3) + 8 (g % 8)
+    //   B sub-tiles: group g -> tile columns 64 (g / 4) + 32 (s == 2) + 8 (g % 4)
+    const _Float16* src[4][2];
+    int dst[4][2];                                   // byte offset of the 8-row group inside a stage
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = wid + 8 * i;
+            const bool is_a = sb == 0 || sb == 3;
+            const int row0 = is_a ? 128 * (g >> 3) + (sb == 3 ? 64 : 0) + 8 * (g & 7) : 64 * (g >> 2) + (sb == 2 ? 32 : 0) + 8 * (g & 3);
+            const int row = row0 + (lane >> 3);      // this lane's row of the group, 16-byte slot lane & 7
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            if (is_a) {
+                int64_t m = m0 + row;
+                if (m >= a.m) m = a.m - 1;
+                src[sb][i] = x16 + m * a.lda + c * 8;
+                dst[sb][i] = row0 * 128;
+            } else {
+                int nn = n0 + row;
+                if (nn >= a.n) nn = a.n - 1;
+                src[sb][i] = a.w + (int64_t)nn * ktot + c * 8;
+                dst[sb][i] = (BM + row0) * 128;
+            }
+        }
+    auto issue = [&](int kt, int sb) {               // (sb is a compile-time constant at every call)
+        unsigned char* base = ring + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds(src[sb][i] + kt * 64, (__attribute__((address_space(3))) void*)(base + dst[sb][i]), 16, 0, 0);
+    };
+
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    int a_off[4], a_sw[4], b_off[2], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lr = wm * 128 + i * 32 + r;
+        a_off[i] = lr * 128;
+        a_sw[i] = (lr >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = wn * 64 + j * 32 + r;
+        b_off[j] = BM * 128 + lr * 128;
+        b_sw[j] = (lr >> 1) & 7;
+    }
+    half8 fa[2][4], fb[2][4];                        // two row tiles x 4 k-steps of the current A sub-tile; both column tiles x 4 k-steps
+    auto read_a = [&](const unsigned char* st, int i0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fa[i][ks] = *reinterpret_cast<const half8*>(st + a_off[i0 + i] + (((ks * 2 + h) ^ a_sw[i0 + i]) << 4));
+    };
+    auto read_b = [&](const unsigned char* st, int j) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[j][ks] = *reinterpret_cast<const half8*>(st + b_off[j] + (((ks * 2 + h) ^ b_sw[j]) << 4));
+    };
+    auto mma = [&](int i0, int j) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i0 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // the counted wait in front of the NEXT phase's reads.  rem = sub-tiles of the sequence behind this phase's own index P
+    // (4 nkt - 1 - P); requested so far: through S_(P + min(6, rem)); needed: through S_(P + min(need, rem)).
+    auto wait_for = [&](int rem, int need) {
+        const int left = (rem < 6 ? rem : 6) - (rem < need ? rem : need);
+        if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const bool trail = wm == 1;                      // the trailing group: one barrier behind, waits in its read section
+    const int last = 4 * nkt - 1;
+
+    // ---- prologue: S_0 .. S_5 (K tile 0 whole, A0 and B0 of K tile 1); S_0, S_1 must have landed before phase 0
+    issue(0, 0);
+    issue(0, 1);
+    issue(0, 2);
+    issue(0, 3);
+    if (nkt > 1) {
+        issue(1, 0);
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                    // (global barrier 0: every wave's part of S_0, S_1 is in LDS)
+    if (trail) __builtin_amdgcn_s_barrier();
+
+#define RING8_PHASE(STEADY, P, READS, ISSUE_KT, SB, I0, J, NEED)                                              \
+    do {                                                                                                      \
+        const int rem = last - (4 * kt + (P));                                                                \
+        READS;                                                                                                \
+        if (STEADY || rem >= 6) issue(ISSUE_KT, SB);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (trail) {                                                                                          \
+            if (STEADY) wait_vmcnt<2 * (6 - (NEED))>();                                                       \
+            else wait_for(rem, NEED);                                                                         \
+        }                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mma(I0, J);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (!trail) {                                                                                         \
+            if (STEADY) wait_vmcnt<2 * (6 - (NEED))>();                                                       \
+            else wait_for(rem, NEED);                                                                         \
+        }                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                         \
+    } while (0)
+#define RING8_TILE(STEADY)                                                                                                                     \
+    do {                                                                                                                                       \
+        const unsigned char* st = ring + (kt & 1) * STAGE_BYTES;                                                                               \
+        RING8_PHASE(STEADY, 0, (read_b(st, 0), __builtin_amdgcn_sched_barrier(0), read_a(st, 0)), kt + 1, 2, 0, 0, 2); /* requests B1(kt + 1); p1 reads B1(kt) */ \
+        RING8_PHASE(STEADY, 1, read_b(st, 1), kt + 1, 3, 0, 1, 2);                                  /* requests A1(kt + 1); p2 reads A1(kt) */  \
+        RING8_PHASE(STEADY, 2, read_a(st, 2), kt + 2, 0, 2, 1, 1);                                  /* requests A0(kt + 2); p3 reads nothing */ \
+        RING8_PHASE(STEADY, 3, (void)0, kt + 2, 1, 2, 0, 2);                                        /* requests B0(kt + 2); p0 reads A0, B0(kt + 1) */ \
+    } while (0)
+
+    int kt = 0;
+    for (; kt < nkt - 2; ++kt) RING8_TILE(true);     // steady state: every phase requests, every wait is a constant
+    for (; kt < nkt; ++kt) RING8_TILE(false);        // the last two K tiles: requests run out, the counts shrink
+#undef RING8_TILE
+#undef RING8_PHASE
+    if (!trail) __builtin_amdgcn_s_barrier();        // (the barrier the trailing group took up front)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // all fragment reads done, no DMA outstanding: the ring becomes slab space
+    tile_epilogue<4, 2>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
 #endif
 }
 
@@ -1236,12 +1434,24 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         // embedder's q|k|v) 807 -> 1025, 15 360 x 8192 x 3072 832 -> 1037, 23 680 x 1024 x 4096 700 -> 916, the kNN scan 256 x 6144 x 100k
         // 639 -> 796; needs more than a round of blocks (86 blocks: 349 against 548) and deep K (the flow's K = 256 projections at 44 032
         // rows: 532 against 463 back to back, but the 64-sequence flow solve measured 123.8 ms with it and 121.0 without).
+        // Round 6: the rule's 256 x 256 tile runs on the eight-phase schedule (gemm_ring8: bit-identical results, +8-10 % -- alternating
+        // A/B in one process, scripts/ring_ab.py, profiles/r06_ring8_ab.log: 8192^3 1066 -> 1171, 15 360 x 3072 x 5120 1005 -> 1087,
+        // the kNN scan 783 -> 861 TFLOP/s on N(0, 1) operands; on zero-filled operands 1425 -> 1667, i.e. what is left is the clock the
+        // chip holds under fp16 MFMA load on real data (1.71 GHz measured, GRBM_GUI_ACTIVE), not the schedule).
         const int64_t b256 = blocks(256, 256);
         if (a.n > 128 && b256 >= 320 && a.cin_pad >= 1024) mode = 4;
         else if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512)) mode = 1;
         else if (a.n >= 512 && blocks(128, 64) >= 160) mode = 2;
         else mode = 3;
+        if (mode == 4) mode = 5;            // the rule's 256 x 256 tile is the eight-phase kernel; a FORCED 4 keeps the one-barrier form (A/B, tests)
         if (ring_env > 0) mode = ring_env;
+        if (mode == 5 && a.n > 128) {       // 256 x 256 on the eight-phase schedule (gemm_ring8)
+            static std::once_flag attr85;
+            std::call_once(attr85, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+            });
+            hipLaunchKernelGGL(gemm_ring8, dim3((unsigned)(cdiv(a.m, 256) * cdiv(a.n, 256))), dim3(512), 2 * 512 * 128, st, a);
+        } else
         if (mode == 4 && a.n > 128) {       // 256 x 256, eight waves, two stages (128 KB): twice the flops per byte in flight
             static std::once_flag attr8;
             std::call_once(attr8, [] {
@@ -1310,7 +1520,7 @@ static int check_gemm_args(const char* who, const float* x, const void* w, float
 extern "C" {
 
 int astts_op_gemm_set_ring_mode(int32_t mode) {
-    ASTTS_REQUIRE(mode >= -1 && mode <= 4, ASTTS_ERR_INVALID, "astts_op_gemm_set_ring_mode: mode=%d (-1 auto, 0 off, 1..4 tile)", mode);
+    ASTTS_REQUIRE(mode >= -1 && mode <= 5, ASTTS_ERR_INVALID, "astts_op_gemm_set_ring_mode: mode=%d (-1 auto, 0 off, 1..5 tile)", mode);
     g_ring_mode_override = mode;
     return ASTTS_OK;
 }

@@ -33,7 +33,7 @@ RING_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [-1, 1, 2, 3, 4, 0])
+@pytest.mark.parametrize("mode", [-1, 1, 2, 3, 4, 5, 0])
 @pytest.mark.parametrize("shape", RING_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}-{s[3]}")
 def test_ring_gemm_bench_shapes_every_tile(shape, mode):
     from astts import ops
@@ -62,6 +62,37 @@ def test_ring_gemm_bench_shapes_every_tile(shape, mode):
     print(f"ring mode {mode} {shape}: rel err {err:.2e} (tol {tol:.1e})")
     assert err < tol
     assert y.dtype == (torch.float16 if o16 else torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(256, 64, 256), (300, 192, 260), (5000, 1024, 4097), (8192, 2048, 2048), (256, 6144, 20000), (40000, 256, 1536)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_eight_phase_ring_is_bit_identical_to_the_one_barrier_ring(shape):
+    """gemm_ring8 (the launcher's 256 x 256 tile from round 6; forced: ring mode 5) multiplies the same tile with the same accumulation
+    order per accumulator as gemm_ring<4, 2, 2, 4, 8> (forced: mode 4), so their outputs are equal bit for bit; its LDS-DMA data is ordered
+    only by counted vmcnt + barriers, so the comparison repeats on fresh inputs (a missed wait shows as a flicker).  One, two, three K
+    tiles (prologue / tail paths of the six-deep request pipeline), ragged edges, a single row panel, shallow K with many tiles."""
+    from astts import ops
+
+    m, k, n = shape
+    g = torch.Generator().manual_seed(m * 7 + n)
+    w, b = torch.randn(n, k, generator=g) / 8, torch.randn(n, generator=g) * 0.1
+    pw = ops.PackedWeight(w, b)
+    try:
+        for rep in range(6):
+            x = torch.randn(m, k, generator=g).half()
+            xd = x.to(DEV)
+            ops.set_gemm_ring_mode(4)
+            y4 = ops.gemm(xd, pw, out=torch.empty((m, n), dtype=torch.float32, device=DEV))
+            ops.set_gemm_ring_mode(5)
+            y5 = ops.gemm(xd, pw, out=torch.empty((m, n), dtype=torch.float32, device=DEV))
+            torch.cuda.synchronize()
+            assert torch.equal(y4, y5), f"rep {rep}: {int((y4 != y5).sum())} elements differ"
+            if rep == 0:       # (and both are right: exact accumulation of the same fp16-rounded operands)
+                rows = torch.randperm(m, generator=g)[:64]
+                ref = F.linear(x[rows].double(), w.half().double(), b.double())
+                assert float((y5[rows.to(DEV)].double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    finally:
+        ops.set_gemm_ring_mode(-1)
 
 
 def test_fullshape_estimator_pass_config2_geometry():
