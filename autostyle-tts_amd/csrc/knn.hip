@@ -799,23 +799,143 @@ __global__ __launch_bounds__(kSelThreads) void knn_select(const float* __restric
                     bias ? qscale_g[blockIdx.x] : 0.0f, mask ? mask + (int64_t)blockIdx.x * mask_stride : nullptr, seg);
 }
 
-// merge the per-segment candidate lists of one query (one wave) into the final top-C
+// merge the per-segment candidate lists of one query (one wave) into the final top-C; the lists of sixteen segments are requested
+// together (as one load per segment in front of its offer, every segment cost a global round trip: 21.6 us for 13 segments)
 __global__ __launch_bounds__(64) void knn_select_merge(const int* __restrict__ seg_idx, const float* __restrict__ seg_s,
                                                        int nseg, int c, int* __restrict__ cand_idx,
                                                        float* __restrict__ cand_s) {
     const int q = blockIdx.x, lane = threadIdx.x;
     TopList<float> tl;
     tl.init();
-    for (int sg = 0; sg < nseg; ++sg) {
-        const size_t o = ((size_t)q * nseg + sg) * 64 + lane;
-        const int vi = lane < c ? seg_idx[o] : -1;
-        const float v = lane < c ? seg_s[o] : -INFINITY;
-        if (sg == 0)
-            tl.seed(v, vi, vi >= 0, lane);
-        else
-            tl.offer(v, vi, vi >= 0, lane, c);
+    for (int s0 = 0; s0 < nseg; s0 += 16) {
+        int vi[16];
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int sg = s0 + u < nseg ? s0 + u : nseg - 1;
+            const size_t o = ((size_t)q * nseg + sg) * 64 + lane;
+            const bool live = lane < c && s0 + u < nseg;
+            vi[u] = live ? seg_idx[o] : -1;
+            v[u] = live ? seg_s[o] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (s0 + u >= nseg) break;
+            if (s0 + u == 0)
+                tl.seed(v[u], vi[u], vi[u] >= 0, lane);
+            else
+                tl.offer(v[u], vi[u], vi[u] >= 0, lane, c);
+        }
     }
     if (lane < c) {
+        cand_idx[q * 64 + lane] = (tl.idx == kNoIdx) ? -1 : tl.idx;
+        cand_s[q * 64 + lane] = tl.s;
+    }
+}
+
+// Selection over a LONG score row for a large query group (the GEMM scan: one plane, >= 64 queries): ONE block per query streams
+// the row against the c-th best score so far.  The first 8192-score tile goes through the histogram selection of knn_select_body and
+// seeds the list; after it the row is taken in spans of NV scores per thread whose loads are all requested before the first compare
+// (no barrier inside a span -- a __syncthreads() drains vmcnt, which exposed the load latency once per tile in the tile-at-a-time form:
+// 68 us), survivors (strictly above the c-th best at the start of the span: on a random row ~c x span / rows-so-far of them) go to an LDS
+// pool through an atomic cursor, and behind ONE barrier per span wave 0 inserts the pool into its sorted list.  A span that overflows the
+// pool (an ascending row) is redone tile by tile with the histogram selection.  The result is the top c by (score desc, row asc), the
+// same set and order knn_select + knn_select_merge produce, from 256 blocks instead of 256 x 13 + 256 (119 + 22 us ->
+// profiles/r06_knn_q256_kernel_stats.csv).
+static constexpr int kStreamPool = 512;
+template <int NV, bool EXTRA>   // scores per thread and span (NV x 1024 scores per span); EXTRA: a row mask and / or L2's per-row constant
+__global__ __launch_bounds__(kSelThreads) void knn_select_stream(const float* __restrict__ s_plane, int nld, int64_t n, int c,
+                                                                 int* __restrict__ cand_idx, float* __restrict__ cand_s,
+                                                                 const float* __restrict__ inv_norm, const float* __restrict__ bias,
+                                                                 const float* __restrict__ qscale_g, const uint8_t* __restrict__ mask,
+                                                                 int64_t mask_stride) {
+    __shared__ float seg[kSelSeg];
+    __shared__ int f_ci[64];
+    __shared__ float f_cs[64];
+    __shared__ float pool_s[kStreamPool];
+    __shared__ int pool_i[kStreamPool];
+    __shared__ int s_pool_n;
+    __shared__ float s_tau;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* base = s_plane + (size_t)q * nld;
+    const uint8_t* mq = EXTRA && mask ? mask + (int64_t)q * mask_stride : nullptr;
+    if (!EXTRA) bias = nullptr;
+    const float qs = bias ? qscale_g[q] : 0.0f;
+    TopList<float> tl;           // wave 0's: the best c so far
+    tl.init();
+    if (tid == 0) {
+        s_pool_n = 0;
+        s_tau = -INFINITY;
+    }
+    // one 8192-score tile through the histogram selection, its c candidates offered to the list (all threads; ends behind a barrier)
+    auto tile_by_histogram = [&](int t) {
+        knn_select_body(s_plane, 1, 0, nld, n, c, kSelSeg, q, t, f_ci, f_cs, inv_norm, bias, qs, mq, seg);
+        __syncthreads();
+        if (wid == 0) {
+            const int ci = lane < c ? f_ci[lane] : -1;
+            tl.offer(lane < c ? f_cs[lane] : -INFINITY, ci, ci >= 0, lane, c);
+            if (lane == c - 1) s_tau = tl.idx == kNoIdx ? -INFINITY : tl.s;
+        }
+        __syncthreads();
+    };
+    tile_by_histogram(0);
+    constexpr int64_t kSpan = (int64_t)NV * kSelThreads;
+    static_assert(kSpan % kSelSeg == 0, "a span is whole tiles");
+    for (int64_t s0 = kSelSeg; s0 < n; s0 += kSpan) {
+        const int64_t left = n - s0;
+        const float tau = s_tau;            // (written before the barrier that ended the previous span)
+        float v[NV], w[NV];
+        unsigned live = 0u;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {      // every load of the span, with exactly the arithmetic of knn_select_body's staging below
+            const int64_t i = (int64_t)tid + u * kSelThreads;
+            const int64_t at = s0 + (i < left ? i : left - 1);
+            v[u] = base[at];
+            w[u] = inv_norm ? inv_norm[at] : 1.0f;
+            if (i < left && (!mq || mq[at])) live |= 1u << u;
+        }
+        if (bias) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int64_t i = (int64_t)tid + u * kSelThreads;
+                v[u] = fmaf(qs, bias[s0 + (i < left ? i : left - 1)], v[u] * w[u]);
+            }
+        } else if (inv_norm) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) v[u] *= w[u];
+        }
+        // survivors: strictly above the c-th best so far (rows arrive in ascending order, so a tie loses to the row already listed)
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+            if (((live >> u) & 1u) && v[u] > tau) {
+                const int pos = atomicAdd(&s_pool_n, 1);
+                if (pos < kStreamPool) {
+                    pool_s[pos] = v[u];
+                    pool_i[pos] = (int)(s0 + tid + u * kSelThreads);
+                }
+            }
+        __syncthreads();
+        const int cnt = s_pool_n;
+        if (cnt == 0) continue;             // (nobody writes the cursor before the next span's barrier unless it has a survivor)
+        if (cnt <= kStreamPool) {
+            if (wid == 0) {
+                for (int b0 = 0; b0 < cnt; b0 += 64) {
+                    const int li = b0 + lane;
+                    const bool ok = li < cnt;
+                    tl.offer(ok ? pool_s[li] : -INFINITY, ok ? pool_i[li] : kNoIdx, ok, lane, c);
+                }
+                if (lane == c - 1) s_tau = tl.idx == kNoIdx ? -INFINITY : tl.s;
+                if (lane == 0) s_pool_n = 0;
+            }
+            __syncthreads();
+        } else {                            // more survivors than the pool holds: this span again, tile by tile
+            __syncthreads();                // (every thread has read the cursor)
+            if (tid == 0) s_pool_n = 0;
+            const int t_end = (int)(((s0 + kSpan < n ? s0 + kSpan : n) + kSelSeg - 1) / kSelSeg);
+            for (int t = (int)(s0 / kSelSeg); t < t_end; ++t) tile_by_histogram(t);
+        }
+    }
+    if (wid == 0 && lane < c) {
         cand_idx[q * 64 + lane] = (tl.idx == kNoIdx) ? -1 : tl.idx;
         cand_s[q * 64 + lane] = tl.s;
     }
@@ -1376,6 +1496,7 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
     }
 
     static const bool no_direct = getenv("ASTTS_KNN_NO_DIRECT") != nullptr;       // A/B: the three-launch form for small banks
+    static const bool no_stream = getenv("ASTTS_KNN_NO_STREAM_SELECT") != nullptr;   // A/B: per-segment selection + merge for large query groups
     const bool direct = p.direct_ok && !no_direct && (((uintptr_t)queries) & 15) == 0;
     if (direct) {
         // two launches: the scan reads the fp32 queries itself; selection + fp64 re-score + certification in one kernel
@@ -1461,6 +1582,14 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
                 hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
                                    h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0,
                                    mask_g, mstride);
+                ASTTS_CHECK_LAUNCH();
+            } else if (as_gemm && !no_stream) {     // a long row per query, >= 64 queries: one streaming block per query
+                if (sel_bias || mask_g)     // (a third / fourth load per score: half the span keeps the registers)
+                    hipLaunchKernelGGL((knn_select_stream<8, true>), dim3(qg), dim3(kSelThreads), 0, st, spart, h->nld, h->n, p.c,
+                                       cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0, mask_g, mstride);
+                else
+                    hipLaunchKernelGGL((knn_select_stream<16, false>), dim3(qg), dim3(kSelThreads), 0, st, spart, h->nld, h->n, p.c,
+                                       cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0, mask_g, mstride);
                 ASTTS_CHECK_LAUNCH();
             } else {
                 hipLaunchKernelGGL(knn_select, dim3(qg, p.nseg), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
