@@ -50,7 +50,11 @@ bool prof_events(int kind, double work, hipEvent_t* e0, hipEvent_t* e1);
     } while (0)
 
 // the kNN scan as one GEMM on the LDS-DMA ring kernel (ops_gemm.hip), row panels of one bank tile first
-int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st);
+// (blockmax given: the scores leave scaled -- out = dot * col_scale (+ row_qs * col_bias) -- with the maximum of every (query, 64-row
+// block) beside them; ring kernels only: ASTTS_ERR_INVALID when the shape is outside them)
+int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st,
+              const float* col_scale = nullptr, const float* col_bias = nullptr, const float* row_qs = nullptr, float* blockmax = nullptr,
+              int32_t bm_ld = 0);
 
 // an integer experiment switch from the environment (`dflt` when unset).  A set variable is reported once on stderr: these switches
 // change which kernel form runs (same results), and a stray one in a user's environment should not go unnoticed (runtime.hip)

@@ -557,15 +557,13 @@ __device__ __forceinline__ unsigned sel_key(float f) {
 static constexpr int kSelThreads = 1024;
 // body of the selection for query q, segment segy; the c candidates go to cand_idx / cand_s [0, c) (global memory: the
 // stand-alone kernel; LDS: the fused select + re-score kernel)
+__device__ __forceinline__ void knn_select_staged(const float* seg, int nl, int64_t seg0, int c, int* cand_idx, float* cand_s,
+                                                  const uint8_t* __restrict__ mask);
 __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part, int ksplit, int qpad, int nld, int64_t n_all, int c,
                                                 int seg_len, int q, int segy, int* cand_idx, float* cand_s,
                                                 const float* __restrict__ inv_norm, const float* __restrict__ bias, float qs,
                                                 const uint8_t* __restrict__ mask, float* seg /* LDS [kSelSeg], the caller's */) {
-    __shared__ float sh_s[kSelThreads];
-    __shared__ int sh_i[kSelThreads];
-    __shared__ unsigned hist[2048];
-    __shared__ int s_sel_bin, s_cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x;
     const size_t plane = (size_t)qpad * nld;
     const float* base = s_part + (size_t)q * nld;
     // this block's segment of the row: [seg0, n)
@@ -625,6 +623,18 @@ __device__ __forceinline__ void knn_select_body(const float* __restrict__ s_part
         for (int i = tid; i < nl; i += kSelThreads)
             if (!mask[seg0 + i]) seg[i] = -INFINITY;
     }
+    knn_select_staged(seg, nl, seg0, c, cand_idx, cand_s, mask);
+}
+
+// the selection proper: top c of seg[0, nl) (LDS, written by every thread's own stores: the first barrier below publishes them) by
+// (score desc, position asc); candidate j is row seg0 + position
+__device__ __forceinline__ void knn_select_staged(const float* seg, int nl, int64_t seg0, int c, int* cand_idx, float* cand_s,
+                                                  const uint8_t* __restrict__ mask) {
+    __shared__ float sh_s[kSelThreads];
+    __shared__ int sh_i[kSelThreads];
+    __shared__ unsigned hist[2048];
+    __shared__ int s_sel_bin, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
         s_cnt = 0;
         s_sel_bin = 2048;       // (nothing to gather unless the histogram walk finds the bin)
@@ -941,6 +951,48 @@ __global__ __launch_bounds__(kSelThreads) void knn_select_stream(const float* __
     }
 }
 
+// Selection for a large query group whose scan left BLOCK MAXIMA beside the scores (gemm_scan's epilogue: the largest score of
+// every 64 bank rows, per query).  The c blocks with the largest maxima -- by (maximum desc, block asc) -- hold the top c scores: each of
+// them has a score >= T = the c-th largest maximum, every other block's scores are <= T, and a score equal to T in an unlisted block
+// sits at a higher row than the T-scores of the listed ones.  So the block reads its query's n / 64 maxima (25 KB of a 400 KB row at
+// 100k), selects c of them with the selection every segment goes through, puts the listed blocks in ascending order (positions then
+// ascend with the row index: ties), gathers their c x 64 scores and selects again.  Same candidates, same order as knn_select_stream /
+// knn_select + merge; no row mask (a mask changes the maxima): masked and multi-pass searches keep the streaming form.
+__global__ __launch_bounds__(kSelThreads) void knn_select_blocks(const float* __restrict__ s_plane, int nld, int64_t n, int c,
+                                                                 const float* __restrict__ bmax, int bm_ld, int nblk,
+                                                                 int* __restrict__ cand_idx, float* __restrict__ cand_s) {
+    __shared__ float seg[kSelSeg];
+    __shared__ int f_ci[64], f_blk[64];
+    __shared__ float f_cs[64];
+    __shared__ int s_nb;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < nblk; i += kSelThreads) seg[i] = bmax[(size_t)q * bm_ld + i];
+    knn_select_staged(seg, nblk, 0, c, f_ci, f_cs, nullptr);
+    __syncthreads();
+    if (wid == 0) {
+        const int b = lane < c ? f_ci[lane] : -1;
+        TopList<float> tl;
+        tl.seed(-(float)b, b, b >= 0, lane);        // ascending block index (< 2^24: exact as a float)
+        f_blk[lane] = tl.idx;
+        const int nb = __popcll(__ballot(tl.idx != kNoIdx));
+        if (lane == 0) s_nb = nb;
+    }
+    __syncthreads();
+    const int nl = s_nb * 64;
+    const float* row = s_plane + (size_t)q * nld;
+    for (int p = tid; p < nl; p += kSelThreads) {
+        const int64_t at = (int64_t)f_blk[p >> 6] * 64 + (p & 63);
+        seg[p] = at < n ? row[at] : -INFINITY;
+    }
+    knn_select_staged(seg, nl, 0, c, f_ci, f_cs, nullptr);
+    __syncthreads();
+    if (tid < c) {
+        const int p = f_ci[tid];
+        cand_idx[q * 64 + tid] = p >= 0 ? f_blk[p >> 6] * 64 + (p & 63) : -1;
+        cand_s[q * 64 + tid] = f_cs[tid];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // 4. fp64 re-score of the candidates (16 waves, one candidate each per round), then wave 0 orders
 // them by the exact score, emits the top-k and certifies the candidate set.
@@ -1218,7 +1270,8 @@ struct KnnPlan {
     int qt, rt, ksplit, lines_per_split, tiles, qpad, c, nseg, seg_len;
     bool gemm;       // query groups of >= 64: the scan is a plain GEMM on the ring kernel (MFMA-side regime)
     size_t off_qrow;
-    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, off_mask, total;
+    size_t off_nflag, off_flagged, off_qh, off_qf, off_qn, off_qscale, off_spart, off_cidx, off_cs, off_sidx, off_ss, off_mask, off_bmax, total;
+    int nblk, bm_ld; // 64-row blocks of the bank; block maxima beside the GEMM scan's scores when nblk <= 8192 (one selection segment)
     int passes;      // k > 32: ceil(k / 32) selection + re-score passes over ONE scan, per chunk of <= 256 queries
     bool direct_ok;  // shape allows the two-launch form (scan straight from the caller's fp32 queries + fused select / re-score)
 };
@@ -1284,6 +1337,9 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.off_sidx = take(sizeof(int) * (size_t)kMaxQPerPass * p.nseg * 64);
     p.off_ss = take(sizeof(float) * (size_t)kMaxQPerPass * p.nseg * 64);
     p.off_mask = take(p.passes > 1 ? (size_t)nq * (size_t)h->n : 16);
+    p.nblk = (int)cdiv(h->n, 64);
+    p.bm_ld = (int)align_up((size_t)p.nblk, 4);         // (the GEMM stores a tile's four maxima of a row as one vector)
+    p.off_bmax = take(p.gemm && p.nblk <= kSelSeg ? sizeof(float) * (size_t)kMaxQPerPass * p.bm_ld : 16);
     p.total = o;
     // small bank, one query tile: no preparation launch (the caller's pointer alignment is checked at the call)
     p.direct_ok = p.passes == 1 && nq <= 32 && p.nseg == 1 && !p.gemm && p.qt == 1 && p.rt == 1 && h->dp == h->d && (h->dp & 127) == 0 &&
@@ -1497,6 +1553,7 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
 
     static const bool no_direct = getenv("ASTTS_KNN_NO_DIRECT") != nullptr;       // A/B: the three-launch form for small banks
     static const bool no_stream = getenv("ASTTS_KNN_NO_STREAM_SELECT") != nullptr;   // A/B: per-segment selection + merge for large query groups
+    static const bool no_blocks = getenv("ASTTS_KNN_NO_BLOCK_MAX") != nullptr;       // A/B: the GEMM scan without its block-maximum epilogue
     const bool direct = p.direct_ok && !no_direct && (((uintptr_t)queries) & 15) == 0;
     if (direct) {
         // two launches: the scan reads the fp32 queries itself; selection + fp64 re-score + certification in one kernel
@@ -1538,6 +1595,8 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
         const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
         if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
         const bool as_gemm = p.gemm && qg >= 64;
+        // block maxima beside the scores (and the scores scaled by the GEMM's epilogue): unmasked single-pass searches
+        const bool use_blocks = as_gemm && !no_blocks && p.nblk <= kSelSeg && p.nseg > 1 && !multi && !mask && !exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0);
         if (as_gemm) {
             // S[q][n] = <q, b_n> as one GEMM: activations = this group's queries (row-major fp16), "weights" = the bank's
             // row-major fp16 plane [n][dp]; the LDS-DMA ring kernel runs it at 400+ TFLOP/s where the register-streaming scan
@@ -1547,6 +1606,9 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
             if (n_first)
                 rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
                                       h->dp, h->dp, 1, h->dp, h->nld, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f, stream);
+            else if (use_blocks)
+                rc = gemm_scan(qrow + (size_t)q0 * h->dp, h->plane16, spart, qg, h->n, h->dp, h->nld, st, h->inv_norm, h->bias, qscale + q0,
+                               (float*)(ws + p.off_bmax), p.bm_ld);
             else
                 rc = gemm_scan(qrow + (size_t)q0 * h->dp, h->plane16, spart, qg, h->n, h->dp, h->nld, st);
         } else
@@ -1565,8 +1627,8 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
             ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_used += 2;
         }
-        const float* sel_inv = as_gemm ? h->inv_norm : nullptr;
-        const float* sel_bias = as_gemm ? h->bias : nullptr;
+        const float* sel_inv = as_gemm && !use_blocks ? h->inv_norm : nullptr;
+        const float* sel_bias = as_gemm && !use_blocks ? h->bias : nullptr;
         const int sel_ks = as_gemm ? 1 : p.ksplit;
         const uint8_t* mask_g = mask ? mask + (int64_t)q0 * mstride : nullptr;
         if (p.nseg == 1 && nq <= kMaxQPerPass && !multi) {      // one segment, one query group: selection + re-score in one launch
@@ -1582,6 +1644,10 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
                 hipLaunchKernelGGL(knn_select, dim3(qg, 1), dim3(kSelThreads), 0, st, spart, sel_ks, p.qpad, h->nld,
                                    h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0,
                                    mask_g, mstride);
+                ASTTS_CHECK_LAUNCH();
+            } else if (use_blocks) {                // the scan left block maxima: c blocks of 64 scores per query instead of the row
+                hipLaunchKernelGGL(knn_select_blocks, dim3(qg), dim3(kSelThreads), 0, st, spart, h->nld, h->n, p.c,
+                                   (const float*)(ws + p.off_bmax), p.bm_ld, p.nblk, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
                 ASTTS_CHECK_LAUNCH();
             } else if (as_gemm && !no_stream) {     // a long row per query, >= 64 queries: one streaming block per query
                 if (sel_bias || mask_g)     // (a third / fourth load per score: half the span keeps the registers)

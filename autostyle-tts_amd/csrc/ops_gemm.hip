@@ -80,6 +80,13 @@ struct GemmArgs {
     // projections), 1 = the row panels of one N tile first (blocks that share a WEIGHT tile are neighbours on one XCD and ask its L2 for
     // the same lines at the same time: the kNN scan, where the "weights" are the 1.2 GB bank and the activations 256 queries)
     int m_first;
+    // the kNN scan's epilogue (gemm_scan): y[m][n] = acc * col_scale[n] (+ row_qs[m] * col_bias[n]) is what leaves, and the largest y of
+    // every (row, 64-column block) goes to blockmax[m * bm_ld + n / 64] -- the selection then reads c blocks per query, not the row
+    const float* col_scale;
+    const float* col_bias;
+    const float* row_qs;
+    float* blockmax;
+    int bm_ld;
 };
 
 #ifdef EPI_DBG_LOCAL
@@ -232,6 +239,105 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& a, float16v (&a
             h4[2] = (_Float16)((v[it].z - mean[it]) * rstd * ga.z + be.z);
             h4[3] = (_Float16)((v[it].w - mean[it]) * rstd * ga.w + be.w);
             *reinterpret_cast<half4*>(lnout + EPI_ROW(m) * a.ldc2 + nb) = h4;
+        }
+    }
+}
+
+// Epilogue of the kNN scan (GemmArgs::blockmax): the slab transpose of tile_epilogue, then per 16-byte vector the score
+// y = acc * col_scale (+ row_qs * col_bias: L2's -|b|^2 / 2 on the query's scale) with exactly the arithmetic the selection kernels
+// applied to the raw dot products before (knn.hip, knn_select_body), the store, and the maximum over the wave's 64 columns of the row:
+// the 16 lanes that hold one slab row reduce it with four lane exchanges and leave it in bm_lds[tile row][wave column]; the kernel
+// stores the tile's maxima behind a barrier, one 8- or 16-byte vector per row (tile_store_blockmax: a 4-byte store per (row, block)
+// straight from here was 1/4 of the epilogue's cost).  Columns past n take no part; NaNs never win an fmaxf.
+template <int TM, int TN, int WN, bool INTERIOR>
+__device__ __forceinline__ void tile_epilogue_knn_t(const GemmArgs& a, float16v (&acc)[TM][TN], float* slab_base, float* bm_lds, int64_t m0,
+                                                    int n0, int wm, int wn, int wid, int lane) {
+    constexpr int EPI_W = 32 * TN + 4, VPR = 8 * TN, RPI = 64 / VPR, NIT = 32 / RPI;
+    const int r = lane & 31, h = lane >> 5;
+    const int vq = lane % VPR, vr = lane / VPR;
+    float* slab = slab_base + wid * 32 * EPI_W;
+    const int nb = n0 + wn * 64 + vq * 4;
+    float cs[4], cb[4];
+    bool ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ok[e] = INTERIOR || nb + e < a.n;
+        cs[e] = ok[e] ? a.col_scale[nb + e] : 0.0f;
+        cb[e] = ok[e] && a.col_bias ? a.col_bias[nb + e] : 0.0f;
+    }
+    const bool has_bias = a.col_bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_W + j * 32 + r] = acc[i][j][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float qs[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int64_t m = m0 + (wm * TM + i) * 32 + it * RPI + vr;
+            qs[it] = has_bias && (INTERIOR || m < a.m) ? a.row_qs[m] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + vr;
+            const int64_t m = m0 + (wm * TM + i) * 32 + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * EPI_W + vq * 4]);
+            float y[4] = {v.x * cs[0], v.y * cs[1], v.z * cs[2], v.w * cs[3]};
+            if (has_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaf(qs[it], cb[e], y[e]);
+            }
+            float mx;
+            if constexpr (INTERIOR) {
+                mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+            } else {
+                mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ok[e]) mx = fmaxf(mx, y[e]);
+            }
+#pragma unroll
+            for (int off = 1; off < VPR; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            if (vq == 0) bm_lds[((wm * TM + i) * 32 + row) * WN + wn] = mx;
+            if (INTERIOR) {
+                *reinterpret_cast<float4*>(a.out + m * a.ldc + nb) = make_float4(y[0], y[1], y[2], y[3]);
+            } else if (m < a.m) {
+                float* op = a.out + m * a.ldc + nb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ok[e]) op[e] = y[e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void tile_epilogue_knn(const GemmArgs& a, float16v (&acc)[TM][TN], float* slab_base, float* bm_lds, int64_t m0,
+                                                  int n0, int wm, int wn, int wid, int lane, bool interior) {
+    if constexpr (TN == 2) {
+        if (interior && (a.ldc & 3) == 0 && ((uintptr_t)a.out & 15) == 0) tile_epilogue_knn_t<TM, TN, WN, true>(a, acc, slab_base, bm_lds, m0, n0, wm, wn, wid, lane);
+        else tile_epilogue_knn_t<TM, TN, WN, false>(a, acc, slab_base, bm_lds, m0, n0, wm, wn, wid, lane);
+    }
+}
+
+// the tile's block maxima, bm_lds[BM rows][WN blocks], to blockmax[m][n0 / 64 ..): one vector per row (bm_ld and n0 / 64 are multiples of WN)
+template <int BM, int WN>
+__device__ __forceinline__ void tile_store_blockmax(const GemmArgs& a, const float* bm_lds, int64_t m0, int n0, int tid, int nthreads) {
+    __syncthreads();
+    for (int row = tid; row < BM; row += nthreads) {
+        const int64_t m = m0 + row;
+        if (m >= a.m) continue;
+        float* dst = a.blockmax + m * a.bm_ld + (n0 >> 6);
+        if (n0 + 64 * WN <= a.n + 63 && (a.bm_ld % WN) == 0) {      // every block of the tile has a column below n
+            if constexpr (WN == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(bm_lds + row * 4);
+            else if constexpr (WN == 2) *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(bm_lds + row * 2);
+        } else {
+            for (int w = 0; w < WN; ++w)
+                if (n0 + 64 * w < a.n) dst[w] = bm_lds[row * WN + w];
         }
     }
 }
@@ -681,7 +787,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
             return;
         }
     }
-    tile_epilogue<TM, TN>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+    if (a.blockmax) {
+        if constexpr (TN == 2 && (WN == 2 || WN == 4) && NW * 32 * EPI_W * 4 + BM * WN * 4 <= STAGES * STAGE_BYTES) {
+            float* bm_lds = reinterpret_cast<float*>(ring + NW * 32 * EPI_W * 4);      // behind the waves' slabs
+            tile_epilogue_knn<TM, TN, WN>(a, acc, reinterpret_cast<float*>(ring), bm_lds, m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+            tile_store_blockmax<BM, WN>(a, bm_lds, m0, n0, tid, NW * 64);
+        }
+    } else {
+        tile_epilogue<TM, TN>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+    }
 #else
     if (acc[0][0][0] == 123.0f) a.out[0] = 1.0f;
 #endif
@@ -874,7 +988,14 @@ __global__ __launch_bounds__(512) void gemm_ring8(GemmArgs a) {
     if (!trail) __builtin_amdgcn_s_barrier();        // (the barrier the trailing group took up front)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                 // all fragment reads done, no DMA outstanding: the ring becomes slab space
-    tile_epilogue<4, 2>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+    if (a.blockmax) {
+        static_assert(8 * 32 * EPI_W * 4 + BM * 4 * 4 <= 2 * STAGE_BYTES, "block maxima behind the slabs");
+        float* bm_lds = reinterpret_cast<float*>(ring + 8 * 32 * EPI_W * 4);
+        tile_epilogue_knn<4, 2, 4>(a, acc, reinterpret_cast<float*>(ring), bm_lds, m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+        tile_store_blockmax<BM, 4>(a, bm_lds, m0, n0, tid, 512);
+    } else {
+        tile_epilogue<4, 2>(a, acc, reinterpret_cast<float*>(ring), m0, n0, wm, wn, wid, lane, m0 + BM <= a.m && n0 + BN <= a.n);
+    }
 #endif
 }
 
@@ -1445,6 +1566,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         else mode = 3;
         if (mode == 4) mode = 5;            // the rule's 256 x 256 tile is the eight-phase kernel; a FORCED 4 keeps the one-barrier form (A/B, tests)
         if (ring_env > 0) mode = ring_env;
+        if (a.blockmax && mode != 4 && mode != 5) mode = 1;     // (the block maxima are per 64 columns of a wave: the tiles with TN = 2)
         if (mode == 5 && a.n > 128) {       // 256 x 256 on the eight-phase schedule (gemm_ring8)
             static std::once_flag attr85;
             std::call_once(attr85, [] {
@@ -1469,6 +1591,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         ASTTS_CHECK_LAUNCH();
         return ASTTS_OK;
     }
+    if (a.blockmax) {          // (gemm_scan checks the shape; what is left is a ring path switched off: astts_op_gemm_set_ring_mode(0))
+        set_error("gemm_scan: the block-maximum epilogue needs the ring kernels");
+        return ASTTS_ERR_INVALID;
+    }
     const int64_t want = 384;  // >= 1.5 blocks per CU
     // K tile: cin_pad is a multiple of 64, so 64 never straddles a tap; 128 needs cin_pad % 128 == 0
     const bool k128 = (a.cin_pad % 128) == 0 && a.taps * a.cin_pad >= 256;
@@ -1490,11 +1616,24 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
 
 // the kNN scan as one GEMM (knn.hip): scores[q][n] = <query q, bank row n>, fp16 operands, fp32 out [qg][ldc]; row panels of one bank
 // tile first (GemmArgs::m_first), so that the bank is fetched from HBM once however many 128-query panels there are
-int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st) {
+int gemm_scan(const _Float16* queries, const _Float16* bank, float* out, int32_t qg, int64_t n, int32_t dp, int32_t ldc, hipStream_t st,
+              const float* col_scale, const float* col_bias, const float* row_qs, float* blockmax, int32_t bm_ld) {
     GemmArgs a{(const float*)queries, bank, nullptr, nullptr, nullptr, out, qg, (int)n, dp, dp, 1,
                dp, ldc, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f,
                nullptr, nullptr, nullptr, 0.0f, nullptr, 0, 0, 1, 0, 0};
     a.m_first = 1;
+    if (blockmax) {
+        // (only the ring kernels carry that epilogue: their launch conditions, restated -- the caller takes the plain scan otherwise)
+        if (!(qg >= 64 && n > 64 && (dp & 63) == 0 && ((uintptr_t)queries & 15) == 0 && col_scale && (!col_bias || row_qs))) {
+            set_error("gemm_scan: shape outside the ring kernels (qg=%d n=%lld dp=%d)", qg, (long long)n, dp);
+            return ASTTS_ERR_INVALID;
+        }
+        a.col_scale = col_scale;
+        a.col_bias = col_bias;
+        a.row_qs = row_qs;
+        a.blockmax = blockmax;
+        a.bm_ld = bm_ld;
+    }
     return launch_gemm(a, st);
 }
 
