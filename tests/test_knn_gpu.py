@@ -152,13 +152,15 @@ def test_gemm_scan_path_large_query_groups():
     _check(bank32, rng.standard_normal((130, 384)).astype(np.float32), 3, sb=sb32)
 
 
-def test_streaming_selection_on_ordered_rows():
-    """Large query groups rank a long score row in ONE block per query that streams it against the c-th best so far
-    (knn_select_stream).  Scores that ASCEND with the row index make every score a survivor (the pool overflows in every span: the
-    tile-by-tile histogram selection takes over), scores that DESCEND leave none after the first tile, and a bank of a few distinct rows
-    repeated is all ties (decided by row index) -- each against the oracle, with 3 and with 20 hits (the 16- and 64-entry lists)."""
+def test_large_query_group_selection_on_ordered_rows():
+    """Query groups of >= 64 against a long score row take one of two selections: from the block maxima the GEMM scan leaves beside
+    its scores (knn_select_blocks: unmasked single-pass searches), or one streaming block per query against the c-th best so far
+    (knn_select_stream: searches with a row mask -- here a mask of ones -- and the passes of limit > 32).  Scores that ASCEND with the row
+    index make every score a survivor of the stream (its pool overflows in every span: the tile-by-tile histogram selection takes over),
+    scores that DESCEND leave none after the first tile, a bank of seven distinct rows repeated is all ties (decided by row index, across
+    blocks), and n is no multiple of 64 -- each against the oracle, with 3 and with 20 hits (the 16- and 64-entry lists)."""
     rng = np.random.default_rng(3)
-    n, d = 40000, 64
+    n, d = 40013, 64
     u = rng.standard_normal(d)
     u /= np.linalg.norm(u)
     v = rng.standard_normal(d)
@@ -167,13 +169,21 @@ def test_streaming_selection_on_ordered_rows():
     t = np.linspace(2.0, 0.05, n)[:, None]                   # angle to u shrinks with the row index: cosine ascends
     asc = (u[None, :] + t * v[None, :]).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
     q = (u[None, :] + 0.01 * rng.standard_normal((64, d))).astype(np.float32)
+    ones = np.ones(n, np.uint8)
     for bank in (asc, asc[::-1].copy()):
         sb = _check(bank, q, 3)
-        _check(bank, q[:64], 20, sb=sb)
+        _check(bank, q, 20, sb=sb)
+        _check_metric(bank, q, 3, "COSINE", mask=ones, sb=sb)
+        _check_metric(bank, q, 20, "COSINE", mask=ones, sb=sb)
     few = rng.standard_normal((7, d)).astype(np.float16)
     ties = few[rng.integers(0, 7, n)]
-    sb = _check(ties, rng.standard_normal((70, d)).astype(np.float32), 5)
+    qt = rng.standard_normal((70, d)).astype(np.float32)
+    sb = _check(ties, qt, 5)
     _check(ties, few.astype(np.float32).repeat(10, 0), 20, sb=sb)
+    _check_metric(ties, qt, 5, "COSINE", mask=ones, sb=sb)
+    for metric in ("IP", "L2"):                              # the epilogue's per-row constant (L2) and the plain scale (IP), ties included
+        sbm = _check_metric(ties, qt, 5, metric)
+        _check_metric(ties, qt, 20, metric, mask=ones, sb=sbm)
 
 
 def test_duplicates_ties_zero_rows_and_small_banks():
