@@ -328,7 +328,8 @@ def gemm_fused(x: torch.Tensor, w: PackedWeight, m: int, gather: Optional[torch.
 
 
 def set_gemm_ring_mode(mode: int) -> None:
-    """-1 auto (default), 0 ring kernel off, 1 / 2 / 3 / 4 force the 128x128 / 128x64 / 64x64 / 256x256 (eight waves) ring tile (tests, tuning)."""
+    """-1 auto (default), 0 ring kernel off, 1 / 2 / 3 / 4 / 5 force the 128x128 / 128x64 / 64x64 / 256x256 one-barrier / 256x256
+    eight-phase ring tile (tests, tuning)."""
     _lib.check(_L().astts_op_gemm_set_ring_mode(int(mode)))
 
 

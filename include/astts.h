@@ -208,7 +208,8 @@ int astts_op_gemm_fused(const float* x, const int32_t* gather, const float* ln_g
  * (diffusers BasicTransformerBlock: `hidden = attn(norm1(hidden)) + hidden; hidden = ff(norm3(hidden)) + hidden`, [EXT]). */
 /* Tile choice of the LDS-DMA ring GEMM (fp16 activations): -1 = by shape (default; env ASTTS_GEMM_RING overrides), 0 = ring
  * kernel off (register-staged tiles), 1 = 128x128 two-stage, 2 = 128x64 two-stage, 3 = 64x64 four-stage, 4 = 256x256 two-stage
- * with eight waves (large GEMMs: the embedder's projections, the kNN scan of >= 64 queries).  Process-global
+ * with eight waves on one barrier per K tile, 5 = the same tile on the eight-phase schedule (what "by shape" picks for large GEMMs: the
+ * embedder's projections, the kNN scan of >= 64 queries; results bit-identical to 4).  Process-global
  * test / tuning switch: the parity tests run the benchmark's projection shapes through every tile. */
 int astts_op_gemm_set_ring_mode(int32_t mode);
 int astts_op_gemm_ln(const void* x_f16, const void* w_f16, const float* bias, const float* residual, float* out,

@@ -1,5 +1,6 @@
-"""fp16-activation GEMMs on the LDS-DMA ring kernel, forced tile (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x256 with eight waves) against the
-launcher's own choice (-1): us per launch and TFLOP/s on shapes of the embedder, the LM prefill, the 64-sequence flow and the kNN scan."""
+"""fp16-activation GEMMs on the LDS-DMA ring kernel, forced tile (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x256 with eight waves and one barrier per K tile,
+5: 256x256 on the eight-phase schedule) against the launcher's own choice (-1): us per launch and TFLOP/s on shapes of the embedder, the LM prefill, the
+64-sequence flow and the kNN scan.  ONE pass per mode: the first kernel on a cold chip reads ~15 % low -- scripts/ring_ab.py alternates two modes."""
 import sys
 sys.path[:0] = ['.', 'autostyle-tts_amd']
 import torch
