@@ -11,7 +11,9 @@ from astts import ops
 modes = [int(v) for v in os.environ.get('RING_MODES', '4,5').split(',')]
 rounds = int(os.environ.get('ROUNDS', '7'))
 uniform = os.environ.get('UNIFORM', '0') == '1'
-shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (15360, 3072, 5120), (15360, 8192, 3072), (15360, 3072, 3072), (23680, 1024, 4096), (23680, 4096, 1024),
+if os.environ.get('RING_SHAPES'):          # "m,k,n;m,k,n;..."
+    shapes_env = [tuple(int(v) for v in t.split(',')) for t in os.environ['RING_SHAPES'].split(';')]
+shapes = shapes_env if os.environ.get('RING_SHAPES') else [(4096, 4096, 4096), (8192, 8192, 8192), (15360, 3072, 5120), (15360, 8192, 3072), (15360, 3072, 3072), (23680, 1024, 4096), (23680, 4096, 1024),
           (1920, 3072, 5120), (44032, 256, 1536), (256, 6144, 100000)]
 
 
