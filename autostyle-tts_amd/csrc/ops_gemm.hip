@@ -1559,9 +1559,15 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
         // A/B in one process, scripts/ring_ab.py, profiles/r06_ring8_ab.log: 8192^3 1066 -> 1171, 15 360 x 3072 x 5120 1005 -> 1087,
         // the kNN scan 783 -> 861 TFLOP/s on N(0, 1) operands; on zero-filled operands 1425 -> 1667, i.e. what is left is the clock the
         // chip holds under fp16 MFMA load on real data (1.71 GHz measured, GRBM_GUI_ACTIVE), not the schedule).
+        // Round 6, with the eight-phase kernel and the grouped tile order (alternating A/B of tiles 1 / 2 / 5 on 17 embedder, prefill and
+        // frontend shapes, profiles/r06_ring_rule_ab.log): what decides for the 256 x 256 tile is how full its LAST round of 256 blocks is
+        // -- 180 or 235 blocks (one round, 0.70 / 0.92 full) win by 10-19 % at K >= 3072, 264, 300 or 516 blocks (0.52 - 0.67) lose by 7-47 % --
+        // and shallow K needs a fuller round (K = 1024-1280: wins at 0.92, even at 0.87, loses at 0.70); below it 128 x 128 beats 128 x 64
+        // on every deep-K shape with >= 256 tiles (the K = 256 projections of the flow keep their in-situ rule).
         const int64_t b256 = blocks(256, 256);
-        if (a.n > 128 && b256 >= 320 && a.cin_pad >= 1024) mode = 4;
-        else if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512)) mode = 1;
+        const int64_t fill_pct = b256 * 100 / (cdiv(b256, 256) * 256);          // how full the rounds of 256 x 256 tiles are
+        if (a.n > 128 && ((a.cin_pad >= 2048 && fill_pct >= 68) || (a.cin_pad >= 1024 && fill_pct >= 85))) mode = 4;
+        else if (b128 >= (a.n >= 512 ? 2048 : 1024) || (a.cin_pad >= 4096 && b128 >= 512) || (a.cin_pad >= 1024 && a.n >= 512 && b128 >= 256)) mode = 1;
         else if (a.n >= 512 && blocks(128, 64) >= 160) mode = 2;
         else mode = 3;
         if (mode == 4) mode = 5;            // the rule's 256 x 256 tile is the eight-phase kernel; a FORCED 4 keeps the one-barrier form (A/B, tests)

@@ -29,7 +29,8 @@ RING_SHAPES = [
     (11008, 1024, 256, "none", False, True),
     (32768, 256, 1024, "gelu", True, False),     # 256 x 8 = 2048 tiles of 128x128: ring mode 1 by the rule
     (5520, 256, 512, "none", False, False),      # ragged last row tile
-    (5000, 1024, 4097, "none", False, True),     # 20 x 17 = 340 tiles of 256x256 at K = 1024: ring mode 4 by the rule; ragged in both directions
+    (5000, 1024, 4097, "none", False, True),     # 20 x 17 = 340 tiles of 256x256 (forced modes 4 / 5; 128x128 by the rule: 0.66 of two rounds); ragged in both directions
+    (3800, 2048, 3000, "none", True, False),     # 15 x 12 = 180 tiles of 256x256 = 0.70 of a round at K = 2048: the eight-phase tile by the rule; ragged
 ]
 
 
