@@ -342,10 +342,10 @@ def knn_stress(args, dev, traffic_table):
             q_dev = torch.from_numpy(q_host).to(dev)
             oi = torch.empty((nq, args.topk), dtype=torch.int64, device=dev)
             osc = torch.empty((nq, args.topk), dtype=torch.float32, device=dev)
-            for _ in range(5):
+            for _ in range(40):         # (a chip coming out of idle runs its first milliseconds at a lower clock: 5 warm-up searches read 12 % low)
                 sb.search_device(q_dev, args.topk, out_idx=oi, out_score=osc)
             torch.cuda.synchronize()
-            n_it = 30
+            n_it = 100
             t0 = time.perf_counter()
             for _ in range(n_it):
                 sb.search_device(q_dev, args.topk, out_idx=oi, out_score=osc)
