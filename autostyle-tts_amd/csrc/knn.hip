@@ -958,14 +958,14 @@ __global__ __launch_bounds__(kSelThreads) void knn_select_stream(const float* __
 // 100k), selects c of them with the selection every segment goes through, puts the listed blocks in ascending order (positions then
 // ascend with the row index: ties), gathers their c x 64 scores and selects again.  Same candidates, same order as knn_select_stream /
 // knn_select + merge; no row mask (a mask changes the maxima): masked and multi-pass searches keep the streaming form.
-__global__ __launch_bounds__(kSelThreads) void knn_select_blocks(const float* __restrict__ s_plane, int nld, int64_t n, int c,
-                                                                 const float* __restrict__ bmax, int bm_ld, int nblk,
-                                                                 int* __restrict__ cand_idx, float* __restrict__ cand_s) {
-    __shared__ float seg[kSelSeg];
+// (body: the c candidates -- rows and scores -- go to out_ci / out_cs [0, c), global memory or LDS)
+__device__ __forceinline__ void knn_select_blocks_body(const float* __restrict__ s_plane, int nld, int64_t n, int c,
+                                                       const float* __restrict__ bmax, int bm_ld, int nblk, int q, int* out_ci,
+                                                       float* out_cs, float* seg /* LDS [kSelSeg], the caller's */) {
     __shared__ int f_ci[64], f_blk[64];
     __shared__ float f_cs[64];
     __shared__ int s_nb;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < nblk; i += kSelThreads) seg[i] = bmax[(size_t)q * bm_ld + i];
     knn_select_staged(seg, nblk, 0, c, f_ci, f_cs, nullptr);
     __syncthreads();
@@ -988,8 +988,8 @@ __global__ __launch_bounds__(kSelThreads) void knn_select_blocks(const float* __
     __syncthreads();
     if (tid < c) {
         const int p = f_ci[tid];
-        cand_idx[q * 64 + tid] = p >= 0 ? f_blk[p >> 6] * 64 + (p & 63) : -1;
-        cand_s[q * 64 + tid] = f_cs[tid];
+        out_ci[tid] = p >= 0 ? f_blk[p >> 6] * 64 + (p & 63) : -1;
+        out_cs[tid] = f_cs[tid];
     }
 }
 
@@ -1236,6 +1236,24 @@ __global__ __launch_bounds__(1024) void knn_select_rescore(
     }
     knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, f_ci, f_cs, err_bound, force_exact, out_idx, out_score,
                            out_score64, nflag, flagged, metric, bmax, mq, k, 0, direct, direct != 0, pre0, pre1, direct ? seg : nullptr);
+}
+
+// the same pair for a large query group behind the GEMM scan: selection from the block maxima + fp64 re-score, one block per query
+template <typename RowT>
+__global__ __launch_bounds__(1024) void knn_blocks_rescore(
+    const float* __restrict__ s_plane, int nld, const float* __restrict__ bmax, int bm_ld, int nblk,
+    const float* __restrict__ qf, const double* __restrict__ qn64, const float* __restrict__ qscale,
+    const RowT* __restrict__ plane, const double* __restrict__ norm64, int64_t n, int dp, int c, int k, double err_bound,
+    int force_exact, int64_t* __restrict__ out_idx, float* __restrict__ out_score, double* __restrict__ out_score64,
+    int* __restrict__ nflag, int* __restrict__ flagged, int metric, double bmax_norm) {
+    __shared__ int c_ci[64];
+    __shared__ float c_cs[64];
+    __shared__ float seg[kSelSeg];
+    const int q = blockIdx.x;
+    knn_select_blocks_body(s_plane, nld, n, c, bmax, bm_ld, nblk, q, c_ci, c_cs, seg);
+    __syncthreads();
+    knn_rescore_body<RowT>(q, qf, qn64, qscale, plane, norm64, n, dp, c, k, c_ci, c_cs, err_bound, force_exact, out_idx, out_score,
+                           out_score64, nflag, flagged, metric, bmax_norm, nullptr, k, 0);
 }
 
 }  // namespace astts
@@ -1588,8 +1606,12 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
         ASTTS_CHECK_LAUNCH();                                                                                                       \
     } while (0)
 
-    for (int q0 = 0; q0 < nq; q0 += kMaxQPerPass) {
-        const int qg = (nq - q0) < kMaxQPerPass ? (nq - q0) : kMaxQPerPass;
+    int finished = 0;           // leading queries whose hits a fused selection + re-score launch has already written
+    // query groups of <= 256; behind the GEMM scan EQUAL groups (300 queries = 150 + 150, not 256 + a tail of 44 that falls back to the
+    // register-streaming scan with eight query tiles per wave: 3.1 ms of a 3.5 ms search at 100k x 6144)
+    const int gstep = p.gemm ? (int)cdiv(nq, cdiv(nq, kMaxQPerPass)) : kMaxQPerPass;
+    for (int q0 = 0; q0 < nq; q0 += gstep) {
+        const int qg = (nq - q0) < gstep ? (nq - q0) : gstep;
         const _Float16* qh_g = qh + (size_t)q0 * h->dp;
         int rc;
         const bool prof = h->profile && h->ev_used + 2 <= h->ev.size();
@@ -1645,10 +1667,13 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
                                    h->n, p.c, p.seg_len, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64, sel_inv, sel_bias, qscale + q0,
                                    mask_g, mstride);
                 ASTTS_CHECK_LAUNCH();
-            } else if (use_blocks) {                // the scan left block maxima: c blocks of 64 scores per query instead of the row
-                hipLaunchKernelGGL(knn_select_blocks, dim3(qg), dim3(kSelThreads), 0, st, spart, h->nld, h->n, p.c,
-                                   (const float*)(ws + p.off_bmax), p.bm_ld, p.nblk, cidx + (size_t)q0 * 64, cs + (size_t)q0 * 64);
-                ASTTS_CHECK_LAUNCH();
+            } else if (use_blocks) {                // the scan left block maxima: c blocks of 64 scores per query instead of the row,
+                                                    // and the fp64 re-score behind the selection in the same launch (use_blocks: !multi)
+                KNN_RESCORE(knn_blocks_rescore, dim3(qg), spart, h->nld, (const float*)(ws + p.off_bmax), p.bm_ld, p.nblk,
+                            qf + (size_t)q0 * h->dp, qn + q0, qscale + q0, PLANE, h->norm64, h->n, h->dp, p.c, k, h->err_bound, force,
+                            out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k, out_score64 ? out_score64 + (size_t)q0 * k : nullptr,
+                            nflag, flagged + q0, h->metric, h->bmax);
+                finished = q0 + qg;                 // (groups come in order and only the last can be a tail below 64 queries)
             } else if (as_gemm && !no_stream) {     // a long row per query, >= 64 queries: one streaming block per query
                 if (sel_bias || mask_g)     // (a third / fourth load per score: half the span keeps the registers)
                     hipLaunchKernelGGL((knn_select_stream<8, true>), dim3(qg), dim3(kSelThreads), 0, st, spart, h->nld, h->n, p.c,
@@ -1681,10 +1706,14 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
             }
         }
     }
-    if (multi) return ASTTS_OK;
-    KNN_RESCORE(knn_rescore_finalize, dim3(nq), qf, qn, qscale, PLANE, h->norm64,
-                h->n, h->dp, p.c, k, cidx, cs, h->err_bound, force, out_idx, out_score, out_score64, nflag, flagged, h->metric, h->bmax,
-                mask, mstride, k, 0);
+    if (multi || finished == nq) return ASTTS_OK;
+    {       // (the queries no fused launch has finished: all of them, or the tail group)
+        const int f = finished;
+        KNN_RESCORE(knn_rescore_finalize, dim3(nq - f), qf + (size_t)f * h->dp, qn + f, qscale + f, PLANE, h->norm64,
+                    h->n, h->dp, p.c, k, cidx + (size_t)f * 64, cs + (size_t)f * 64, h->err_bound, force, out_idx + (size_t)f * k,
+                    out_score + (size_t)f * k, out_score64 ? out_score64 + (size_t)f * k : nullptr, nflag, flagged + f, h->metric, h->bmax,
+                    mask ? mask + (int64_t)f * mstride : nullptr, mstride, k, 0);
+    }
 #undef KNN_RESCORE
     return ASTTS_OK;
 }

@@ -154,7 +154,7 @@ def test_gemm_scan_path_large_query_groups():
 
 def test_large_query_group_selection_on_ordered_rows():
     """Query groups of >= 64 against a long score row take one of two selections: from the block maxima the GEMM scan leaves beside
-    its scores (knn_select_blocks: unmasked single-pass searches), or one streaming block per query against the c-th best so far
+    its scores (knn_blocks_rescore: unmasked single-pass searches), or one streaming block per query against the c-th best so far
     (knn_select_stream: searches with a row mask -- here a mask of ones -- and the passes of limit > 32).  Scores that ASCEND with the row
     index make every score a survivor of the stream (its pool overflows in every span: the tile-by-tile histogram selection takes over),
     scores that DESCEND leave none after the first tile, a bank of seven distinct rows repeated is all ties (decided by row index, across
