@@ -1572,6 +1572,7 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
     static const bool no_direct = getenv("ASTTS_KNN_NO_DIRECT") != nullptr;       // A/B: the three-launch form for small banks
     static const bool no_stream = getenv("ASTTS_KNN_NO_STREAM_SELECT") != nullptr;   // A/B: per-segment selection + merge for large query groups
     static const bool no_blocks = getenv("ASTTS_KNN_NO_BLOCK_MAX") != nullptr;       // A/B: the GEMM scan without its block-maximum epilogue
+    static const bool n_first = exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0) != 0;       // A/B: the projections' tile order (bank read once per panel)
     const bool direct = p.direct_ok && !no_direct && (((uintptr_t)queries) & 15) == 0;
     if (direct) {
         // two launches: the scan reads the fp32 queries itself; selection + fp64 re-score + certification in one kernel
@@ -1618,13 +1619,12 @@ int knn_search_chunk(astts_knn* h, const KnnPlan& p, const float* queries, int n
         if (prof) ASTTS_CHECK_HIP(hipEventRecord(h->ev[h->ev_used], st));
         const bool as_gemm = p.gemm && qg >= 64;
         // block maxima beside the scores (and the scores scaled by the GEMM's epilogue): unmasked single-pass searches
-        const bool use_blocks = as_gemm && !no_blocks && p.nblk <= kSelSeg && p.nseg > 1 && !multi && !mask && !exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0);
+        const bool use_blocks = as_gemm && !no_blocks && p.nblk <= kSelSeg && p.nseg > 1 && !multi && !mask && !n_first;
         if (as_gemm) {
             // S[q][n] = <q, b_n> as one GEMM: activations = this group's queries (row-major fp16), "weights" = the bank's
             // row-major fp16 plane [n][dp]; the LDS-DMA ring kernel runs it at 400+ TFLOP/s where the register-streaming scan
             // (built for the HBM-bound small-Q regime) re-reads the query tile from L2 per bank tile.  1 / |b_n| (and L2's
             // constant) are applied by the selection kernel.
-            static const bool n_first = exp_env_int("ASTTS_KNN_GEMM_N_FIRST", 0) != 0;     // A/B: the projections' tile order (bank read once per panel)
             if (n_first)
                 rc = astts_op_gemm_ex(qrow + (size_t)q0 * h->dp, 1, h->plane16, nullptr, nullptr, nullptr, spart, 0, qg, (int32_t)h->n,
                                       h->dp, h->dp, 1, h->dp, h->nld, 0, qg, qg, 1, 1, 0, ASTTS_ACT_NONE, 1.0f, 0.1f, stream);
