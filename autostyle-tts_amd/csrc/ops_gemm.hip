@@ -817,9 +817,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_ring(GemmArgs a) {
 //   p0: (A0, B0) after reading both    p1: (A0, B1) after reading B1    p2: (A1, B1) after reading A1    p3: (A1, B0), B0 kept in registers
 // so S_j is read for the first time in phase j (A0) or j - 1 and for the LAST time no later than phase j.
 //
-// Depth.  The kernel is bound by the bytes a CU keeps in flight against the latency of L2 / the fabric, so the DMA runs as far ahead as
-// the slots allow: phase P requests S_(P+6) into the slot of S_(P-2), whose last read is two phases back (the restaging distance the
-// guide asks for with staggered groups) -- five sub-tiles (80 KB) in flight after the request, four after the wait.
+// Depth.  The DMA runs as far ahead as the slots allow: phase P requests S_(P+6) into the slot of S_(P-2), whose last read is two
+// phases back (the restaging distance the guide asks for with staggered groups) -- five sub-tiles (80 KB) in flight after the request,
+// four after the wait (measured: no faster than three ahead -- the kernel is not bound by bytes in flight -- and never slower).
 //
 // Ordering of the LDS-DMA data (nothing but the issuing wave's counted vmcnt followed by a barrier the READER has passed orders it):
 // what phase P + 1 reads first -- everything up to S_(P+2); up to S_(P+1) when P + 1 is a p3 -- is waited for by every wave before global
