@@ -186,6 +186,19 @@ def test_large_query_group_selection_on_ordered_rows():
         _check_metric(ties, qt, 20, metric, mask=ones, sb=sbm)
 
 
+def test_large_query_group_beyond_the_block_maximum_range():
+    """More than 8192 blocks of 64 rows (n > 524 288): the block maxima no longer fit one selection segment, so an unmasked search of a
+    large query group streams the row as a masked one does; the shortest GEMM-scanned row (two segments, n just above 8192) and a query
+    count that is cut into equal groups (300 = 150 + 150) ride along."""
+    rng = np.random.default_rng(17)
+    bank = rng.standard_normal((530000, 64)).astype(np.float16)
+    q = bank[rng.integers(0, 530000, 70)].astype(np.float32) + 0.3 * rng.standard_normal((70, 64)).astype(np.float32)
+    sb = _check(bank, q, 3)
+    _check(bank, q[:64], 20, sb=sb)
+    small = rng.standard_normal((8200, 128)).astype(np.float16)
+    _check(small, rng.standard_normal((300, 128)).astype(np.float32), 5)
+
+
 def test_duplicates_ties_zero_rows_and_small_banks():
     rng = np.random.default_rng(0)
     bank = rng.standard_normal((200, 128)).astype(np.float16)
