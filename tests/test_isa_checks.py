@@ -189,3 +189,46 @@ def test_untracked_prefetch_loads_keep_their_destination_register_to_themselves(
                     assert not named, f"{name}: v{r} (destination of the untracked prefetch at line {i + 1}) is used again at line {j}: {ins}"
             assert "scratch_" not in body, f"{name}: uses scratch"
     assert total >= 6, total          # 3 in tfm_attn_fused, 1 in each tfm_ffn_fused variant, 2 per rconv_lds variant
+
+
+def test_eight_phase_ring_steady_loop_has_no_slack_eaters(tmp_path):
+    """gemm_ring8 (ops_gemm.hip): the hand-off between its two wave groups has no slack -- a phase's last MFMA issues 32 cycles before the
+    pipe drains, so every instruction between it and s_barrier idles the MFMA pipe (the first cut, with a counted-wait ladder and a
+    divergent group branch in every phase, ran 3-5 % BEHIND the one-barrier ring; the steady-state loop with constant waits runs 8-10 %
+    ahead: EXPERIMENTS.md P).  Hold the emitted steady-state K-tile loop to that shape: 32 MFMAs in four clusters of eight, eight raw
+    barriers, 24 fragment reads, 8 LDS-DMA requests, waits with IMMEDIATE counts only (vmcnt(8) / vmcnt(10), never 0), scalar group
+    branches (no exec-mask save), no scratch traffic, and nothing but s_setprio / a scalar branch / the counted wait between a cluster's
+    last MFMA and the barrier behind it (at most a dozen instructions: the first cut had 25)."""
+    ks = _kernels(_asm(os.path.join(CSRC, "ops_gemm.hip"), tmp_path), r"gemm_ring8")
+    assert len(ks) == 1, sorted(ks)
+    lines = [l.split(";")[0].strip() for l in next(iter(ks.values())).splitlines()]
+    lines = [l for l in lines if l]
+    # the steady-state loop: from a loop-header label to its backward branch, containing exactly 32 MFMAs
+    labels = {l[:-1]: i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:$", l)}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)$", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            body = lines[labels[m.group(1)]:i + 1]
+            if sum(x.startswith("v_mfma") for x in body) == 32:
+                loops.append(body)
+    assert loops, "no K-tile loop with 32 MFMAs found"
+    steady = min(loops, key=len)          # (the tail loop carries the counted-wait ladder and is longer)
+    count = lambda pred: sum(bool(pred(x)) for x in steady)
+    assert count(lambda x: x == "s_barrier") == 8
+    assert count(lambda x: x.startswith("ds_read_b128")) == 24
+    assert count(lambda x: x.startswith("global_load_lds_dwordx4")) == 8
+    assert count(lambda x: x.startswith("scratch_")) == 0
+    assert count(lambda x: "saveexec" in x) == 0, "the group branch must be scalar (wid through readfirstlane)"
+    waits = [x for x in steady if x.startswith("s_waitcnt vmcnt")]
+    assert waits and all(re.fullmatch(r"s_waitcnt vmcnt\((8|10)\)", x) for x in waits), waits
+    # between the last MFMA of a cluster and the next barrier
+    for i, x in enumerate(steady):
+        if x.startswith("v_mfma") and not steady[i + 1].startswith("v_mfma"):
+            j = i + 1
+            while steady[j] != "s_barrier":
+                # (the compiler may lift one address add of the next phase's DMA request above the barrier)
+                assert re.match(r"(s_setprio|s_cbranch_|s_waitcnt vmcnt|s_and_b64 vcc|s_andn2_b64 vcc|\.LBB|v_cndmask|v_cmp_ne_u32|s_mov_b64|"
+                                r"v_lshl_add_u64|s_add_i32|v_add_u32)", steady[j]), f"'{steady[j]}' between a phase's last MFMA and its barrier"
+                j += 1
+            assert j - i <= 12, steady[i:j + 1]
