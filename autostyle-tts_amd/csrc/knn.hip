@@ -1324,8 +1324,10 @@ KnnPlan make_plan(const astts_knn* h, int nq, int k) {
     p.lines_per_split = (int)cdiv(total_lines, ks);
     p.ksplit = (int)cdiv(total_lines, p.lines_per_split);
     static const bool nogemm_env = getenv("ASTTS_KNN_NO_GEMM") != nullptr;
-    // ... once the GEMM grid fills the chip; a small bank keeps the K-split scan (16 blocks x 96 K tiles would crawl)
-    p.gemm = !nogemm_env && qgroup >= 64 && cdiv(qgroup, 128) * cdiv(h->n, 64) >= 256;
+    // ... once the GEMM grid fills the chip with 64 x 64 tiles; a small bank keeps the K-split scan (16 blocks x 96 K tiles would crawl).
+    // (Round 6: counted in 64-row query tiles, not 128 -- the speech tokenizer's quantiser, 4096 codes x 1280 against groups of 240
+    // frames, took the register-streaming scan with eight query tiles per wave at 95 us per group; as a GEMM: see DESIGN section 3.)
+    p.gemm = !nogemm_env && qgroup >= 64 && cdiv(qgroup, 64) * cdiv(h->n, 64) >= 256;
     if (p.gemm) {        // one score plane; a tail group of < 64 queries runs the register-streaming scan unsplit
         p.ksplit = 1;
         p.lines_per_split = total_lines;
