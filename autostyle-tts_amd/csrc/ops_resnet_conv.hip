@@ -96,10 +96,15 @@ __device__ __forceinline__ void rc_merge_lanes(float nb_l, float mb_l, float qb_
     *rstd_out = rsqrtf((n > 0.0f ? m2 / n : 0.0f) + eps);
 }
 
-template <int CIN>
+// SHARE: the form for grids of two rounds of workgroups and more (long-form batches).  A workgroup is one latency chain -- rows in,
+// statistics merge, staging transform, three taps of 16 MFMAs per wave, epilogue: 13 % MFMA-busy -- so two of them per CU cover each
+// other's prologue and epilogue: the weights come in HALF units (8 fragments = 32 VGPRs, the next half requested under this one's
+// MFMAs) instead of whole units two deep (128 VGPRs), which fits the wave into 128 registers.  Same operations in the same order:
+// bit-identical outputs.
+template <int CIN, bool SHARE = false>
 // Leading parameters = what the first loads need: preloaded into SGPRs by the command processor (-amdgpu-kernarg-preload-count,
 // csrc/Makefile; a by-value struct is not), the struct carries the rest.
-__global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Float16* p_w, const float* p_in_stats, const int* p_lens, int p_t, int p_taps,
+__global__ __launch_bounds__(512, SHARE ? 2 : 1) void rconv_lds(const float* p_x, const _Float16* p_w, const float* p_in_stats, const int* p_lens, int p_t, int p_taps,
                                                     float p_eps, RconvArgs a_in) {
     RconvArgs a = a_in;
     a.x = p_x; a.w = p_w; a.in_stats = p_in_stats; a.lens = p_lens; a.t = p_t; a.taps = p_taps; a.eps = p_eps;
@@ -131,15 +136,17 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Flo
         const int t = min(max(t0 - halo + r0 + RPP * u, 0), a.t - 1);
         v[u] = *reinterpret_cast<const float4*>(a.x + (seq + t) * CIN + col);
     }
-    half8 wf[2][16];
+    constexpr int WFN = SHARE ? 8 : 16;               // fragments per weight buffer: half a unit / a unit
+    half8 wf[2][WFN];
     const _Float16* wbase = a.w + ((int64_t)wid * (CIN / 16) * 64 + lane) * 8;
-    auto load_unit = [&](int u, half8 (&dst)[16]) {   // unit = tap * KC + slice
-        const int tap = u / KC, kc = u - tap * KC;
-        const _Float16* p = wbase + ((int64_t)tap * 8 * (CIN / 16) + kc * 16) * 512;
+    auto load_unit = [&](int u, half8 (&dst)[WFN]) {  // unit = tap * KC + slice; SHARE: u counts half units
+        const int uu = SHARE ? u >> 1 : u;
+        const int tap = uu / KC, kc = uu - tap * KC;
+        const _Float16* p = wbase + ((int64_t)tap * 8 * (CIN / 16) + kc * 16 + (SHARE ? (u & 1) * 8 : 0)) * 512;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) dst[ks] = *reinterpret_cast<const half8*>(p + (int64_t)ks * 512);
+        for (int ks = 0; ks < WFN; ++ks) dst[ks] = *reinterpret_cast<const half8*>(p + (int64_t)ks * 512);
     };
-    const int nunits = a.taps * KC;
+    const int nunits = a.taps * KC * (SHARE ? 2 : 1);
     load_unit(0, wf[0]);
     load_unit(nunits > 1 ? 1 : 0, wf[1]);
     // (everything above needs preloaded arguments only; what follows needs the struct -- res_stats, in_gamma ... -- whose scalar load has
@@ -232,16 +239,18 @@ __global__ __launch_bounds__(512, 1) void rconv_lds(const float* p_x, const _Flo
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     const _Float16* arow = rc_smem + (size_t)c * RS + 8 * hh;
-    auto compute_unit = [&](int u, const half8 (&w)[16]) {
-        const int tap = u / KC, kc = u - tap * KC;
-        const _Float16* ap = arow + (size_t)tap * RS + kc * 256;
+    auto compute_unit = [&](int u, const half8 (&w)[WFN]) {
+        const int uu = SHARE ? u >> 1 : u;
+        const int tap = uu / KC, kc = uu - tap * KC;
+        const _Float16* ap = arow + (size_t)tap * RS + kc * 256 + (SHARE ? (u & 1) * 128 : 0);
+        constexpr int AB = SHARE ? 4 : 8;             // A fragments read ahead of their MFMAs
 #pragma unroll
-        for (int ks0 = 0; ks0 < 16; ks0 += 8) {
-            half8 af[8];
+        for (int ks0 = 0; ks0 < WFN; ks0 += AB) {
+            half8 af[AB];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const half8*>(ap + 16 * (ks0 + ks));
+            for (int ks = 0; ks < AB; ++ks) af[ks] = *reinterpret_cast<const half8*>(ap + 16 * (ks0 + ks));
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], w[ks0 + ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < AB; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], w[ks0 + ks], acc, 0, 0, 0);
         }
     };
     for (int u = 0; u < nunits; u += 2) {
@@ -355,8 +364,13 @@ int astts_op_resnet_conv_pf(const float* x, const void* w_frag_f16, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(32 + 2) * (cin + 8) * sizeof(_Float16);
     const bool prof = prof_begin(ASTTS_PROF_GEMM_TILE, st, 2.0 * (double)b * t * cin * RC_C * taps);
-    if (cin == RC_C) hipLaunchKernelGGL(rconv_lds<256>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
-    else hipLaunchKernelGGL(rconv_lds<512>, dim3((unsigned)((t + 31) / 32), b), dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
+    // two workgroups per CU once the grid is two rounds of 256 and more (ASTTS_RCONV_SHARE=0 / 1 forces one form: A/B)
+    static const int share_env = [] { const char* e = getenv("ASTTS_RCONV_SHARE"); return e ? atoi(e) : -1; }();
+    const bool share = cin == RC_C && (share_env >= 0 ? share_env != 0 : (int64_t)((t + 31) / 32) * b >= 512);   // (512 input channels: 136 registers, one workgroup per CU either way)
+    const dim3 grid((unsigned)((t + 31) / 32), b);
+    if (cin == RC_C && share) hipLaunchKernelGGL((rconv_lds<256, true>), grid, dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
+    else if (cin == RC_C) hipLaunchKernelGGL((rconv_lds<256, false>), grid, dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
+    else hipLaunchKernelGGL((rconv_lds<512, false>), grid, dim3(512), lds, st, a.x, a.w, a.in_stats, a.lens, a.t, a.taps, a.eps, a);
     if (prof) prof_end(ASTTS_PROF_GEMM_TILE, st);
     ASTTS_CHECK_LAUNCH();
     return ASTTS_OK;

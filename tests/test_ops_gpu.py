@@ -891,7 +891,7 @@ def test_conv1d_snake_matches_definition(c, l, taps, dil):
 
 
 @pytest.mark.parametrize("b,t,ragged,cin", [(2, 70, True, 256), (16, 344, False, 256), (3, 33, True, 256), (1, 1, False, 256), (2, 688, True, 256),
-                                             (2, 70, True, 512), (16, 344, False, 512)])
+                                             (2, 70, True, 512), (16, 344, False, 512), (48, 344, True, 256)])
 def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged, cin):
     """A ResnetBlock1D as three astts_op_resnet_conv launches (GroupNorm statistics taken by the producing convolution's epilogue,
     normalise + Mish + time-embedding add + mask applied by the consumer) against the fp64 definition (oracle semantics: statistics
@@ -945,6 +945,13 @@ def test_resnet_conv_block_matches_definition_and_five_launch_path(b, t, ragged,
         assert e_ref < 4e-3 and e_five < 4e-3, (i, e_ref, e_five)
     assert torch.equal(out, ops.resnet_conv(xg, pr, fr, lens=lg, res_gn=(h2, s2, gd[2], gd[3])).cpu())
     assert bool(torch.isfinite(out).all())
+    if b * ((t + 31) // 32) >= 512:
+        # a grid of two rounds of workgroups takes the two-workgroups-per-CU form (weights in half units): the same operations in the same
+        # order, so a sequence's rows equal, bit for bit, what the one-workgroup-per-CU form computes for it in a batch of two
+        h1s, s1s = ops.resnet_conv(xg[:2], p1, f1, lens=lg[:2], want_stats=True)
+        h2s, s2s = ops.resnet_conv(h1s, p2, f2, lens=lg[:2], in_gn=(s1s, gd[0], gd[1]), in_add=tproj[:2].to(dev), want_stats=True)
+        outs = ops.resnet_conv(xg[:2], pr, fr, lens=lg[:2], res_gn=(h2s, s2s, gd[2], gd[3])).cpu()
+        assert torch.equal(h1[:2].cpu(), h1s.cpu()) and torch.equal(h2[:2].cpu(), h2s.cpu()) and torch.equal(out[:2], outs)
 
 
 def test_cu_masked_stream_runs_kernels_with_the_same_results():
