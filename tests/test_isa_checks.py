@@ -111,7 +111,8 @@ def test_render_kernels_issue_their_prologue_loads_in_one_batch(tmp_path):
     """The same property for the flow / vocoder kernels whose prologues were chains of guarded loads (EXPERIMENTS.md G): the frame rows of
     rconv_lds (+ its two units of weights) and of conv_lds' staging pass, the weight fragments + first row chunks of tfm_attn_fused, the A / B
     chunks of a gemm_tile K tile."""
-    cases = [("ops_resnet_conv.hip", r"rconv_ldsILi256E", 5 + 32), ("ops_resnet_conv.hip", r"rconv_ldsILi512E", 9 + 32),
+    cases = [("ops_resnet_conv.hip", r"rconv_ldsILi256ELb0E", 5 + 32), ("ops_resnet_conv.hip", r"rconv_ldsILi512ELb0E", 9 + 32),
+             ("ops_resnet_conv.hip", r"rconv_ldsILi256ELb1E", 5 + 16),      # (two workgroups per CU: weights in half units)
              ("ops_conv_lds.hip", r"conv_ldsILi128ELi128E", 12), ("ops_tfm_fused.hip", r"tfm_attn_fusedILb0E", 16 + 4),
              ("ops_tfm_fused.hip", r"tfm_attn_fusedILb1E", 16 + 4),
              ("ops_gemm.hip", r"gemm_tileILi2ELi2ELi1ELi1ELb0ELi128E", 8 + 4)]
